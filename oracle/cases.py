@@ -1,0 +1,131 @@
+"""Oracle (test infrastructure): the seeded parity cases shared by make_golden.py and tests/.
+
+A case = model dims + weight seed + input seed.  Inputs/weights are regenerated from seeds
+everywhere; only the reference's OUTPUTS are stored under tests/golden.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from patchrefinerv2_amd import weights as W
+
+
+def rand_image(seed: int, b: int, h: int, w: int) -> torch.Tensor:
+    """image_hr = torch.rand(B,3,H,W, generator=manual_seed(f)) in [0,1)."""
+    return torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(seed))
+
+
+def randn(seed: int, *shape) -> torch.Tensor:
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+# -- tiny DepthAnythingV2: patch 14, pos-embed grid 5x5 (img 70), D 64, 4 blocks, 2 heads --------
+TINY_DAV2 = dict(
+    model_cfg=dict(encoder="vits", features=32, out_channels=[16, 32, 64, 64], max_depth=20.0,
+                   vit=dict(dim=64, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70)),
+    seed=1,
+    inputs=dict(rect=(56, 84), square=(70, 70), big=(112, 98)),
+)
+
+
+def tiny_dav2_sd(prefix: str = "", seed: int = 7):
+    return W.synth_state_dict(W.dav2_spec(prefix, TINY_DAV2["model_cfg"]), seed=seed)
+
+
+# -- FusionUnet, reduced channels (real cfg: configs/patchrefiner_dav2/pr_u4k.py:44-48) -----------
+def _pyramid(seed, b, chl, sizes):
+    return [randn(seed + i, b, c, h, w) for i, (c, (h, w)) in enumerate(zip(chl, sizes))]
+
+
+def _fu_inputs():
+    sizes = [(28, 42), (16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    c = _pyramid(100, 2, [16, 32, 32, 32, 32, 32], sizes)
+    f = _pyramid(200, 2, [16, 32, 32, 32, 32, 32], sizes)
+    pred1 = torch.rand(2, 1, 28, 42, generator=torch.Generator().manual_seed(301)) * 10
+    pred2 = torch.rand(2, 1, 28, 42, generator=torch.Generator().manual_seed(302)) * 10
+    return dict(c_feat=c, f_feat=f, pred1=pred1, pred2=pred2)
+
+
+TINY_FUSION_UNET = dict(input_chl=[32, 64, 64, 64, 64, 64], temp_chl=[16, 34, 32, 32, 32, 32],
+                        dec_chl=[32, 32, 32, 32, 16], seed=21, make_inputs=_fu_inputs)
+
+
+# -- BiDirectionalFusion 'coarse-gated' (C2F features=256 is hard-wired -> tiny spatial sizes) -----
+def _bd_inputs(tag):
+    f_sizes = [(32, 48), (16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    c_sizes = f_sizes if tag == "same" else [(32, 48), (18, 26), (9, 13), (5, 7), (3, 4), (2, 2)]
+    c = _pyramid(400, 1, [32, 256, 256, 256, 256, 256], c_sizes)
+    f = _pyramid(500, 1, [32, 32, 32, 64, 96, 960], f_sizes)  # index 0 = dropped 2x copy
+    pred1 = torch.rand(1, 1, 32, 48, generator=torch.Generator().manual_seed(601)) * 10
+    pred2 = torch.zeros(1, 1, 32, 48)
+    return dict(c_feat=c, f_feat=f, pred1=pred1, pred2=pred2)
+
+
+TINY_BIDIR = dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64, 96, 960],
+                  fine_chl_after=[32, 256, 256, 256, 256, 256], temp_chl=[32, 64, 64, 128, 256, 512],
+                  dec_chl=[512, 256, 128, 64, 32], seed=31, make_inputs=_bd_inputs)
+
+
+# -- end-to-end V1: PatchRefiner(DA2 tiny x2 + FusionUnet), 216x384 frame, 2x2 -------------------
+_E2E_DA2 = dict(encoder="vits", features=32, out_channels=[16, 32, 64, 64],
+                vit=dict(dim=64, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))
+E2E_V1 = dict(
+    raw=[216, 384], split=[2, 2], pps=[56, 84], max_depth=80.0, seed=0, modes=["m1", "m2", "r8"],
+    da2_cfg=_E2E_DA2,
+    fusion=dict(input_chl=[32, 64, 64, 64, 64, 64], temp_chl=[16, 32, 32, 32, 32, 32], dec_chl=[32, 32, 32, 32, 16]),
+)
+E2E_V1["ref_config"] = dict(
+    image_raw_shape=E2E_V1["raw"], patch_process_shape=E2E_V1["pps"], patch_raw_shape=[108, 192],
+    patch_split_num=E2E_V1["split"], fusion_feat_level=6, min_depth=1e-3, max_depth=80.0,
+    pretrain_coarse_model=None, pretrain_fine_model=None, strategy_refiner_target="offset_coarse",
+    coarse_branch=dict(type="DA2", pretrained="dummy_da2", model_cfg=dict(encoder="vits")),
+    refiner=dict(fine_branch=dict(type="DA2", pretrained="dummy_da2", model_cfg=dict(encoder="vits")),
+                 fusion_model=dict(type="FusionUnet", **E2E_V1["fusion"])),
+    sigloss=dict(type="SILogLoss"), pretrained=None, pre_norm_bbox=True)
+
+
+def e2e_v1_sd(seed: int = 41):
+    spec = OrderedDict()
+    spec.update(W.dav2_spec("coarse_branch.", _E2E_DA2))
+    spec.update(W.dav2_spec("refiner_fine_branch.", _E2E_DA2))
+    spec.update(W.fusion_unet_spec("refiner_fusion_model.", **E2E_V1["fusion"]))
+    return W.synth_state_dict(spec, seed=seed)
+
+
+# -- end-to-end V2: PatchRefinerPlus(DA2 tiny w/ 256 features + MNv4-S + BiDirectionalFusion) ----
+# NB the reference only resizes the coarse pyramid to the refiner's sizes when the LOWEST level
+# differs (bi_directional_fusion_model.py:389-393); P must make (P/28) != ceil(P/32) on one axis
+# (true for the real 448x448 config: 16 vs 14), otherwise torch.cat fails at a middle level.
+_E2E2_DA2 = dict(encoder="vits", features=256, out_channels=[16, 32, 64, 64],
+                 vit=dict(dim=64, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))
+E2E_V2 = dict(
+    raw=[256, 512], split=[2, 2], pps=[112, 224], max_depth=80.0, seed=0, modes=["m1", "r4"],
+    da2_cfg=_E2E2_DA2,
+    fusion=dict(coarse_chl=[128, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64, 96, 960],
+                fine_chl_after_coarse2fine=[128, 256, 256, 256, 256, 256], temp_chl=[32, 64, 64, 128, 256, 512],
+                dec_chl=[512, 256, 128, 64, 32]),
+)
+E2E_V2["ref_config"] = dict(
+    e2e_training=True, pretrain_stage=False, image_raw_shape=E2E_V2["raw"], patch_process_shape=E2E_V2["pps"],
+    patch_raw_shape=[128, 256], patch_split_num=E2E_V2["split"], fusion_feat_level=6, min_depth=1e-3, max_depth=80.0,
+    pretrain_coarse_model=None, strategy_refiner_target="offset_coarse",
+    coarse_branch=dict(type="DA2", pretrained="dummy_da2", model_cfg=dict(encoder="vits")),
+    refiner=dict(
+        fine_branch=dict(type="LightWeightRefiner", coarse_condition=True, with_decoder=False,
+                         encoder_name="mobilenetv4_conv_small.e2400_r224_in1k"),
+        fusion_model=dict(type="BiDirectionalFusion", encoder_name="mobilenetv4_conv_small.e2400_r224_in1k",
+                          coarse2fine=True, coarse2fine_type="coarse-gated", **E2E_V2["fusion"])),
+    sigloss=dict(type="SILogLoss"), gmloss=dict(type="GradMatchLoss"), sigweight=1, pre_norm_bbox=True,
+    pretrained=None, whole_pretrained=None)
+
+
+def e2e_v2_sd(seed: int = 43):
+    spec = OrderedDict()
+    spec.update(W.dav2_spec("coarse_branch.", _E2E2_DA2))
+    spec.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
+    f = E2E_V2["fusion"]
+    spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
+                                    f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
+    return W.synth_state_dict(spec, seed=seed)

@@ -1,0 +1,405 @@
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (imported from
+/root/reference under stubs, see refharness.py) on seeded inputs + synthetic weights,
+and assert the oracle restatement agrees while doing so.
+
+Run in the build container only:   cd /root/reference && PYTHONPATH=/root/repo python /root/repo/oracle/make_golden.py
+The committed .npz files hold inputs' seeds and the reference's outputs (data only).
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.chdir("/root/reference")
+
+from oracle import refharness  # noqa: E402
+
+refharness.install()
+
+from oracle import dav2 as o_dav2, fusion as o_fusion, mnv4 as o_mnv4, ops as o_ops, tiling as o_tiling  # noqa: E402
+from oracle.cases import (TINY_DAV2, TINY_FUSION_UNET, TINY_BIDIR, E2E_V1, E2E_V2, rand_image, tiny_dav2_sd,  # noqa: E402
+                          e2e_v1_sd, e2e_v2_sd)
+from patchrefinerv2_amd import weights as W  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB)")
+
+
+# --------------------------------------------------------------------------------------
+def build_ref_dav2(model_cfg, sd, prefix=""):
+    """Reference DepthAnythingV2 with (possibly reduced) dims, loaded strictly from ``sd``."""
+    dpt = refharness.ref_module("external.depth_anything_v2.dpt")
+    dinov2 = refharness.ref_module("external.depth_anything_v2.dinov2")
+    cfg = W.dav2_cfg(model_cfg)
+    vit = cfg["vit"]
+    m = dpt.DepthAnythingV2.__new__(dpt.DepthAnythingV2)
+    torch.nn.Module.__init__(m)
+    m.intermediate_layer_idx = {cfg["encoder"]: vit["taps"]}
+    m.max_depth = cfg["max_depth"]
+    m.encoder = cfg["encoder"]
+    from functools import partial
+    m.pretrained = dinov2.DinoVisionTransformer(
+        img_size=vit["img_size"], patch_size=vit["patch"], embed_dim=vit["dim"], depth=vit["depth"],
+        num_heads=vit["heads"], mlp_ratio=vit["mlp_ratio"], init_values=1.0, ffn_layer="mlp", block_chunks=0,
+        num_register_tokens=0, interpolate_antialias=False, interpolate_offset=0.1,
+        block_fn=partial(dinov2.Block, attn_class=dinov2.MemEffAttention))
+    m.depth_head = dpt.DPTHead(vit["dim"], cfg["features"], False, out_channels=cfg["out_channels"], use_clstoken=False)
+    m.register_buffer("refiner_pixel_mean", torch.Tensor([0.485, 0.456, 0.406]).view(-1, 1, 1), False)
+    m.register_buffer("refiner_pixel_std", torch.Tensor([0.229, 0.224, 0.225]).view(-1, 1, 1), False)
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    m.load_state_dict(sub, strict=True)
+    return m.eval()
+
+
+def g_dav2():
+    print("[dav2_tiny]")
+    sd = tiny_dav2_sd()
+    m = build_ref_dav2(TINY_DAV2["model_cfg"], sd)
+    cfg = W.dav2_cfg(TINY_DAV2["model_cfg"])
+    res = {}
+    for tag, (h, w) in TINY_DAV2["inputs"].items():
+        x = rand_image(TINY_DAV2["seed"], 2, h, w)
+        ref = m(x, return_final_centers=True)
+        ora = o_dav2.dav2_forward(sd, "", x, cfg)
+        d = maxdiff(ref["metric_depth"], ora["metric_depth"])
+        print(f"  {tag}: depth range [{float(ref['metric_depth'].min()):.3f}, {float(ref['metric_depth'].max()):.3f}]"
+              f" oracle-vs-ref max|d| {d:.2e}")
+        assert d < 1e-4, d
+        for k in ref["temp_features"]:
+            dd = maxdiff(ref["temp_features"][k], ora["temp_features"][k])
+            assert dd < 1e-3 * max(1.0, float(ref["temp_features"][k].abs().max())), (k, dd)
+        res[f"{tag}_depth"] = ref["metric_depth"]
+        res[f"{tag}_x_d0"] = ref["temp_features"]["x_d0"]
+        res[f"{tag}_final_feat_mean"] = ref["temp_features"]["midas_final_feat"].mean(dim=1)
+    # spec check against the real-size reference modules (names + shapes only)
+    names = {}
+    for enc, mc in (("vits", dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384])),
+                    ("vitl", dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024]))):
+        dpt = refharness.ref_module("external.depth_anything_v2.dpt")
+        full = dpt.DepthAnythingV2(**mc)
+        ref_shapes = {k: tuple(v.shape) for k, v in full.state_dict().items()}
+        spec = {k: tuple(v) for k, v in W.dav2_spec("", mc).items()}
+        assert ref_shapes == spec, (set(ref_shapes) ^ set(spec))
+        names[enc] = {k: list(v) for k, v in ref_shapes.items()}
+        print(f"  spec {enc}: {len(spec)} tensors, {sum(int(np.prod(v)) for v in spec.values()) / 1e6:.1f} M elements == reference")
+    with open(os.path.join(OUT, "dav2_state_dict_shapes.json"), "w") as f:
+        json.dump(names, f)
+    save("dav2_tiny", **res)
+
+
+def g_vit_block():
+    """One real-size ViT-S block (D=384, 6 heads) on 1025 tokens; row slice stored."""
+    print("[vit_block]")
+    blk_mod = refharness.ref_module("external.depth_anything_v2.dinov2_layers.block")
+    att_mod = refharness.ref_module("external.depth_anything_v2.dinov2_layers.attention")
+    spec = {k: v for k, v in W.dinov2_spec("", W.vit_cfg("vits", depth=1)).items() if k.startswith("blocks.0.")}
+    sd = W.synth_state_dict(spec, seed=11)
+    blk = blk_mod.Block(384, 6, mlp_ratio=4, qkv_bias=True, proj_bias=True, ffn_bias=True, init_values=1.0,
+                        attn_class=att_mod.MemEffAttention).eval()
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items()}, strict=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 1025, 384, generator=g)
+    ref = blk(x)
+    ora = o_dav2.block(sd, "blocks.0.", x, 6)
+    print(f"  oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
+    assert maxdiff(ref, ora) < 1e-4
+    save("vit_block", out_rows=ref[0, ::64].clone())
+
+
+def g_fusion_unet():
+    print("[fusion_unet]")
+    fm = refharness.ref_module("estimator.models.blocks.fusion_model")
+    c = TINY_FUSION_UNET
+    spec = W.fusion_unet_spec("", c["input_chl"], c["temp_chl"], c["dec_chl"])
+    sd = W.synth_state_dict(spec, seed=c["seed"])
+    m = fm.FusionUnet(input_chl=list(c["input_chl"]), temp_chl=list(c["temp_chl"]), dec_chl=list(c["dec_chl"])).eval()
+    m.load_state_dict(sd, strict=True)
+    inp = c["make_inputs"]()
+    ref = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]], pred1=inp["pred1"],
+            pred2=inp["pred2"], update_base=inp["pred1"])
+    ora = o_fusion.fusion_unet(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"], update_base=inp["pred1"])
+    print(f"  out range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
+    assert maxdiff(ref, ora) < 1e-4
+    # real-size spec check (V1 DAv2-L cfg, configs/patchrefiner_dav2/pr_u4k.py:44-48)
+    with torch.device("meta"):
+        full = fm.FusionUnet(input_chl=[256, 512, 512, 512, 512, 512], temp_chl=[128, 256, 256, 256, 256, 256],
+                             dec_chl=[256, 256, 256, 256, 128])
+    assert {k: tuple(v.shape) for k, v in full.state_dict().items()} == \
+        {k: tuple(v) for k, v in W.fusion_unet_spec("", [256, 512, 512, 512, 512, 512], [128, 256, 256, 256, 256, 256],
+                                                    [256, 256, 256, 256, 128]).items()}
+    save("fusion_unet", out=ref)
+
+
+def g_bidir():
+    print("[bidir_fusion]")
+    bm = refharness.ref_module("estimator.models.blocks.bi_directional_fusion_model")
+    c = TINY_BIDIR
+    spec = W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"])
+    sd = W.synth_state_dict(spec, seed=c["seed"])
+    m = bm.BiDirectionalFusion(coarse2fine=True, coarse2fine_type="coarse-gated", coarse_chl=list(c["coarse_chl"]),
+                               fine_chl=list(c["fine_chl"]), fine_chl_after_coarse2fine=list(c["fine_chl_after"]),
+                               temp_chl=list(c["temp_chl"]), dec_chl=list(c["dec_chl"])).eval()
+    missing = m.load_state_dict(sd, strict=True)
+    print("  strict load ok:", missing)
+    res = {}
+    for tag in ("same", "resized"):
+        inp = c["make_inputs"](tag)
+        ref = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]],
+                pred1=inp["pred1"], pred2=inp["pred2"], update_base=inp["pred1"])
+        ora = o_fusion.bidirectional_fusion(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"],
+                                            update_base=inp["pred1"])
+        print(f"  {tag}: out range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
+        assert maxdiff(ref, ora) < 2e-4
+        res[tag] = ref
+    save("bidir_fusion", **res)
+
+
+def g_tiling():
+    print("[tiling]")
+    utils = refharness.ref_module("estimator.models.utils")
+    bp = refharness.ref_module("estimator.models.baseline_pretrain")
+    res = {}
+    # RunningAverageMap sequence incl. zero-weight pixels and resize
+    g = torch.Generator().manual_seed(3)
+    H, W_ = 48, 64
+    avg0 = torch.rand(H, W_, generator=g) * 10
+    cnt0 = (torch.rand(H, W_, generator=g) > 0.3).float() * torch.rand(H, W_, generator=g)
+    ref = utils.RunningAverageMap(avg0.clone(), cnt0.clone())
+    ora = o_tiling.RunningAverageMap(avg0.clone(), cnt0.clone())
+    for i in range(3):
+        p = torch.rand(H, W_, generator=g) * 10
+        c = torch.rand(H, W_, generator=g)
+        c[:, : 8 * (i + 1)] = 0
+        ref.update(p.clone(), c.clone())
+        ora.update(p.clone(), c.clone())
+    assert maxdiff(ref.average_map, ora.average_map) == 0 and maxdiff(ref.count_map, ora.count_map) == 0
+    res["ram_avg"], res["ram_cnt"] = ref.average_map.clone(), ref.count_map.clone()
+    ref.resize((108, 100))
+    ora.resize((108, 100))
+    assert maxdiff(ref.average_map, ora.average_map) == 0 and maxdiff(ref.count_map, ora.count_map) == 0
+    res["ram_avg_rs"], res["ram_cnt_rs"] = ref.average_map.clone(), ref.count_map.clone()
+    # generatemask through the reference function (blur itself = oracle restatement; unpinned)
+    for (h, w) in ((384, 512), (448, 448), (540, 960), (56, 84)):
+        mk = utils.generatemask((h, w), border=0.15)
+        assert np.array_equal(mk, o_ops.generatemask((h, w), border=0.15))
+        res[f"mask_{h}x{w}_rowsum"] = mk.sum(axis=1)
+        res[f"mask_{h}x{w}_colsum"] = mk.sum(axis=0)
+        res[f"mask_{h}x{w}_zeros"] = np.array([(mk == 0).sum()])
+    # prepare_tile_cfg + tile plans through the reference's own regular_tile / random_tile
+    plans = {}
+
+    class Probe(bp.BaselinePretrain):
+        def __init__(self, pps):
+            torch.nn.Module.__init__(self)
+            self.patch_process_shape = pps
+            self.log = []
+
+            class R:
+                def __call__(s, x):
+                    return torch.zeros(1, 3, pps[0], pps[1])
+            self.resizer = R()
+
+        def infer_forward(self, imgs_crop, *a):
+            return torch.zeros(imgs_crop.shape[0], 1, *self.patch_process_shape)
+
+        def coarse_postprocess_test(self, bboxs, bboxs_feat, **kw):
+            self.log.append((bboxs.clone(), bboxs_feat.clone()))
+            return dict(coarse_depth_roi=torch.zeros(bboxs.shape[0], 1, 1, 1), coarse_feats_roi=[torch.zeros(bboxs.shape[0], 1, 1, 1)])
+
+    for name, (raw, split, pps, mode) in dict(
+            c2=((1080, 1920), (2, 2), (448, 448), "m1"), c3=((2160, 3840), (4, 4), (384, 512), "r32"),
+            c4=((2160, 3840), (4, 4), (448, 448), "r64"), small=((216, 384), (2, 2), (56, 84), "r8")).items():
+        pr = Probe(pps)
+        tc = pr.prepare_tile_cfg(raw, split)
+        otc = o_tiling.prepare_tile_cfg(pps, raw, split)
+        assert {k: list(v) for k, v in tc.items()} == {k: list(v) for k, v in otc.items()}
+        random.seed(621)
+        img = torch.zeros(3, *raw)
+        blur = torch.zeros(pps)
+        tt = dict(coarse_prediction=None, coarse_features=None)
+        rh, rw = tc["patch_raw_shape"]
+        avg = pr.regular_tile([0, 0], [0, 0], img, init_flag=True, tile_temp=tt, blur_mask=blur, tile_cfg=tc, process_num=4)
+        if mode != "m1":
+            for off, offp in (([0, rw // 2], [0, pps[1] // 2]), ([rh // 2, 0], [pps[0] // 2, 0]),
+                              ([rh // 2, rw // 2], [pps[0] // 2, pps[1] // 2])):
+                avg = pr.regular_tile(off, offp, img, init_flag=False, tile_temp=tt, blur_mask=blur, avg_depth_map=avg,
+                                      tile_cfg=tc, process_num=4)
+        if mode[0] == "r":
+            avg.resize(tc["image_raw_shape"])
+            blur_r = torch.zeros(rh, rw)
+            for _ in range(int(mode[1:]) // 4):
+                avg = pr.random_tile(img, tile_temp=tt, blur_mask=blur_r, avg_depth_map=avg, tile_cfg=tc, process_num=4)
+        bb = torch.cat([b for b, _ in pr.log]).numpy()
+        bf = torch.cat([f for _, f in pr.log]).numpy()
+        plans[name] = dict(raw=list(raw), split=list(split), pps=list(pps), mode=mode, n=int(bb.shape[0]))
+        res[f"plan_{name}_bboxs"] = bb.astype(np.int32)
+        res[f"plan_{name}_bboxs_feat"] = bf.astype(np.float32)
+        print(f"  plan {name}: {bb.shape[0]} tiles")
+    with open(os.path.join(OUT, "tile_plans.json"), "w") as f:
+        json.dump(plans, f)
+    # Resize (both flavours) on a small random crop
+    rda = refharness.ref_module("external.depth_anything.transform").Resize
+    rzoe = refharness.ref_module("external.zoedepth.models.base_models.midas").Resize
+    crop = torch.rand(1, 3, 54, 96, generator=torch.Generator().manual_seed(9))
+    a = rda(84, 56, keep_aspect_ratio=False, ensure_multiple_of=14, resize_method="minimal")(crop)
+    assert maxdiff(a, o_ops.resize_da(crop, 84, 56)) == 0
+    assert maxdiff(a, o_ops.bilinear_ac_explicit(crop, (56, 84))) < 1e-6
+    b = rda(512, 384, keep_aspect_ratio=False, ensure_multiple_of=14, resize_method="minimal")(crop)
+    assert tuple(b.shape[-2:]) == (378, 518)
+    z = rzoe(512, 384, keep_aspect_ratio=False, ensure_multiple_of=32, resize_method="minimal")(crop)
+    assert maxdiff(z, o_ops.resize_zoe(crop)) == 0
+    res["resize_da_56x84"] = a
+    res["resize_zoe_rowmean"] = z.mean(dim=-1)
+    save("tiling", **res)
+
+
+def _patch_torch_load(sd_for):
+    real = torch.load
+
+    def fake(path, *a, **k):
+        for key, fn in sd_for.items():
+            if key in str(path):
+                return fn()
+        return real(path, *a, **k)
+    torch.load = fake
+    return real
+
+
+def g_e2e_v1():
+    print("[e2e_v1]")
+    c = E2E_V1
+    sd = e2e_v1_sd()
+    dpt = refharness.ref_module("external.depth_anything_v2.dpt")
+    # reduced DA2 dims: the reference class is built by name, so swap its ctor for the reduced builder
+    orig = dpt.DepthAnythingV2
+    pr_mod = refharness.ref_module("estimator.models.patchrefiner")
+    refharness.ref_module("estimator.models.blocks.fusion_model")
+    built = []
+
+    def small_da2(**kw):
+        prefix = "coarse_branch." if not built else "refiner_fine_branch."
+        built.append(prefix)
+        return build_ref_dav2({**c["da2_cfg"], "max_depth": kw["max_depth"]}, sd, prefix)
+    pr_mod.DepthAnythingV2 = small_da2
+    real = _patch_torch_load({"dummy_da2": lambda: None})
+    try:
+        torch.nn.Module.load_state_dict_orig = torch.nn.Module.load_state_dict
+        cfg = refharness.AttrDict(c["ref_config"])
+        # DA2 branch calls self.coarse_branch.load_state_dict(torch.load(pretrained)) -> tolerate None
+        orig_lsd = torch.nn.Module.load_state_dict
+        torch.nn.Module.load_state_dict = lambda self, s, strict=True, **k: (orig_lsd(self, s, strict=strict, **k) if s is not None else None)
+        m = pr_mod.PatchRefiner(cfg).eval()
+        torch.nn.Module.load_state_dict = orig_lsd
+    finally:
+        torch.load = real
+        pr_mod.DepthAnythingV2 = orig
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    ora = o_tiling.OraclePatchRefiner(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                      W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                      patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+    image_hr = rand_image(c["seed"], 1, *c["raw"])
+    image_lr = m.resizer(image_hr)
+    res = {}
+    for mode in c["modes"]:
+        random.seed(621)
+        ref, log = m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=dict(image_raw_shape=c["raw"], patch_split_num=c["split"]),
+                     image_lr=image_lr, image_hr=image_hr)
+        random.seed(621)
+        out, olog = ora(mode="infer", cai_mode=mode, process_num=4, tile_cfg=dict(image_raw_shape=c["raw"], patch_split_num=c["split"]),
+                        image_lr=image_lr, image_hr=image_hr)
+        d = maxdiff(ref, out)
+        print(f"  {mode}: out {tuple(ref.shape)} range [{float(ref.min()):.3f},{float(ref.max()):.3f}] coarse range "
+              f"[{float(log['coarse_prediction'].min()):.3f},{float(log['coarse_prediction'].max()):.3f}] oracle-vs-ref max|d| {d:.2e}")
+        assert d < 2e-4, d
+        res[mode] = ref
+        res[mode + "_coarse"] = log["coarse_prediction"]
+    save("e2e_v1", **res)
+
+
+def g_e2e_v2():
+    print("[e2e_v2]")
+    c = E2E_V2
+    sd = e2e_v2_sd()
+    import timm
+
+    class Enc(torch.nn.Module):
+        """timm.create_model stand-in (timm absent): the oracle's MNv4-small restatement with a
+        3-channel stem; the reference then performs its 4-channel stem surgery on ``conv_stem``."""
+        default_cfg = dict(mean=W.MNV4_SMALL["mean"], std=W.MNV4_SMALL["std"])
+
+        def __init__(self):
+            super().__init__()
+            self.conv_stem = torch.nn.Conv2d(3, 32, 3, 2, 1, bias=False)
+            self.sd = {}  # plain dict (not registered): filled from the synthetic state dict below
+
+        def forward(self, x):
+            d = dict(self.sd)
+            d["conv_stem.weight"] = self.conv_stem.weight
+            return o_mnv4.mnv4_features(d, "", x)
+
+    timm.create_model = lambda name, pretrained=True, features_only=True: Enc()
+    prp = refharness.ref_module("estimator.models.patchrefinerplus")
+    refharness.ref_module("estimator.models.blocks.lightweight_refiner")
+    refharness.ref_module("estimator.models.blocks.bi_directional_fusion_model")
+    orig = prp.DepthAnythingV2
+    prp.DepthAnythingV2 = lambda **kw: build_ref_dav2({**c["da2_cfg"], "max_depth": kw["max_depth"]}, sd, "coarse_branch.")
+    prp.Conv2dSame = torch.nn.Conv2d
+    orig_lsd = torch.nn.Module.load_state_dict
+    real = _patch_torch_load({"dummy_da2": lambda: None})
+    try:
+        torch.nn.Module.load_state_dict = lambda self, s, strict=True, **k: (orig_lsd(self, s, strict=strict, **k) if s is not None else None)
+        m = prp.PatchRefinerPlus(refharness.AttrDict(c["ref_config"])).eval()
+    finally:
+        torch.nn.Module.load_state_dict = orig_lsd
+        torch.load = real
+        prp.DepthAnythingV2 = orig
+    # load everything by name (the encoder's buffers go through Enc._load_from_state_dict)
+    res_load = m.load_state_dict(dict(sd), strict=False)
+    assert not res_load.missing_keys, res_load.missing_keys[:5]
+    ep = "refiner_fine_branch.refiner_encoder."
+    assert all(k.startswith(ep) for k in res_load.unexpected_keys)
+    m.refiner_fine_branch.refiner_encoder.sd = {k[len(ep):]: v for k, v in sd.items() if k.startswith(ep)}
+    assert tuple(m.refiner_fine_branch.refiner_encoder.conv_stem.weight.shape) == (32, 4, 3, 3)
+    ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                          patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+    image_hr = rand_image(c["seed"], 1, *c["raw"])
+    image_lr = m.resizer(image_hr)
+    res = {}
+    for mode in c["modes"]:
+        random.seed(621)
+        ref, log = m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=dict(image_raw_shape=c["raw"], patch_split_num=c["split"]),
+                     image_lr=image_lr, image_hr=image_hr)
+        random.seed(621)
+        out, _ = ora(mode="infer", cai_mode=mode, process_num=4, tile_cfg=dict(image_raw_shape=c["raw"], patch_split_num=c["split"]),
+                     image_lr=image_lr, image_hr=image_hr)
+        d = maxdiff(ref, out)
+        print(f"  {mode}: out {tuple(ref.shape)} range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {d:.2e}")
+        assert d < 2e-4, d
+        res[mode] = ref
+    save("e2e_v2", **res)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2"]
+    for w in which:
+        globals()["g_" + w]()
+    print("done")

@@ -1,0 +1,236 @@
+"""Oracle (test infrastructure): tiling, ROI pyramid, blend and the two frame drivers.
+
+prepare_tile_cfg        estimator/models/baseline_pretrain.py:96-124
+random_tile             baseline_pretrain.py:149-231
+regular_tile            baseline_pretrain.py:235-375
+RunningAverageMap       estimator/models/utils.py:22-49
+coarse_postprocess_test estimator/models/patchrefinerplus.py:263-296 / patchrefiner.py:199-217
+PatchRefinerPlus infer  patchrefinerplus.py:330-365, 470-530
+PatchRefiner infer      patchrefiner.py:219-283, 341-401
+"""
+from __future__ import annotations
+
+import random
+
+import torch
+
+from . import dav2, fusion, mnv4
+from .ops import bilinear_ac, generatemask, nearest, resize_da, resize_zoe, roi_align
+
+
+def prepare_tile_cfg(patch_process_shape, image_raw_shape, patch_split_num):
+    ph, pw = patch_process_shape
+    sh, sw = patch_split_num
+    raw = (image_raw_shape[0] // sh, image_raw_shape[1] // sw)
+    return dict(
+        patch_split_num=list(patch_split_num),
+        patch_reensemble_shape=(ph * sh, pw * sw),
+        patch_raw_shape=raw,
+        image_raw_shape=list(image_raw_shape),
+        raw_h_split_point=[int(raw[0] * i) for i in range(sh)],
+        raw_w_split_point=[int(raw[1] * i) for i in range(sw)])
+
+
+class RunningAverageMap:
+    def __init__(self, average_map, count_map):
+        self.count_map = count_map
+        self.average_map_init = average_map
+        self.average_map = average_map
+        self.update_flag = False
+
+    def update(self, pred_map, ct_map):
+        self.update_flag = True
+        mask = ct_map > 0
+        self.average_map[mask] = (pred_map[mask] * ct_map[mask] + self.count_map[mask] * self.average_map[mask]) / \
+            (self.count_map[mask] + ct_map[mask])
+        self.count_map[mask] = self.count_map[mask] + ct_map[mask]
+
+    def resize(self, resolution):
+        self.average_map = nearest(self.average_map[None, None], resolution).squeeze()
+        self.count_map = bilinear_ac(self.count_map[None, None], resolution).squeeze()
+
+    def get_avg_map(self):
+        return self.average_map if self.update_flag else self.average_map_init
+
+
+def bboxs_to_feat(bboxs, image_raw_shape, patch_process_shape):
+    """baseline_pretrain.py:289-296 (float32 tensor arithmetic, including the 1/x*y order)."""
+    H, W = image_raw_shape
+    ph, pw = patch_process_shape
+    factor = torch.tensor([1 / W * pw, 1 / H * ph, 1 / W * pw, 1 / H * ph]).unsqueeze(0)
+    bf = bboxs.int() * factor
+    inds = torch.arange(bboxs.shape[0]).unsqueeze(-1)
+    return torch.cat((inds, bf), dim=-1)
+
+
+def coarse_postprocess_test(coarse_prediction, coarse_features, bboxs_feat, ph):
+    """feat.repeat(K) + roi_align per level (patchrefinerplus.py:263-283)."""
+    K = bboxs_feat.shape[0]
+    rois = []
+    for feat in coarse_features:
+        h, w = feat.shape[-2:]
+        rois.append(roi_align(feat.repeat(K, 1, 1, 1), bboxs_feat, (h, w), h / ph, aligned=True))
+    h, w = coarse_prediction.shape[-2:]
+    depth_roi = roi_align(coarse_prediction.repeat(K, 1, 1, 1), bboxs_feat, (h, w), h / ph, aligned=True)
+    return dict(coarse_depth_roi=depth_roi, coarse_feats_roi=rois)
+
+
+class OracleRefiner:
+    """Shared driver; subclasses provide coarse_forward / infer_forward."""
+
+    def __init__(self, sd, patch_process_shape, image_raw_shape, patch_split_num, resizer="da"):
+        self.sd = sd
+        self.patch_process_shape = tuple(patch_process_shape)
+        self.tile_cfg = prepare_tile_cfg(self.patch_process_shape, image_raw_shape, patch_split_num)
+        self.resizer_kind = resizer
+        self.trace = None  # optional dict for tests: records the tile plan
+
+    def resizer(self, x):
+        ph, pw = self.patch_process_shape
+        return resize_da(x, pw, ph, 14) if self.resizer_kind == "da" else resize_zoe(x)
+
+    # -- tiles ------------------------------------------------------------------
+    def _crops(self, image_hr, h_starts, w_starts, height, width):
+        crops, bboxs = [], []
+        for hs in h_starts:
+            for ws in w_starts:
+                crop = image_hr[:, hs:hs + height, ws:ws + width]
+                crops.append(self.resizer(crop.unsqueeze(0)).squeeze(0))
+                bboxs.append(torch.tensor([ws, hs, ws + width, hs + height]))
+        return torch.stack(crops), torch.stack(bboxs)
+
+    def random_tile(self, image_hr, tile_temp, blur_mask, avg, tile_cfg, process_num):
+        height, width = tile_cfg["patch_raw_shape"]
+        H, W = tile_cfg["image_raw_shape"]
+        h_starts = [random.randint(0, H - height - 1) for _ in range(process_num)]
+        w_starts = [random.randint(0, W - width - 1)]
+        crops, bboxs = self._crops(image_hr, h_starts, w_starts, height, width)
+        bf = bboxs_to_feat(bboxs, (H, W), self.patch_process_shape)
+        post = coarse_postprocess_test(tile_temp["coarse_prediction"], tile_temp["coarse_features"], bf,
+                                       self.patch_process_shape[0])
+        pred = self.infer_forward(crops, post)
+        pred = nearest(pred, (height, width))
+        if self.trace is not None:
+            self.trace.setdefault("tiles", []).extend(("r", hs, w_starts[0]) for hs in h_starts)
+        i = 0
+        for hs in h_starts:
+            for ws in w_starts:
+                count = torch.zeros((H, W))
+                pd = torch.zeros((H, W))
+                count[hs:hs + height, ws:ws + width] = blur_mask
+                pd[hs:hs + height, ws:ws + width] = pred[i]
+                avg.update(pd, count)
+                i += 1
+        return avg
+
+    def regular_tile(self, offset, offset_process, image_hr, init_flag, tile_temp, blur_mask, avg, tile_cfg,
+                     process_num):
+        height, width = tile_cfg["patch_raw_shape"]
+        H, W = tile_cfg["image_raw_shape"]
+        ph, pw = self.patch_process_shape
+        RH, RW = tile_cfg["patch_reensemble_shape"]
+        h_starts = [height * h + offset[0] for h in range((H - offset[0]) // height)]
+        w_starts = [width * w + offset[1] for w in range((W - offset[1]) // width)]
+        hp_starts = [ph * h + offset_process[0] for h in range((RH - offset_process[0]) // ph)]
+        wp_starts = [pw * w + offset_process[1] for w in range((RW - offset_process[1]) // pw)]
+        crops, bboxs = self._crops(image_hr, h_starts, w_starts, height, width)
+        bf = bboxs_to_feat(bboxs, (H, W), self.patch_process_shape)
+        post = coarse_postprocess_test(tile_temp["coarse_prediction"], tile_temp["coarse_features"], bf, ph)
+        preds = []
+        for idx, batch in enumerate(torch.split(crops, process_num, dim=0)):
+            sl = slice(idx * process_num, (idx + 1) * process_num)
+            sub = dict(coarse_depth_roi=post["coarse_depth_roi"][sl],
+                       coarse_feats_roi=[f[sl] for f in post["coarse_feats_roi"]])
+            preds.append(self.infer_forward(batch, sub))
+        preds = torch.cat(preds, dim=0)
+        if self.trace is not None:
+            self.trace.setdefault("tiles", []).extend(("g", hs, ws) for hs in h_starts for ws in w_starts)
+            self.trace.setdefault("preds", []).append(preds.clone())
+        count = torch.zeros((RH, RW))
+        pd = torch.zeros((RH, RW))
+        i = 0
+        for hs in hp_starts:
+            for ws in wp_starts:
+                if init_flag:
+                    count[hs:hs + ph, ws:ws + pw] = blur_mask
+                    pd[hs:hs + ph, ws:ws + pw] = preds[i]
+                else:
+                    count = torch.zeros((RH, RW))
+                    pd = torch.zeros((RH, RW))
+                    count[hs:hs + ph, ws:ws + pw] = blur_mask
+                    pd[hs:hs + ph, ws:ws + pw] = preds[i]
+                    avg.update(pd, count)
+                i += 1
+        if init_flag:
+            avg = RunningAverageMap(pd, count)
+        return avg
+
+    # -- frame driver -------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, mode="infer", cai_mode="m1", process_num=4, tile_cfg=None, image_lr=None, image_hr=None,
+                 **_ignored):
+        assert mode == "infer"
+        if tile_cfg is None:
+            tile_cfg = self.tile_cfg
+        else:
+            tile_cfg = prepare_tile_cfg(self.patch_process_shape, tile_cfg["image_raw_shape"],
+                                        tile_cfg["patch_split_num"])
+        assert image_hr.shape[0] == 1
+        feats, coarse_pred = self.coarse_forward(image_lr)
+        tile_temp = dict(coarse_prediction=coarse_pred, coarse_features=feats)
+        ph, pw = self.patch_process_shape
+        rh, rw = tile_cfg["patch_raw_shape"]
+        blur = torch.tensor(generatemask((ph, pw), border=0.15))
+        kw = dict(image_hr=image_hr[0], tile_temp=tile_temp, tile_cfg=tile_cfg, process_num=process_num)
+        avg = self.regular_tile([0, 0], [0, 0], init_flag=True, blur_mask=blur, avg=None, **kw)
+        if cai_mode == "m2" or cai_mode[0] == "r":
+            avg = self.regular_tile([0, rw // 2], [0, pw // 2], init_flag=False, blur_mask=blur, avg=avg, **kw)
+            avg = self.regular_tile([rh // 2, 0], [ph // 2, 0], init_flag=False, blur_mask=blur, avg=avg, **kw)
+            avg = self.regular_tile([rh // 2, rw // 2], [ph // 2, pw // 2], init_flag=False, blur_mask=blur,
+                                    avg=avg, **kw)
+        if cai_mode[0] == "r":
+            blur = torch.tensor(generatemask((rh, rw), border=0.15) + 1e-3)
+            avg.resize(tile_cfg["image_raw_shape"])
+            for _ in range(int(cai_mode[1:]) // process_num):
+                avg = self.random_tile(blur_mask=blur, avg=avg, **kw)
+        depth = avg.get_avg_map()[None, None]
+        return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=None, coarse_prediction=coarse_pred)
+
+
+class OraclePatchRefiner(OracleRefiner):
+    """V1: DA2 coarse + DA2 per-patch + FusionUnet (configs/patchrefiner_dav2/pr_u4k.py)."""
+
+    def __init__(self, sd, coarse_cfg, fine_cfg, **kw):
+        super().__init__(sd, **kw)
+        self.coarse_cfg, self.fine_cfg = coarse_cfg, fine_cfg
+
+    def coarse_forward(self, image_lr):
+        return dav2.coarse_features(dav2.dav2_forward(self.sd, "coarse_branch.", image_lr, self.coarse_cfg))
+
+    def infer_forward(self, imgs_crop, post):
+        r_feats, r_depth = dav2.coarse_features(
+            dav2.dav2_forward(self.sd, "refiner_fine_branch.", imgs_crop, self.fine_cfg))
+        return fusion.fusion_unet(self.sd, "refiner_fusion_model.", post["coarse_feats_roi"][::-1], r_feats[::-1],
+                                  post["coarse_depth_roi"], r_depth, update_base=post["coarse_depth_roi"])
+
+
+class OraclePatchRefinerPlus(OracleRefiner):
+    """V2: DA2 coarse + LightWeightRefiner(MNv4-S) + BiDirectionalFusion
+    (configs/patchrefinerv2_dav2/plus_mobile_u4k_base_coarse_e2e_c2f_pretrain.py)."""
+
+    def __init__(self, sd, coarse_cfg, coarse_fn=None, **kw):
+        super().__init__(sd, **kw)
+        self.coarse_cfg = coarse_cfg
+        self.coarse_fn = coarse_fn
+
+    def coarse_forward(self, image_lr):
+        if self.coarse_fn is not None:
+            return self.coarse_fn(image_lr)
+        return dav2.coarse_features(dav2.dav2_forward(self.sd, "coarse_branch.", image_lr, self.coarse_cfg))
+
+    def infer_forward(self, imgs_crop, post):
+        r_feats, r_depth = mnv4.lightweight_refiner(self.sd, "refiner_fine_branch.", imgs_crop,
+                                                    post["coarse_depth_roi"])
+        return fusion.bidirectional_fusion(self.sd, "refiner_fusion_model.", post["coarse_feats_roi"][::-1],
+                                           r_feats[::-1], post["coarse_depth_roi"], r_depth,
+                                           update_base=post["coarse_depth_roi"])

@@ -1,0 +1,355 @@
+"""State-dict contract of the hot path + deterministic synthetic weights.
+
+The reference ships no checkpoints (README.md:14,45), so parity and benchmarks
+run on synthetic weights.  What IS a contract is the parameter naming/shape of
+the reference modules; the ``*_spec`` functions below
+enumerate it so that a real checkpoint, once released, loads by name.
+
+Reference modules mirrored (names + shapes only, no code):
+  * DepthAnythingV2          external/depth_anything_v2/dpt.py:153-181
+    DinoVisionTransformer    external/depth_anything_v2/dinov2.py:44-176
+    DPTHead                  external/depth_anything_v2/dpt.py:38-114
+  * FusionUnet               estimator/models/blocks/fusion_model.py:53-82
+  * BiDirectionalFusion      estimator/models/blocks/bi_directional_fusion_model.py:290-377
+    C2FModule                ...bi_directional_fusion_model.py:148-182
+  * LightWeightRefiner       estimator/models/blocks/lightweight_refiner.py:242-283
+    (timm ``mobilenetv4_conv_small`` features_only encoder -- un-vendored,
+    names follow timm's MobileNetV3Features module tree; parity unpinned)
+"""
+from __future__ import annotations
+
+import hashlib
+import re
+from collections import OrderedDict
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+Spec = "OrderedDict[str, Tuple[int, ...]]"
+
+VIT_CFG = {
+    # encoder: (embed_dim, depth, heads, taps)  dinov2.py:340-395, dpt.py:165-170
+    "vits": dict(dim=384, depth=12, heads=6, taps=[2, 5, 8, 11]),
+    "vitb": dict(dim=768, depth=12, heads=12, taps=[2, 5, 8, 11]),
+    "vitl": dict(dim=1024, depth=24, heads=16, taps=[4, 11, 17, 23]),
+}
+
+
+def vit_cfg(encoder: str, **over) -> dict:
+    cfg = dict(VIT_CFG[encoder]) if encoder in VIT_CFG else {}
+    cfg.update(over)
+    cfg.setdefault("patch", 14)
+    cfg.setdefault("img_size", 518)  # DINOv2() builder, dinov2.py:407
+    cfg.setdefault("mlp_ratio", 4)
+    return cfg
+
+
+def dinov2_spec(prefix: str, cfg: dict) -> Spec:
+    D, L, p = cfg["dim"], cfg["depth"], cfg["patch"]
+    n_pos = (cfg["img_size"] // p) ** 2 + 1
+    hid = int(D * cfg["mlp_ratio"])
+    s: Spec = OrderedDict()
+    s[prefix + "cls_token"] = (1, 1, D)
+    s[prefix + "pos_embed"] = (1, n_pos, D)
+    s[prefix + "mask_token"] = (1, D)
+    s[prefix + "patch_embed.proj.weight"] = (D, 3, p, p)
+    s[prefix + "patch_embed.proj.bias"] = (D,)
+    for i in range(L):
+        b = f"{prefix}blocks.{i}."
+        s[b + "norm1.weight"] = (D,)
+        s[b + "norm1.bias"] = (D,)
+        s[b + "attn.qkv.weight"] = (3 * D, D)
+        s[b + "attn.qkv.bias"] = (3 * D,)
+        s[b + "attn.proj.weight"] = (D, D)
+        s[b + "attn.proj.bias"] = (D,)
+        s[b + "ls1.gamma"] = (D,)
+        s[b + "norm2.weight"] = (D,)
+        s[b + "norm2.bias"] = (D,)
+        s[b + "mlp.fc1.weight"] = (hid, D)
+        s[b + "mlp.fc1.bias"] = (hid,)
+        s[b + "mlp.fc2.weight"] = (D, hid)
+        s[b + "mlp.fc2.bias"] = (D,)
+        s[b + "ls2.gamma"] = (D,)
+    s[prefix + "norm.weight"] = (D,)
+    s[prefix + "norm.bias"] = (D,)
+    return s
+
+
+def dpt_head_spec(prefix: str, D: int, features: int, out_channels: Sequence[int]) -> Spec:
+    F_, oc = features, list(out_channels)
+    s: Spec = OrderedDict()
+    for i in range(4):
+        s[f"{prefix}projects.{i}.weight"] = (oc[i], D, 1, 1)
+        s[f"{prefix}projects.{i}.bias"] = (oc[i],)
+    s[prefix + "resize_layers.0.weight"] = (oc[0], oc[0], 4, 4)  # ConvTranspose2d [in,out,k,k]
+    s[prefix + "resize_layers.0.bias"] = (oc[0],)
+    s[prefix + "resize_layers.1.weight"] = (oc[1], oc[1], 2, 2)
+    s[prefix + "resize_layers.1.bias"] = (oc[1],)
+    s[prefix + "resize_layers.3.weight"] = (oc[3], oc[3], 3, 3)
+    s[prefix + "resize_layers.3.bias"] = (oc[3],)
+    for i in range(4):
+        s[f"{prefix}scratch.layer{i + 1}_rn.weight"] = (F_, oc[i], 3, 3)
+    for r in range(1, 5):
+        b = f"{prefix}scratch.refinenet{r}."
+        s[b + "out_conv.weight"] = (F_, F_, 1, 1)
+        s[b + "out_conv.bias"] = (F_,)
+        for u in (1, 2):
+            for c in (1, 2):
+                s[f"{b}resConfUnit{u}.conv{c}.weight"] = (F_, F_, 3, 3)
+                s[f"{b}resConfUnit{u}.conv{c}.bias"] = (F_,)
+    s[prefix + "scratch.output_conv1.weight"] = (F_ // 2, F_, 3, 3)
+    s[prefix + "scratch.output_conv1.bias"] = (F_ // 2,)
+    s[prefix + "scratch.output_conv2.0.weight"] = (32, F_ // 2, 3, 3)
+    s[prefix + "scratch.output_conv2.0.bias"] = (32,)
+    s[prefix + "scratch.output_conv2.2.weight"] = (1, 32, 1, 1)
+    s[prefix + "scratch.output_conv2.2.bias"] = (1,)
+    return s
+
+
+def dav2_spec(prefix: str, model_cfg: dict) -> Spec:
+    """DepthAnythingV2(encoder, features, out_channels) parameter table."""
+    cfg = dav2_cfg(model_cfg)
+    s = dinov2_spec(prefix + "pretrained.", cfg["vit"])
+    s.update(dpt_head_spec(prefix + "depth_head.", cfg["vit"]["dim"], cfg["features"], cfg["out_channels"]))
+    return s
+
+
+def dav2_cfg(model_cfg: dict) -> dict:
+    """Normalise a reference ``model_cfg`` dict (configs/patchrefiner_dav2/pr_u4k.py:31-35).
+
+    ``vit`` may be given explicitly for reduced test models (the reference has
+    no such knob; tests build the reference module with the same dims)."""
+    model_cfg = dict(model_cfg)
+    enc = model_cfg.get("encoder", "vitl")
+    vit = vit_cfg(enc, **model_cfg.get("vit", {}))
+    return dict(
+        encoder=enc,
+        vit=vit,
+        features=model_cfg.get("features", 256),
+        out_channels=list(model_cfg.get("out_channels", [256, 512, 1024, 1024])),
+        max_depth=float(model_cfg.get("max_depth", 20.0)),
+    )
+
+
+def fusion_unet_spec(prefix: str, input_chl, temp_chl, dec_chl) -> Spec:
+    s: Spec = OrderedDict()
+    for l, (ic, tc) in enumerate(zip(input_chl, temp_chl)):
+        s[f"{prefix}encoder_layers_1.{l}.single_conv.0.weight"] = (tc, ic, 3, 3)
+        s[f"{prefix}encoder_layers_1.{l}.single_conv.1.weight"] = (tc,)
+        s[f"{prefix}encoder_layers_1.{l}.single_conv.1.bias"] = (tc,)
+        s[f"{prefix}encoder_layers_2.{l}.single_conv.0.weight"] = (tc, tc + 2, 3, 3)
+        s[f"{prefix}encoder_layers_2.{l}.single_conv.1.weight"] = (tc,)
+        s[f"{prefix}encoder_layers_2.{l}.single_conv.1.bias"] = (tc,)
+    t = list(temp_chl)[::-1]
+    ch = t[0]
+    for j, (tc, dc) in enumerate(zip(t[1:], dec_chl)):
+        n = tc + ch + 2
+        s[f"{prefix}decoder_layers.{j}.conv.double_conv.0.weight"] = (n, n, 3, 3)
+        s[f"{prefix}decoder_layers.{j}.conv.double_conv.2.weight"] = (dc, n, 3, 3)
+        ch = dc
+    last = dec_chl[-1] if len(dec_chl) else ch
+    s[prefix + "final_conv.weight"] = (1, last, 3, 3)
+    return s
+
+
+def _gated_unit_spec(s: Spec, b: str, F_: int):
+    s[b + "conv.weight"] = (F_, F_, 3, 3)
+    s[b + "conv.bias"] = (F_,)
+    s[b + "fusion_conv.0.weight"] = (F_, 2 * F_, 3, 3)
+    s[b + "fusion_conv.0.bias"] = (F_,)
+    s[b + "fusion_conv.1.weight"] = (F_,)
+    s[b + "fusion_conv.1.bias"] = (F_,)
+    s[b + "fusion_conv.3.weight"] = (F_, F_, 1, 1)
+
+
+def _gated_block_spec(s: Spec, b: str, F_: int):
+    s[b + "out_conv.weight"] = (F_, F_, 1, 1)
+    s[b + "out_conv.bias"] = (F_,)
+    _gated_unit_spec(s, b + "GateresConfUnit1.", F_)
+    _gated_unit_spec(s, b + "GateresConfUnit2.", F_)
+
+
+def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
+                      features: int = 256) -> Spec:
+    """BiDirectionalFusion(coarse2fine_type='coarse-gated') parameter table."""
+    s: Spec = OrderedDict()
+    for l, (cc, fc, tc) in enumerate(zip(coarse_chl, fine_chl_after_coarse2fine, temp_chl)):
+        s[f"{prefix}fusion_layers_1.{l}.single_conv.0.weight"] = (tc, cc + fc, 3, 3)
+        s[f"{prefix}fusion_layers_1.{l}.single_conv.1.weight"] = (tc,)
+        s[f"{prefix}fusion_layers_1.{l}.single_conv.1.bias"] = (tc,)
+        s[f"{prefix}fusion_layers_2.{l}.single_conv.0.weight"] = (tc, tc + 2, 3, 3)
+        s[f"{prefix}fusion_layers_2.{l}.single_conv.1.weight"] = (tc,)
+        s[f"{prefix}fusion_layers_2.{l}.single_conv.1.bias"] = (tc,)
+    t = list(temp_chl)[::-1]
+    ch = t[0]
+    for j, (tc, dc) in enumerate(zip(t[1:], dec_chl)):
+        n = tc + ch + 2
+        s[f"{prefix}f2r_agg.{j}.conv.double_conv.0.weight"] = (n, n, 3, 3)
+        s[f"{prefix}f2r_agg.{j}.conv.double_conv.2.weight"] = (dc, n, 3, 3)
+        ch = dc
+    last = dec_chl[-1] if len(dec_chl) else ch
+    s[prefix + "final_conv.weight"] = (1, last, 3, 3)
+    c = prefix + "c2f.scratch."
+    for i in range(5):
+        s[f"{c}layer{i + 1}_rn.weight"] = (features, fine_chl[i], 3, 3)
+    for r in range(1, 6):
+        _gated_block_spec(s, f"{c}refinenet{r}.", features)
+    h2 = coarse_chl[0]
+    s[c + "output_conv1.weight"] = (features // 2, features, 3, 3)
+    s[c + "output_conv1.bias"] = (features // 2,)
+    s[c + "output_conv2.0.weight"] = (h2, features // 2, 3, 3)
+    s[c + "output_conv2.0.bias"] = (h2,)
+    _gated_block_spec(s, c + "output_conv2_fusion.", h2)
+    s[c + "output_conv3.0.weight"] = (1, h2, 1, 1)
+    s[c + "output_conv3.0.bias"] = (1,)
+    return s
+
+
+# ----------------------------------------------------------------------------
+# timm mobilenetv4_conv_small (features_only) -- un-vendored third party.
+# Architecture restated from the public MobileNetV4 definition (conv-small):
+#   stem 3x3 s2 -> 32
+#   stage0: cn 3x3 s2 ->32, cn 1x1 ->32            (/4,  32)
+#   stage1: cn 3x3 s2 ->96, cn 1x1 ->64            (/8,  64)
+#   stage2: uir(5,5,s2,e3)->96, 4x uir(0,3,e2)->96, uir(3,0,e4)->96   (/16, 96)
+#   stage3: uir(3,3,s2,e6)->128, uir(5,5,e4), uir(0,5,e4), uir(0,5,e3),
+#           uir(0,3,e4), uir(0,3,e4) ->128         (/32, 128)
+#   stage4: cn 1x1 -> 960                          (/32, 960)
+# feature taps (features_only): stem act (/2, 32), stage0, stage1, stage2, stage4.
+# Every conv is followed by BatchNorm (+ReLU except the projection conv).
+# ----------------------------------------------------------------------------
+MNV4_SMALL = dict(
+    stem=32,
+    stages=[
+        [("cn", 3, 2, 32), ("cn", 1, 1, 32)],
+        [("cn", 3, 2, 96), ("cn", 1, 1, 64)],
+        [("uir", 5, 5, 2, 3.0, 96), ("uir", 0, 3, 1, 2.0, 96), ("uir", 0, 3, 1, 2.0, 96),
+         ("uir", 0, 3, 1, 2.0, 96), ("uir", 0, 3, 1, 2.0, 96), ("uir", 3, 0, 1, 4.0, 96)],
+        [("uir", 3, 3, 2, 6.0, 128), ("uir", 5, 5, 1, 4.0, 128), ("uir", 0, 5, 1, 4.0, 128),
+         ("uir", 0, 5, 1, 3.0, 128), ("uir", 0, 3, 1, 4.0, 128), ("uir", 0, 3, 1, 4.0, 128)],
+        [("cn", 1, 1, 960)],
+    ],
+    feature_stages=[0, 1, 2, 4],  # + the stem
+    mean=(0.485, 0.456, 0.406),
+    std=(0.229, 0.224, 0.225),
+)
+
+
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+def _bn_spec(s: Spec, b: str, c: int):
+    s[b + "weight"] = (c,)
+    s[b + "bias"] = (c,)
+    s[b + "running_mean"] = (c,)
+    s[b + "running_var"] = (c,)
+
+
+def mnv4_layers(arch: dict = MNV4_SMALL, in_chans: int = 4):
+    """Flatten the architecture into a list of primitive (conv+bn[+relu]) layers.
+
+    Returns (layers, taps): each layer is a dict(name, kind, cin, cout, k, stride,
+    groups, act, block_start, block_end/residual); taps = indices after which a
+    feature map is emitted."""
+    layers = []
+    taps = []
+    c = arch["stem"]
+    layers.append(dict(conv="conv_stem", bn="bn1", cin=in_chans, cout=c, k=3, s=2, g=1, act=True))
+    taps.append(len(layers) - 1)
+    for si, stage in enumerate(arch["stages"]):
+        for bi, blk in enumerate(stage):
+            b = f"blocks.{si}.{bi}."
+            if blk[0] == "cn":
+                _, k, st, co = blk
+                layers.append(dict(conv=b + "conv", bn=b + "bn1", cin=c, cout=co, k=k, s=st, g=1, act=True))
+                c = co
+            else:
+                _, k0, k1, st, e, co = blk
+                mid = make_divisible(c * e)
+                first = len(layers)
+                if k0:
+                    # start depthwise: strided only if there is no mid depthwise
+                    layers.append(dict(conv=b + "dw_start.conv", bn=b + "dw_start.bn", cin=c, cout=c, k=k0,
+                                       s=(1 if k1 else st), g=c, act=False))
+                layers.append(dict(conv=b + "pw_exp.conv", bn=b + "pw_exp.bn", cin=c, cout=mid, k=1, s=1, g=1, act=True))
+                if k1:
+                    layers.append(dict(conv=b + "dw_mid.conv", bn=b + "dw_mid.bn", cin=mid, cout=mid, k=k1, s=st, g=mid, act=True))
+                layers.append(dict(conv=b + "pw_proj.conv", bn=b + "pw_proj.bn", cin=mid, cout=co, k=1, s=1, g=1, act=False))
+                if st == 1 and c == co:
+                    layers[first]["res_begin"] = True
+                    layers[-1]["res_end"] = True
+                c = co
+        if si in arch["feature_stages"]:
+            taps.append(len(layers) - 1)
+    return layers, taps
+
+
+def mnv4_spec(prefix: str, arch: dict = MNV4_SMALL, in_chans: int = 4) -> Spec:
+    s: Spec = OrderedDict()
+    layers, _ = mnv4_layers(arch, in_chans)
+    for L in layers:
+        s[prefix + L["conv"] + ".weight"] = (L["cout"], L["cin"] // L["g"], L["k"], L["k"])
+        _bn_spec(s, prefix + L["bn"] + ".", L["cout"])
+    return s
+
+
+# ----------------------------------------------------------------------------
+# synthetic weights
+# ----------------------------------------------------------------------------
+def _rng(name: str, seed: int) -> np.random.Generator:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return np.random.Generator(np.random.PCG64(int.from_bytes(h[:8], "little")))
+
+
+def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tensor:
+    """Deterministic value for one named parameter (numpy PCG64 keyed by name).
+
+    Scaling keeps activations O(1) through the ~45-layer chain so that neither
+    the sigmoid depth head nor the clamp saturates."""
+    g = _rng(name, seed)
+    leaf = name.rsplit(".", 1)[-1]
+    n = int(np.prod(shape)) if len(shape) else 1
+    z = g.standard_normal(n).astype(np.float32).reshape(shape)
+    if leaf == "gamma":  # LayerScale
+        v = 1.0 + 0.05 * z
+    elif leaf == "running_var":
+        v = 1.0 + 0.1 * np.abs(z)
+    elif leaf == "running_mean":
+        v = 0.1 * z
+    elif leaf in ("cls_token", "pos_embed"):
+        v = 0.02 * z
+    elif leaf == "mask_token":
+        v = 0.0 * z
+    elif leaf == "bias":
+        v = (0.1 if len(shape) == 1 and _is_norm(name) else 0.02) * z
+    elif len(shape) == 1:  # norm weight
+        v = 1.0 + 0.1 * z
+    else:
+        if "resize_layers.0." in name or "resize_layers.1." in name or "upsample_convx" in name:
+            fan_in = shape[0]  # ConvTranspose2d [in, out, k, k], k == stride
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        if name.endswith("final_conv.weight"):
+            gain = 0.5  # offset head: O(1) metres on top of the coarse depth
+        elif "output_conv2.2." in name:
+            gain = 1.5  # pre-sigmoid logits O(1): the depth head must not saturate
+        elif re.search(r"resConfUnit\d\.conv2\.|GateresConfUnit\d\.conv\.", name):
+            gain = 0.4  # residual branches: keep the pyramid's scale flat across levels
+        else:
+            gain = 1.0
+        v = z * (gain / np.sqrt(max(fan_in, 1)))
+    return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+
+
+def _is_norm(name: str) -> bool:
+    return any(t in name for t in (".norm", "norm1", "norm2", "single_conv.1", "fusion_conv.1", ".bn"))
+
+
+def synth_state_dict(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return OrderedDict((k, synth_tensor(k, tuple(shp), seed)) for k, shp in spec.items())
