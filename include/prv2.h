@@ -1,0 +1,169 @@
+/*
+ * prv2.h -- C ABI of the MI355X (gfx950) hot path of patch-refined depth inference.
+ *
+ * The reference (zhyever/PatchRefinerV2) is pure Python/PyTorch: it has no FFI.  The seam this
+ * library sits behind is therefore the set of torch ops the reference's hot path dispatches
+ * (SURVEY.md 2.1 / 8b).  Each entry point below names the reference call site(s) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless the name ends in _host or the type says otherwise;
+ *   - activations are NHWC: element (n,y,x,c) lives at base[n*bstride + (y*W + x)*ld + c];
+ *     ``ld`` (pixel stride, in floats) lets a producer write straight into a channel slice of
+ *     a wider concatenation buffer, which is how every torch.cat on the path is made free;
+ *   - ``stream`` is a hipStream_t passed as void*; all work is enqueued, nothing synchronises;
+ *   - return value: 0 on success, non-zero on a rejected argument or a HIP error;
+ *     prv2_last_error() returns the message of the calling thread's last failure;
+ *   - no allocation, no hidden global state, graph-capture safe.
+ */
+#ifndef PRV2_H
+#define PRV2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRV2_ABI_VERSION 1
+
+enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3 };
+
+/* arithmetic of the matrix kernels */
+enum prv2_prec {
+  PRV2_PREC_F32 = 0,    /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate            */
+  PRV2_PREC_BF16X3 = 1, /* operands split hi+lo bf16; hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 */
+  PRV2_PREC_BF16 = 2    /* plain bf16 operands (fast, ~1e-3 relative; not the parity path)          */
+};
+
+int prv2_abi_version(void);
+const char* prv2_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer with fused epilogue.
+ * Replaces nn.Conv2d / nn.Linear / nn.ConvTranspose2d(k==stride) on the path:
+ *   fusion convs     estimator/models/blocks/convs.py:39-41,70; bi_directional_fusion_model.py:40-51
+ *   DPT head convs   external/depth_anything_v2/dpt.py:51-81, util/blocks.py:45-47
+ *   ViT linears      external/depth_anything_v2/dinov2_layers/attention.py:44,46; mlp.py:30,32
+ *
+ *   y[m, n] = epilogue( sum_{ky,kx,c} pre(x[pix(m) + (ky,kx), c]) * w[n, ky, kx, c] )
+ *   epilogue: v = acc + bias[n]; v = act(v); v *= gamma[n]; v = mul[m,n] * v; v += res[m,n] + res2[m,n]
+ *   (every pointer optional).  pre = ReLU when relu_in != 0.  Zero padding.
+ *
+ * Weights are pre-packed by prv2_pack_conv_weight(): [cout_pad][kh*kw][cin_pad] with
+ * cin_pad = roundup(cin, 32), cout_pad = roundup(cout, 128), zero filled.
+ * convt_k > 0 turns the call into ConvTranspose2d(kernel=stride=convt_k): kh=kw=1, the GEMM has
+ * convt_k^2 * cout columns ordered (ky, kx, co) and each column block is scattered to
+ * output pixel (y*k+ky, x*k+kx).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct prv2_conv_desc {
+  int32_t n, h, w;       /* input batch / spatial size                                   */
+  int32_t cin, cout;
+  int32_t kh, kw, stride, pad;
+  int32_t ldx, ldy;      /* pixel strides (floats)                                       */
+  int64_t x_bstride;     /* image stride of x in floats (0 => h*w*ldx)                   */
+  int64_t y_bstride;     /* image stride of y in floats (0 => oh*ow*ldy)                 */
+  int32_t relu_in;       /* apply ReLU to x while loading                                */
+  int32_t act;           /* enum prv2_act                                                */
+  int32_t convt_k;       /* 0, or k for ConvTranspose2d(k, stride=k)                     */
+  int32_t ld_mul, ld_res, ld_res2;
+  int32_t prec;          /* enum prv2_prec                                               */
+  int32_t reserved;
+} prv2_conv_desc;
+
+/* host-side helpers: sizes of the packed weight buffers (in bytes) */
+int64_t prv2_packed_weight_bytes(int32_t cout, int32_t cin, int32_t kh, int32_t kw, int32_t convt_k, int32_t prec);
+
+/* w_src: device fp32, PyTorch layout [cout][cin][kh][kw] (Conv2d / Linear with kh=kw=1) or
+ * [cin][cout][k][k] when convt_k>0 (ConvTranspose2d).  bn_scale (optional, [cout]) is folded in. */
+int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, void* w_packed, int32_t cout, int32_t cin,
+                          int32_t kh, int32_t kw, int32_t convt_k, int32_t prec, void* stream);
+
+int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
+                const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream);
+
+/* Convolution with ONE output channel (direct, HBM-bound):
+ *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118
+ *   output_conv2.2 1x1 32->1 + Sigmoid * max_depth          external/depth_anything_v2/dpt.py:111-113,190
+ *   output_conv3 1x1 32->1                                   bi_directional_fusion_model.py:178-179
+ * w: device fp32 PyTorch layout [1][cin][k][k].  y = post( act(conv + bias) * scale + res ), post = max(.,0) if clamp0.
+ * y / res are dense [n, h, w] (ld 1). */
+int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx, const float* wgt,
+                      int32_t k, const float* bias, int32_t act, float scale, const float* res, int32_t clamp0,
+                      float* y, void* stream);
+
+/* Depthwise kxk convolution (+folded BatchNorm bias, optional ReLU) for the MobileNetV4 refiner
+ * encoder (timm, un-vendored; lightweight_refiner.py:260-262,296).  w: device [c][k][k] with the
+ * BN scale already folded; bias [c]. */
+int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
+                  const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row LayerNorm (+activation).  Rows of ``c`` contiguous floats with strides ldx / ldy.
+ * Replaces nn.LayerNorm(eps=1e-6) on tokens (dinov2.py:95, block.py:56,68) and -- because the
+ * activations are NHWC -- the channels-first LayerNorm of the fusion convs (convs.py:21-29)
+ * including the GELU / ReLU that follows it (convs.py:70-72, bi_directional_fusion_model.py:49-50).
+ * ------------------------------------------------------------------------------------------ */
+int prv2_layernorm(const float* x, int64_t rows, int32_t c, int32_t ldx, const float* weight, const float* bias,
+                   float eps, int32_t act, float* y, int32_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ViT token plumbing (external/depth_anything_v2/dinov2.py:212-231, patch_embed.py:69-82)
+ * ------------------------------------------------------------------------------------------ */
+/* img NHWC [b, gh*p, gw*p, 3] (ld 3..) -> rows [b*gh*gw, ldo] with (ky, kx, c) column order, zero padded to ldo */
+int prv2_patchify(const float* img, int32_t b, int32_t gh, int32_t gw, int32_t p, int32_t ldi, float* rows,
+                  int32_t ldo, void* stream);
+/* tokens[b, 0] = cls + pos[0]; tokens[b, 1+i] = emb[b, i] + pos[1+i] */
+int prv2_assemble_tokens(const float* emb, const float* cls, const float* pos, int32_t b, int32_t np, int32_t dim,
+                         float* tokens, void* stream);
+/* softmax((q*scale) k^T) v per (batch, head); qkv rows are [3][heads][hd] as produced by the qkv
+ * Linear (attention.py:49-62).  hd must be 64.  out rows are [heads][hd]. */
+int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out, int32_t prec,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gathers
+ * ------------------------------------------------------------------------------------------ */
+/* Crop + bilinear(align_corners=True) resize of K tiles of a CHW image into NHWC patches, with the
+ * (v - mean[c]) / std[c] input normalisation fused.
+ *   baseline_pretrain.py:169-170,274-275 -> external/depth_anything/transform.py:127-129 (ResizeDA)
+ *   or external/zoedepth/models/base_models/midas.py:171-174 (ResizeZoe); dpt.py:183; lightweight_refiner.py:293.
+ * tiles: device int32 [k][2] = (h_start, w_start); crop size ch x cw; output [k, oh, ow, ldo] channels 0..2. */
+int prv2_crop_resize(const float* img_chw, int32_t img_h, int32_t img_w, const int32_t* tiles, int32_t k, int32_t ch,
+                     int32_t cw, int32_t oh, int32_t ow, const float* mean3_host, const float* std3_host, float* out,
+                     int32_t ldo, void* stream);
+
+/* torchvision.ops.roi_align(feat.repeat(K), boxes, (oh, ow), spatial_scale, sampling_ratio=-1, aligned=True)
+ * without materialising the K copies (patchrefinerplus.py:263-276, patchrefiner.py:199-210).
+ * feat NHWC [1, h, w, c]; boxes device fp32 [k][4] = (x1, y1, x2, y2) in lr-frame pixels. */
+int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes, int32_t k,
+                   float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=True) on NHWC (every decoder upsample; Appendix C row 1) */
+int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t oh,
+                           int32_t ow, float* y, int32_t ldy, void* stream);
+
+/* NCHW <-> NHWC layout changes at the boundary (image_lr in, coarse_prediction out) */
+int prv2_nchw_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, float* y, int32_t ldy, void* stream);
+int prv2_nhwc_to_nchw(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ldx, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Overlap blend = RunningAverageMap kept on the device (estimator/models/utils.py:22-49,
+ * paste/update loops baseline_pretrain.py:212-229, 347-373).
+ * avg / cnt: dense [H, W] maps.  pred: [k, ph, pw] patch predictions.  mask: [th, tw] blend weights.
+ * tiles: device int32 [k][2] = (h_start, w_start) in map coordinates; tile size th x tw.
+ * When (ph, pw) != (th, tw) the prediction is upsampled with legacy 'nearest' (baseline_pretrain.py:210).
+ * Tiles are applied in order k = 0..K-1 (the running mean is order dependent).
+ * ------------------------------------------------------------------------------------------ */
+int prv2_blend_paste(float* avg, float* cnt, int32_t map_h, int32_t map_w, const float* pred, int32_t ph, int32_t pw,
+                     const float* mask, const int32_t* tiles, int32_t k, int32_t th, int32_t tw, void* stream);
+int prv2_blend_update(float* avg, float* cnt, int32_t map_h, int32_t map_w, const float* pred, int32_t ph,
+                      int32_t pw, const float* mask, const int32_t* tiles, int32_t k, int32_t th, int32_t tw,
+                      void* stream);
+/* RunningAverageMap.resize: avg -> nearest, cnt -> bilinear(align_corners=True) (utils.py:38-43) */
+int prv2_blend_resize(const float* avg, const float* cnt, int32_t h, int32_t w, float* avg_out, float* cnt_out,
+                      int32_t oh, int32_t ow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRV2_H */

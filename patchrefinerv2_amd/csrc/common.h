@@ -1,0 +1,73 @@
+// Shared helpers for the gfx950 kernels (internal; the public surface is include/prv2.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/prv2.h"
+
+namespace prv2 {
+
+void set_error(const char* fmt, ...);
+
+#define PRV2_REQUIRE(cond, ...)       \
+  do {                                \
+    if (!(cond)) {                    \
+      prv2::set_error(__VA_ARGS__);   \
+      return 1;                       \
+    }                                 \
+  } while (0)
+
+#define PRV2_LAUNCH_CHECK(name)                                                      \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      prv2::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return 2;                                                                      \
+    }                                                                                \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t roundup(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// memory-bound grids: cap at 256 CUs x 8 blocks and grid-stride the rest
+static inline int flat_grid(int64_t work_items, int block) {
+  int64_t g = cdiv(work_items, block);
+  if (g > 2048 * 4) g = 2048 * 4;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case PRV2_ACT_RELU: return v > 0.f ? v : 0.f;
+    case PRV2_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact-erf GELU (mlp.py:31)
+    case PRV2_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+// bilinear / align_corners=True source coordinate (float32, PyTorch's area_pixel_compute_scale)
+struct AxisTap {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ __forceinline__ AxisTap ac_tap(int dst, float scale, int n_in) {
+  float src = scale * (float)dst;
+  int i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  int i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  float w1 = src - (float)i0;
+  AxisTap t = {i0, i1, 1.0f - w1, w1};
+  return t;
+}
+static inline float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f; }
+
+// legacy 'nearest': min(floor(dst * float(in/out)), in-1)
+__device__ __forceinline__ int nearest_src(int dst, float scale, int n_in) {
+  int s = (int)floorf((float)dst * scale);
+  return s < n_in - 1 ? s : n_in - 1;
+}
+
+}  // namespace prv2

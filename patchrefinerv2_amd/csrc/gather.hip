@@ -1,0 +1,263 @@
+// HBM-bound gather kernels: crop+resize, ROI pyramid gather, bilinear upsample, layout changes.
+// One work item = one output pixel x one 16-byte channel group; consecutive lanes walk the
+// channel dimension first (NHWC), so every load/store instruction covers whole 64-1024 B runs.
+#include "common.h"
+
+namespace prv2 {
+
+// ---------------------------------------------------------------------------------------------
+// crop + bilinear(align_corners) resize, CHW image -> NHWC patches, (v-mean)/std fused
+// ---------------------------------------------------------------------------------------------
+struct Norm3 {
+  float mean[3];
+  float std[3];
+};
+
+__global__ void __launch_bounds__(256) crop_resize_kernel(const float* __restrict__ img, int H, int W,
+                                                          const int* __restrict__ tiles, int K, int ch, int cw, int oh,
+                                                          int ow, float sy, float sx, Norm3 nrm, float* __restrict__ out,
+                                                          int ldo) {
+  int64_t total = (int64_t)K * oh * ow;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int ox = (int)(idx % ow);
+    int oy = (int)((idx / ow) % oh);
+    int k = (int)(idx / ((int64_t)ow * oh));
+    int h0 = tiles[2 * k], w0 = tiles[2 * k + 1];
+    AxisTap ty = ac_tap(oy, sy, ch), tx = ac_tap(ox, sx, cw);
+    const float* base = img + (int64_t)(h0)*W + w0;
+    float* o = out + idx * ldo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* p = base + (int64_t)c * H * W;
+      float v00 = p[(int64_t)ty.i0 * W + tx.i0], v01 = p[(int64_t)ty.i0 * W + tx.i1];
+      float v10 = p[(int64_t)ty.i1 * W + tx.i0], v11 = p[(int64_t)ty.i1 * W + tx.i1];
+      float v = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
+      o[c] = (v - nrm.mean[c]) / nrm.std[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// roi_align(aligned=True, sampling_ratio=-1) from ONE feature map to K outputs (no repeat(K))
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+  using type = float4;
+};
+template <>
+struct VecT<1> {
+  using type = float;
+};
+
+__device__ __forceinline__ void vfma(float4& a, float w, const float4& v) {
+  a.x += w * v.x;
+  a.y += w * v.y;
+  a.z += w * v.z;
+  a.w += w * v.w;
+}
+__device__ __forceinline__ void vfma(float& a, float w, const float& v) { a += w * v; }
+__device__ __forceinline__ float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vscale(float4& a, float s) {
+  a.x *= s;
+  a.y *= s;
+  a.z *= s;
+  a.w *= s;
+}
+__device__ __forceinline__ void vscale(float& a, float s) { a *= s; }
+__device__ __forceinline__ void vdiv(float4& a, float s) {
+  a.x /= s;
+  a.y /= s;
+  a.z /= s;
+  a.w /= s;
+}
+__device__ __forceinline__ void vdiv(float& a, float s) { a /= s; }
+
+template <int VEC>
+__global__ void __launch_bounds__(256) roi_align_kernel(const float* __restrict__ feat, int H, int W, int C, int ldf,
+                                                        const float* __restrict__ boxes, int K, float scale, int oh,
+                                                        int ow, float* __restrict__ out, int ldo) {
+  using V = typename VecT<VEC>::type;
+  const int cg = C / VEC;
+  int64_t total = (int64_t)K * oh * ow * cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cg) * VEC;
+    int64_t pix = idx / cg;
+    int px = (int)(pix % ow);
+    int py = (int)((pix / ow) % oh);
+    int k = (int)(pix / ((int64_t)ow * oh));
+    const float* b = boxes + 4 * k;
+    // torchvision roi_align_forward_kernel_impl, aligned=True
+    float rsw = b[0] * scale - 0.5f, rsh = b[1] * scale - 0.5f;
+    float rew = b[2] * scale - 0.5f, reh = b[3] * scale - 0.5f;
+    float roi_w = rew - rsw, roi_h = reh - rsh;
+    float bin_h = roi_h / (float)oh, bin_w = roi_w / (float)ow;
+    int gh = (int)ceilf(roi_h / (float)oh), gw = (int)ceilf(roi_w / (float)ow);
+    float count = (float)max(gh * gw, 1);
+    V acc;
+    if constexpr (VEC == 4) acc = vzero4(); else acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = rsh + (float)py * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = rsw + (float)px * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+        if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+        float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+        int yl = (int)yy, xl = (int)xx, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+        if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+        float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+        float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const V v1 = *reinterpret_cast<const V*>(feat + ((int64_t)yl * W + xl) * ldf + c);
+        const V v2 = *reinterpret_cast<const V*>(feat + ((int64_t)yl * W + xh) * ldf + c);
+        const V v3 = *reinterpret_cast<const V*>(feat + ((int64_t)yh * W + xl) * ldf + c);
+        const V v4 = *reinterpret_cast<const V*>(feat + ((int64_t)yh * W + xh) * ldf + c);
+        // val = w1*v1 + w2*v2 + w3*v3 + w4*v4 (left to right), then output_val += val
+        V val;
+        if constexpr (VEC == 4) val = vzero4(); else val = 0.f;
+        vfma(val, w1, v1);
+        vfma(val, w2, v2);
+        vfma(val, w3, v3);
+        vfma(val, w4, v4);
+        vfma(acc, 1.0f, val);
+      }
+    }
+    vdiv(acc, count);
+    *reinterpret_cast<V*>(out + pix * ldo + c) = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear align_corners=True upsample, NHWC
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) upsample_bilinear_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                                int ldx, int oh, int ow, float sy, float sx,
+                                                                float* __restrict__ y, int ldy) {
+  using V = typename VecT<VEC>::type;
+  const int cg = C / VEC;
+  int64_t total = (int64_t)N * oh * ow * cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cg) * VEC;
+    int64_t pix = idx / cg;
+    int ox = (int)(pix % ow);
+    int oy = (int)((pix / ow) % oh);
+    int n = (int)(pix / ((int64_t)ow * oh));
+    AxisTap ty = ac_tap(oy, sy, H), tx = ac_tap(ox, sx, W);
+    const float* p = x + (int64_t)n * H * W * ldx + c;
+    const V v00 = *reinterpret_cast<const V*>(p + ((int64_t)ty.i0 * W + tx.i0) * ldx);
+    const V v01 = *reinterpret_cast<const V*>(p + ((int64_t)ty.i0 * W + tx.i1) * ldx);
+    const V v10 = *reinterpret_cast<const V*>(p + ((int64_t)ty.i1 * W + tx.i0) * ldx);
+    const V v11 = *reinterpret_cast<const V*>(p + ((int64_t)ty.i1 * W + tx.i1) * ldx);
+    V top, bot, r;
+    if constexpr (VEC == 4) { top = vzero4(); bot = vzero4(); r = vzero4(); } else { top = 0.f; bot = 0.f; r = 0.f; }
+    vfma(top, tx.w0, v00);
+    vfma(top, tx.w1, v01);
+    vfma(bot, tx.w0, v10);
+    vfma(bot, tx.w1, v11);
+    vfma(r, ty.w0, top);
+    vfma(r, ty.w1, bot);
+    *reinterpret_cast<V*>(y + pix * ldy + c) = r;
+  }
+}
+
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W,
+                                                           float* __restrict__ y, int ldy) {
+  int64_t total = (int64_t)N * H * W * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % C);
+    int64_t pix = idx / C;
+    int64_t hw = pix % ((int64_t)H * W);
+    int n = (int)(pix / ((int64_t)H * W));
+    y[pix * ldy + c] = x[((int64_t)n * C + c) * H * W + hw];
+  }
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ x, int N, int C, int H, int W,
+                                                           int ldx, float* __restrict__ y) {
+  int64_t total = (int64_t)N * H * W * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t hw = idx % ((int64_t)H * W);
+    int c = (int)((idx / ((int64_t)H * W)) % C);
+    int n = (int)(idx / ((int64_t)H * W * C));
+    y[idx] = x[((int64_t)n * H * W + hw) * ldx + c];
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace prv2
+
+using namespace prv2;
+
+extern "C" int prv2_crop_resize(const float* img, int32_t H, int32_t W, const int32_t* tiles, int32_t K, int32_t ch,
+                                int32_t cw, int32_t oh, int32_t ow, const float* mean3, const float* std3, float* out,
+                                int32_t ldo, void* stream) {
+  PRV2_REQUIRE(img && tiles && out, "crop_resize: null pointer");
+  PRV2_REQUIRE(K > 0 && ch > 0 && cw > 0 && oh > 0 && ow > 0 && ch <= H && cw <= W && ldo >= 3,
+               "crop_resize: bad geometry K=%d crop=%dx%d out=%dx%d img=%dx%d ldo=%d", K, ch, cw, oh, ow, H, W, ldo);
+  Norm3 n;
+  for (int i = 0; i < 3; ++i) {
+    n.mean[i] = mean3 ? mean3[i] : 0.f;
+    n.std[i] = std3 ? std3[i] : 1.f;
+  }
+  int64_t total = (int64_t)K * oh * ow;
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, img, H, W, tiles,
+                     K, ch, cw, oh, ow, ac_scale(ch, oh), ac_scale(cw, ow), n, out, ldo);
+  PRV2_LAUNCH_CHECK("crop_resize");
+  return 0;
+}
+
+extern "C" int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes,
+                              int32_t k, float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo,
+                              void* stream) {
+  PRV2_REQUIRE(feat && boxes && out, "roi_align: null pointer");
+  PRV2_REQUIRE(h > 0 && w > 0 && c > 0 && k > 0 && oh > 0 && ow > 0 && ldf >= c && ldo >= c, "roi_align: bad geometry");
+  bool vec = (c % 4 == 0) && (ldf % 4 == 0) && (ldo % 4 == 0) && aligned16(feat) && aligned16(out);
+  int64_t total = (int64_t)k * oh * ow * (vec ? c / 4 : c);
+  if (vec)
+    hipLaunchKernelGGL(roi_align_kernel<4>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, h, w,
+                       c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo);
+  else
+    hipLaunchKernelGGL(roi_align_kernel<1>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, h, w,
+                       c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo);
+  PRV2_LAUNCH_CHECK("roi_align");
+  return 0;
+}
+
+extern "C" int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx,
+                                      int32_t oh, int32_t ow, float* y, int32_t ldy, void* stream) {
+  PRV2_REQUIRE(x && y, "upsample_bilinear: null pointer");
+  PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0 && ldx >= c && ldy >= c,
+               "upsample_bilinear: bad geometry");
+  bool vec = (c % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y);
+  int64_t total = (int64_t)n * oh * ow * (vec ? c / 4 : c);
+  if (vec)
+    hipLaunchKernelGGL(upsample_bilinear_kernel<4>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       h, w, c, ldx, oh, ow, ac_scale(h, oh), ac_scale(w, ow), y, ldy);
+  else
+    hipLaunchKernelGGL(upsample_bilinear_kernel<1>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       h, w, c, ldx, oh, ow, ac_scale(h, oh), ac_scale(w, ow), y, ldy);
+  PRV2_LAUNCH_CHECK("upsample_bilinear");
+  return 0;
+}
+
+extern "C" int prv2_nchw_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, float* y, int32_t ldy,
+                                 void* stream) {
+  PRV2_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && ldy >= c, "nchw_to_nhwc: bad arguments");
+  int64_t total = (int64_t)n * c * h * w;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, c, h, w, y,
+                     ldy);
+  PRV2_LAUNCH_CHECK("nchw_to_nhwc");
+  return 0;
+}
+
+extern "C" int prv2_nhwc_to_nchw(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ldx, float* y,
+                                 void* stream) {
+  PRV2_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && ldx >= c, "nhwc_to_nchw: bad arguments");
+  int64_t total = (int64_t)n * c * h * w;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, c, h, w,
+                     ldx, y);
+  PRV2_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}

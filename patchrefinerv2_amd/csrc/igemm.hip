@@ -1,0 +1,401 @@
+// Implicit-GEMM convolution / linear for gfx950 (MI355X), NHWC activations, fused epilogue.
+//
+//   C[m, n] = sum_{tap, c} A[pix(m) + tap, c] * W[n, tap, c]        m = output pixel, n = out channel
+//
+// Tile: 128 pixels x BN channels x 32 input channels per step, 256 threads = 4 waves (2x2),
+// each wave owns 64 x BN/2 as 32x32 MFMA accumulators.  Operands are staged
+// global -> registers -> LDS (the register hop applies the zero padding, the fused input ReLU
+// and, for the split-bf16 mode, the hi/lo split), double buffered: the global loads of step
+// s+1 are issued before the MFMAs of step s and written to the other LDS buffer after them,
+// one barrier per step.
+//
+// LDS rows are 32 floats padded to 36: the MFMA fragment reads are ds_read_b128 at
+// [row][8*ks + 4*half] -- with a 144-byte row stride the 16 lanes of every ds_read_b128 lane
+// group land on 16 distinct 16-byte bank slots (rows distinct mod 16), i.e. conflict free;
+// the staging ds_write_b128 of 8 consecutive lanes covers one contiguous 128-byte row.
+//
+// PRV2_PREC_F32   : v_mfma_f32_32x32x2_f32 -- exact fp32 products (k-ordered fmaf chain), the
+//                   parity path.  One float4 per operand feeds 4 MFMAs: lane half h takes
+//                   channels 8ks+4h..+3 so the k index of MFMA e is channel 8ks+4h+e on both
+//                   operands (the k order inside a step is free as long as A and B agree).
+// PRV2_PREC_BF16X3: fp32 operands split into bf16 hi + bf16 lo while staging; three
+//                   v_mfma_f32_32x32x16_bf16 per k-step (hi*hi, hi*lo, lo*hi), fp32 accumulate.
+//                   ~2^-17 relative per product, 5.3x the fp32-MFMA rate.
+//
+// Workgroup -> tile mapping is XCD aware: the 8 XCDs each get a contiguous run of tiles, and
+// within a run the BN-tiles of one pixel tile are adjacent, so the A tile and its 3x3 halo
+// re-reads stay inside one XCD's L2.
+#include "common.h"
+
+namespace prv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct IgemmParams {
+  const float* x;
+  const void* w;
+  const float* bias;
+  const float* gamma;
+  const float* mul;
+  const float* res;
+  const float* res2;
+  float* y;
+  int N, H, W, OH, OW;
+  int Cin, Cin_pad, Cout, Ncols;  // Ncols = GEMM columns (= Cout, or k*k*Cout for convT)
+  int KH, KW, stride, pad;
+  int ldx, ldy, ld_mul, ld_res, ld_res2;
+  long long x_bstride, y_bstride;
+  long long M;
+  int relu_in, act, convt_k, vec_ok, vec_epi;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad)
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  v.x = fmaxf(v.x, 0.f);
+  v.y = fmaxf(v.y, 0.f);
+  v.z = fmaxf(v.z, 0.f);
+  v.w = fmaxf(v.w, 0.f);
+  return v;
+}
+
+// round-to-nearest-even fp32 -> bf16 (finite inputs), returned as the high 16 bits
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_bf16(float f, unsigned& hi, unsigned& lo) {
+  hi = bf16_rne(f);
+  float r = f - __uint_as_float(hi << 16);
+  lo = bf16_rne(r);
+}
+
+template <int BN, int PREC>
+__global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
+  constexpr int NJ = BN / 64;  // 32-wide column sub-tiles per wave
+  constexpr int NB = BN / 32;  // B rows loaded per thread per step (float4 each)
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+  constexpr int STAGE = (BM + BN) * LDS_LD;  // A rows then B rows
+
+  // ---- XCD-aware, bijective block -> tile map -------------------------------------------
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n;
+  const int tile_m = bid / p.tiles_n;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  // ---- per-thread A rows (pixels) ---------------------------------------------------------
+  const int chunk = tid & 7;   // which float4 of the 32-channel slab
+  const int row0 = tid >> 3;   // 0..31, rows row0 + 32*i
+  const long long ohw = (long long)p.OH * p.OW;
+  const float* a_ptr[4];  // &x[n, iy0, ix0, chunk*4]; may point outside the image -- only dereferenced when in range
+  int a_iy0[4], a_ix0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long m = (long long)tile_m * BM + row0 + 32 * i;
+    if (m < p.M) {
+      int n = (int)(m / ohw);
+      int rem = (int)(m - (long long)n * ohw);
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad;
+      a_ptr[i] = p.x + (long long)n * p.x_bstride + ((long long)a_iy0[i] * p.W + a_ix0[i]) * p.ldx + chunk * 4;
+    } else {
+      a_iy0[i] = -(1 << 28);  // never in range
+      a_ix0[i] = 0;
+      a_ptr[i] = p.x;
+    }
+  }
+  const long long w_row_stride = (long long)p.KH * p.KW * p.Cin_pad;
+  const float* wbase = reinterpret_cast<const float*>(p.w) + ((long long)tile_n * BN + row0) * w_row_stride + chunk * 4;
+
+  const int cchunks = p.Cin_pad / BK;
+  const int nsteps = p.KH * p.KW * cchunks;
+  const int cin4 = (p.Cin + 3) & ~3;  // channels [Cin, cin4) are read (finite, host guaranteed) and hit zero weights
+
+  f32x4 ra[4], rb[NB];
+
+  auto load_step = [&](int s) {
+    const int tap = s / cchunks;
+    const int cb = (s - tap * cchunks) * BK;  // channel base of this step (wave uniform)
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int tap_off = (ky * p.W + kx) * p.ldx + cb;
+    const bool c_ok = cb + chunk * 4 < cin4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + tap_off);
+      if (p.relu_in) v = relu4(v);
+      ra[i] = v;
+    }
+    const float* wsrc = wbase + (long long)tap * p.Cin_pad + cb;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wsrc + (long long)(32 * i) * w_row_stride);
+  };
+
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (row0 + 32 * i) * LDS_LD + chunk * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (BM + row0 + 32 * i) * LDS_LD + chunk * 4]) = rb[i];
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  auto compute_step = [&](int buf) {
+    const float* Ab = smem + buf * STAGE + (wm * 64 + r32) * LDS_LD + half * 4;
+    const float* Bb = smem + buf * STAGE + (BM + wn * (BN / 2) + r32) * LDS_LD + half * 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 a[2], b[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + ks * 8);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + ks * 8);
+      if constexpr (PREC == PRV2_PREC_F32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  for (int s = 0; s + 1 < nsteps; ++s) {
+    const int buf = s & 1;
+    load_step(s + 1);      // global -> registers, in flight under the MFMAs below
+    compute_step(buf);
+    store_step(buf ^ 1);   // registers -> the other LDS buffer
+    __syncthreads();
+  }
+  compute_step((nsteps - 1) & 1);
+
+  // ---- epilogue: accumulators -> LDS tile -> 16-byte row-wise stores ------------------------
+  // acc[i][j][reg]: row = (reg&3) + 8*(reg>>2) + 4*half, col = r32 (cdna_hip_programming.md section 3).
+  // Going through LDS turns the 2-rows-x-128-B store shape of the accumulator layout into whole
+  // 512-byte output rows and lets bias / residual / gate operands be read as float4.
+  constexpr int CLD = BN + 4;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        smem[row * CLD + wn * (BN / 2) + j * 32 + r32] = acc[i][j][reg];
+      }
+  __syncthreads();
+
+  constexpr int C4 = BN / 4;          // float4 per tile row
+  constexpr int RPP = 256 / C4;       // rows per pass
+  const int col4 = tid % C4;
+  const int ncol = tile_n * BN + col4 * 4;
+  if (ncol >= p.Ncols) return;
+  const int kk = p.convt_k > 0 ? p.convt_k : 1;
+  int co = ncol, sub_y = 0, sub_x = 0;
+  if (p.convt_k > 0) {
+    int t = ncol / p.Cout;
+    co = ncol - t * p.Cout;
+    sub_y = t / kk;
+    sub_x = t - sub_y * kk;
+  }
+  const int nvalid = min(4, (p.convt_k > 0 ? p.Cout - co : p.Ncols - ncol));
+  const bool vec = p.vec_epi && nvalid == 4;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < nvalid && p.bias) bias[e] = p.bias[co + e];
+    if (e < nvalid && p.gamma) gam[e] = p.gamma[co + e];
+  }
+  for (int rr = tid / C4; rr < BM; rr += RPP) {
+    const long long m = (long long)tile_m * BM + rr;
+    if (m >= p.M) break;
+    const float4 cv = *reinterpret_cast<const float4*>(&smem[rr * CLD + col4 * 4]);
+    float v[4] = {cv.x, cv.y, cv.z, cv.w};
+    const int n_img = (int)(m / ohw);
+    const int rem = (int)(m - (long long)n_img * ohw);
+    long long o;
+    if (p.convt_k > 0) {
+      const int iy = rem / p.OW, ix = rem - iy * p.OW;
+      o = (long long)n_img * p.y_bstride + ((long long)(iy * kk + sub_y) * (p.OW * kk) + ix * kk + sub_x) * p.ldy + co;
+    } else {
+      o = (long long)n_img * p.y_bstride + (long long)rem * p.ldy + co;
+    }
+    float mulv[4] = {1.f, 1.f, 1.f, 1.f}, resv[4] = {0.f, 0.f, 0.f, 0.f}, res2v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + m * p.ld_mul + co); mulv[0] = t.x; mulv[1] = t.y; mulv[2] = t.z; mulv[3] = t.w; }
+      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + m * p.ld_res + co); resv[0] = t.x; resv[1] = t.y; resv[2] = t.z; resv[3] = t.w; }
+      if (p.res2) { float4 t = *reinterpret_cast<const float4*>(p.res2 + m * p.ld_res2 + co); res2v[0] = t.x; res2v[1] = t.y; res2v[2] = t.z; res2v[3] = t.w; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (e < nvalid && p.mul) mulv[e] = p.mul[m * p.ld_mul + co + e];
+        if (e < nvalid && p.res) resv[e] = p.res[m * p.ld_res + co + e];
+        if (e < nvalid && p.res2) res2v[e] = p.res2[m * p.ld_res2 + co + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = act_apply(v[e] + bias[e], p.act);
+      if (p.gamma) t *= gam[e];
+      if (p.mul) t = mulv[e] * t;
+      if (p.res) t += resv[e];
+      if (p.res2) t += res2v[e];
+      v[e] = t;
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nvalid) p.y[o + e] = v[e];
+    }
+  }
+}
+
+// ---- weight packing: [cout][cin][kh][kw] (or ConvT [cin][cout][k][k]) -> [cout_pad][taps][cin_pad] ----
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                          float* __restrict__ dst, int Cout, int Cin, int KH, int KW,
+                                                          int convt_k, int rows, int rows_pad, int cin_pad) {
+  const int taps = convt_k > 0 ? 1 : KH * KW;
+  long long total = (long long)rows_pad * taps * cin_pad;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cin_pad);
+    int t = (int)((idx / cin_pad) % taps);
+    int r = (int)(idx / ((long long)cin_pad * taps));
+    float v = 0.f;
+    if (r < rows && c < Cin) {
+      if (convt_k > 0) {
+        int sub = r / Cout, co = r - sub * Cout;  // row = (ky*k + kx)*Cout + co
+        v = src[((long long)c * Cout + co) * convt_k * convt_k + sub];
+        if (scale) v *= scale[co];
+      } else {
+        v = src[((long long)r * Cin + c) * taps + t];
+        if (scale) v *= scale[r];
+      }
+    }
+    dst[idx] = v;
+  }
+}
+
+static inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace prv2
+
+using namespace prv2;
+
+static inline int gemm_rows(int cout, int convt_k) { return convt_k > 0 ? convt_k * convt_k * cout : cout; }
+
+extern "C" int64_t prv2_packed_weight_bytes(int32_t cout, int32_t cin, int32_t kh, int32_t kw, int32_t convt_k,
+                                            int32_t prec) {
+  (void)prec;
+  int64_t taps = convt_k > 0 ? 1 : (int64_t)kh * kw;
+  return roundup(gemm_rows(cout, convt_k), 128) * taps * roundup(cin, BK) * 4;
+}
+
+extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, void* w_packed, int32_t cout, int32_t cin,
+                                     int32_t kh, int32_t kw, int32_t convt_k, int32_t prec, void* stream) {
+  (void)prec;
+  PRV2_REQUIRE(w_src && w_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_conv_weight: bad arguments");
+  PRV2_REQUIRE(convt_k == 0 || (kh == convt_k && kw == convt_k), "pack_conv_weight: convt needs kh == kw == k");
+  int rows = gemm_rows(cout, convt_k), rows_pad = (int)roundup(rows, 128), cin_pad = (int)roundup(cin, BK);
+  int64_t total = (int64_t)rows_pad * (convt_k > 0 ? 1 : kh * kw) * cin_pad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w_src, bn_scale,
+                     (float*)w_packed, cout, cin, kh, kw, convt_k, rows, rows_pad, cin_pad);
+  PRV2_LAUNCH_CHECK("pack_conv_weight");
+  return 0;
+}
+
+extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
+                           const float* gamma, const float* mul, const float* res, const float* res2, float* y,
+                           void* stream) {
+  PRV2_REQUIRE(d && x && w_packed && y, "conv2d: null pointer");
+  PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
+  PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
+  PRV2_REQUIRE(d->ldx >= d->cin, "conv2d: ldx %d < cin %d", d->ldx, d->cin);
+  PRV2_REQUIRE(d->prec == PRV2_PREC_F32, "conv2d: precision mode %d not built", d->prec);
+  PRV2_REQUIRE(aligned16(w_packed), "conv2d: packed weights must be 16-byte aligned");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
+  p.N = d->n; p.H = d->h; p.W = d->w;
+  p.Cin = d->cin; p.Cin_pad = (int)roundup(d->cin, BK); p.Cout = d->cout;
+  p.convt_k = d->convt_k;
+  if (d->convt_k > 0) {
+    PRV2_REQUIRE(d->kh == d->convt_k && d->kw == d->convt_k && d->stride == d->convt_k && d->pad == 0,
+                 "conv2d: convt_k needs kernel == stride == k, pad 0");
+    p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
+    p.OH = d->h; p.OW = d->w;
+    p.Ncols = d->convt_k * d->convt_k * d->cout;
+  } else {
+    p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.OH = (d->h + 2 * d->pad - d->kh) / d->stride + 1;
+    p.OW = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+    p.Ncols = d->cout;
+  }
+  PRV2_REQUIRE(p.OH > 0 && p.OW > 0, "conv2d: empty output");
+  PRV2_REQUIRE(d->ldy >= d->cout, "conv2d: ldy %d < cout %d", d->ldy, d->cout);
+  p.ldx = d->ldx; p.ldy = d->ldy; p.ld_mul = d->ld_mul; p.ld_res = d->ld_res; p.ld_res2 = d->ld_res2;
+  PRV2_REQUIRE(!mul || d->ld_mul >= d->cout, "conv2d: ld_mul");
+  PRV2_REQUIRE(!res || d->ld_res >= d->cout, "conv2d: ld_res");
+  PRV2_REQUIRE(!res2 || d->ld_res2 >= d->cout, "conv2d: ld_res2");
+  p.x_bstride = d->x_bstride ? d->x_bstride : (long long)d->h * d->w * d->ldx;
+  const int kk = d->convt_k > 0 ? d->convt_k : 1;
+  p.y_bstride = d->y_bstride ? d->y_bstride : (long long)p.OH * kk * p.OW * kk * d->ldy;
+  p.M = (long long)d->n * p.OH * p.OW;
+  p.relu_in = d->relu_in; p.act = d->act;
+  PRV2_REQUIRE((d->ldx % 4 == 0) && aligned16(x) && (p.x_bstride % 4 == 0) && d->ldx >= roundup(d->cin, 4),
+               "conv2d: x must be 16-byte aligned with ldx %% 4 == 0 and ldx >= roundup(cin,4) (ldx=%d cin=%d)", d->ldx, d->cin);
+  p.vec_ok = 1;
+  {
+    bool ve = (d->ldy % 4 == 0) && aligned16(y) && (p.y_bstride % 4 == 0) && (d->cout % 4 == 0);
+    if (mul) ve = ve && (d->ld_mul % 4 == 0) && aligned16(mul);
+    if (res) ve = ve && (d->ld_res % 4 == 0) && aligned16(res);
+    if (res2) ve = ve && (d->ld_res2 % 4 == 0) && aligned16(res2);
+    p.vec_epi = ve;
+  }
+  p.tiles_m = (int)cdiv(p.M, BM);
+  hipStream_t s = (hipStream_t)stream;
+  if (p.Ncols > 64) {
+    p.tiles_n = (int)cdiv(p.Ncols, 128);
+    hipLaunchKernelGGL((igemm_kernel<128, PRV2_PREC_F32>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+  } else {
+    p.tiles_n = 1;
+    hipLaunchKernelGGL((igemm_kernel<64, PRV2_PREC_F32>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+  }
+  PRV2_LAUNCH_CHECK("conv2d");
+  return 0;
+}

@@ -1,0 +1,286 @@
+// Row LayerNorm(+act), ViT token plumbing, and the two small direct convolutions (Cout==1,
+// depthwise).  All HBM-bound: 16-byte accesses along the channel dimension, one wave per row
+// for the reductions (no LDS, no barriers).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace prv2 {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per row; the row lives in registers between the two passes (C <= 64*4*MAXV)
+template <int MAXV>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, int64_t rows, int C, int ldx,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, int act, float* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int nv = C >> 2;  // float4 per row
+  for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * wpb) {
+    const float4* px = reinterpret_cast<const float4*>(x + r * ldx);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int j = lane + 64 * i;
+      if (j < nv) {
+        v[i] = px[j];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int j = lane + 64 * i;
+      if (j < nv) {
+        float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + bb * bb) + (c * c + d * d);
+      }
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float4* py = reinterpret_cast<float4*>(y + r * ldy);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int j = lane + 64 * i;
+      if (j < nv) {
+        float4 ww = reinterpret_cast<const float4*>(w)[j], bb = reinterpret_cast<const float4*>(b)[j], o;
+        o.x = act_apply((v[i].x - mean) * rstd * ww.x + bb.x, act);
+        o.y = act_apply((v[i].y - mean) * rstd * ww.y + bb.y, act);
+        o.z = act_apply((v[i].z - mean) * rstd * ww.z + bb.z, act);
+        o.w = act_apply((v[i].w - mean) * rstd * ww.w + bb.w, act);
+        py[j] = o;
+      }
+    }
+  }
+}
+
+// scalar fallback (C % 4 != 0 or unaligned): one wave per row, re-reads the row
+__global__ void __launch_bounds__(256) layernorm_scalar_kernel(const float* __restrict__ x, int64_t rows, int C, int ldx,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               float eps, int act, float* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * wpb) {
+    const float* px = x + r * ldx;
+    float s = 0.f;
+    for (int j = lane; j < C; j += 64) s += px[j];
+    float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int j = lane; j < C; j += 64) {
+      float d = px[j] - mean;
+      q += d * d;
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    for (int j = lane; j < C; j += 64) y[r * ldy + j] = act_apply((px[j] - mean) * rstd * w[j] + b[j], act);
+  }
+}
+
+__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ img, int B, int gh, int gw, int p,
+                                                       int ldi, float* __restrict__ rows, int ldo) {
+  const int kcols = p * p * 3;
+  int64_t total = (int64_t)B * gh * gw * ldo;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int col = (int)(idx % ldo);
+    int64_t row = idx / ldo;
+    float v = 0.f;
+    if (col < kcols) {
+      int c = col % 3, kx = (col / 3) % p, ky = col / (3 * p);
+      int gx = (int)(row % gw), gy = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gw * gh));
+      int64_t pix = ((int64_t)b * gh * p + gy * p + ky) * ((int64_t)gw * p) + gx * p + kx;
+      v = img[pix * ldi + c];
+    }
+    rows[idx] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) assemble_tokens_kernel(const float* __restrict__ emb,
+                                                              const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, int B, int np, int D,
+                                                              float* __restrict__ tok) {
+  int64_t total = (int64_t)B * (np + 1) * D;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int d = (int)(idx % D);
+    int t = (int)((idx / D) % (np + 1));
+    int b = (int)(idx / ((int64_t)D * (np + 1)));
+    float v = t == 0 ? cls[d] : emb[((int64_t)b * np + (t - 1)) * D + d];
+    tok[idx] = v + pos[(int64_t)t * D + d];
+  }
+}
+
+// Cout == 1 convolution: one thread per output pixel; weights staged in LDS as [tap][cin]
+__global__ void __launch_bounds__(256) conv_cout1_kernel(const float* __restrict__ x, int N, int H, int W, int Cin,
+                                                         int ldx, const float* __restrict__ wgt, int k,
+                                                         const float* __restrict__ bias, int act, float scale,
+                                                         const float* __restrict__ res, int clamp0,
+                                                         float* __restrict__ y) {
+  extern __shared__ float wl[];  // [k*k][Cin]
+  const int taps = k * k;
+  for (int i = threadIdx.x; i < taps * Cin; i += blockDim.x) {
+    int c = i % Cin, t = i / Cin;
+    wl[i] = wgt[c * taps + t];
+  }
+  __syncthreads();
+  const int pad = k / 2;
+  const float b0 = bias ? bias[0] : 0.f;
+  const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0);
+  int64_t total = (int64_t)N * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int ox = (int)(idx % W), oy = (int)((idx / W) % H);
+    int n = (int)(idx / ((int64_t)W * H));
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      int iy = oy + ky - pad;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        int ix = ox + kx - pad;
+        if (ix < 0 || ix >= W) continue;
+        const float* px = x + (((int64_t)n * H + iy) * W + ix) * ldx;
+        const float* pw = wl + (ky * k + kx) * Cin;
+        if (vec) {
+          for (int c = 0; c < Cin; c += 4) {
+            float4 v = *reinterpret_cast<const float4*>(px + c);
+            acc += v.x * pw[c] + v.y * pw[c + 1] + v.z * pw[c + 2] + v.w * pw[c + 3];
+          }
+        } else {
+          for (int c = 0; c < Cin; ++c) acc += px[c] * pw[c];
+        }
+      }
+    }
+    float v = act_apply(acc + b0, act) * scale;
+    if (res) v += res[idx];
+    if (clamp0) v = v > 0.f ? v : 0.f;
+    y[idx] = v;
+  }
+}
+
+// depthwise kxk, float4 over channels; weights tap-major [k*k][C]
+__global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                     const float* __restrict__ wgt, const float* __restrict__ bias, int k,
+                                                     int stride, int relu, int OH, int OW, float* __restrict__ y,
+                                                     int ldy) {
+  const int cg = C >> 2;
+  const int pad = k / 2;
+  int64_t total = (int64_t)N * OH * OW * cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % cg) * 4;
+    int64_t pix = idx / cg;
+    int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
+    int n = (int)(pix / ((int64_t)OW * OH));
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < k; ++ky) {
+      int iy = oy * stride + ky - pad;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        int ix = ox * stride + kx - pad;
+        if (ix < 0 || ix >= W) continue;
+        float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + iy) * W + ix) * ldx + c);
+        float4 ww = *reinterpret_cast<const float4*>(wgt + (int64_t)(ky * k + kx) * C + c);
+        acc.x += v.x * ww.x;
+        acc.y += v.y * ww.y;
+        acc.z += v.z * ww.z;
+        acc.w += v.w * ww.w;
+      }
+    }
+    if (relu) {
+      acc.x = fmaxf(acc.x, 0.f);
+      acc.y = fmaxf(acc.y, 0.f);
+      acc.z = fmaxf(acc.z, 0.f);
+      acc.w = fmaxf(acc.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + pix * ldy + c) = acc;
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace prv2
+
+using namespace prv2;
+
+extern "C" int prv2_abi_version(void) { return PRV2_ABI_VERSION; }
+extern "C" const char* prv2_last_error(void) { return prv2::g_err; }
+
+extern "C" int prv2_layernorm(const float* x, int64_t rows, int32_t c, int32_t ldx, const float* weight,
+                              const float* bias, float eps, int32_t act, float* y, int32_t ldy, void* stream) {
+  PRV2_REQUIRE(x && y && weight && bias, "layernorm: null pointer");
+  PRV2_REQUIRE(rows > 0 && c > 0 && ldx >= c && ldy >= c, "layernorm: bad geometry rows=%lld c=%d", (long long)rows, c);
+  int grid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  bool vec = (c % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(weight) &&
+             aligned16(bias) && c <= 2048;
+  if (!vec)
+    hipLaunchKernelGGL(layernorm_scalar_kernel, dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, act, y, ldy);
+  else if (c <= 256)
+    hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, act, y, ldy);
+  else if (c <= 512)
+    hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, act, y, ldy);
+  else if (c <= 1024)
+    hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, act, y, ldy);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, act, y, ldy);
+  PRV2_LAUNCH_CHECK("layernorm");
+  return 0;
+}
+
+extern "C" int prv2_patchify(const float* img, int32_t b, int32_t gh, int32_t gw, int32_t p, int32_t ldi, float* rows,
+                             int32_t ldo, void* stream) {
+  PRV2_REQUIRE(img && rows && b > 0 && gh > 0 && gw > 0 && p > 0 && ldi >= 3 && ldo >= p * p * 3, "patchify: bad arguments");
+  int64_t total = (int64_t)b * gh * gw * ldo;
+  hipLaunchKernelGGL(patchify_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, img, b, gh, gw, p,
+                     ldi, rows, ldo);
+  PRV2_LAUNCH_CHECK("patchify");
+  return 0;
+}
+
+extern "C" int prv2_assemble_tokens(const float* emb, const float* cls, const float* pos, int32_t b, int32_t np,
+                                    int32_t dim, float* tokens, void* stream) {
+  PRV2_REQUIRE(emb && cls && pos && tokens && b > 0 && np > 0 && dim > 0, "assemble_tokens: bad arguments");
+  int64_t total = (int64_t)b * (np + 1) * dim;
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, emb, cls, pos,
+                     b, np, dim, tokens);
+  PRV2_LAUNCH_CHECK("assemble_tokens");
+  return 0;
+}
+
+extern "C" int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx,
+                                 const float* wgt, int32_t k, const float* bias, int32_t act, float scale,
+                                 const float* res, int32_t clamp0, float* y, void* stream) {
+  PRV2_REQUIRE(x && wgt && y, "conv2d_cout1: null pointer");
+  PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && ldx >= cin && (k == 1 || k == 3), "conv2d_cout1: bad geometry");
+  PRV2_REQUIRE((size_t)k * k * cin * 4 <= 64 * 1024, "conv2d_cout1: cin too large");
+  int64_t total = (int64_t)n * h * w;
+  hipLaunchKernelGGL(conv_cout1_kernel, dim3(flat_grid(total, 256)), dim3(256), (size_t)k * k * cin * 4,
+                     (hipStream_t)stream, x, n, h, w, cin, ldx, wgt, k, bias, act, scale, res, clamp0, y);
+  PRV2_LAUNCH_CHECK("conv2d_cout1");
+  return 0;
+}
+
+extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
+                             const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy,
+                             void* stream) {
+  PRV2_REQUIRE(x && wgt && y, "dwconv2d: null pointer");
+  PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= c && ldy >= c &&
+                   (k == 3 || k == 5) && (stride == 1 || stride == 2),
+               "dwconv2d: bad geometry c=%d k=%d stride=%d", c, k, stride);
+  PRV2_REQUIRE(aligned16(x) && aligned16(y) && aligned16(wgt), "dwconv2d: pointers must be 16-byte aligned");
+  int oh = (h + 2 * (k / 2) - k) / stride + 1, ow = (w + 2 * (k / 2) - k) / stride + 1;
+  int64_t total = (int64_t)n * oh * ow * (c / 4);
+  hipLaunchKernelGGL(dwconv_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt,
+                     bias, k, stride, relu, oh, ow, y, ldy);
+  PRV2_LAUNCH_CHECK("dwconv2d");
+  return 0;
+}

@@ -1,0 +1,84 @@
+"""ctypes binding of libprv2_hip.so (the C ABI declared in include/prv2.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the
+product raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C patchrefinerv2_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprv2_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("ldx", C.c_int32), ("ldy", C.c_int32),
+        ("x_bstride", C.c_int64), ("y_bstride", C.c_int64),
+        ("relu_in", C.c_int32), ("act", C.c_int32), ("convt_k", C.c_int32),
+        ("ld_mul", C.c_int32), ("ld_res", C.c_int32), ("ld_res2", C.c_int32),
+        ("prec", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/prv2.h declares
+SIGNATURES = {
+    "prv2_abi_version": (_I, []),
+    "prv2_last_error": (C.c_char_p, []),
+    "prv2_packed_weight_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "prv2_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prv2_conv2d_cout1": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _P]),
+    "prv2_dwconv2d": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "prv2_layernorm": (_I, [_P, _L, _I, _I, _P, _P, _F, _I, _P, _I, _P]),
+    "prv2_patchify": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "prv2_assemble_tokens": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "prv2_attention": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "prv2_crop_resize": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _I, _P]),
+    "prv2_roi_align": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P, _I, _P]),
+    "prv2_upsample_bilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "prv2_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "prv2_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "prv2_blend_paste": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "prv2_blend_update": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "prv2_blend_resize": (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the gfx950 HIP library has not been built "
+            "(run `make -C patchrefinerv2_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.prv2_abi_version() != ABI_VERSION:
+        raise ImportError(f"libprv2_hip.so ABI {lib.prv2_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().prv2_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {code}): {msg}")

@@ -1,0 +1,278 @@
+"""Host-side wrappers over the C ABI: torch supplies device memory and the stream, nothing else.
+
+``Feat`` is an NHWC activation view (optionally a channel slice of a wider buffer) -- the
+mechanism that makes every ``torch.cat`` of the reference free: producers write into slices.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as L
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F32  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, Feat):
+        return t.ptr
+    return t.data_ptr()
+
+
+def _require_dev(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise ValueError("prv2 ops need float32 tensors on the GPU (no CPU fallback exists)")
+
+
+def roundup(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Feat:
+    """NHWC fp32 activation [n, h, w, c] living in ``buf`` ([n, h, w, ld]) at channel offset c0."""
+
+    __slots__ = ("buf", "n", "h", "w", "c", "c0")
+
+    def __init__(self, buf: torch.Tensor, c: Optional[int] = None, c0: int = 0):
+        assert buf.dim() == 4 and buf.is_contiguous()
+        _require_dev(buf)
+        self.buf = buf
+        self.n, self.h, self.w = buf.shape[0], buf.shape[1], buf.shape[2]
+        self.c = buf.shape[3] - c0 if c is None else c
+        self.c0 = c0
+        assert 0 <= c0 and c0 + self.c <= buf.shape[3]
+
+    @staticmethod
+    def alloc(n, h, w, c, device, pad_to: int = 4) -> "Feat":
+        ld = roundup(c, pad_to)
+        # pad channels are read by the conv loader (x zero weights): they must be finite
+        buf = torch.zeros((n, h, w, ld), device=device, dtype=torch.float32) if ld != c else \
+            torch.empty((n, h, w, ld), device=device, dtype=torch.float32)
+        return Feat(buf, c)
+
+    @property
+    def ld(self) -> int:
+        return self.buf.shape[3]
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + 4 * self.c0
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def slice(self, c0: int, c: int) -> "Feat":
+        return Feat(self.buf, c, self.c0 + c0)
+
+    def batch(self, b0: int, b1: int) -> "Feat":
+        return Feat(self.buf[b0:b1], self.c, self.c0)
+
+    def to_nchw(self) -> torch.Tensor:
+        """Debug / boundary helper: dense NCHW copy (through the HIP layout kernel)."""
+        out = torch.empty((self.n, self.c, self.h, self.w), device=self.device, dtype=torch.float32)
+        L.check(L.load().prv2_nhwc_to_nchw(self.ptr, self.n, self.c, self.h, self.w, self.ld, out.data_ptr(),
+                                           _stream()), "nhwc_to_nchw")
+        return out
+
+    @staticmethod
+    def from_nchw(x: torch.Tensor, pad_to: int = 4) -> "Feat":
+        _require_dev(x)
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        f = Feat.alloc(n, h, w, c, x.device, pad_to)
+        L.check(L.load().prv2_nchw_to_nhwc(x.data_ptr(), n, c, h, w, f.ptr, f.ld, _stream()), "nchw_to_nhwc")
+        return f
+
+
+@dataclass
+class ConvW:
+    """A packed convolution / linear weight (prv2_pack_conv_weight layout) + its bias."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cout: int
+    cin: int
+    kh: int
+    kw: int
+    stride: int = 1
+    pad: int = 0
+    convt_k: int = 0
+    prec: int = PREC_F32
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: Optional[int] = None,
+              convt_k: int = 0, bn_scale: Optional[torch.Tensor] = None, prec: int = PREC_F32, device=None) -> ConvW:
+    """weight: PyTorch layout [cout, cin, kh, kw] / [cout, cin] (Linear) / [cin, cout, k, k] (ConvTranspose2d)."""
+    lib = L.load()
+    device = device or weight.device
+    w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    if convt_k:
+        cin, cout, kh, kw = w.shape
+    else:
+        cout, cin, kh, kw = w.shape
+    if pad is None:
+        pad = kh // 2 if not convt_k else 0
+    nbytes = lib.prv2_packed_weight_bytes(cout, cin, kh, kw, convt_k, prec)
+    packed = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+    sc = bn_scale.detach().to(device=device, dtype=torch.float32).contiguous() if bn_scale is not None else None
+    L.check(lib.prv2_pack_conv_weight(w.data_ptr(), _ptr(sc), packed.data_ptr(), cout, cin, kh, kw, convt_k, prec,
+                                      _stream()), "pack_conv_weight")
+    b = bias.detach().to(device=device, dtype=torch.float32).contiguous() if bias is not None else None
+    return ConvW(packed, b, cout, cin, kh, kw, convt_k if convt_k else stride, pad, convt_k, prec)
+
+
+def conv_out_hw(cw: ConvW, h: int, w: int):
+    if cw.convt_k:
+        return h * cw.convt_k, w * cw.convt_k
+    return (h + 2 * cw.pad - cw.kh) // cw.stride + 1, (w + 2 * cw.pad - cw.kw) // cw.stride + 1
+
+
+def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = False, act: int = ACT_NONE,
+           gamma: Optional[torch.Tensor] = None, mul: Optional[Feat] = None, res: Optional[Feat] = None,
+           res2: Optional[Feat] = None, x_bstride: int = 0) -> Feat:
+    """y = epilogue(conv(x)); see include/prv2.h::prv2_conv2d."""
+    assert x.c == cw.cin, (x.c, cw.cin)
+    oh, ow = conv_out_hw(cw, x.h, x.w)
+    if out is None:
+        out = Feat.alloc(x.n, oh, ow, cw.cout, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cw.cout), ((out.n, out.h, out.w, out.c), (x.n, oh, ow, cw.cout))
+    d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad,
+                   ldx=x.ld, ldy=out.ld, x_bstride=x_bstride, y_bstride=0, relu_in=int(relu_in), act=act,
+                   convt_k=cw.convt_k, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0,
+                   ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, reserved=0)
+    for aux in (mul, res, res2):
+        if aux is not None:
+            assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
+    L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma), _ptr(mul), _ptr(res),
+                                 _ptr(res2), out.ptr, _stream()), "conv2d")
+    return out
+
+
+def linear(x2d: torch.Tensor, cw: ConvW, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+    """rows [M, K] @ W^T (+ epilogue) -> [M, N]; a 1x1 convolution over an M x 1 image."""
+    M, K = x2d.shape
+    xf = Feat(x2d.view(1, M, 1, K), cw.cin)
+    if out is None:
+        out = torch.empty((M, cw.cout), device=x2d.device, dtype=torch.float32)
+    of = Feat(out.view(1, M, 1, out.shape[1]), cw.cout)
+    for k in ("mul", "res", "res2"):
+        if kw.get(k) is not None and not isinstance(kw[k], Feat):
+            t = kw[k]
+            kw[k] = Feat(t.view(1, M, 1, t.shape[1]), cw.cout)
+    conv2d(xf, cw, of, **kw)
+    return out
+
+
+def conv2d_cout1(x: Feat, weight: torch.Tensor, bias: Optional[torch.Tensor], k: int, *, act: int = ACT_NONE,
+                 scale: float = 1.0, res: Optional[torch.Tensor] = None, clamp0: bool = False) -> torch.Tensor:
+    """Single-output-channel conv -> dense [n, 1, h, w] tensor (NCHW == NHWC for one channel)."""
+    y = torch.empty((x.n, 1, x.h, x.w), device=x.device, dtype=torch.float32)
+    L.check(L.load().prv2_conv2d_cout1(x.ptr, x.n, x.h, x.w, x.c, x.ld, weight.data_ptr(), k, _ptr(bias), act, scale,
+                                       _ptr(res), int(clamp0), y.data_ptr(), _stream()), "conv2d_cout1")
+    return y
+
+
+def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int, relu: bool) -> Feat:
+    oh = (x.h + 2 * (k // 2) - k) // stride + 1
+    ow = (x.w + 2 * (k // 2) - k) // stride + 1
+    out = Feat.alloc(x.n, oh, ow, x.c, x.device)
+    L.check(L.load().prv2_dwconv2d(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(), _ptr(bias), k, stride,
+                                   int(relu), out.ptr, out.ld, _stream()), "dwconv2d")
+    return out
+
+
+def layernorm_rows(x: torch.Tensor, rows: int, c: int, ldx: int, weight, bias, eps: float, act: int, y: torch.Tensor,
+                   ldy: int, x_off: int = 0, y_off: int = 0):
+    L.check(L.load().prv2_layernorm(x.data_ptr() + 4 * x_off, rows, c, ldx, weight.data_ptr(), bias.data_ptr(), eps,
+                                    act, y.data_ptr() + 4 * y_off, ldy, _stream()), "layernorm")
+
+
+def layernorm_feat(x: Feat, weight, bias, eps: float = 1e-6, act: int = ACT_NONE, out: Optional[Feat] = None) -> Feat:
+    """channels-first LayerNorm of the reference == row LayerNorm in NHWC (convs.py:21-29)."""
+    if out is None:
+        out = x
+    L.check(L.load().prv2_layernorm(x.ptr, x.n * x.h * x.w, x.c, x.ld, weight.data_ptr(), bias.data_ptr(), eps, act,
+                                    out.ptr, out.ld, _stream()), "layernorm")
+    return out
+
+
+def patchify(img: Feat, p: int, ldo: int) -> torch.Tensor:
+    gh, gw = img.h // p, img.w // p
+    rows = torch.empty((img.n * gh * gw, ldo), device=img.device, dtype=torch.float32)
+    L.check(L.load().prv2_patchify(img.ptr, img.n, gh, gw, p, img.ld, rows.data_ptr(), ldo, _stream()), "patchify")
+    return rows
+
+
+def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: int, np_: int, dim: int) -> torch.Tensor:
+    tok = torch.empty((b, np_ + 1, dim), device=emb.device, dtype=torch.float32)
+    L.check(L.load().prv2_assemble_tokens(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), b, np_, dim, tok.data_ptr(),
+                                          _stream()), "assemble_tokens")
+    return tok
+
+
+def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32) -> torch.Tensor:
+    out = torch.empty((b * ntok, heads * 64), device=qkv.device, dtype=torch.float32)
+    L.check(L.load().prv2_attention(qkv.data_ptr(), b, ntok, heads, 64, out.data_ptr(), prec, _stream()), "attention")
+    return out
+
+
+def crop_resize(img_chw: torch.Tensor, tiles: torch.Tensor, ch: int, cw: int, oh: int, ow: int,
+                mean: Optional[Sequence[float]], std: Optional[Sequence[float]], out: Feat):
+    """img_chw [3,H,W] device; tiles int32 [k,2] device; writes channels 0..2 of ``out`` [k,oh,ow,*]."""
+    _require_dev(img_chw)
+    assert tiles.dtype == torch.int32 and tiles.is_cuda and img_chw.is_contiguous()
+    k = tiles.shape[0]
+    m = (C.c_float * 3)(*mean) if mean is not None else None
+    s = (C.c_float * 3)(*std) if std is not None else None
+    L.check(L.load().prv2_crop_resize(img_chw.data_ptr(), img_chw.shape[1], img_chw.shape[2], tiles.data_ptr(), k, ch,
+                                      cw, oh, ow, m, s, out.ptr, out.ld, _stream()), "crop_resize")
+
+
+def roi_align(feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow: int, out: Optional[Feat] = None) -> Feat:
+    assert feat.n == 1 and boxes.dtype == torch.float32 and boxes.is_cuda and boxes.shape[1] == 4
+    k = boxes.shape[0]
+    if out is None:
+        out = Feat.alloc(k, oh, ow, feat.c, feat.device)
+    L.check(L.load().prv2_roi_align(feat.ptr, feat.h, feat.w, feat.c, feat.ld, boxes.data_ptr(), k, spatial_scale, oh,
+                                    ow, out.ptr, out.ld, _stream()), "roi_align")
+    return out
+
+
+def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> Feat:
+    if out is None:
+        out = Feat.alloc(x.n, oh, ow, x.c, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, x.c)
+    L.check(L.load().prv2_upsample_bilinear(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, out.ptr, out.ld, _stream()),
+            "upsample_bilinear")
+    return out
+
+
+def blend_paste(avg, cnt, pred, mask, tiles, th, tw):
+    L.check(L.load().prv2_blend_paste(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], pred.data_ptr(),
+                                      pred.shape[-2], pred.shape[-1], mask.data_ptr(), tiles.data_ptr(), tiles.shape[0],
+                                      th, tw, _stream()), "blend_paste")
+
+
+def blend_update(avg, cnt, pred, mask, tiles, th, tw):
+    L.check(L.load().prv2_blend_update(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], pred.data_ptr(),
+                                       pred.shape[-2], pred.shape[-1], mask.data_ptr(), tiles.data_ptr(), tiles.shape[0],
+                                       th, tw, _stream()), "blend_update")
+
+
+def blend_resize(avg, cnt, oh, ow):
+    a = torch.empty((oh, ow), device=avg.device, dtype=torch.float32)
+    c = torch.empty((oh, ow), device=avg.device, dtype=torch.float32)
+    L.check(L.load().prv2_blend_resize(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], a.data_ptr(),
+                                       c.data_ptr(), oh, ow, _stream()), "blend_resize")
+    return a, c

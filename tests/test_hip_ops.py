@@ -1,0 +1,271 @@
+"""GPU parity: every C-ABI kernel against the oracle / plain torch fp32 on the CPU, same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as o_ops  # noqa: E402
+from oracle import tiling as o_tiling  # noqa: E402
+from oracle.dav2 import attention as o_attention  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def P():
+    from patchrefinerv2_amd import ops
+    ops.L.load()
+    return ops
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def close(got, ref, tol, what=""):
+    got = got.detach().cpu()
+    err = float((got - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert err <= tol * scale, f"{what}: max|d|={err:.3e} (scale {scale:.2f})"
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, opts
+    (2, 24, 32, 64, 128, 3, 1, {}),
+    (1, 17, 23, 34, 32, 3, 1, {}),                      # +2 concat channels, ragged spatial, BN=64 path
+    (2, 12, 16, 98, 98, 3, 1, dict(act="gelu")),        # f2r_agg-like odd channels
+    (1, 16, 16, 256, 200, 3, 1, dict(bias=True, relu_in=True, res=True)),
+    (1, 20, 28, 96, 256, 1, 1, dict(bias=True)),
+    (1, 32, 32, 64, 64, 3, 2, dict(bias=True)),        # DPT resize_layers.3 / MNv4 strided
+    (3, 9, 7, 48, 24, 1, 1, dict(bias=True, act="sigmoid", mul=True)),
+    (1, 8, 8, 130, 128, 3, 1, dict(res=True, res2=True, gamma=True, bias=True)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(P, case):
+    n, h, w, cin, cout, k, stride, o = case
+    x = rnd(1, n, cin, h, w)
+    wt = rnd(2, cout, cin, k, k) / np.sqrt(cin * k * k)
+    bias = rnd(3, cout) if o.get("bias") else None
+    act = {"gelu": P.ACT_GELU, "sigmoid": P.ACT_SIGMOID, None: P.ACT_NONE}[o.get("act")]
+    xin = F.relu(x) if o.get("relu_in") else x
+    ref = F.conv2d(xin, wt, bias, stride=stride, padding=k // 2)
+    if o.get("act") == "gelu":
+        ref = F.gelu(ref)
+    if o.get("act") == "sigmoid":
+        ref = torch.sigmoid(ref)
+    gamma = rnd(4, cout) if o.get("gamma") else None
+    if gamma is not None:
+        ref = ref * gamma.view(1, -1, 1, 1)
+    mul = rnd(5, *ref.shape) if o.get("mul") else None
+    res = rnd(6, *ref.shape) if o.get("res") else None
+    res2 = rnd(7, *ref.shape) if o.get("res2") else None
+    if mul is not None:
+        ref = mul * ref
+    if res is not None:
+        ref = ref + res
+    if res2 is not None:
+        ref = ref + res2
+    cw = P.pack_conv(wt.to(DEV), bias.to(DEV) if bias is not None else None, stride=stride)
+    f = lambda t: P.Feat.from_nchw(t.to(DEV)) if t is not None else None  # noqa: E731
+    y = P.conv2d(f(x), cw, relu_in=bool(o.get("relu_in")), act=act, gamma=gamma.to(DEV) if gamma is not None else None,
+                 mul=f(mul), res=f(res), res2=f(res2))
+    close(y.to_nchw(), ref, 2e-5, f"conv {case}")
+
+
+def test_conv_into_concat_slice(P):
+    """producer writes into a channel slice of a wider buffer == torch.cat"""
+    x = rnd(1, 1, 32, 10, 12)
+    w1, w2 = rnd(2, 64, 32, 3, 3) / 17, rnd(3, 34, 32, 3, 3) / 17
+    ref = torch.cat([F.conv2d(x, w1, padding=1), F.conv2d(x, w2, padding=1)], dim=1)
+    xf = P.Feat.from_nchw(x.to(DEV))
+    cat = P.Feat.alloc(1, 10, 12, 98, DEV)
+    P.conv2d(xf, P.pack_conv(w1.to(DEV)), cat.slice(0, 64))
+    P.conv2d(xf, P.pack_conv(w2.to(DEV)), cat.slice(64, 34))
+    close(cat.to_nchw(), ref, 2e-5)
+    # and is consumable as a 98-channel input
+    w3 = rnd(4, 40, 98, 3, 3) / 30
+    close(P.conv2d(cat, P.pack_conv(w3.to(DEV))).to_nchw(), F.conv2d(ref, w3, padding=1), 2e-5)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_conv_transpose(P, k):
+    x = rnd(1, 2, 48, 6, 9)
+    wt = rnd(2, 48, 40, k, k) / 7
+    b = rnd(3, 40)
+    ref = F.conv_transpose2d(x, wt, b, stride=k)
+    cw = P.pack_conv(wt.to(DEV), b.to(DEV), convt_k=k)
+    close(P.conv2d(P.Feat.from_nchw(x.to(DEV)), cw).to_nchw(), ref, 2e-5)
+
+
+def test_linear_vit_shapes(P):
+    x = rnd(1, 2 * 1025, 384)
+    w, b, g = rnd(2, 1536, 384) / 20, rnd(3, 1536), None
+    ref = F.gelu(F.linear(x, w, b))
+    y = P.linear(x.to(DEV), P.pack_conv(w.to(DEV), b.to(DEV)), act=P.ACT_GELU)
+    close(y, ref, 2e-5)
+    w2, b2, g = rnd(4, 384, 1536) / 40, rnd(5, 384), rnd(6, 384)
+    ref2 = x + F.linear(ref, w2, b2) * g
+    y2 = P.linear(y, P.pack_conv(w2.to(DEV), b2.to(DEV)), gamma=g.to(DEV), res=x.to(DEV))
+    close(y2, ref2, 2e-5)
+
+
+def test_conv_cout1_and_dw(P):
+    x = rnd(1, 2, 32, 20, 24)
+    w = rnd(2, 1, 32, 3, 3) / 17
+    base = rnd(3, 2, 1, 20, 24) + 1
+    ref = torch.clamp(base + F.conv2d(x, w, padding=1), min=0)
+    xf = P.Feat.from_nchw(x.to(DEV))
+    close(P.conv2d_cout1(xf, w.to(DEV), None, 3, res=base.to(DEV), clamp0=True), ref, 1e-5)
+    w1, b1 = rnd(4, 1, 32, 1, 1) / 6, rnd(5, 1)
+    close(P.conv2d_cout1(xf, w1.to(DEV), b1.to(DEV), 1, act=P.ACT_SIGMOID, scale=80.0), torch.sigmoid(F.conv2d(x, w1, b1)) * 80, 1e-5)
+    for k, s in ((3, 1), (3, 2), (5, 1), (5, 2)):
+        wd, bd = rnd(6, 32, 1, k, k) / k, rnd(7, 32)
+        refd = F.relu(F.conv2d(x, wd, bd, stride=s, padding=k // 2, groups=32))
+        wt = wd.view(32, k * k).t().contiguous().to(DEV)
+        close(P.dwconv2d(xf, wt, bd.to(DEV), k, s, True).to_nchw(), refd, 1e-5, f"dw k{k}s{s}")
+
+
+@pytest.mark.parametrize("c", [32, 98, 256, 384, 1024])
+def test_layernorm(P, c):
+    x = rnd(1, 3, c, 7, 5) * 3 + 1
+    w, b = rnd(2, c), rnd(3, c)
+    from oracle.fusion import ln_cf
+    ref = F.gelu(ln_cf(x, w, b))
+    xf = P.Feat.from_nchw(x.to(DEV))
+    out = P.layernorm_feat(xf, w.to(DEV), b.to(DEV), 1e-6, P.ACT_GELU)
+    close(out.to_nchw(), ref, 1e-5, f"ln c={c}")
+
+
+@pytest.mark.parametrize("shape", [(1, 1025, 6), (2, 197, 2), (1, 64, 1)])
+def test_attention(P, shape):
+    b, n, heads = shape
+    D = heads * 64
+    x = rnd(1, b, n, D)
+    sd = {"qkv.weight": rnd(2, 3 * D, D) / np.sqrt(D), "qkv.bias": rnd(3, 3 * D) * 0.1,
+          "proj.weight": torch.eye(D), "proj.bias": torch.zeros(D)}
+    ref = o_attention(sd, "", x, heads)
+    qkv = F.linear(x, sd["qkv.weight"], sd["qkv.bias"]).reshape(b * n, 3 * D)
+    out = P.attention(qkv.to(DEV).contiguous(), b, n, heads)
+    close(out.view(b, n, D), ref, 1e-5, f"attention {shape}")
+
+
+def test_attention_spiky(P):
+    """rows whose max jumps tile to tile (online-softmax rescale path) + large logits"""
+    b, n, heads = 1, 300, 1
+    q = rnd(1, n, 64)
+    k = rnd(2, n, 64)
+    k[70] = q[5] * 6
+    k[200] = q[5] * 9
+    k[299] = q[17] * 12
+    v = rnd(3, n, 64)
+    qkv = torch.stack([q, k, v], dim=1).reshape(n, 192)
+    att = ((q * 0.125) @ k.t()).softmax(-1) @ v
+    out = P.attention(qkv.to(DEV).contiguous(), b, n, heads)
+    close(out, att, 1e-5)
+
+
+def test_patchify_tokens(P):
+    img = rnd(1, 2, 3, 28, 42)
+    w, bias = rnd(2, 64, 3, 14, 14) / 24, rnd(3, 64)
+    cls, pos = rnd(4, 1, 1, 64), rnd(5, 1, 7, 64)
+    emb = F.conv2d(img, w, bias, stride=14).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(2, -1, -1), emb], 1) + pos
+    f = P.Feat.from_nchw(img.to(DEV))
+    rows = P.patchify(f, 14, 592)
+    wl = w.permute(0, 2, 3, 1).reshape(64, 588)
+    e = P.linear(rows, P.pack_conv(wl.to(DEV), bias.to(DEV)))
+    tok = P.assemble_tokens(e, cls.to(DEV).contiguous(), pos.to(DEV).contiguous(), 2, 6, 64)
+    close(tok, ref, 1e-5)
+
+
+def test_crop_resize(P):
+    img = torch.rand(3, 216, 384, generator=torch.Generator().manual_seed(1))
+    tiles = torch.tensor([[0, 0], [108, 192], [54, 96], [107, 191]], dtype=torch.int32)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = P.Feat.alloc(4, 56, 84, 4, DEV)
+    P.crop_resize(img.to(DEV), tiles.to(DEV), 108, 192, 56, 84, mean, std, out)
+    got = out.to_nchw()[:, :3]
+    for i, (h0, w0) in enumerate(tiles.tolist()):
+        ref = o_ops.resize_da(img[None, :, h0:h0 + 108, w0:w0 + 192], 84, 56)
+        ref = (ref - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        close(got[i:i + 1], ref, 2e-6, f"crop {i}")
+    # identity size == plain layout change
+    out2 = P.Feat.alloc(1, 216, 384, 3, DEV, pad_to=1)
+    P.crop_resize(img.to(DEV), torch.zeros(1, 2, dtype=torch.int32, device=DEV), 216, 384, 216, 384, None, None, out2)
+    assert torch.equal(out2.to_nchw().cpu()[0], img)
+
+
+def test_roi_align(P):
+    feat = rnd(1, 1, 32, 24, 32)
+    depth = rnd(2, 1, 1, 56, 84)
+    bboxs = torch.tensor([[0, 0, 192, 108], [192, 108, 384, 216], [96, 54, 288, 162], [191, 107, 383, 215]])
+    bf = o_tiling.bboxs_to_feat(bboxs, (216, 384), (56, 84))
+    ref = o_ops.roi_align(feat.repeat(4, 1, 1, 1), bf, (24, 32), 24 / 56, aligned=True)
+    got = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), bf[:, 1:].contiguous().to(DEV), 24 / 56, 24, 32)
+    close(got.to_nchw(), ref, 1e-5, "roi feat")
+    refd = o_ops.roi_align(depth.repeat(4, 1, 1, 1), bf, (56, 84), 1.0, aligned=True)
+    gotd = P.roi_align(P.Feat.from_nchw(depth.to(DEV), pad_to=1), bf[:, 1:].contiguous().to(DEV), 1.0, 56, 84)
+    close(gotd.to_nchw(), refd, 1e-5, "roi depth")
+    # down-sampling ROI (adaptive sampling grid > 1)
+    big = torch.tensor([[0, 0.0, 0.0, 84.0, 56.0]])
+    ref2 = o_ops.roi_align(feat, big, (5, 7), 24 / 56, aligned=True)
+    got2 = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), big[:, 1:].contiguous().to(DEV), 24 / 56, 5, 7)
+    close(got2.to_nchw(), ref2, 1e-5, "roi grid")
+
+
+@pytest.mark.parametrize("case", [(2, 32, 12, 16, 24, 32), (1, 1, 56, 84, 28, 42), (1, 98, 7, 11, 14, 21), (1, 256, 16, 16, 14, 14)])
+def test_upsample(P, case):
+    n, c, h, w, oh, ow = case
+    x = rnd(1, n, c, h, w)
+    got = P.upsample_bilinear(P.Feat.from_nchw(x.to(DEV)), oh, ow)
+    close(got.to_nchw(), o_ops.bilinear_ac(x, (oh, ow)), 2e-6)
+
+
+def test_blend_sequence(P):
+    g = torch.Generator().manual_seed(4)
+    ph, pw, MH, MW = 24, 32, 48, 64
+    mask = torch.tensor(o_ops.generatemask((ph, pw), border=0.15))
+    assert int((mask == 0).sum()) > 0
+    preds = torch.rand(4, ph, pw, generator=g) * 10
+    tiles0 = torch.tensor([[0, 0], [0, 32], [24, 0], [24, 32]], dtype=torch.int32)
+    pd, cnt = torch.zeros(MH, MW), torch.zeros(MH, MW)
+    for i, (h0, w0) in enumerate(tiles0.tolist()):
+        cnt[h0:h0 + ph, w0:w0 + pw] = mask
+        pd[h0:h0 + ph, w0:w0 + pw] = preds[i]
+    ram = o_tiling.RunningAverageMap(pd, cnt)
+    avg_d = torch.zeros(MH, MW, device=DEV)
+    cnt_d = torch.zeros(MH, MW, device=DEV)
+    P.blend_paste(avg_d, cnt_d, preds.to(DEV), mask.to(DEV), tiles0.to(DEV), ph, pw)
+    assert torch.equal(avg_d.cpu(), ram.average_map) and torch.equal(cnt_d.cpu(), ram.count_map)
+    # second pass: offset tiles incl. two overlapping ones (order matters)
+    preds2 = torch.rand(3, ph, pw, generator=g) * 10
+    tiles1 = torch.tensor([[12, 16], [20, 24], [0, 16]], dtype=torch.int32)
+    for i, (h0, w0) in enumerate(tiles1.tolist()):
+        c, p = torch.zeros(MH, MW), torch.zeros(MH, MW)
+        c[h0:h0 + ph, w0:w0 + pw] = mask
+        p[h0:h0 + ph, w0:w0 + pw] = preds2[i]
+        ram.update(p, c)
+    P.blend_update(avg_d, cnt_d, preds2.to(DEV), mask.to(DEV), tiles1.to(DEV), ph, pw)
+    assert torch.equal(avg_d.cpu(), ram.average_map) and torch.equal(cnt_d.cpu(), ram.count_map)
+    # resize + raw-resolution tiles with nearest-upsampled predictions
+    ram.resize((54, 96))
+    a2, c2 = P.blend_resize(avg_d, cnt_d, 54, 96)
+    assert torch.equal(a2.cpu(), ram.average_map)
+    close(c2, ram.count_map, 1e-6)
+    rh, rw = 27, 48
+    mask_r = torch.tensor(o_ops.generatemask((rh, rw), border=0.15) + 1e-3)
+    preds3 = torch.rand(2, ph, pw, generator=g) * 10
+    tiles2 = torch.tensor([[3, 7], [20, 7]], dtype=torch.int32)
+    up = o_ops.nearest(preds3[:, None], (rh, rw))[:, 0]
+    ram.count_map = c2.cpu().clone()
+    for i, (h0, w0) in enumerate(tiles2.tolist()):
+        c, p = torch.zeros(54, 96), torch.zeros(54, 96)
+        c[h0:h0 + rh, w0:w0 + rw] = mask_r
+        p[h0:h0 + rh, w0:w0 + rw] = up[i]
+        ram.update(p, c)
+    P.blend_update(a2, c2, preds3.to(DEV), mask_r.to(DEV), tiles2.to(DEV), rh, rw)
+    assert torch.equal(a2.cpu(), ram.average_map) and torch.equal(c2.cpu(), ram.count_map)
