@@ -1,0 +1,256 @@
+"""The per-patch fusion networks on the HIP kernels.
+
+Host-side mirrors of
+  FusionUnet           estimator/models/blocks/fusion_model.py:53-122
+  BiDirectionalFusion  estimator/models/blocks/bi_directional_fusion_model.py:290-446 ('coarse-gated')
+  C2FModule / GatedFusionBlock / GatedConvUnit   ...bi_directional_fusion_model.py:26-208
+with the reference constructor arguments and state-dict names.
+
+Layout: NHWC ``Feat``s.  Every ``torch.cat`` of the reference is realised by letting producers
+write into channel slices of one pre-allocated buffer; the channels-first LayerNorm+GELU is the
+row-LayerNorm kernel run in place on the conv output; residual / gate / bias / activation are
+conv-epilogue flags.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from . import weights as W
+from .dav2 import StateDictModule
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, Feat
+
+
+def as_feat1(t: torch.Tensor) -> Feat:
+    """dense [B,1,H,W] tensor == NHWC [B,H,W,1]."""
+    B, _, H, Wd = t.shape
+    return Feat(t.contiguous().view(B, H, Wd, 1))
+
+
+def place(src: Feat, dst: Feat):
+    """bilinear(align_corners) resize of ``src`` into ``dst`` (an exact copy when sizes match)."""
+    ops.upsample_bilinear(src, dst.h, dst.w, out=dst)
+
+
+class _EncDec(StateDictModule):
+    """Shared fine2coarse encoder + decoder of FusionUnet / BiDirectionalFusion."""
+
+    ENC1 = ENC2 = DEC = ""
+
+    def _init_encdec(self, in_chl: Sequence[int], temp_chl: Sequence[int], dec_chl: Sequence[int]):
+        self.in_chl, self.temp_chl, self.dec_chl = list(in_chl), list(temp_chl), list(dec_chl)
+        t = self.temp_chl[::-1]
+        self.dec_in = []
+        ch = t[0]
+        for tc, dc in zip(t[1:], self.dec_chl):
+            self.dec_in.append((ch, tc, dc))  # (x1 channels, x2 channels, out channels)
+            ch = dc
+        self.last_chl = self.dec_chl[-1] if self.dec_chl else ch
+
+    def _pack_encdec(self):
+        P = {}
+        for l in range(len(self.temp_chl)):
+            for e in (self.ENC1, self.ENC2):
+                P[f"{e}.{l}"] = (self._conv(f"{e}.{l}.single_conv.0"), self._dev(f"{e}.{l}.single_conv.1.weight"),
+                                 self._dev(f"{e}.{l}.single_conv.1.bias"))
+        for j in range(len(self.dec_in)):
+            P[f"{self.DEC}.{j}"] = (self._conv(f"{self.DEC}.{j}.conv.double_conv.0"),
+                                    self._conv(f"{self.DEC}.{j}.conv.double_conv.2"))
+        P["final_w"] = self._dev("final_conv.weight")
+        return P
+
+    def _encode_decode(self, P, pairs, sizes, pred1: Feat, pred2: Feat, update_base: Optional[torch.Tensor], out=None):
+        """pairs[l] = (fill_fn(dst_cat: Feat) writing the level-l [c, f] concat), sizes[l] = (h, w);
+        levels high -> low resolution (fusion_model.py:91-118)."""
+        B, dev = pred1.n, pred1.device
+        L_ = len(self.temp_chl)
+        nd = len(self.dec_in)
+        # decoder concat buffers [up(x1) | x2 | pred1 | pred2]; level l feeds decoder stage nd-1-l as x2
+        dec_bufs = []
+        for j, (c1, c2, dc) in enumerate(self.dec_in):
+            h, w = sizes[L_ - 2 - j]
+            dec_bufs.append(Feat.alloc(B, h, w, c1 + c2 + 2, dev))
+        temps = [None] * L_
+        for l in range(L_):
+            h, w = sizes[l]
+            tc = self.temp_chl[l]
+            cat1 = Feat.alloc(B, h, w, self.in_chl[l], dev)
+            pairs[l](cat1)
+            conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
+            cat2 = Feat.alloc(B, h, w, tc + 2, dev)
+            f = ops.conv2d(cat1, conv, cat2.slice(0, tc))
+            ops.layernorm_feat(f, lnw, lnb, 1e-6, ACT_GELU)
+            place(pred1, cat2.slice(tc, 1))
+            place(pred2, cat2.slice(tc + 1, 1))
+            conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
+            j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
+            if 0 <= j < nd:
+                c1, c2, _ = self.dec_in[j]
+                assert c2 == tc
+                dst = dec_bufs[j].slice(c1, c2)
+            else:
+                dst = Feat.alloc(B, h, w, tc, dev)
+            temps[l] = ops.conv2d(cat2, conv, dst)
+            ops.layernorm_feat(temps[l], lnw, lnb, 1e-6, ACT_GELU)
+        feat = temps[L_ - 1] if nd > 0 else temps[0]
+        for j, (c1, c2, dc) in enumerate(self.dec_in):
+            buf = dec_bufs[j]
+            place(feat, buf.slice(0, c1))
+            place(pred1, buf.slice(c1 + c2, 1))
+            place(pred2, buf.slice(c1 + c2 + 1, 1))
+            c0w, c2w = P[f"{self.DEC}.{j}"]
+            t = ops.conv2d(buf, c0w, act=ACT_GELU)
+            feat = ops.conv2d(t, c2w, act=ACT_GELU)
+        # final_conv 3x3 -> 1 ; clamp(update_base + offset, min=0)
+        return ops.conv2d_cout1(feat, P["final_w"], None, 3, res=update_base, clamp0=update_base is not None, out=out)
+
+
+class FusionUnet(_EncDec):
+    ENC1, ENC2, DEC = "encoder_layers_1", "encoder_layers_2", "decoder_layers"
+
+    def __init__(self, input_chl=(64, 512, 512), temp_chl=(32, 256, 256), dec_chl=(256, 32), device="cuda", prec="f32"):
+        super().__init__()
+        self.device = torch.device(device)
+        self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
+        self._init_encdec(input_chl, temp_chl, dec_chl)
+        self._spec = W.fusion_unet_spec("", input_chl, temp_chl, dec_chl)
+        self._packed = None
+        self.glb_att = False
+
+    def _pack(self):
+        if len(self._sd) == len(self._spec):
+            self._packed = self._pack_encdec()
+
+    def forward(self, c_feat: List[Feat], f_feat: List[Feat], pred1: torch.Tensor, pred2: torch.Tensor,
+                update_base: Optional[torch.Tensor] = None, out=None) -> torch.Tensor:
+        """c_feat / f_feat: high -> low resolution; pred1/pred2/update_base dense [B,1,H,W]."""
+        if self._packed is None:
+            raise RuntimeError("FusionUnet: weights not loaded")
+
+        def fill(l):
+            def fn(cat: Feat):
+                place(c_feat[l], cat.slice(0, c_feat[l].c))
+                place(f_feat[l], cat.slice(c_feat[l].c, f_feat[l].c))
+            return fn
+
+        sizes = [(f.h, f.w) for f in f_feat]
+        return self._encode_decode(self._packed, [fill(l) for l in range(len(c_feat))], sizes, as_feat1(pred1),
+                                   as_feat1(pred2), update_base, out=out)
+
+    __call__ = forward
+
+
+class BiDirectionalFusion(_EncDec):
+    ENC1, ENC2, DEC = "fusion_layers_1", "fusion_layers_2", "f2r_agg"
+    FEATURES = 256  # hard-wired in C2FModule (bi_directional_fusion_model.py:149)
+
+    def __init__(self, encoder_name="", coarse2fine=True, coarse2fine_type="coarse-gated", fine2coarse=True,
+                 coarse_chl=(32, 256, 256, 256, 256, 256), fine_chl=(32, 32, 64, 96, 960),
+                 fine_chl_after_coarse2fine=(32, 256, 256, 256, 256, 256), temp_chl=(32, 64, 64, 128, 256, 512),
+                 dec_chl=(512, 256, 128, 64, 32), glb_att=False, device="cuda", prec="f32", **_unused):
+        super().__init__()
+        if not coarse2fine or coarse2fine_type != "coarse-gated" or glb_att:
+            raise NotImplementedError("only coarse2fine_type='coarse-gated', glb_att=False is on the hot path "
+                                      "(every V2 config in configs/patchrefinerv2_*)")
+        self.device = torch.device(device)
+        self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
+        self.encoder_name = encoder_name
+        self.glb_att = False
+        self.coarse_chl, self.fine_chl = list(coarse_chl), list(fine_chl)
+        self._init_encdec([c + f for c, f in zip(coarse_chl, fine_chl_after_coarse2fine)], temp_chl, dec_chl)
+        self._spec = W.bidir_fusion_spec("", coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl)
+        self._packed = None
+
+    def _pack(self):
+        if len(self._sd) < len(self._spec):
+            return
+        P = self._pack_encdec()
+        s = "c2f.scratch."
+        P["rn"] = [self._conv(f"{s}layer{i + 1}_rn") for i in range(5)]
+
+        def unit(b):
+            return dict(conv=self._conv(b + "conv"), f0=self._conv(b + "fusion_conv.0"),
+                        lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
+                        f3=self._conv(b + "fusion_conv.3"))
+
+        def block(b):
+            return dict(out_conv=self._conv(b + "out_conv"), u1=unit(b + "GateresConfUnit1."),
+                        u2=unit(b + "GateresConfUnit2."))
+
+        P["refine"] = {r: block(f"{s}refinenet{r}.") for r in range(1, 6)}
+        P["out1"] = self._conv(s + "output_conv1")
+        P["out2_0"] = self._conv(s + "output_conv2.0")
+        P["out2_fusion"] = block(s + "output_conv2_fusion.")
+        P["out3_w"] = self._dev(s + "output_conv3.0.weight")
+        P["out3_b"] = self._dev(s + "output_conv3.0.bias")
+        self._packed = P
+
+    # -- coarse2fine ---------------------------------------------------------------------------
+    @staticmethod
+    def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None) -> Feat:
+        """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
+        half already holds the coarse feature; the lower half receives ``out``."""
+        out = ops.conv2d(x, u["conv"], cat.slice(0, F_), relu_in=True, res=x)            # conv(relu(x)) + x
+        fused = ops.conv2d(cat, u["f0"])
+        ops.layernorm_feat(fused, u["lnw"], u["lnb"], 1e-6, ACT_RELU)
+        return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])
+
+    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True) -> Feat:
+        """GatedFusionBlock.forward (bi_directional_fusion_model.py:116-146)."""
+        ref = xs[-1]
+        cat = Feat.alloc(ref.n, ref.h, ref.w, 2 * F_, ref.device)
+        place(coarse, cat.slice(F_, F_))
+        out = xs[0]
+        if len(xs) == 2:
+            out = self._gated_unit(blk["u1"], xs[1], cat, F_, res=xs[0])
+        out = self._gated_unit(blk["u2"], out, cat, F_)
+        if upscale:
+            out = ops.upsample_bilinear(out, size[0], size[1])
+        return ops.conv2d(out, blk["out_conv"])
+
+    def _c2f(self, P, fine: List[Feat], coarse: List[Feat]):
+        """C2FModule.forward (bi_directional_fusion_model.py:184-208); fine: 5 maps, coarse: 6 maps, high -> low."""
+        F_ = self.FEATURES
+        rn = [ops.conv2d(fine[i], P["rn"][i]) for i in range(5)]
+        R = P["refine"]
+        path5 = self._gated_block(R[5], [rn[4]], coarse[5], F_, size=(rn[3].h, rn[3].w))
+        path4 = self._gated_block(R[4], [path5, rn[3]], coarse[4], F_, size=(rn[2].h, rn[2].w))
+        path3 = self._gated_block(R[3], [path4, rn[2]], coarse[3], F_, size=(rn[1].h, rn[1].w))
+        path2 = self._gated_block(R[2], [path3, rn[1]], coarse[2], F_, size=(rn[0].h, rn[0].w))
+        path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=(rn[0].h * 2, rn[0].w * 2))
+        out = ops.conv2d(path1, P["out1"])
+        last = ops.conv2d(out, P["out2_0"], act=ACT_RELU)
+        last = self._gated_block(P["out2_fusion"], [last], coarse[0], self.coarse_chl[0], upscale=False)
+        depth = ops.conv2d_cout1(last, P["out3_w"], P["out3_b"], 1)
+        return [rn[4], path5, path4, path3, path2, last], depth
+
+    def forward(self, c_feat: List[Feat], f_feat: List[Optional[Feat]], pred1: torch.Tensor, pred2: torch.Tensor,
+                update_base: Optional[torch.Tensor] = None, f_sizes=None, out=None, **_unused) -> torch.Tensor:
+        """c_feat: 6 coarse ROI maps high -> low.  f_feat: 6 refiner maps high -> low, where entry 0 (the
+        2x-upsampled copy the reference builds and then drops, :408) may be None; ``f_sizes`` gives the
+        six (h, w) the reference would see."""
+        P = self._packed
+        if P is None:
+            raise RuntimeError("BiDirectionalFusion: weights not loaded")
+        if f_sizes is None:
+            f_sizes = [(f.h, f.w) for f in f_feat]
+        c_feat = list(c_feat)
+        if (c_feat[-1].h, c_feat[-1].w) != tuple(f_sizes[-1]):
+            # the reference resizes ALL coarse maps iff the lowest level differs (:389-393)
+            c_feat = [ops.upsample_bilinear(c, s[0], s[1]) for c, s in zip(c_feat, f_sizes)]
+        feats, out_depth = self._c2f(P, list(f_feat[1:]), c_feat)
+        feats = feats[::-1]
+
+        def fill(l):
+            def fn(cat: Feat):
+                place(c_feat[l], cat.slice(0, c_feat[l].c))
+                place(feats[l], cat.slice(c_feat[l].c, feats[l].c))
+            return fn
+
+        sizes = [(f.h, f.w) for f in feats]
+        return self._encode_decode(P, [fill(l) for l in range(6)], sizes, as_feat1(pred1), as_feat1(out_depth),
+                                   update_base, out=out)
+
+    __call__ = forward

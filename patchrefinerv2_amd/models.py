@@ -1,0 +1,411 @@
+"""Frame-level drivers: tiling -> per-patch networks -> overlap blend, all on the device.
+
+Host-side mirrors, registered under the reference ``type`` names:
+  BaselinePretrain   estimator/models/baseline_pretrain.py:45-464 (tile planner, regular/random tile)
+  PatchRefiner       estimator/models/patchrefiner.py:54-404        (V1: DA2 coarse + DA2 per patch + FusionUnet)
+  PatchRefinerPlus   estimator/models/patchrefinerplus.py:60-533    (V2: DA2 coarse + LightWeightRefiner + BiDirectionalFusion)
+Call contract (tester.py:69, patchrefinerplus.py:367-380,526-530):
+  depth, log = model(mode='infer', cai_mode, process_num, tile_cfg, image_lr, image_hr)
+  depth: [1,1,H',W'] fp32 CPU tensor; log['coarse_prediction']: [1,1,ph,pw] device tensor.
+
+What differs from the reference on purpose (results identical):
+  * the complete tile list is drawn up-front (consuming Python's ``random`` in the reference's
+    order) so patches can be batched / sharded freely -- per-patch results do not depend on batching;
+  * the blend state stays on the device (one D2H at the end) instead of a CPU map per tile;
+  * no ``feat.repeat(K)``: ROI gathers read the single coarse pyramid;
+  * no ``torch.cuda.empty_cache()`` per mini-batch.
+"""
+from __future__ import annotations
+
+import random
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .dav2 import DepthAnythingV2, IMAGENET_MEAN, IMAGENET_STD, StateDictModule
+from .fusion import BiDirectionalFusion, FusionUnet
+from .ops import Feat
+from .refiner import LightWeightRefiner
+from .registry import MODELS, ConfigDict, build_model
+
+MODELS.register_module(module=FusionUnet)
+MODELS.register_module(module=BiDirectionalFusion)
+MODELS.register_module(module=LightWeightRefiner)
+
+
+@MODELS.register_module()
+class SILogLoss:  # training-only; constructed by the reference at model init (patchrefinerplus.py:83)
+    def __init__(self, **kw):
+        pass
+
+
+@MODELS.register_module()
+class GradMatchLoss:
+    def __init__(self, **kw):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side pieces of the path: blend mask + resize target (tiny, once per frame / model)
+# ------------------------------------------------------------------------------------------------
+def _gaussian_kernel1d(ksize: int, sigma: float) -> np.ndarray:
+    c = (ksize - 1) * 0.5
+    i = np.arange(ksize, dtype=np.float64)
+    k = np.exp(-((i - c) ** 2) / (2.0 * float(sigma) ** 2))
+    return (k / k.sum()).astype(np.float32)
+
+
+def generatemask(size, border: float = 0.1) -> np.ndarray:
+    """estimator/models/utils.py:51-60 with cv2.GaussianBlur restated in numpy (separable Gaussian,
+    BORDER_REFLECT_101).  Host logic exactly as in the reference (it runs cv2 on the CPU, once per
+    mode per frame); the zero band of the box is wider than the half kernel on every shape of the
+    path, so the border mode never matters."""
+    h, w = int(size[0]), int(size[1])
+    mask = np.zeros((h, w), dtype=np.float32)
+    sigma = int(h / 16)
+    k_size = int(2 * np.ceil(2 * int(h / 16)) + 1)
+    mask[int(border * h): h - int(border * h), int(border * w): w - int(border * w)] = 1
+    k = _gaussian_kernel1d(k_size, sigma)
+    r = k_size // 2
+    pad = np.pad(mask, ((0, 0), (r, r)), mode="reflect")
+    tmp = np.zeros_like(mask)
+    for i in range(k_size):
+        tmp += k[i] * pad[:, i:i + w]
+    pad = np.pad(tmp, ((r, r), (0, 0)), mode="reflect")
+    out = np.zeros_like(mask)
+    for i in range(k_size):
+        out += k[i] * pad[i:i + h, :]
+    out = (out - out.min()) / (out.max() - out.min())
+    return out.astype(np.float32)
+
+
+_MASK_CACHE = {}
+
+
+def blend_mask(size, border, add, device) -> torch.Tensor:
+    key = (int(size[0]), int(size[1]), float(border), float(add), str(device))
+    if key not in _MASK_CACHE:
+        _MASK_CACHE[key] = torch.from_numpy(generatemask(size, border) + np.float32(add)).to(device)
+    return _MASK_CACHE[key]
+
+
+class Resizer:
+    """``model.resizer`` of the reference: ResizeDA (external/depth_anything/transform.py:6-129,
+    keep_aspect_ratio=False, 'minimal', multiple of 14) or ResizeZoe (midas.py:171-174, fixed 384x512),
+    executed by the crop+resize HIP kernel."""
+
+    def __init__(self, width: int, height: int, kind: str = "da"):
+        if kind == "da":
+            self.out_hw = (int(np.round(height / 14) * 14), int(np.round(width / 14) * 14))
+        else:
+            self.out_hw = (384, 512)
+        self.kind = kind
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("Resizer runs on the GPU (HIP crop+resize kernel); move the image to the device")
+        B, _, H, W = x.shape
+        oh, ow = self.out_hw
+        out = Feat.alloc(B, oh, ow, 3, x.device, pad_to=1)
+        zero = torch.zeros((1, 2), dtype=torch.int32, device=x.device)
+        for b in range(B):
+            ops.crop_resize(x[b].contiguous().float(), zero, H, W, oh, ow, None, None, out.batch(b, b + 1))
+        return out.to_nchw()
+
+
+class DeviceRunningAverageMap:
+    """RunningAverageMap (estimator/models/utils.py:22-49) resident in HBM."""
+
+    def __init__(self, h, w, device):
+        self.avg = torch.zeros((h, w), device=device)
+        self.cnt = torch.zeros((h, w), device=device)
+
+    def paste(self, preds, mask, tiles, th, tw):
+        ops.blend_paste(self.avg, self.cnt, preds, mask, tiles, th, tw)
+
+    def update(self, preds, mask, tiles, th, tw):
+        ops.blend_update(self.avg, self.cnt, preds, mask, tiles, th, tw)
+
+    def resize(self, resolution):
+        self.avg, self.cnt = ops.blend_resize(self.avg, self.cnt, int(resolution[0]), int(resolution[1]))
+
+
+def _cfg(config):
+    if isinstance(config, ConfigDict):
+        return config
+    if hasattr(config, "to_dict"):
+        return ConfigDict(config.to_dict())
+    return ConfigDict(dict(config))
+
+
+class _PatchModel(StateDictModule):
+    """Tiling + blending driver shared by PatchRefiner / PatchRefinerPlus (they inherit it from
+    BaselinePretrain in the reference)."""
+
+    crop_channels = 3
+    crop_mean, crop_std = IMAGENET_MEAN, IMAGENET_STD
+
+    # -- BaselinePretrain.prepare_tile_cfg (baseline_pretrain.py:96-124) ---------------------------
+    def prepare_tile_cfg(self, image_raw_shape, patch_split_num):
+        ph, pw = self.patch_process_shape
+        sh, sw = patch_split_num
+        if image_raw_shape[0] % (2 * sh) or image_raw_shape[1] % (2 * sw):
+            # the reference only documents this (docs/user_infer.md:16, asserts commented out)
+            raise ValueError(f"image_raw_shape {list(image_raw_shape)} must be divisible by 2*patch_split_num "
+                             f"{[2 * sh, 2 * sw]}")
+        raw = (image_raw_shape[0] // sh, image_raw_shape[1] // sw)
+        return dict(patch_split_num=list(patch_split_num), patch_reensemble_shape=(ph * sh, pw * sw),
+                    patch_raw_shape=raw, image_raw_shape=list(image_raw_shape),
+                    raw_h_split_point=[int(raw[0] * i) for i in range(sh)],
+                    raw_w_split_point=[int(raw[1] * i) for i in range(sw)])
+
+    # -- tile plan --------------------------------------------------------------------------------
+    def plan_tiles(self, tile_cfg, cai_mode: str, process_num: int):
+        """Every tile of the frame, in the reference's execution order.  Returns a list of passes
+        ``dict(kind, raw=[(h,w)], proc=[(h,w)])``; kind 'init' | 'grid' | 'random'."""
+        H, W = tile_cfg["image_raw_shape"]
+        rh, rw = tile_cfg["patch_raw_shape"]
+        RH, RW = tile_cfg["patch_reensemble_shape"]
+        ph, pw = self.patch_process_shape
+
+        def grid(off, offp):
+            assert off[0] >= 0 and off[1] >= 0
+            hs = [rh * i + off[0] for i in range((H - off[0]) // rh)]
+            ws = [rw * i + off[1] for i in range((W - off[1]) // rw)]
+            hps = [ph * i + offp[0] for i in range((RH - offp[0]) // ph)]
+            wps = [pw * i + offp[1] for i in range((RW - offp[1]) // pw)]
+            return [(h, w) for h in hs for w in ws], [(h, w) for h in hps for w in wps]
+
+        passes = []
+        r, p = grid((0, 0), (0, 0))
+        passes.append(dict(kind="init", raw=r, proc=p))
+        if cai_mode == "m2" or cai_mode[0] == "r":
+            for off, offp in (((0, rw // 2), (0, pw // 2)), ((rh // 2, 0), (ph // 2, 0)),
+                              ((rh // 2, rw // 2), (ph // 2, pw // 2))):
+                r, p = grid(off, offp)
+                passes.append(dict(kind="grid", raw=r, proc=p))
+        elif cai_mode != "m1":
+            raise ValueError(f"unknown cai_mode {cai_mode!r} (expected m1, m2 or r<N>)")
+        if cai_mode[0] == "r":
+            tiles = []
+            for _ in range(int(cai_mode[1:]) // process_num):
+                # baseline_pretrain.py:160-161: process_num h-starts, then ONE w-start, per call
+                hs = [random.randint(0, H - rh - 1) for _ in range(process_num)]
+                ws = random.randint(0, W - rw - 1)
+                tiles += [(h, ws) for h in hs]
+            passes.append(dict(kind="random", raw=tiles, proc=tiles))
+        return passes
+
+    # -- coarse pyramid ROI + crops for a set of tiles ---------------------------------------------
+    def _boxes(self, tiles, tile_cfg) -> np.ndarray:
+        """bboxs * bboxs_feat_factor in float32 (baseline_pretrain.py:289-296)."""
+        H, W = tile_cfg["image_raw_shape"]
+        rh, rw = tile_cfg["patch_raw_shape"]
+        ph, pw = self.patch_process_shape
+        bb = np.array([[w, h, w + rw, h + rh] for h, w in tiles], dtype=np.int32).astype(np.float32)
+        fac = np.array([1 / W * pw, 1 / H * ph, 1 / W * pw, 1 / H * ph], dtype=np.float32)
+        return (bb * fac[None]).astype(np.float32)
+
+    def _prepare_batch(self, image_hr_chw, tiles, tile_cfg, coarse_feats: List[Feat], coarse_depth: Feat):
+        dev = image_hr_chw.device
+        ph, pw = self.patch_process_shape
+        rh, rw = tile_cfg["patch_raw_shape"]
+        K = len(tiles)
+        t = torch.tensor(tiles, dtype=torch.int32).to(dev)
+        crops = Feat.alloc(K, ph, pw, self.crop_channels, dev, pad_to=4)
+        ops.crop_resize(image_hr_chw, t, rh, rw, ph, pw, self.crop_mean, self.crop_std, crops)
+        boxes = torch.from_numpy(self._boxes(tiles, tile_cfg)).to(dev)
+        # roi_align(feat, boxes, (h, w), h / ph, aligned=True) per level (patchrefinerplus.py:268-276)
+        rois = [ops.roi_align(f, boxes, f.h / ph, f.h, f.w) for f in coarse_feats]
+        depth_roi = ops.roi_align(coarse_depth, boxes, coarse_depth.h / ph, coarse_depth.h, coarse_depth.w,
+                                  out=Feat(torch.empty((K, coarse_depth.h, coarse_depth.w, 1), device=dev)))
+        return crops, rois, depth_roi
+
+    # -- forward -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, mode=None, image_lr=None, image_hr=None, crops_image_hr=None, depth_gt=None, crop_depths=None,
+                bboxs=None, tile_cfg=None, cai_mode="m1", process_num=4, select_patch=-1, shard=None,
+                return_device=False, **kwargs):
+        if mode != "infer":
+            raise NotImplementedError("only mode='infer' is built (training is out of scope, SURVEY.md 2 #12-13)")
+        if select_patch != -1:
+            raise NotImplementedError("select_patch (feature visualisation hook) is not on the inference path")
+        tile_cfg = self.tile_cfg if tile_cfg is None else self.prepare_tile_cfg(tile_cfg["image_raw_shape"],
+                                                                              tile_cfg["patch_split_num"])
+        assert image_hr.shape[0] == 1
+        if not (image_lr.is_cuda and image_hr.is_cuda):
+            raise RuntimeError("image_lr / image_hr must be on the GPU (tester.py:43-49 moves them); no CPU path")
+        dev = image_hr.device
+        ph, pw = self.patch_process_shape
+        rh, rw = tile_cfg["patch_raw_shape"]
+        RH, RW = tile_cfg["patch_reensemble_shape"]
+
+        coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
+        coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
+        passes = self.plan_tiles(tile_cfg, cai_mode, process_num)
+        flat = [t for p in passes for t in p["raw"]]
+        self.last_plan = passes
+
+        # ---- per-patch networks over the flat tile list (any batching; optional rank sharding) ----
+        image_chw = image_hr[0].contiguous().float()
+        idx = list(range(len(flat)))
+        if shard is not None:
+            rank, world = shard
+            idx = idx[rank::world]
+        bs = max(1, int(getattr(self, "max_batch", None) or process_num))
+        preds = torch.empty((len(idx), 1, ph, pw), device=dev)  # this rank's predictions, in tile order
+        for s in range(0, len(idx), bs):
+            sel = idx[s:s + bs]
+            crops, rois, depth_roi = self._prepare_batch(image_chw, [flat[i] for i in sel], tile_cfg, coarse_feats,
+                                                         coarse_depth)
+            self.infer_forward(crops, rois, depth_roi, out=preds[s:s + len(sel)])
+        if shard is not None and shard[1] > 1:
+            preds = self._gather_predictions(preds, len(flat), shard)
+        preds = preds.view(len(flat), ph, pw)
+
+        # ---- overlap blend, in the reference's order ----------------------------------------------
+        mask = blend_mask((ph, pw), 0.15, 0.0, dev)
+        ram = DeviceRunningAverageMap(RH, RW, dev)
+        o = 0
+        for p in passes:
+            k = len(p["raw"])
+            pr = preds[o:o + k]
+            o += k
+            if p["kind"] == "init":
+                ram.paste(pr, mask, torch.tensor(p["proc"], dtype=torch.int32).to(dev), ph, pw)
+            elif p["kind"] == "grid":
+                ram.update(pr, mask, torch.tensor(p["proc"], dtype=torch.int32).to(dev), ph, pw)
+            else:
+                mask_r = blend_mask((rh, rw), 0.15, 1e-3, dev)  # generatemask(...) + 1e-3 (patchrefinerplus.py:514)
+                ram.resize(tile_cfg["image_raw_shape"])
+                if k:
+                    ram.update(pr, mask_r, torch.tensor(p["proc"], dtype=torch.int32).to(dev), rh, rw)
+        depth = ram.avg[None, None]
+        if not return_device:
+            depth = depth.cpu()
+        return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+
+    __call__ = forward
+
+    def _gather_predictions(self, preds, n_total, shard):
+        """The path's only exchange step: all-gather (RCCL over xGMI) of the per-rank prediction stacks.
+        Rank r holds tiles r, r+world, ...; the gathered [world, per] stack read column-major is tile order."""
+        import torch.distributed as dist
+        rank, world = shard
+        per = (n_total + world - 1) // world
+        mine = torch.zeros((per,) + tuple(preds.shape[1:]), device=preds.device)
+        mine[:preds.shape[0]] = preds
+        allp = torch.empty((world,) + tuple(mine.shape), device=preds.device)
+        dist.all_gather_into_tensor(allp, mine)
+        return allp.transpose(0, 1).reshape((per * world,) + tuple(preds.shape[1:]))[:n_total].contiguous()
+
+    # -- checkpoint contract (patchrefinerplus.py:212-216) ------------------------------------------
+    def load_dict(self, sd):
+        return self.load_state_dict(sd, strict=False)
+
+    def get_save_dict(self):
+        return self.state_dict()
+
+    def _make_da2(self, branch_cfg, max_depth):
+        mc = dict(branch_cfg["model_cfg"])
+        return DepthAnythingV2(**{**mc, "max_depth": max_depth}, device=self.device, prec=self.prec)
+
+    def _common_init(self, config):
+        config = _cfg(config)
+        self.config = config
+        self.min_depth, self.max_depth = config.min_depth, config.max_depth
+        self.patch_process_shape = tuple(config.patch_process_shape)
+        self.tile_cfg = self.prepare_tile_cfg(config.image_raw_shape, config.patch_split_num)
+        self.prec = ops.L.PREC_NAMES[config.get("prec", "f32")]
+        self.device = torch.device(config.get("device", "cuda"))
+        self.max_batch = config.get("max_batch", None)
+        self.strategy_refiner_target = config.strategy_refiner_target
+        self.fusion_feat_level = config.fusion_feat_level
+        ctype = config.coarse_branch["type"]
+        if ctype == "DA2":
+            self.coarse_branch = self._make_da2(config.coarse_branch, config.max_depth)
+            self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
+        else:
+            raise NotImplementedError(
+                f"coarse_branch type {ctype!r}: the ZoeDepth metric-bins head over the MiDaS DPT-BEiT-L core "
+                "(torch.hub, un-vendored in the reference) is not built yet; use type='DA2'")
+        if self.strategy_refiner_target != "offset_coarse":
+            raise NotImplementedError("strategy_refiner_target: every shipped config uses 'offset_coarse'")
+        return config
+
+    def coarse_forward(self, image_lr):
+        """patchrefinerplus.py:218-237: one backbone forward; pyramid low -> high + metric depth."""
+        out = self.coarse_branch(image_lr, return_final_centers=True)
+        t = out["temp_features"]
+        feats = [t["x_d0"], t["x_blocks_feat_0"], t["x_blocks_feat_1"], t["x_blocks_feat_2"], t["x_blocks_feat_3"],
+                 t["midas_final_feat"]]
+        return feats, out["metric_depth"]
+
+
+@MODELS.register_module()
+class PatchRefiner(_PatchModel):
+    """V1 (estimator/models/patchrefiner.py:54)."""
+
+    def __init__(self, config):
+        super().__init__()
+        config = self._common_init(config)
+        fb = config.refiner.fine_branch
+        if fb["type"] != "DA2":
+            raise NotImplementedError("refiner fine_branch type must be 'DA2' (ZoeDepth core un-vendored)")
+        self.refiner_fine_branch = self._make_da2(fb, config.max_depth)
+        self.refiner_fusion_model = build_model({**config.refiner.fusion_model.to_dict(), "device": self.device,
+                                                 "prec": self.prec})
+        self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
+                              refiner_fusion_model=self.refiner_fusion_model)
+
+    def _pack(self):
+        pass
+
+    def get_save_dict(self):  # patchrefiner.py:158-166: the coarse branch is not saved
+        return {k: v for k, v in self.state_dict().items() if "coarse_branch." not in k}
+
+    def infer_forward(self, crops: Feat, rois: List[Feat], depth_roi: Feat, out=None):
+        """patchrefiner.py:258-283."""
+        fine = self.refiner_fine_branch.forward_nhwc(crops)
+        t = fine["temp_features"]
+        r_feats = [t["x_d0"], t["x_blocks_feat_0"], t["x_blocks_feat_1"], t["x_blocks_feat_2"], t["x_blocks_feat_3"],
+                   t["midas_final_feat"]]
+        n = self.fusion_feat_level
+        base = depth_roi.buf.view(depth_roi.n, 1, depth_roi.h, depth_roi.w)
+        return self.refiner_fusion_model(c_feat=rois[-n:][::-1], f_feat=r_feats[-n:][::-1], pred1=base,
+                                         pred2=fine["metric_depth"], update_base=base, out=out)
+
+
+@MODELS.register_module()
+class PatchRefinerPlus(_PatchModel):
+    """V2 (estimator/models/patchrefinerplus.py:60)."""
+
+    crop_channels = 4
+
+    def __init__(self, config):
+        super().__init__()
+        config = self._common_init(config)
+        if config.get("pretrain_stage", False):
+            raise NotImplementedError("pretrain_stage=True is a training configuration")
+        self.refiner_fine_branch = build_model({**config.refiner.fine_branch.to_dict(), "device": self.device,
+                                                "prec": self.prec})
+        self.refiner_fusion_model = build_model({**config.refiner.fusion_model.to_dict(), "device": self.device,
+                                                 "prec": self.prec})
+        self.crop_mean, self.crop_std = self.refiner_fine_branch.mean, self.refiner_fine_branch.std
+        self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
+                              refiner_fusion_model=self.refiner_fusion_model)
+
+    def _pack(self):
+        pass
+
+    def infer_forward(self, crops: Feat, rois: List[Feat], depth_roi: Feat, out=None):
+        """patchrefinerplus.py:330-365: encoder on [norm(rgb), coarse depth roi] then BiDirectionalFusion."""
+        ops.upsample_bilinear(depth_roi, crops.h, crops.w, out=crops.slice(3, 1))  # 4th input channel (exact copy)
+        f_feat, f_sizes = self.refiner_fine_branch(crops)
+        n = self.fusion_feat_level
+        base = depth_roi.buf.view(depth_roi.n, 1, depth_roi.h, depth_roi.w)
+        zeros = torch.zeros_like(base)  # out_depth = zeros (lightweight_refiner.py:320); replaced by c2f's output
+        return self.refiner_fusion_model(c_feat=rois[-n:][::-1], f_feat=f_feat, pred1=base, pred2=zeros,
+                                         update_base=base, f_sizes=f_sizes, out=out)

@@ -175,9 +175,11 @@ def linear(x2d: torch.Tensor, cw: ConvW, out: Optional[torch.Tensor] = None, **k
 
 
 def conv2d_cout1(x: Feat, weight: torch.Tensor, bias: Optional[torch.Tensor], k: int, *, act: int = ACT_NONE,
-                 scale: float = 1.0, res: Optional[torch.Tensor] = None, clamp0: bool = False) -> torch.Tensor:
+                 scale: float = 1.0, res: Optional[torch.Tensor] = None, clamp0: bool = False,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Single-output-channel conv -> dense [n, 1, h, w] tensor (NCHW == NHWC for one channel)."""
-    y = torch.empty((x.n, 1, x.h, x.w), device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty((x.n, 1, x.h, x.w), device=x.device, dtype=torch.float32)
+    assert y.is_contiguous() and y.numel() == x.n * x.h * x.w
     L.check(L.load().prv2_conv2d_cout1(x.ptr, x.n, x.h, x.w, x.c, x.ld, weight.data_ptr(), k, _ptr(bias), act, scale,
                                        _ptr(res), int(clamp0), y.data_ptr(), _stream()), "conv2d_cout1")
     return y

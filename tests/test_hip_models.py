@@ -1,0 +1,188 @@
+"""GPU parity of the assembled networks and the frame drivers against the oracle and the golden
+vectors generated from the reference (tests/golden).  Tolerance: the north star's per-pixel
+AbsRel <= 1e-4 (fp32 MFMA path is ~1e-6)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dav2 as o_dav2, fusion as o_fusion, mnv4 as o_mnv4, tiling as o_tiling  # noqa: E402
+from oracle.cases import (E2E_V1, E2E_V2, TINY_BIDIR, TINY_DAV2, TINY_FUSION_UNET, e2e_v1_sd, e2e_v2_sd, rand_image,  # noqa: E402
+                          tiny_dav2_sd)
+from patchrefinerv2_amd import weights as W  # noqa: E402
+
+DEV = "cuda"
+ABSREL_TOL = 1e-4
+torch.set_grad_enabled(False)
+
+
+def absrel(out, ref, min_depth=1e-3):
+    out, ref = out.detach().cpu().double(), torch.as_tensor(ref).double()
+    m = ref > min_depth
+    return float(((out - ref).abs()[m] / ref[m]).mean()), float((out - ref).abs().max())
+
+
+def close(got, ref, tol=2e-5, what=""):
+    got, ref = got.detach().cpu(), torch.as_tensor(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = float((got - ref).abs().max())
+    assert err <= tol * max(1.0, float(ref.abs().max())), f"{what}: max|d| {err:.3e}"
+
+
+@pytest.fixture(scope="module")
+def P():
+    from patchrefinerv2_amd import ops
+    ops.L.load()
+    return ops
+
+
+def test_dav2_tiny(P, golden):
+    from patchrefinerv2_amd.dav2 import DepthAnythingV2
+    g = golden("dav2_tiny")
+    sd = tiny_dav2_sd()
+    m = DepthAnythingV2(**TINY_DAV2["model_cfg"])
+    m.load_state_dict(sd, strict=True)
+    cfg = W.dav2_cfg(TINY_DAV2["model_cfg"])
+    for tag, (h, w) in TINY_DAV2["inputs"].items():
+        x = rand_image(TINY_DAV2["seed"], 2, h, w)
+        out = m(x.to(DEV), return_final_centers=True)
+        ref = o_dav2.dav2_forward(sd, "", x, cfg)
+        close(out["metric_depth"], g[f"{tag}_depth"], 2e-5, f"{tag} depth vs golden")
+        for k, v in ref["temp_features"].items():
+            close(out["temp_features"][k].to_nchw(), v, 2e-5, f"{tag} {k}")
+        ar, _ = absrel(out["metric_depth"], ref["metric_depth"])
+        assert ar < ABSREL_TOL
+
+
+def test_dav2_vits_block_stack(P):
+    """real-width ViT-S (D=384, 6 heads) x 3 blocks + DPT head at 448x448 (1025 tokens)."""
+    from patchrefinerv2_amd.dav2 import DepthAnythingV2
+    mc = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], max_depth=80.0,
+              vit=dict(depth=4, taps=[0, 1, 2, 3]))
+    sd = W.synth_state_dict(W.dav2_spec("", mc), seed=5)
+    m = DepthAnythingV2(**mc)
+    m.load_state_dict(sd)
+    x = rand_image(3, 1, 448, 448)
+    out = m(x.to(DEV))
+    ref = o_dav2.dav2_forward(sd, "", x, W.dav2_cfg(mc))
+    ar, mx = absrel(out["metric_depth"], ref["metric_depth"])
+    assert ar < 1e-5, (ar, mx)
+    close(out["temp_features"]["x_blocks_feat_3"].to_nchw(), ref["temp_features"]["x_blocks_feat_3"], 5e-5)
+
+
+def test_fusion_unet(P, golden):
+    from patchrefinerv2_amd.fusion import FusionUnet
+    c = TINY_FUSION_UNET
+    sd = W.synth_state_dict(W.fusion_unet_spec("", c["input_chl"], c["temp_chl"], c["dec_chl"]), seed=c["seed"])
+    m = FusionUnet(c["input_chl"], c["temp_chl"], c["dec_chl"])
+    m.load_state_dict(sd)
+    i = c["make_inputs"]()
+    f = lambda ts: [P.Feat.from_nchw(t.to(DEV)) for t in ts]  # noqa: E731
+    out = m(f(i["c_feat"]), f(i["f_feat"]), i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV))
+    close(out, golden("fusion_unet")["out"], 2e-5)
+
+
+def test_bidir_fusion(P, golden):
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    c = TINY_BIDIR
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"],
+                                                c["dec_chl"]), seed=c["seed"])
+    m = BiDirectionalFusion(coarse2fine_type="coarse-gated", coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                            fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"])
+    m.load_state_dict(sd)
+    g = golden("bidir_fusion")
+    for tag in ("same", "resized"):
+        i = c["make_inputs"](tag)
+        f = lambda ts: [P.Feat.from_nchw(t.to(DEV)) for t in ts]  # noqa: E731
+        ff = f(i["f_feat"])
+        out = m(f(i["c_feat"]), [None] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV),
+                f_sizes=[(t.shape[-2], t.shape[-1]) for t in i["f_feat"]])
+        close(out, g[tag], 3e-5, tag)
+
+
+def test_lightweight_refiner(P):
+    from patchrefinerv2_amd.refiner import LightWeightRefiner
+    sd = W.synth_state_dict(W.mnv4_spec("refiner_encoder.", in_chans=4), seed=9)
+    m = LightWeightRefiner("mobilenetv4_conv_small.e2400_r224_in1k", coarse_condition=True)
+    m.load_state_dict(sd)
+    img = rand_image(2, 2, 96, 128)
+    depth = torch.rand(2, 1, 96, 128, generator=torch.Generator().manual_seed(3)) * 40
+    ref_feats, _ = o_mnv4.lightweight_refiner(sd, "", img, depth)  # low -> high, 2x copy last
+    mean = torch.tensor(W.MNV4_SMALL["mean"]).view(1, 3, 1, 1)
+    std = torch.tensor(W.MNV4_SMALL["std"]).view(1, 3, 1, 1)
+    x4 = torch.cat([(img - mean) / std, depth], dim=1)
+    feats, sizes = m(P.Feat.from_nchw(x4.to(DEV)))
+    assert feats[0] is None and sizes[0] == tuple(ref_feats[-1].shape[-2:])
+    for got, ref in zip(feats[1:], ref_feats[::-1][1:]):
+        close(got.to_nchw(), ref, 3e-5, f"mnv4 {tuple(ref.shape)}")
+
+
+def _build(kind, c, sd, **extra):
+    from patchrefinerv2_amd.models import PatchRefiner, PatchRefinerPlus  # noqa: F401
+    from patchrefinerv2_amd.registry import build_model
+    cfg = dict(c["ref_config"])
+    for br in ("coarse_branch",):
+        cfg[br] = dict(type="DA2", pretrained=None, model_cfg={**c["da2_cfg"]})
+    if kind == "PatchRefiner":
+        cfg["refiner"] = dict(cfg["refiner"])
+        cfg["refiner"]["fine_branch"] = dict(type="DA2", pretrained=None, model_cfg={**c["da2_cfg"]})
+    cfg.update(extra)
+    m = build_model(dict(type=kind, config=cfg))
+    res = m.load_state_dict(sd, strict=True)
+    assert not res["missing_keys"] and not res["unexpected_keys"]
+    return m
+
+
+def _run(m, c, mode, **kw):
+    image_hr = rand_image(c["seed"], 1, *c["raw"]).to(DEV)
+    image_lr = m.resizer(image_hr)
+    random.seed(621)
+    return m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=dict(image_raw_shape=c["raw"], patch_split_num=c["split"]),
+             image_lr=image_lr, image_hr=image_hr, **kw)
+
+
+def test_e2e_v1_vs_reference_golden(P, golden):
+    c, g = E2E_V1, golden("e2e_v1")
+    m = _build("PatchRefiner", c, e2e_v1_sd())
+    for mode in c["modes"]:
+        depth, log = _run(m, c, mode)
+        assert not depth.is_cuda and log["coarse_prediction"].is_cuda
+        assert tuple(depth.shape) == tuple(g[mode].shape)
+        ar, mx = absrel(depth, g[mode])
+        assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)
+        close(log["coarse_prediction"], g[mode + "_coarse"], 2e-5)
+
+
+def test_e2e_v2_vs_reference_golden(P, golden):
+    c, g = E2E_V2, golden("e2e_v2")
+    m = _build("PatchRefinerPlus", c, e2e_v2_sd())
+    for mode in c["modes"]:
+        depth, _ = _run(m, c, mode)
+        assert tuple(depth.shape) == tuple(g[mode].shape)
+        ar, mx = absrel(depth, g[mode])
+        assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)
+
+
+def test_batching_independence(P):
+    """per-patch results do not depend on the mini-batch size (the licence for large batches)."""
+    c = E2E_V1
+    m = _build("PatchRefiner", c, e2e_v1_sd())
+    a, _ = _run(m, c, "r8")
+    m.max_batch = 7
+    b, _ = _run(m, c, "r8")
+    assert torch.equal(a, b)
+
+
+def test_rejects_cpu_inputs_and_bad_shapes(P):
+    c = E2E_V1
+    m = _build("PatchRefiner", c, e2e_v1_sd())
+    hr = rand_image(0, 1, *c["raw"])
+    with pytest.raises(RuntimeError):
+        m(mode="infer", cai_mode="m1", image_lr=hr[:, :, :56, :84], image_hr=hr)
+    with pytest.raises(ValueError):
+        m.prepare_tile_cfg([217, 384], [2, 2])
+    with pytest.raises(ValueError):
+        _run(m, c, "x3")

@@ -1,0 +1,89 @@
+"""CPU: host-side logic of the product (tile planner, boxes, mask, config/registry) against the
+golden vectors captured from the reference -- no GPU, no oracle in the product path."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from patchrefinerv2_amd import models as M
+from patchrefinerv2_amd.registry import MODELS, Config, ConfigDict, build_model
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class _Planner(M._PatchModel):
+    def __init__(self, pps):
+        super().__init__()
+        self.patch_process_shape = tuple(pps)
+
+    def _pack(self):
+        pass
+
+
+def test_tile_plans_match_reference():
+    g = np.load(os.path.join(GOLD, "tiling.npz"))
+    plans = json.load(open(os.path.join(GOLD, "tile_plans.json")))
+    for name, p in plans.items():
+        pl = _Planner(p["pps"])
+        tc = pl.prepare_tile_cfg(p["raw"], p["split"])
+        random.seed(621)
+        passes = pl.plan_tiles(tc, p["mode"], 4)
+        flat = [t for ps in passes for t in ps["raw"]]
+        assert len(flat) == p["n"]
+        rh, rw = tc["patch_raw_shape"]
+        bb = np.array([[w, h, w + rw, h + rh] for h, w in flat], dtype=np.int32)
+        assert np.array_equal(bb, g[f"plan_{name}_bboxs"])
+        assert np.array_equal(pl._boxes(flat, tc), g[f"plan_{name}_bboxs_feat"][:, 1:])
+
+
+def test_patch_counts():
+    pl = _Planner((384, 512))
+    tc = pl.prepare_tile_cfg([2160, 3840], [4, 4])
+    for mode, n in (("m1", 16), ("m2", 49), ("r32", 81), ("r64", 113), ("r128", 177)):
+        assert sum(len(p["raw"]) for p in pl.plan_tiles(tc, mode, 4)) == n
+    assert tc["patch_reensemble_shape"] == (1536, 2048) and tc["patch_raw_shape"] == (540, 960)
+
+
+def test_blend_mask_matches_reference_statistics():
+    g = np.load(os.path.join(GOLD, "tiling.npz"))
+    for (h, w) in ((384, 512), (448, 448), (540, 960)):
+        mk = M.generatemask((h, w), border=0.15)
+        np.testing.assert_allclose(mk.sum(axis=1), g[f"mask_{h}x{w}_rowsum"], rtol=2e-6, atol=1e-5)
+        assert int((mk == 0).sum()) == int(g[f"mask_{h}x{w}_zeros"][0])
+
+
+def test_registry_and_config(tmp_path):
+    for t in ("PatchRefiner", "PatchRefinerPlus", "FusionUnet", "BiDirectionalFusion", "LightWeightRefiner", "SILogLoss"):
+        assert t in MODELS
+    with pytest.raises(KeyError):
+        build_model(dict(type="NoSuchModel"))
+    (tmp_path / "base.py").write_text("min_depth=1e-3\nmodel=dict(type='FusionUnet', input_chl=[8, 8], temp_chl=[4, 4], dec_chl=[4])\n")
+    (tmp_path / "cfg.py").write_text("_base_=['base.py']\nmodel=dict(dec_chl=[8])\nextra=3\n")
+    cfg = Config.fromfile(str(tmp_path / "cfg.py"))
+    assert cfg.model.type == "FusionUnet" and cfg.model.dec_chl == [8] and cfg.min_depth == 1e-3 and cfg.extra == 3
+    cfg.merge_from_dict({"model.temp_chl": [2, 2]})
+    assert cfg.model.temp_chl == [2, 2]
+    m = build_model(cfg.model)
+    assert list(m.spec())[0] == "encoder_layers_1.0.single_conv.0.weight"
+    assert isinstance(ConfigDict(a=dict(b=1)).a, ConfigDict)
+
+
+def test_state_dict_contract_and_loud_failures():
+    from oracle.cases import E2E_V2, e2e_v2_sd
+    cfg = dict(E2E_V2["ref_config"])
+    cfg["coarse_branch"] = dict(type="DA2", pretrained=None, model_cfg=dict(E2E_V2["da2_cfg"]))
+    m = build_model(dict(type="PatchRefinerPlus", config=cfg))
+    spec = m.spec()
+    assert set(spec) == set(e2e_v2_sd().keys())
+    assert "refiner_fine_branch.refiner_encoder.conv_stem.weight" in spec and spec[
+        "refiner_fine_branch.refiner_encoder.conv_stem.weight"] == (32, 4, 3, 3)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"bogus": 0}, strict=True)
+    with pytest.raises(NotImplementedError):
+        m(mode="train")
+    bad = dict(cfg)
+    bad["coarse_branch"] = dict(type="ZoeDepth")
+    with pytest.raises(NotImplementedError):
+        build_model(dict(type="PatchRefinerPlus", config=bad))
