@@ -24,7 +24,7 @@ def randn(seed: int, *shape) -> torch.Tensor:
 # -- tiny DepthAnythingV2: patch 14, pos-embed grid 5x5 (img 70), D 64, 4 blocks, 2 heads --------
 TINY_DAV2 = dict(
     model_cfg=dict(encoder="vits", features=32, out_channels=[16, 32, 64, 64], max_depth=20.0,
-                   vit=dict(dim=64, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70)),
+                   vit=dict(dim=128, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70)),
     seed=1,
     inputs=dict(rect=(56, 84), square=(70, 70), big=(112, 98)),
 )
@@ -70,7 +70,7 @@ TINY_BIDIR = dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64
 
 # -- end-to-end V1: PatchRefiner(DA2 tiny x2 + FusionUnet), 216x384 frame, 2x2 -------------------
 _E2E_DA2 = dict(encoder="vits", features=32, out_channels=[16, 32, 64, 64],
-                vit=dict(dim=64, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))
+                vit=dict(dim=128, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))
 E2E_V1 = dict(
     raw=[216, 384], split=[2, 2], pps=[56, 84], max_depth=80.0, seed=0, modes=["m1", "m2", "r8"],
     da2_cfg=_E2E_DA2,
@@ -99,7 +99,7 @@ def e2e_v1_sd(seed: int = 41):
 # differs (bi_directional_fusion_model.py:389-393); P must make (P/28) != ceil(P/32) on one axis
 # (true for the real 448x448 config: 16 vs 14), otherwise torch.cat fails at a middle level.
 _E2E2_DA2 = dict(encoder="vits", features=256, out_channels=[16, 32, 64, 64],
-                 vit=dict(dim=64, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))
+                 vit=dict(dim=128, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))
 E2E_V2 = dict(
     raw=[256, 512], split=[2, 2], pps=[112, 224], max_depth=80.0, seed=0, modes=["m1", "r4"],
     da2_cfg=_E2E2_DA2,

@@ -120,6 +120,9 @@ class DepthAnythingV2(StateDictModule):
             raise NotImplementedError("use_bn / use_clstoken are never set on the inference path")
         self.cfg = W.dav2_cfg(dict(encoder=encoder, features=features, out_channels=list(out_channels),
                                    max_depth=max_depth, vit=vit or {}))
+        if self.cfg["vit"]["dim"] != 64 * self.cfg["vit"]["heads"]:
+            raise NotImplementedError("the attention kernel is built for head_dim 64 (every DINOv2 size: "
+                                      "384/6, 768/12, 1024/16)")
         self.max_depth = float(max_depth)
         self.encoder = encoder
         self.device = torch.device(device)
