@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: 4K depth maps/sec in cai-mode r32 on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one 4K frame through the whole hot path: coarse forward -> 81 tiles (crop+resize,
+ROI pyramid gather, refiner encoder, BiDirectionalFusion) -> overlap blend -> depth map returned
+exactly as the reference returns it (CPU tensor).  Inputs (image_hr, image_lr) are resident in HBM
+when the timed region starts.  Synthetic frames (torch.rand, seeded) and synthetic weights
+(numpy PCG64 keyed by parameter name): the reference ships neither checkpoints nor images.
+
+Multi-GPU (one process per GPU): ``--shard frames`` (default) = the reference's own data
+parallelism, frame f -> rank f mod N, no data-path collective, weak scaling;
+``--shard patches`` = tiles of ONE frame sharded over the ranks + one RCCL all-gather of the
+per-tile predictions (strong scaling).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` (dominant kernel,
+HIP-event timed on its launch stream) and ``cpu_baseline`` (the oracle restatement on host cores,
+bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--prec", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--shard", default="frames", choices=["frames", "patches"])
+    ap.add_argument("--max-batch", type=int, default=8, help="patches per launch batch (results are batch independent)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(name, sd, frame_seed):
+    """Oracle (fp32 PyTorch restatement of the reference graph) on the host cores, bounded sample:
+    one coarse forward + ONE tile through the per-patch path, extrapolated by the exact tile count."""
+    from oracle import tiling as o_tiling
+    from patchrefinerv2_amd import weights as W
+    from patchrefinerv2_amd.workloads import WORKLOADS
+    w = WORKLOADS[name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd_cpu = {k: v.float() for k, v in sd.items()}
+    ccfg = W.dav2_cfg({**w["coarse"], "max_depth": 80.0})
+    kw = dict(patch_process_shape=w["pps"], image_raw_shape=w["raw"], patch_split_num=w["split"])
+    if w["kind"] == "PatchRefinerPlus":
+        m = o_tiling.OraclePatchRefinerPlus(sd_cpu, ccfg, **kw)
+    else:
+        m = o_tiling.OraclePatchRefiner(sd_cpu, ccfg, W.dav2_cfg({**w["fine"], "max_depth": 80.0}), **kw)
+    image_hr = torch.rand(1, 3, *w["raw"], generator=torch.Generator().manual_seed(frame_seed))
+    image_lr = m.resizer(image_hr)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feats, pred = m.coarse_forward(image_lr)
+        t_coarse = time.perf_counter() - t0
+        rh, rw = m.tile_cfg["patch_raw_shape"]
+        t0 = time.perf_counter()
+        crops, bboxs = m._crops(image_hr[0], [0], [0], rh, rw)
+        bf = o_tiling.bboxs_to_feat(bboxs, w["raw"], w["pps"])
+        post = o_tiling.coarse_postprocess_test(pred, feats, bf, w["pps"][0])
+        m.infer_forward(crops, post)
+        t_patch = time.perf_counter() - t0
+    t_frame = t_coarse + w["patches"] * t_patch
+    return dict(value=1.0 / t_frame, unit="depth maps/s", cores=cores, kind="port",
+                sample=f"1 coarse forward ({t_coarse:.1f} s) + 1 of {w['patches']} tiles through crop/ROI/encoder/fusion "
+                       f"({t_patch:.1f} s), extrapolated to the frame ({t_frame:.0f} s); blend excluded (<1%)")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from patchrefinerv2_amd import ops, weights as W
+    from patchrefinerv2_amd.registry import build_model
+    from patchrefinerv2_amd import models  # noqa: F401  (registers the model types)
+    from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD, WORKLOADS, model_config, state_spec
+
+    name = args.workload or DEFAULT_WORKLOAD
+    w = WORKLOADS[name]
+    mc = model_config(name, prec=args.prec, max_batch=args.max_batch)
+    mc["config"]["device"] = str(dev)
+    model = build_model(mc)
+    sd = W.synth_state_dict(state_spec(name), seed=0)
+    model.load_state_dict(sd, strict=True)
+
+    tile_cfg = dict(image_raw_shape=w["raw"], patch_split_num=w["split"])
+    n_frames = args.steps + args.warmup
+    shard = (rank, world) if (world > 1 and args.shard == "patches") else None
+
+    def frame(i):
+        seed = i if shard is not None else rank * 100003 + i
+        hr = torch.rand(1, 3, *w["raw"], generator=torch.Generator().manual_seed(seed)).to(dev)
+        return hr, model.resizer(hr)
+
+    frames = [frame(i) for i in range(min(n_frames, 2))]  # resident inputs (2 alternating frames)
+
+    def step(i):
+        hr, lr = frames[i % len(frames)]
+        random.seed(621)
+        depth, _ = model(mode="infer", cai_mode=w["mode"], process_num=4, tile_cfg=tile_cfg, image_lr=lr, image_hr=hr,
+                         shard=shard)
+        return depth
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_done = args.steps * (world if shard is None else 1)
+
+    result = dict(
+        metric="4K depth maps/sec (cai-mode r32)" if w["mode"] == "r32" else f"depth maps/sec (cai-mode {w['mode']})",
+        value=frames_done / elapsed, unit="depth maps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+        ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak" if shard is None else "strong",
+        vs_baseline=None, dtype=args.prec, data="synthetic",
+        config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
+                    patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
+                    coarse_branch=w["coarse"]["encoder"], shard=args.shard if world > 1 else "none",
+                    max_batch=args.max_batch, out_shape=list(out.shape)))
+
+    if rank == 0 and not args.no_roofline:
+        # one extra, instrumented frame: HIP events on the launch stream around every matrix-kernel launch
+        ops.PROFILER.start(timed=True)
+        step(0)
+        torch.cuda.synchronize()
+        ops.PROFILER.stop()
+        summ = ops.PROFILER.summary()
+        tot_ms = sum(d["ms"] for d in summ.values())
+        dom = max(summ, key=lambda k: summ[k]["ms"])
+        d = summ[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        peak = PEAK[args.prec]
+        result["roofline"] = dict(
+            bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
+            launches_per_frame=d["launches"], avg_launch_ms=d["ms"] / d["launches"],
+            algorithmic_gflop_per_launch=d["flops"] / d["launches"] / 1e9,
+            frame_algorithmic_tflop=sum(x["flops"] for x in summ.values()) / 1e12,
+            matrix_kernel_ms_per_frame=tot_ms,
+            kernels={k: dict(launches=v["launches"], ms=round(v["ms"], 3), tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12
+                                                                                  if v["ms"] > 0 else None))
+                     for k, v in summ.items()})
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(name, sd, 0)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,50 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Profiler:
+    """Optional per-launch accounting for bench.py: algorithmic FLOPs (2*MAC) and, when ``timed``,
+    HIP events recorded on the launch stream around each matrix-kernel launch."""
+
+    def __init__(self):
+        self.enabled = False
+        self.timed = False
+        self.records = []  # (kernel tag, algorithmic flops, start event, end event)
+
+    def start(self, timed=False):
+        self.enabled, self.timed, self.records = True, timed, []
+
+    def stop(self):
+        self.enabled = False
+        return self.records
+
+    def launch(self, tag, flops, fn):
+        if not self.enabled:
+            return fn()
+        if self.timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            self.records.append((tag, flops, e0, e1))
+        else:
+            fn()
+            self.records.append((tag, flops, None, None))
+
+    def summary(self):
+        """{tag: dict(launches, flops, ms)} (call after torch.cuda.synchronize())."""
+        out = {}
+        for tag, fl, e0, e1 in self.records:
+            d = out.setdefault(tag, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            if e0 is not None:
+                d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILER = Profiler()
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -154,8 +198,12 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     for aux in (mul, res, res2):
         if aux is not None:
             assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
-    L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma), _ptr(mul), _ptr(res),
-                                 _ptr(res2), out.ptr, _stream()), "conv2d")
+    ncols = cw.cout * (cw.convt_k ** 2 if cw.convt_k else 1)
+    taps = 1 if cw.convt_k else cw.kh * cw.kw
+    m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
+    PROFILER.launch("igemm_kernel<128>" if ncols > 64 else "igemm_kernel<64>", 2.0 * m_rows * ncols * cw.cin * taps,
+                    lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma),
+                                                         _ptr(mul), _ptr(res), _ptr(res2), out.ptr, _stream()), "conv2d"))
     return out
 
 
@@ -180,8 +228,10 @@ def conv2d_cout1(x: Feat, weight: torch.Tensor, bias: Optional[torch.Tensor], k:
     """Single-output-channel conv -> dense [n, 1, h, w] tensor (NCHW == NHWC for one channel)."""
     y = out if out is not None else torch.empty((x.n, 1, x.h, x.w), device=x.device, dtype=torch.float32)
     assert y.is_contiguous() and y.numel() == x.n * x.h * x.w
-    L.check(L.load().prv2_conv2d_cout1(x.ptr, x.n, x.h, x.w, x.c, x.ld, weight.data_ptr(), k, _ptr(bias), act, scale,
-                                       _ptr(res), int(clamp0), y.data_ptr(), _stream()), "conv2d_cout1")
+    PROFILER.launch("conv_cout1_kernel", 2.0 * x.n * x.h * x.w * x.c * k * k,
+                    lambda: L.check(L.load().prv2_conv2d_cout1(x.ptr, x.n, x.h, x.w, x.c, x.ld, weight.data_ptr(), k,
+                                                               _ptr(bias), act, scale, _ptr(res), int(clamp0),
+                                                               y.data_ptr(), _stream()), "conv2d_cout1"))
     return y
 
 
@@ -189,8 +239,10 @@ def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k:
     oh = (x.h + 2 * (k // 2) - k) // stride + 1
     ow = (x.w + 2 * (k // 2) - k) // stride + 1
     out = Feat.alloc(x.n, oh, ow, x.c, x.device)
-    L.check(L.load().prv2_dwconv2d(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(), _ptr(bias), k, stride,
-                                   int(relu), out.ptr, out.ld, _stream()), "dwconv2d")
+    PROFILER.launch("dwconv_kernel", 2.0 * x.n * oh * ow * x.c * k * k,
+                    lambda: L.check(L.load().prv2_dwconv2d(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(),
+                                                           _ptr(bias), k, stride, int(relu), out.ptr, out.ld, _stream()),
+                                    "dwconv2d"))
     return out
 
 
@@ -225,7 +277,9 @@ def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: 
 
 def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32) -> torch.Tensor:
     out = torch.empty((b * ntok, heads * 64), device=qkv.device, dtype=torch.float32)
-    L.check(L.load().prv2_attention(qkv.data_ptr(), b, ntok, heads, 64, out.data_ptr(), prec, _stream()), "attention")
+    PROFILER.launch("attention_f32_kernel", 4.0 * b * heads * ntok * ntok * 64,
+                    lambda: L.check(L.load().prv2_attention(qkv.data_ptr(), b, ntok, heads, 64, out.data_ptr(), prec,
+                                                            _stream()), "attention"))
     return out
 
 

@@ -1,0 +1,76 @@
+"""Named full-size workloads (BASELINE.json configs made concrete) + algorithmic
+FLOP accounting (2*MAC over conv / linear / attention matmuls, what torch's FlopCounterMode reports).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+from . import weights as W
+
+DA2_L = dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024])
+DA2_S = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384])
+
+BIDIR_DAV2 = dict(coarse_chl=[128, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64, 96, 960],
+                  fine_chl_after_coarse2fine=[128, 256, 256, 256, 256, 256], temp_chl=[32, 64, 64, 128, 256, 512],
+                  dec_chl=[512, 256, 128, 64, 32])
+
+WORKLOADS = {
+    # configs/patchrefinerv2_dav2/plus_mobile_u4k_base_coarse_e2e_c2f_pretrain.py at 4K 4x4 r32:
+    # the V2 model (MNv4-S refiner + BiDirectionalFusion) over the fully vendored DAv2 ViT-L coarse
+    # branch -- BASELINE config[2]'s shape (4K, 4x4, r32, 81 patches) with config[3]'s backbone.
+    "v2_dav2l_4k_r32": dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[448, 448], mode="r32",
+                            coarse=DA2_L, fusion=BIDIR_DAV2, patches=81),
+    "v2_dav2l_4k_r64": dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[448, 448], mode="r64",
+                            coarse=DA2_L, fusion=BIDIR_DAV2, patches=113),
+    "v2_dav2l_4k_r128": dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[448, 448], mode="r128",
+                             coarse=DA2_L, fusion=BIDIR_DAV2, patches=177),
+    # BASELINE config[1]: DAv2 ViT-S, 1080x1920, 2x2, m1 -> V1 PatchRefiner
+    "v1_dav2s_1080p_m1": dict(kind="PatchRefiner", raw=[1080, 1920], split=[2, 2], pps=[448, 448], mode="m1",
+                              coarse=DA2_S, fine=DA2_S,
+                              fusion=dict(input_chl=[64, 128, 128, 128, 128, 128], temp_chl=[32, 64, 64, 64, 64, 64],
+                                          dec_chl=[64, 64, 64, 64, 32]), patches=4),
+    # configs/patchrefiner_dav2/pr_u4k.py: V1 with ViT-L on every patch (the ViT-block-heavy variant)
+    "v1_dav2l_4k_r32": dict(kind="PatchRefiner", raw=[2160, 3840], split=[4, 4], pps=[448, 448], mode="r32",
+                            coarse=DA2_L, fine=DA2_L,
+                            fusion=dict(input_chl=[256, 512, 512, 512, 512, 512], temp_chl=[128, 256, 256, 256, 256, 256],
+                                        dec_chl=[256, 256, 256, 256, 128]), patches=81),
+}
+DEFAULT_WORKLOAD = "v2_dav2l_4k_r32"
+
+
+def model_config(name: str, prec: str = "f32", max_batch=None) -> dict:
+    w = WORKLOADS[name]
+    raw, split = w["raw"], w["split"]
+    cfg = dict(
+        image_raw_shape=raw, patch_process_shape=w["pps"], patch_raw_shape=[raw[0] // split[0], raw[1] // split[1]],
+        patch_split_num=split, fusion_feat_level=6, min_depth=1e-3, max_depth=80.0, pretrain_coarse_model=None,
+        strategy_refiner_target="offset_coarse", coarse_branch=dict(type="DA2", pretrained=None, model_cfg=w["coarse"]),
+        sigloss=dict(type="SILogLoss"), pretrained=None, pre_norm_bbox=True, prec=prec, max_batch=max_batch)
+    if w["kind"] == "PatchRefinerPlus":
+        cfg.update(e2e_training=True, pretrain_stage=False, gmloss=dict(type="GradMatchLoss"), sigweight=1,
+                   whole_pretrained=None,
+                   refiner=dict(fine_branch=dict(type="LightWeightRefiner", coarse_condition=True, with_decoder=False,
+                                                 encoder_name="mobilenetv4_conv_small.e2400_r224_in1k"),
+                                fusion_model=dict(type="BiDirectionalFusion",
+                                                  encoder_name="mobilenetv4_conv_small.e2400_r224_in1k",
+                                                  coarse2fine=True, coarse2fine_type="coarse-gated", **w["fusion"])))
+    else:
+        cfg.update(pretrain_fine_model=None,
+                   refiner=dict(fine_branch=dict(type="DA2", pretrained=None, model_cfg=w["fine"]),
+                                fusion_model=dict(type="FusionUnet", **w["fusion"])))
+    return dict(type=w["kind"], config=cfg)
+
+
+def state_spec(name: str) -> "OrderedDict[str, tuple]":
+    w = WORKLOADS[name]
+    s = OrderedDict()
+    s.update(W.dav2_spec("coarse_branch.", w["coarse"]))
+    if w["kind"] == "PatchRefinerPlus":
+        s.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
+        f = w["fusion"]
+        s.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
+                                     f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
+    else:
+        s.update(W.dav2_spec("refiner_fine_branch.", w["fine"]))
+        s.update(W.fusion_unet_spec("refiner_fusion_model.", **w["fusion"]))
+    return s
