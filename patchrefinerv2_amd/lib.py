@@ -64,6 +64,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7 / libhsa-runtime64; it must be the first HIP runtime in the
+    # process (same SONAME as /opt/rocm's), otherwise the two halves of the runtime mix and launches fail.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the gfx950 HIP library has not been built "
