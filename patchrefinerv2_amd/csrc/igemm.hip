@@ -31,7 +31,8 @@ namespace prv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmParams {
   const float* x;
@@ -64,15 +65,10 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return v;
 }
 
-// round-to-nearest-even fp32 -> bf16 (finite inputs), returned as the high 16 bits
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-  unsigned u = __float_as_uint(f);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split_bf16(float f, unsigned& hi, unsigned& lo) {
-  hi = bf16_rne(f);
-  float r = f - __uint_as_float(hi << 16);
-  lo = bf16_rne(r);
+// fp32 -> bf16 hi + bf16 lo (v_cvt_pk_bf16_f32, round-to-nearest-even); hi + lo carries 16 mantissa bits
+__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+  hi = __builtin_convertvector(v, bf16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
 }
 
 template <int BN, int PREC>
@@ -150,8 +146,18 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
 
   auto store_step = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (row0 + 32 * i) * LDS_LD + chunk * 4]) = ra[i];
+    for (int i = 0; i < 4; ++i) {
+      float* dst = &smem[buf * STAGE + (row0 + 32 * i) * LDS_LD];
+      if constexpr (PREC == PRV2_PREC_F32) {
+        *reinterpret_cast<f32x4*>(dst + chunk * 4) = ra[i];
+      } else {
+        // LDS row = [32 x bf16 hi | 32 x bf16 lo] (same 128 B as 32 floats); this thread owns channels 4*chunk..+3
+        bf16x4 hi, lo;
+        split_bf16(ra[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(dst) + chunk * 8) = hi;
+        if constexpr (PREC == PRV2_PREC_BF16X3) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(dst) + 64 + chunk * 8) = lo;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (BM + row0 + 32 * i) * LDS_LD + chunk * 4]) = rb[i];
@@ -170,6 +176,37 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
   __syncthreads();
 
   auto compute_step = [&](int buf) {
+    if constexpr (PREC != PRV2_PREC_F32) {
+      // v_mfma_f32_32x32x16_bf16: lane (r32, half) holds A[row r32][k = 8*half + j], B[k = 8*half + j][col r32];
+      // k-step ks covers channels 16*ks..+15 -> byte offset 32*ks + 16*half inside the hi (or +64: lo) half-row
+      const char* Ab = reinterpret_cast<const char*>(smem + buf * STAGE + (wm * 64 + r32) * LDS_LD) + half * 16;
+      const char* Bb = reinterpret_cast<const char*>(smem + buf * STAGE + (BM + wn * (BN / 2) + r32) * LDS_LD) + half * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDS_LD * 4 + ks * 32);
+          if constexpr (PREC == PRV2_PREC_BF16X3) al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDS_LD * 4 + 64 + ks * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDS_LD * 4 + ks * 32);
+          if constexpr (PREC == PRV2_PREC_BF16X3) bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDS_LD * 4 + 64 + ks * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if constexpr (PREC == PRV2_PREC_BF16X3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
     const float* Ab = smem + buf * STAGE + (wm * 64 + r32) * LDS_LD + half * 4;
     const float* Bb = smem + buf * STAGE + (BM + wn * (BN / 2) + r32) * LDS_LD + half * 4;
 #pragma unroll
@@ -289,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
 // ---- weight packing: [cout][cin][kh][kw] (or ConvT [cin][cout][k][k]) -> [cout_pad][taps][cin_pad] ----
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ src, const float* __restrict__ scale,
                                                           float* __restrict__ dst, int Cout, int Cin, int KH, int KW,
-                                                          int convt_k, int rows, int rows_pad, int cin_pad) {
+                                                          int convt_k, int rows, int rows_pad, int cin_pad, int prec) {
   const int taps = convt_k > 0 ? 1 : KH * KW;
   long long total = (long long)rows_pad * taps * cin_pad;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -307,7 +344,16 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
         if (scale) v *= scale[r];
       }
     }
-    dst[idx] = v;
+    if (prec == PRV2_PREC_F32) {
+      dst[idx] = v;
+    } else {
+      // per 32-channel chunk: [32 x bf16 hi][32 x bf16 lo] -- the LDS row image of the bf16 modes
+      __bf16 hi = (__bf16)v;
+      __bf16 lo = (__bf16)(v - (float)hi);
+      __bf16* d16 = reinterpret_cast<__bf16*>(dst + (idx - (c & 31)));
+      d16[c & 31] = hi;
+      d16[32 + (c & 31)] = prec == PRV2_PREC_BF16X3 ? lo : (__bf16)0.0f;
+    }
   }
 }
 
@@ -328,13 +374,13 @@ extern "C" int64_t prv2_packed_weight_bytes(int32_t cout, int32_t cin, int32_t k
 
 extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, void* w_packed, int32_t cout, int32_t cin,
                                      int32_t kh, int32_t kw, int32_t convt_k, int32_t prec, void* stream) {
-  (void)prec;
+  PRV2_REQUIRE(prec >= PRV2_PREC_F32 && prec <= PRV2_PREC_BF16, "pack_conv_weight: unknown precision mode %d", prec);
   PRV2_REQUIRE(w_src && w_packed && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_conv_weight: bad arguments");
   PRV2_REQUIRE(convt_k == 0 || (kh == convt_k && kw == convt_k), "pack_conv_weight: convt needs kh == kw == k");
   int rows = gemm_rows(cout, convt_k), rows_pad = (int)roundup(rows, 128), cin_pad = (int)roundup(cin, BK);
   int64_t total = (int64_t)rows_pad * (convt_k > 0 ? 1 : kh * kw) * cin_pad;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w_src, bn_scale,
-                     (float*)w_packed, cout, cin, kh, kw, convt_k, rows, rows_pad, cin_pad);
+                     (float*)w_packed, cout, cin, kh, kw, convt_k, rows, rows_pad, cin_pad, prec);
   PRV2_LAUNCH_CHECK("pack_conv_weight");
   return 0;
 }
@@ -346,7 +392,7 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
   PRV2_REQUIRE(d->ldx >= d->cin, "conv2d: ldx %d < cin %d", d->ldx, d->cin);
-  PRV2_REQUIRE(d->prec == PRV2_PREC_F32, "conv2d: precision mode %d not built", d->prec);
+  PRV2_REQUIRE(d->prec >= PRV2_PREC_F32 && d->prec <= PRV2_PREC_BF16, "conv2d: unknown precision mode %d", d->prec);
   PRV2_REQUIRE(aligned16(w_packed), "conv2d: packed weights must be 16-byte aligned");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -389,13 +435,20 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   }
   p.tiles_m = (int)cdiv(p.M, BM);
   hipStream_t s = (hipStream_t)stream;
+#define PRV2_LAUNCH_IGEMM(BN_, PREC_) \
+  hipLaunchKernelGGL((igemm_kernel<BN_, PREC_>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p)
   if (p.Ncols > 64) {
     p.tiles_n = (int)cdiv(p.Ncols, 128);
-    hipLaunchKernelGGL((igemm_kernel<128, PRV2_PREC_F32>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    if (d->prec == PRV2_PREC_F32) PRV2_LAUNCH_IGEMM(128, PRV2_PREC_F32);
+    else if (d->prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_IGEMM(128, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_IGEMM(128, PRV2_PREC_BF16);
   } else {
     p.tiles_n = 1;
-    hipLaunchKernelGGL((igemm_kernel<64, PRV2_PREC_F32>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    if (d->prec == PRV2_PREC_F32) PRV2_LAUNCH_IGEMM(64, PRV2_PREC_F32);
+    else if (d->prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_IGEMM(64, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_IGEMM(64, PRV2_PREC_BF16);
   }
+#undef PRV2_LAUNCH_IGEMM
   PRV2_LAUNCH_CHECK("conv2d");
   return 0;
 }

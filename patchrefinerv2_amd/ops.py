@@ -201,7 +201,7 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     ncols = cw.cout * (cw.convt_k ** 2 if cw.convt_k else 1)
     taps = 1 if cw.convt_k else cw.kh * cw.kw
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
-    PROFILER.launch("igemm_kernel<128>" if ncols > 64 else "igemm_kernel<64>", 2.0 * m_rows * ncols * cw.cin * taps,
+    PROFILER.launch(f"igemm_kernel<{128 if ncols > 64 else 64},{cw.prec}>", 2.0 * m_rows * ncols * cw.cin * taps,
                     lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma),
                                                          _ptr(mul), _ptr(res), _ptr(res2), out.ptr, _stream()), "conv2d"))
     return out

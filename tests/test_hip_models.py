@@ -186,3 +186,16 @@ def test_rejects_cpu_inputs_and_bad_shapes(P):
         m.prepare_tile_cfg([217, 384], [2, 2])
     with pytest.raises(ValueError):
         _run(m, c, "x3")
+
+
+def test_e2e_bf16x3_meets_absrel_target(P, golden):
+    """the fast arithmetic mode (split-bf16, 3 MFMAs) stays inside the north star's AbsRel <= 1e-4"""
+    for kind, c, sdf, gname in (("PatchRefiner", E2E_V1, e2e_v1_sd, "e2e_v1"), ("PatchRefinerPlus", E2E_V2, e2e_v2_sd, "e2e_v2")):
+        g = golden(gname)
+        m = _build(kind, c, sdf(), prec="bf16x3")
+        mode = c["modes"][-1]
+        depth, _ = _run(m, c, mode)
+        ar, mx = absrel(depth, g[mode])
+        print(kind, mode, "bf16x3 AbsRel", ar, "max|d|", mx)
+        assert ar < ABSREL_TOL, (kind, ar)
+        assert ar > 1e-8  # really the split path

@@ -269,3 +269,24 @@ def test_blend_sequence(P):
         ram.update(p, c)
     P.blend_update(a2, c2, preds3.to(DEV), mask_r.to(DEV), tiles2.to(DEV), rh, rw)
     assert torch.equal(a2.cpu(), ram.average_map) and torch.equal(c2.cpu(), ram.count_map)
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
+def test_conv2d_split_precision(P, prec, tol):
+    """bf16x3 (hi*hi + hi*lo + lo*hi, fp32 accumulate) keeps ~16 mantissa bits; plain bf16 does not."""
+    from patchrefinerv2_amd import lib as L
+    pr = L.PREC_NAMES[prec]
+    for (n, h, w, cin, cout, k) in ((1, 24, 32, 258, 256, 3), (2, 16, 16, 64, 32, 3), (1, 40, 24, 512, 130, 1)):
+        x = rnd(1, n, cin, h, w) * 3
+        wt = rnd(2, cout, cin, k, k) / np.sqrt(cin * k * k)
+        b = rnd(3, cout)
+        ref = F.gelu(F.conv2d(x.double(), wt.double(), b.double(), padding=k // 2)).float()
+        y = P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(wt.to(DEV), b.to(DEV), prec=pr), act=P.ACT_GELU)
+        close(y.to_nchw(), ref, tol, f"{prec} conv {cin}->{cout} k{k}")
+        if prec == "bf16x3":
+            err = float((y.to_nchw().cpu() - ref).abs().max())
+            assert err > 0  # not accidentally the fp32 kernel
+    wt = rnd(4, 48, 40, 2, 2) / 7
+    x = rnd(5, 1, 48, 6, 9)
+    ref = F.conv_transpose2d(x, wt, None, stride=2)
+    close(P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(wt.to(DEV), None, convt_k=2, prec=pr)).to_nchw(), ref, tol)
