@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--max-batch", type=int, default=8, help="patches per launch batch (results are batch independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layer-report", default=None, help="write a per-layer-shape timing table (extra instrumented frame)")
     return ap.parse_args()
 
 
@@ -181,6 +182,18 @@ def main():
             kernels={k: dict(launches=v["launches"], ms=round(v["ms"], 3), tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12
                                                                                   if v["ms"] > 0 else None))
                      for k, v in summ.items()})
+    if rank == 0 and args.layer_report:
+        ops.PROFILER.start(timed=True, by_shape=True)
+        step(0)
+        torch.cuda.synchronize()
+        ops.PROFILER.stop()
+        rows = sorted(ops.PROFILER.summary().items(), key=lambda kv: -kv[1]["ms"])
+        tot = sum(v["ms"] for _, v in rows)
+        with open(args.layer_report, "w") as f:
+            f.write(f"# per-layer matrix-kernel time, one frame, {name}, {args.prec}; total {tot:.1f} ms\n")
+            f.write("ms,pct,launches,TFLOP/s,kernel shape\n")
+            for k, v in rows:
+                f.write(f"{v['ms']:.3f},{100 * v['ms'] / tot:.1f},{v['launches']},{v['flops'] / max(v['ms'], 1e-9) / 1e9:.1f},{k}\n")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(name, sd, 0)
     if rank == 0:

@@ -1,0 +1,201 @@
+// Shared pieces of the implicit-GEMM kernels (igemm.hip: generic; conv3x3.hip: LDS-halo 3x3).
+#pragma once
+#include "common.h"
+
+namespace prv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct IgemmParams {
+  const float* x;
+  const void* w;
+  const float* bias;
+  const float* gamma;
+  const float* mul;
+  const float* res;
+  const float* res2;
+  float* y;
+  int N, H, W, OH, OW;
+  int Cin, Cin_pad, Cout, Ncols;  // Ncols = GEMM columns (= Cout, or k*k*Cout for convT)
+  int KH, KW, stride, pad;
+  int ldx, ldy, ld_mul, ld_res, ld_res2;
+  long long x_bstride, y_bstride;
+  long long M;
+  int relu_in, act, convt_k, vec_ok, vec_epi;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad)
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  v.x = fmaxf(v.x, 0.f);
+  v.y = fmaxf(v.y, 0.f);
+  v.z = fmaxf(v.z, 0.f);
+  v.w = fmaxf(v.w, 0.f);
+  return v;
+}
+
+__device__ __forceinline__ f32x4 floor4(f32x4 v, float lo) {
+  v.x = fmaxf(v.x, lo);
+  v.y = fmaxf(v.y, lo);
+  v.z = fmaxf(v.z, lo);
+  v.w = fmaxf(v.w, lo);
+  return v;
+}
+
+__device__ __forceinline__ f32x4 zero_unless(f32x4 v, bool keep) {
+  v.x = keep ? v.x : 0.f;
+  v.y = keep ? v.y : 0.f;
+  v.z = keep ? v.z : 0.f;
+  v.w = keep ? v.w : 0.f;
+  return v;
+}
+
+// fp32 -> bf16 hi + bf16 lo (v_cvt_pk_bf16_f32, round-to-nearest-even); hi + lo carries 16 mantissa bits
+__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+  hi = __builtin_convertvector(v, bf16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+}
+
+
+// One BK=32 slab of MFMAs for a wave: 2 row sub-tiles (32 rows each) x NJ column sub-tiles.
+// a_row[i] / b_row[j] point at the lane's LDS row (144-byte rows: 32 fp32, or [32 bf16 hi | 32 bf16 lo]),
+// already offset by the lane half (half*16 bytes).
+template <int NJ, int PREC>
+__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NJ], const char* const (&a_row)[2], const char* const (&b_row)[NJ]) {
+  if constexpr (PREC == PRV2_PREC_F32) {
+    // v_mfma_f32_32x32x2_f32: lane half h takes channels 8ks+4h..+3; MFMA e multiplies channel 8ks+4h+e
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 a[2], b[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_row[i] + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_row[j] + ks * 32);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  } else {
+    // v_mfma_f32_32x32x16_bf16: lane (r32, half) holds A[row r32][k = 8*half + j], B[k = 8*half + j][col r32];
+    // k-step ks covers channels 16*ks..+15 -> byte offset 32*ks inside the hi (or +64: lo) half-row
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + ks * 32);
+        if constexpr (PREC == PRV2_PREC_BF16X3) al[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + 64 + ks * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(b_row[j] + ks * 32);
+        if constexpr (PREC == PRV2_PREC_BF16X3) bl[j] = *reinterpret_cast<const bf16x8*>(b_row[j] + 64 + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (PREC == PRV2_PREC_BF16X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+}
+
+// registers (one float4 of 4 channels) -> LDS row image of the precision mode
+template <int PREC>
+__device__ __forceinline__ void stage_a(float* row, int chunk, const f32x4 v) {
+  if constexpr (PREC == PRV2_PREC_F32) {
+    *reinterpret_cast<f32x4*>(row + chunk * 4) = v;
+  } else {
+    bf16x4 hi, lo;
+    split_bf16(v, hi, lo);
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(row) + chunk * 8) = hi;
+    if constexpr (PREC == PRV2_PREC_BF16X3) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(row) + 64 + chunk * 8) = lo;
+  }
+}
+
+// Fused epilogue for one output row segment of 4 channels (see include/prv2.h::prv2_conv2d).
+struct EpiCols {
+  int co, sub_y, sub_x, nvalid;
+  bool vec;
+  float bias[4], gam[4];
+};
+
+__device__ __forceinline__ bool epi_cols(const IgemmParams& p, int ncol, EpiCols& c) {
+  if (ncol >= p.Ncols) return false;
+  const int kk = p.convt_k > 0 ? p.convt_k : 1;
+  c.co = ncol;
+  c.sub_y = 0;
+  c.sub_x = 0;
+  if (p.convt_k > 0) {
+    int t = ncol / p.Cout;
+    c.co = ncol - t * p.Cout;
+    c.sub_y = t / kk;
+    c.sub_x = t - c.sub_y * kk;
+  }
+  c.nvalid = min(4, (p.convt_k > 0 ? p.Cout - c.co : p.Ncols - ncol));
+  c.vec = p.vec_epi && c.nvalid == 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    c.bias[e] = (e < c.nvalid && p.bias) ? p.bias[c.co + e] : 0.f;
+    c.gam[e] = (e < c.nvalid && p.gamma) ? p.gamma[c.co + e] : 1.f;
+  }
+  return true;
+}
+
+// m = dense output pixel index (for mul/res/res2), o = element offset of y[m, co]
+__device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c, const f32x4 cv, long long m, long long o) {
+  float v[4] = {cv.x, cv.y, cv.z, cv.w};
+  float mulv[4] = {1.f, 1.f, 1.f, 1.f}, resv[4] = {0.f, 0.f, 0.f, 0.f}, res2v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c.vec) {
+    if (p.mul) { f32x4 t = *reinterpret_cast<const f32x4*>(p.mul + m * p.ld_mul + c.co); mulv[0] = t.x; mulv[1] = t.y; mulv[2] = t.z; mulv[3] = t.w; }
+    if (p.res) { f32x4 t = *reinterpret_cast<const f32x4*>(p.res + m * p.ld_res + c.co); resv[0] = t.x; resv[1] = t.y; resv[2] = t.z; resv[3] = t.w; }
+    if (p.res2) { f32x4 t = *reinterpret_cast<const f32x4*>(p.res2 + m * p.ld_res2 + c.co); res2v[0] = t.x; res2v[1] = t.y; res2v[2] = t.z; res2v[3] = t.w; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < c.nvalid && p.mul) mulv[e] = p.mul[m * p.ld_mul + c.co + e];
+      if (e < c.nvalid && p.res) resv[e] = p.res[m * p.ld_res + c.co + e];
+      if (e < c.nvalid && p.res2) res2v[e] = p.res2[m * p.ld_res2 + c.co + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = act_apply(v[e] + c.bias[e], p.act);
+    if (p.gamma) t *= c.gam[e];
+    if (p.mul) t = mulv[e] * t;
+    if (p.res) t += resv[e];
+    if (p.res2) t += res2v[e];
+    v[e] = t;
+  }
+  if (c.vec) {
+    f32x4 ov = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p.y + o) = ov;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < c.nvalid) p.y[o + e] = v[e];
+  }
+}
+
+// conv3x3.hip: LDS-halo kernel for 3x3 / stride 1 / pad 1; returns false when the shape is not covered
+bool conv3x3_halo_supported(const IgemmParams& p);
+void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t stream);
+
+}  // namespace prv2

@@ -25,51 +25,9 @@
 // Workgroup -> tile mapping is XCD aware: the 8 XCDs each get a contiguous run of tiles, and
 // within a run the BN-tiles of one pixel tile are adjacent, so the A tile and its 3x3 halo
 // re-reads stay inside one XCD's L2.
-#include "common.h"
+#include "igemm.h"
 
 namespace prv2 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-struct IgemmParams {
-  const float* x;
-  const void* w;
-  const float* bias;
-  const float* gamma;
-  const float* mul;
-  const float* res;
-  const float* res2;
-  float* y;
-  int N, H, W, OH, OW;
-  int Cin, Cin_pad, Cout, Ncols;  // Ncols = GEMM columns (= Cout, or k*k*Cout for convT)
-  int KH, KW, stride, pad;
-  int ldx, ldy, ld_mul, ld_res, ld_res2;
-  long long x_bstride, y_bstride;
-  long long M;
-  int relu_in, act, convt_k, vec_ok, vec_epi;
-  int tiles_m, tiles_n;
-};
-
-constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad)
-
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  v.x = fmaxf(v.x, 0.f);
-  v.y = fmaxf(v.y, 0.f);
-  v.z = fmaxf(v.z, 0.f);
-  v.w = fmaxf(v.w, 0.f);
-  return v;
-}
-
-// fp32 -> bf16 hi + bf16 lo (v_cvt_pk_bf16_f32, round-to-nearest-even); hi + lo carries 16 mantissa bits
-__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo) {
-  hi = __builtin_convertvector(v, bf16x4);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
-}
 
 template <int BN, int PREC>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
@@ -123,21 +81,25 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
   const int cin4 = (p.Cin + 3) & ~3;  // channels [Cin, cin4) are read (finite, host guaranteed) and hit zero weights
 
   f32x4 ra[4], rb[NB];
+  const float x_floor = p.relu_in ? 0.f : -INFINITY;  // fused input ReLU without a branch next to the loads
 
+  unsigned okmask = 0;
   auto load_step = [&](int s) {
     const int tap = s / cchunks;
     const int cb = (s - tap * cchunks) * BK;  // channel base of this step (wave uniform)
     const int ky = tap / p.KW, kx = tap - ky * p.KW;
     const int tap_off = (ky * p.W + kx) * p.ldx + cb;
     const bool c_ok = cb + chunk * 4 < cin4;
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
       const bool ok = c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + tap_off);
-      if (p.relu_in) v = relu4(v);
-      ra[i] = v;
+      // branch-free: select the ADDRESS (a padding lane re-reads x[0..3]); the data is zeroed at store time.
+      // A branch (or any use of the data) next to the load makes hipcc wait vmcnt(0) per load:
+      // 4 serialized L2 round trips per step.
+      ra[i] = *reinterpret_cast<const f32x4*>(ok ? a_ptr[i] + tap_off : p.x);
+      okmask |= (ok ? 1u : 0u) << i;
     }
     const float* wsrc = wbase + (long long)tap * p.Cin_pad + cb;
 #pragma unroll
@@ -146,20 +108,11 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
 
   auto store_step = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* dst = &smem[buf * STAGE + (row0 + 32 * i) * LDS_LD];
-      if constexpr (PREC == PRV2_PREC_F32) {
-        *reinterpret_cast<f32x4*>(dst + chunk * 4) = ra[i];
-      } else {
-        // LDS row = [32 x bf16 hi | 32 x bf16 lo] (same 128 B as 32 floats); this thread owns channels 4*chunk..+3
-        bf16x4 hi, lo;
-        split_bf16(ra[i], hi, lo);
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(dst) + chunk * 8) = hi;
-        if constexpr (PREC == PRV2_PREC_BF16X3) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(dst) + 64 + chunk * 8) = lo;
-      }
-    }
+    for (int i = 0; i < 4; ++i)
+      stage_a<PREC>(&smem[buf * STAGE + (row0 + 32 * i) * LDS_LD], chunk,
+                    floor4(zero_unless(ra[i], (okmask >> i) & 1u), x_floor));
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < NB; ++i)  // packed weights already are the LDS row image: plain 16-byte copy
       *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (BM + row0 + 32 * i) * LDS_LD + chunk * 4]) = rb[i];
   };
 
@@ -171,69 +124,25 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  auto compute_step = [&](int buf) {
+    const char* Ab = reinterpret_cast<const char*>(smem + buf * STAGE + (wm * 64 + r32) * LDS_LD) + half * 16;
+    const char* Bb = reinterpret_cast<const char*>(smem + buf * STAGE + (BM + wn * (BN / 2) + r32) * LDS_LD) + half * 16;
+    const char* a_row[2] = {Ab, Ab + 32 * LDS_LD * 4};
+    const char* b_row[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b_row[j] = Bb + j * 32 * LDS_LD * 4;
+    mma_slab<NJ, PREC>(acc, a_row, b_row);
+  };
+
   load_step(0);
   store_step(0);
   __syncthreads();
-
-  auto compute_step = [&](int buf) {
-    if constexpr (PREC != PRV2_PREC_F32) {
-      // v_mfma_f32_32x32x16_bf16: lane (r32, half) holds A[row r32][k = 8*half + j], B[k = 8*half + j][col r32];
-      // k-step ks covers channels 16*ks..+15 -> byte offset 32*ks + 16*half inside the hi (or +64: lo) half-row
-      const char* Ab = reinterpret_cast<const char*>(smem + buf * STAGE + (wm * 64 + r32) * LDS_LD) + half * 16;
-      const char* Bb = reinterpret_cast<const char*>(smem + buf * STAGE + (BM + wn * (BN / 2) + r32) * LDS_LD) + half * 16;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDS_LD * 4 + ks * 32);
-          if constexpr (PREC == PRV2_PREC_BF16X3) al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDS_LD * 4 + 64 + ks * 32);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDS_LD * 4 + ks * 32);
-          if constexpr (PREC == PRV2_PREC_BF16X3) bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDS_LD * 4 + 64 + ks * 32);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            if constexpr (PREC == PRV2_PREC_BF16X3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
-      }
-      return;
-    }
-    const float* Ab = smem + buf * STAGE + (wm * 64 + r32) * LDS_LD + half * 4;
-    const float* Bb = smem + buf * STAGE + (BM + wn * (BN / 2) + r32) * LDS_LD + half * 4;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      f32x4 a[2], b[NJ];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + ks * 8);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + ks * 8);
-      if constexpr (PREC == PRV2_PREC_F32) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    }
-  };
-
   for (int s = 0; s + 1 < nsteps; ++s) {
     const int buf = s & 1;
     load_step(s + 1);      // global -> registers, in flight under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the loads down to their use
     compute_step(buf);
+    __builtin_amdgcn_sched_barrier(0);
     store_step(buf ^ 1);   // registers -> the other LDS buffer
     __syncthreads();
   }
@@ -259,67 +168,23 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
   constexpr int C4 = BN / 4;          // float4 per tile row
   constexpr int RPP = 256 / C4;       // rows per pass
   const int col4 = tid % C4;
-  const int ncol = tile_n * BN + col4 * 4;
-  if (ncol >= p.Ncols) return;
+  EpiCols ec;
+  if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
   const int kk = p.convt_k > 0 ? p.convt_k : 1;
-  int co = ncol, sub_y = 0, sub_x = 0;
-  if (p.convt_k > 0) {
-    int t = ncol / p.Cout;
-    co = ncol - t * p.Cout;
-    sub_y = t / kk;
-    sub_x = t - sub_y * kk;
-  }
-  const int nvalid = min(4, (p.convt_k > 0 ? p.Cout - co : p.Ncols - ncol));
-  const bool vec = p.vec_epi && nvalid == 4;
-  float bias[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (e < nvalid && p.bias) bias[e] = p.bias[co + e];
-    if (e < nvalid && p.gamma) gam[e] = p.gamma[co + e];
-  }
   for (int rr = tid / C4; rr < BM; rr += RPP) {
     const long long m = (long long)tile_m * BM + rr;
     if (m >= p.M) break;
-    const float4 cv = *reinterpret_cast<const float4*>(&smem[rr * CLD + col4 * 4]);
-    float v[4] = {cv.x, cv.y, cv.z, cv.w};
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
     const int n_img = (int)(m / ohw);
     const int rem = (int)(m - (long long)n_img * ohw);
     long long o;
     if (p.convt_k > 0) {
       const int iy = rem / p.OW, ix = rem - iy * p.OW;
-      o = (long long)n_img * p.y_bstride + ((long long)(iy * kk + sub_y) * (p.OW * kk) + ix * kk + sub_x) * p.ldy + co;
+      o = (long long)n_img * p.y_bstride + ((long long)(iy * kk + ec.sub_y) * (p.OW * kk) + ix * kk + ec.sub_x) * p.ldy + ec.co;
     } else {
-      o = (long long)n_img * p.y_bstride + (long long)rem * p.ldy + co;
+      o = (long long)n_img * p.y_bstride + (long long)rem * p.ldy + ec.co;
     }
-    float mulv[4] = {1.f, 1.f, 1.f, 1.f}, resv[4] = {0.f, 0.f, 0.f, 0.f}, res2v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-      if (p.mul) { float4 t = *reinterpret_cast<const float4*>(p.mul + m * p.ld_mul + co); mulv[0] = t.x; mulv[1] = t.y; mulv[2] = t.z; mulv[3] = t.w; }
-      if (p.res) { float4 t = *reinterpret_cast<const float4*>(p.res + m * p.ld_res + co); resv[0] = t.x; resv[1] = t.y; resv[2] = t.z; resv[3] = t.w; }
-      if (p.res2) { float4 t = *reinterpret_cast<const float4*>(p.res2 + m * p.ld_res2 + co); res2v[0] = t.x; res2v[1] = t.y; res2v[2] = t.z; res2v[3] = t.w; }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (e < nvalid && p.mul) mulv[e] = p.mul[m * p.ld_mul + co + e];
-        if (e < nvalid && p.res) resv[e] = p.res[m * p.ld_res + co + e];
-        if (e < nvalid && p.res2) res2v[e] = p.res2[m * p.ld_res2 + co + e];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = act_apply(v[e] + bias[e], p.act);
-      if (p.gamma) t *= gam[e];
-      if (p.mul) t = mulv[e] * t;
-      if (p.res) t += resv[e];
-      if (p.res2) t += res2v[e];
-      v[e] = t;
-    }
-    if (vec) {
-      *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (e < nvalid) p.y[o + e] = v[e];
-    }
+    epi_store(p, ec, cv, m, o);
   }
 }
 
@@ -435,6 +300,11 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   }
   p.tiles_m = (int)cdiv(p.M, BM);
   hipStream_t s = (hipStream_t)stream;
+  if (conv3x3_halo_supported(p) && !d->reserved) {  // reserved != 0 forces the generic kernel (tests / A-B)
+    launch_conv3x3_halo(p, d->prec, s);
+    PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
+    return 0;
+  }
 #define PRV2_LAUNCH_IGEMM(BN_, PREC_) \
   hipLaunchKernelGGL((igemm_kernel<BN_, PREC_>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p)
   if (p.Ncols > 64) {

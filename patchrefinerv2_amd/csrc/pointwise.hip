@@ -121,46 +121,96 @@ __global__ void __launch_bounds__(256) assemble_tokens_kernel(const float* __res
   }
 }
 
-// Cout == 1 convolution: one thread per output pixel; weights staged in LDS as [tap][cin]
-__global__ void __launch_bounds__(256) conv_cout1_kernel(const float* __restrict__ x, int N, int H, int W, int Cin,
-                                                         int ldx, const float* __restrict__ wgt, int k,
-                                                         const float* __restrict__ bias, int act, float scale,
-                                                         const float* __restrict__ res, int clamp0,
-                                                         float* __restrict__ y) {
-  extern __shared__ float wl[];  // [k*k][Cin]
-  const int taps = k * k;
-  for (int i = threadIdx.x; i < taps * Cin; i += blockDim.x) {
-    int c = i % Cin, t = i / Cin;
-    wl[i] = wgt[c * taps + t];
-  }
+// Cout == 1, 1x1: one thread per output pixel, float4 over channels (a wave reads 64 consecutive
+// pixel rows = one contiguous run)
+__global__ void __launch_bounds__(256) conv_cout1_k1_kernel(const float* __restrict__ x, int64_t total, int Cin, int ldx,
+                                                            const float* __restrict__ wgt,
+                                                            const float* __restrict__ bias, int act, float scale,
+                                                            const float* __restrict__ res, int clamp0,
+                                                            float* __restrict__ y) {
+  extern __shared__ float wl[];  // [Cin]
+  for (int i = threadIdx.x; i < Cin; i += blockDim.x) wl[i] = wgt[i];
   __syncthreads();
-  const int pad = k / 2;
   const float b0 = bias ? bias[0] : 0.f;
   const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0);
-  int64_t total = (int64_t)N * H * W;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int ox = (int)(idx % W), oy = (int)((idx / W) % H);
-    int n = (int)(idx / ((int64_t)W * H));
+    const float* px = x + idx * ldx;
     float acc = 0.f;
-    for (int ky = 0; ky < k; ++ky) {
-      int iy = oy + ky - pad;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        int ix = ox + kx - pad;
-        if (ix < 0 || ix >= W) continue;
-        const float* px = x + (((int64_t)n * H + iy) * W + ix) * ldx;
-        const float* pw = wl + (ky * k + kx) * Cin;
-        if (vec) {
-          for (int c = 0; c < Cin; c += 4) {
-            float4 v = *reinterpret_cast<const float4*>(px + c);
-            acc += v.x * pw[c] + v.y * pw[c + 1] + v.z * pw[c + 2] + v.w * pw[c + 3];
-          }
-        } else {
-          for (int c = 0; c < Cin; ++c) acc += px[c] * pw[c];
-        }
+    if (vec) {
+      for (int c = 0; c < Cin; c += 4) {
+        float4 v = *reinterpret_cast<const float4*>(px + c);
+        acc += v.x * wl[c] + v.y * wl[c + 1] + v.z * wl[c + 2] + v.w * wl[c + 3];
       }
+    } else {
+      for (int c = 0; c < Cin; ++c) acc += px[c] * wl[c];
     }
     float v = act_apply(acc + b0, act) * scale;
+    if (res) v += res[idx];
+    if (clamp0) v = v > 0.f ? v : 0.f;
+    y[idx] = v;
+  }
+}
+
+// Cout == 1, 3x3: workgroup = 8 x 32 output pixels (one per thread).  Per 32-channel slab the
+// 10 x 34 halo is staged in LDS with coalesced 16-byte loads (rows padded to 36 floats: the
+// per-pixel ds_read_b128 of a wave are conflict free) and every thread reads its 9 taps from
+// LDS; weights sit in LDS as [tap][32] and are broadcast.  HBM traffic = one read of x.
+constexpr int C1_TH = 8, C1_TW = 32, C1_HW = C1_TW + 2, C1_HALO = (C1_TH + 2) * C1_HW, C1_LD = 36;
+
+__global__ void __launch_bounds__(256) conv_cout1_k3_kernel(const float* __restrict__ x, int N, int H, int W, int Cin,
+                                                            int ldx, const float* __restrict__ wgt, int act,
+                                                            float scale, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, int clamp0,
+                                                            float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float tile[C1_HALO * C1_LD];
+  __shared__ __attribute__((aligned(16))) float wl[9 * 32];
+  const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int n = t / tiles_y;
+  const int y0 = ty * C1_TH, x0 = tx * C1_TW;
+  const int tid = threadIdx.x;
+  const int py = tid >> 5, px = tid & 31;
+  const int chunk = tid & 7, prow = tid >> 3;
+  const float* img = x + (int64_t)n * H * W * ldx;
+  float acc = 0.f;
+  for (int cb = 0; cb < Cin; cb += 32) {
+    __syncthreads();
+    for (int i = tid; i < 9 * 32; i += 256) {
+      int c = cb + (i & 31), tap = i >> 5;
+      wl[i] = c < Cin ? wgt[c * 9 + tap] : 0.f;
+    }
+    for (int hp = prow; hp < C1_HALO; hp += 32) {
+      const int hy = hp / C1_HW, hx = hp - hy * C1_HW;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const int c = cb + chunk * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c < Cin) {
+        const float* src = img + ((int64_t)iy * W + ix) * ldx + c;
+        if (c + 4 <= Cin) v = *reinterpret_cast<const float4*>(src);
+        else { v.x = src[0]; if (c + 1 < Cin) v.y = src[1]; if (c + 2 < Cin) v.z = src[2]; }
+      }
+      *reinterpret_cast<float4*>(&tile[hp * C1_LD + chunk * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* pt = &tile[((py + tap / 3) * C1_HW + px + tap % 3) * C1_LD];
+      const float* pw = &wl[tap * 32];
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        float4 v = *reinterpret_cast<const float4*>(pt + c);
+        float4 ww = *reinterpret_cast<const float4*>(pw + c);
+        acc += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+      }
+    }
+  }
+  const int oy = y0 + py, ox = x0 + px;
+  if (oy < H && ox < W) {
+    const int64_t idx = ((int64_t)n * H + oy) * W + ox;
+    float v = act_apply(acc + (bias ? bias[0] : 0.f), act) * scale;
     if (res) v += res[idx];
     if (clamp0) v = v > 0.f ? v : 0.f;
     y[idx] = v;
@@ -261,10 +311,17 @@ extern "C" int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w
                                  const float* res, int32_t clamp0, float* y, void* stream) {
   PRV2_REQUIRE(x && wgt && y, "conv2d_cout1: null pointer");
   PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && ldx >= cin && (k == 1 || k == 3), "conv2d_cout1: bad geometry");
-  PRV2_REQUIRE((size_t)k * k * cin * 4 <= 64 * 1024, "conv2d_cout1: cin too large");
+  PRV2_REQUIRE(ldx % 4 == 0 && aligned16(x), "conv2d_cout1: x must be 16-byte aligned with ldx %% 4 == 0");
   int64_t total = (int64_t)n * h * w;
-  hipLaunchKernelGGL(conv_cout1_kernel, dim3(flat_grid(total, 256)), dim3(256), (size_t)k * k * cin * 4,
-                     (hipStream_t)stream, x, n, h, w, cin, ldx, wgt, k, bias, act, scale, res, clamp0, y);
+  if (k == 1) {
+    PRV2_REQUIRE((size_t)cin * 4 <= 64 * 1024, "conv2d_cout1: cin too large");
+    hipLaunchKernelGGL(conv_cout1_k1_kernel, dim3(flat_grid(total, 256)), dim3(256), (size_t)cin * 4, (hipStream_t)stream,
+                       x, total, cin, ldx, wgt, bias, act, scale, res, clamp0, y);
+  } else {
+    const int tiles = n * (int)cdiv(h, C1_TH) * (int)cdiv(w, C1_TW);
+    hipLaunchKernelGGL(conv_cout1_k3_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, n, h, w, cin, ldx, wgt,
+                       act, scale, bias, res, clamp0, y);
+  }
   PRV2_LAUNCH_CHECK("conv2d_cout1");
   return 0;
 }

@@ -26,18 +26,21 @@ class Profiler:
     def __init__(self):
         self.enabled = False
         self.timed = False
+        self.by_shape = False
         self.records = []  # (kernel tag, algorithmic flops, start event, end event)
 
-    def start(self, timed=False):
-        self.enabled, self.timed, self.records = True, timed, []
+    def start(self, timed=False, by_shape=False):
+        self.enabled, self.timed, self.by_shape, self.records = True, timed, by_shape, []
 
     def stop(self):
         self.enabled = False
         return self.records
 
-    def launch(self, tag, flops, fn):
+    def launch(self, tag, flops, fn, shape=None):
         if not self.enabled:
             return fn()
+        if self.by_shape and shape is not None:
+            tag = f"{tag} {shape}"
         if self.timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -184,7 +187,7 @@ def conv_out_hw(cw: ConvW, h: int, w: int):
 
 def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = False, act: int = ACT_NONE,
            gamma: Optional[torch.Tensor] = None, mul: Optional[Feat] = None, res: Optional[Feat] = None,
-           res2: Optional[Feat] = None, x_bstride: int = 0) -> Feat:
+           res2: Optional[Feat] = None, x_bstride: int = 0, force_generic: bool = False) -> Feat:
     """y = epilogue(conv(x)); see include/prv2.h::prv2_conv2d."""
     assert x.c == cw.cin, (x.c, cw.cin)
     oh, ow = conv_out_hw(cw, x.h, x.w)
@@ -194,7 +197,7 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad,
                    ldx=x.ld, ldy=out.ld, x_bstride=x_bstride, y_bstride=0, relu_in=int(relu_in), act=act,
                    convt_k=cw.convt_k, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0,
-                   ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, reserved=0)
+                   ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, reserved=int(force_generic))
     for aux in (mul, res, res2):
         if aux is not None:
             assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
@@ -203,7 +206,8 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
     PROFILER.launch(f"igemm_kernel<{128 if ncols > 64 else 64},{cw.prec}>", 2.0 * m_rows * ncols * cw.cin * taps,
                     lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma),
-                                                         _ptr(mul), _ptr(res), _ptr(res2), out.ptr, _stream()), "conv2d"))
+                                                         _ptr(mul), _ptr(res), _ptr(res2), out.ptr, _stream()), "conv2d"),
+                    shape=f"{cw.cin}->{cw.cout} k{cw.kh}s{cw.stride}{'T' if cw.convt_k else ''} {x.n}x{x.h}x{x.w}")
     return out
 
 

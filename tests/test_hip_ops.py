@@ -41,6 +41,12 @@ CONV_CASES = [
     (1, 32, 32, 64, 64, 3, 2, dict(bias=True)),        # DPT resize_layers.3 / MNv4 strided
     (3, 9, 7, 48, 24, 1, 1, dict(bias=True, act="sigmoid", mul=True)),
     (1, 8, 8, 130, 128, 3, 1, dict(res=True, res2=True, gamma=True, bias=True)),
+    # LDS-halo 3x3 kernel (W >= 24): ragged tiles, multi-slab, both channel-tile widths, fused epilogues
+    (2, 30, 50, 66, 130, 3, 1, dict(bias=True, act="gelu")),
+    (1, 8, 32, 32, 32, 3, 1, {}),
+    (1, 19, 75, 258, 256, 3, 1, dict(bias=True, relu_in=True, res=True)),
+    (3, 7, 24, 98, 40, 3, 1, dict(res=True, res2=True, gamma=True, bias=True)),
+    (1, 56, 56, 512, 256, 3, 1, dict(bias=True)),
 ]
 
 
@@ -290,3 +296,18 @@ def test_conv2d_split_precision(P, prec, tol):
     x = rnd(5, 1, 48, 6, 9)
     ref = F.conv_transpose2d(x, wt, None, stride=2)
     close(P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(wt.to(DEV), None, convt_k=2, prec=pr)).to_nchw(), ref, tol)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_conv3x3_halo_equals_generic(P, prec):
+    """the LDS-halo kernel and the generic per-tap kernel agree (k order differs: slab-major vs tap-major)"""
+    from patchrefinerv2_amd import lib as L
+    x = rnd(1, 2, 70, 21, 45)
+    wt = rnd(2, 136, 70, 3, 3) / 25
+    b = rnd(3, 136)
+    cw = P.pack_conv(wt.to(DEV), b.to(DEV), prec=L.PREC_NAMES[prec])
+    xf = P.Feat.from_nchw(x.to(DEV))
+    a = P.conv2d(xf, cw, act=P.ACT_RELU).to_nchw()
+    g = P.conv2d(xf, cw, act=P.ACT_RELU, force_generic=True).to_nchw()
+    close(a, g.cpu(), 2e-6 if prec == "f32" else 2e-5)
+    assert not torch.equal(a, g) or prec != "f32"  # really two different kernels
