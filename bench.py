@@ -42,9 +42,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--prec", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+                    help="matrix-kernel arithmetic (DESIGN.md 3): bf16x3 = split-bf16, AbsRel ~5e-6; f32 = exact fp32 MFMA")
     ap.add_argument("--shard", default="frames", choices=["frames", "patches"])
-    ap.add_argument("--max-batch", type=int, default=8, help="patches per launch batch (results are batch independent)")
+    ap.add_argument("--max-batch", type=int, default=27, help="patches per launch batch (results are batch independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layer-report", default=None, help="write a per-layer-shape timing table (extra instrumented frame)")

@@ -61,9 +61,11 @@ class _EncDec(StateDictModule):
         P["final_w"] = self._dev("final_conv.weight")
         return P
 
-    def _encode_decode(self, P, pairs, sizes, pred1: Feat, pred2: Feat, update_base: Optional[torch.Tensor], out=None):
+    def _encode_decode(self, P, pairs, sizes, pred1: Feat, pred2: Feat, update_base: Optional[torch.Tensor], out=None,
+                       cat1_bufs=None):
         """pairs[l] = (fill_fn(dst_cat: Feat) writing the level-l [c, f] concat), sizes[l] = (h, w);
-        levels high -> low resolution (fusion_model.py:91-118)."""
+        levels high -> low resolution (fusion_model.py:91-118).  ``cat1_bufs`` = already allocated (and
+        possibly partly filled) level concat buffers."""
         B, dev = pred1.n, pred1.device
         L_ = len(self.temp_chl)
         nd = len(self.dec_in)
@@ -76,7 +78,7 @@ class _EncDec(StateDictModule):
         for l in range(L_):
             h, w = sizes[l]
             tc = self.temp_chl[l]
-            cat1 = Feat.alloc(B, h, w, self.in_chl[l], dev)
+            cat1 = cat1_bufs[l] if cat1_bufs is not None else Feat.alloc(B, h, w, self.in_chl[l], dev)
             pairs[l](cat1)
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
             cat2 = Feat.alloc(B, h, w, tc + 2, dev)
@@ -197,8 +199,11 @@ class BiDirectionalFusion(_EncDec):
         ops.layernorm_feat(fused, u["lnw"], u["lnb"], 1e-6, ACT_RELU)
         return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])
 
-    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True) -> Feat:
-        """GatedFusionBlock.forward (bi_directional_fusion_model.py:116-146)."""
+    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True, dest=None) -> Feat:
+        """GatedFusionBlock.forward (bi_directional_fusion_model.py:116-146).  ``coarse`` may have a
+        different size (it is resized while being placed).  The 1x1 ``out_conv`` is applied BEFORE the
+        bilinear upsample: both are linear and the bilinear weights sum to one, so
+        out_conv(up(x)) == up(out_conv(x)) up to rounding -- 4x fewer FLOPs and no upsampled temporary."""
         ref = xs[-1]
         cat = Feat.alloc(ref.n, ref.h, ref.w, 2 * F_, ref.device)
         place(coarse, cat.slice(F_, F_))
@@ -207,24 +212,26 @@ class BiDirectionalFusion(_EncDec):
             out = self._gated_unit(blk["u1"], xs[1], cat, F_, res=xs[0])
         out = self._gated_unit(blk["u2"], out, cat, F_)
         if upscale:
-            out = ops.upsample_bilinear(out, size[0], size[1])
-        return ops.conv2d(out, blk["out_conv"])
+            y = ops.conv2d(out, blk["out_conv"])
+            return ops.upsample_bilinear(y, size[0], size[1], out=dest)
+        return ops.conv2d(out, blk["out_conv"], dest)
 
-    def _c2f(self, P, fine: List[Feat], coarse: List[Feat]):
-        """C2FModule.forward (bi_directional_fusion_model.py:184-208); fine: 5 maps, coarse: 6 maps, high -> low."""
+    def _c2f(self, P, fine: List[Feat], coarse: List[Feat], dests):
+        """C2FModule.forward (bi_directional_fusion_model.py:184-208); fine: 5 maps, coarse: 6 maps, high -> low.
+        dests[l] = where feature l of the returned list [last, path2, path3, path4, path5, rn5] is written."""
         F_ = self.FEATURES
-        rn = [ops.conv2d(fine[i], P["rn"][i]) for i in range(5)]
+        rn = [ops.conv2d(fine[i], P["rn"][i], dests[5] if i == 4 else None) for i in range(5)]
         R = P["refine"]
-        path5 = self._gated_block(R[5], [rn[4]], coarse[5], F_, size=(rn[3].h, rn[3].w))
-        path4 = self._gated_block(R[4], [path5, rn[3]], coarse[4], F_, size=(rn[2].h, rn[2].w))
-        path3 = self._gated_block(R[3], [path4, rn[2]], coarse[3], F_, size=(rn[1].h, rn[1].w))
-        path2 = self._gated_block(R[2], [path3, rn[1]], coarse[2], F_, size=(rn[0].h, rn[0].w))
+        path5 = self._gated_block(R[5], [rn[4]], coarse[5], F_, size=(rn[3].h, rn[3].w), dest=dests[4])
+        path4 = self._gated_block(R[4], [path5, rn[3]], coarse[4], F_, size=(rn[2].h, rn[2].w), dest=dests[3])
+        path3 = self._gated_block(R[3], [path4, rn[2]], coarse[3], F_, size=(rn[1].h, rn[1].w), dest=dests[2])
+        path2 = self._gated_block(R[2], [path3, rn[1]], coarse[2], F_, size=(rn[0].h, rn[0].w), dest=dests[1])
         path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=(rn[0].h * 2, rn[0].w * 2))
         out = ops.conv2d(path1, P["out1"])
         last = ops.conv2d(out, P["out2_0"], act=ACT_RELU)
-        last = self._gated_block(P["out2_fusion"], [last], coarse[0], self.coarse_chl[0], upscale=False)
+        last = self._gated_block(P["out2_fusion"], [last], coarse[0], self.coarse_chl[0], upscale=False, dest=dests[0])
         depth = ops.conv2d_cout1(last, P["out3_w"], P["out3_b"], 1)
-        return [rn[4], path5, path4, path3, path2, last], depth
+        return depth
 
     def forward(self, c_feat: List[Feat], f_feat: List[Optional[Feat]], pred1: torch.Tensor, pred2: torch.Tensor,
                 update_base: Optional[torch.Tensor] = None, f_sizes=None, out=None, **_unused) -> torch.Tensor:
@@ -237,20 +244,25 @@ class BiDirectionalFusion(_EncDec):
         if f_sizes is None:
             f_sizes = [(f.h, f.w) for f in f_feat]
         c_feat = list(c_feat)
-        if (c_feat[-1].h, c_feat[-1].w) != tuple(f_sizes[-1]):
-            # the reference resizes ALL coarse maps iff the lowest level differs (:389-393)
-            c_feat = [ops.upsample_bilinear(c, s[0], s[1]) for c, s in zip(c_feat, f_sizes)]
-        feats, out_depth = self._c2f(P, list(f_feat[1:]), c_feat)
-        feats = feats[::-1]
+        # The reference resizes ALL coarse maps to the refiner's sizes iff the lowest level differs (:389-393).
+        # Here the resize happens while the map is placed into its two consumers' concat buffers (no temporary).
+        if (c_feat[-1].h, c_feat[-1].w) == tuple(f_sizes[-1]):
+            for c, sz in zip(c_feat, f_sizes):
+                if (c.h, c.w) != tuple(sz):
+                    raise RuntimeError("coarse / refiner pyramids differ at a middle level only: the reference "
+                                       "cannot run this shape either (torch.cat fails)")
+        B, dev = c_feat[0].n, c_feat[0].device
+        # level concat buffers [coarse | c2f feature]; the c2f outputs are written straight into them
+        cat1 = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l], dev) for l in range(6)]
+        dests = [cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]
+        out_depth = self._c2f(P, list(f_feat[1:]), c_feat, dests)
 
         def fill(l):
             def fn(cat: Feat):
                 place(c_feat[l], cat.slice(0, c_feat[l].c))
-                place(feats[l], cat.slice(c_feat[l].c, feats[l].c))
             return fn
 
-        sizes = [(f.h, f.w) for f in feats]
-        return self._encode_decode(P, [fill(l) for l in range(6)], sizes, as_feat1(pred1), as_feat1(out_depth),
-                                   update_base, out=out)
+        return self._encode_decode(P, [fill(l) for l in range(6)], list(f_sizes), as_feat1(pred1), as_feat1(out_depth),
+                                   update_base, out=out, cat1_bufs=cat1)
 
     __call__ = forward

@@ -297,8 +297,9 @@ class _PatchModel(StateDictModule):
         per = (n_total + world - 1) // world
         mine = torch.zeros((per,) + tuple(preds.shape[1:]), device=preds.device)
         mine[:preds.shape[0]] = preds
-        allp = torch.empty((world,) + tuple(mine.shape), device=preds.device)
+        allp = torch.empty((world * per,) + tuple(mine.shape[1:]), device=preds.device)
         dist.all_gather_into_tensor(allp, mine)
+        allp = allp.view((world, per) + tuple(mine.shape[1:]))
         return allp.transpose(0, 1).reshape((per * world,) + tuple(preds.shape[1:]))[:n_total].contiguous()
 
     # -- checkpoint contract (patchrefinerplus.py:212-216) ------------------------------------------

@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the patch-sharded mode's only exchange step (all-gather of the
+per-rank prediction stacks + reorder to tile order) reproduces the single-process ordering."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from patchrefinerv2_amd import models as M
+
+
+class _Host(M._PatchModel):
+    def __init__(self):
+        super().__init__()
+        self.patch_process_shape = (4, 6)
+
+    def _pack(self):
+        pass
+
+
+def _worker(rank, world, port, n_tiles, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_tiles * 24, dtype=torch.float32).view(n_tiles, 1, 4, 6)
+        mine = full[rank::world].contiguous()  # tile i -> rank i mod world
+        got = _Host()._gather_predictions(mine, n_tiles, (rank, world))
+        ok = torch.equal(got, full)
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            out.put(int(flag.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_tiles", [81, 16, 5])
+def test_patch_shard_gather_world2(n_tiles):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + n_tiles
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_tiles, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == 1
+
+
+def test_shard_assignment_covers_every_tile_once():
+    import random
+    h = _Host()
+    h.patch_process_shape = (448, 448)
+    tc = h.prepare_tile_cfg([2160, 3840], [4, 4])
+    random.seed(621)
+    flat = [t for p in h.plan_tiles(tc, "r32", 4) for t in p["raw"]]
+    for world in (2, 4, 8):
+        parts = [list(range(len(flat)))[r::world] for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(81))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
