@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libprv2_hip.so")
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
 ABI_VERSION = 1
 
 

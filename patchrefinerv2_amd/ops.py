@@ -204,7 +204,10 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     ncols = cw.cout * (cw.convt_k ** 2 if cw.convt_k else 1)
     taps = 1 if cw.convt_k else cw.kh * cw.kw
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
-    PROFILER.launch(f"igemm_kernel<{128 if ncols > 64 else 64},{cw.prec}>", 2.0 * m_rows * ncols * cw.cin * taps,
+    halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and cw.pad == 1 and not cw.convt_k and x.w >= 24 and x.h >= 4
+            and not force_generic)  # mirrors conv3x3_halo_supported() in csrc/conv3x3.hip
+    kname = "conv3x3_halo_kernel" if halo else "igemm_kernel"
+    PROFILER.launch(f"{kname}<{128 if ncols > 64 else 64},{L.PREC_LABEL[cw.prec]}>", 2.0 * m_rows * ncols * cw.cin * taps,
                     lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma),
                                                          _ptr(mul), _ptr(res), _ptr(res2), out.ptr, _stream()), "conv2d"),
                     shape=f"{cw.cin}->{cw.cout} k{cw.kh}s{cw.stride}{'T' if cw.convt_k else ''} {x.n}x{x.h}x{x.w}")
