@@ -26,7 +26,7 @@ extern "C" {
 
 #define PRV2_ABI_VERSION 1
 
-enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3 };
+enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4 };
 
 /* arithmetic of the matrix kernels */
 enum prv2_prec {
@@ -92,8 +92,8 @@ int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w, int32_t c
                       float* y, void* stream);
 
 /* Depthwise kxk convolution (+folded BatchNorm bias, optional ReLU) for the MobileNetV4 refiner
- * encoder (timm, un-vendored; lightweight_refiner.py:260-262,296).  w: device [c][k][k] with the
- * BN scale already folded; bias [c]. */
+ * encoder (timm, un-vendored; lightweight_refiner.py:260-262,296).  w: device, TAP-MAJOR [k*k][c] with
+ * the BN scale already folded (so that a lane's 4 channels are one float4); bias [c]. */
 int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
                   const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy, void* stream);
 
@@ -119,6 +119,22 @@ int prv2_assemble_tokens(const float* emb, const float* cls, const float* pos, i
  * Linear (attention.py:49-62).  hd must be 64.  out rows are [heads][hd]. */
 int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out, int32_t prec,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ZoeDepth metric-bins head, elementwise parts (the 1x1 MLPs go through prv2_conv2d)
+ * ------------------------------------------------------------------------------------------ */
+/* y = a + b over [rows, c] with row strides (x + prev_b_embedding, external/zoedepth/models/layers/attractor.py:178) */
+int prv2_add(const float* a, int32_t lda, const float* b, int32_t ldb, int64_t rows, int32_t c, float* y, int32_t ldy,
+             void* stream);
+/* AttractorLayerUnnormed, kind='mean', type='inv' (attractor.py:45-57,186-206):
+ *   out[r, j] = bins[r, j] + mean_i( dx / (1 + alpha * dx^2) ),  dx = attr[r, i] - bins[r, j]               */
+int prv2_zoe_attractor(const float* attr, int32_t ld_attr, int32_t n_attr, const float* bins, int32_t ld_bins,
+                       int32_t n_bins, float alpha, int64_t rows, float* out, int32_t ld_out, void* stream);
+/* ConditionalLogBinomial tail + expectation (dist_layers.py:29-69,100-116; zoedepth_v1.py:219):
+ *   pt[r, 0..3] = softplus MLP output; p = (pt0+eps)/(pt0+pt1+2eps); t = (max-min)*(pt2+eps)/(pt2+pt3+2eps)+min;
+ *   depth[r] = sum_k softmax_k( (logC(K-1,k) + k log p + (K-1-k) log(1-p)) / t ) * centers[r, k]                */
+int prv2_zoe_logbinom_depth(const float* pt, int32_t ld_pt, const float* centers, int32_t ld_c, int32_t n_bins,
+                            float min_temp, float max_temp, int64_t rows, float* depth, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gathers

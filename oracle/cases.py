@@ -129,3 +129,42 @@ def e2e_v2_sd(seed: int = 43):
     spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                     f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
     return W.synth_state_dict(spec, seed=seed)
+
+
+# -- ZoeDepth metric-bins head over the vendored DepthAnything (v1) core, real ViT-S dims ---------------
+# (type='DA-ZoeDepth'; head hyper-parameters as in configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py:10-66)
+ZOE_DA = dict(
+    zcfg=dict(midas_model_type="vits", min_depth=1e-3, max_depth=80, pretrained_resource=None, use_pretrained_midas=False,
+              train_midas=True, freeze_midas_bn=True, do_resize=False, attractor_alpha=1000, attractor_gamma=2,
+              attractor_kind="mean", attractor_type="inv", bin_centers_type="softplus", bin_embedding_dim=128,
+              img_size=[56, 84], inverse_midas=False, max_temp=50.0, min_temp=0.0212, memory_efficient=True,
+              n_attractors=[16, 8, 4, 1], n_bins=64, output_distribution="logbinomial", force_keep_ar=True),
+    seed=51, inputs=dict(rect=(56, 84), square=(70, 70)),
+)
+
+
+# -- end-to-end V2 with the ZoeDepth (DepthAnything ViT-L core) coarse branch: the fully vendored sibling of
+#    configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py (coarse_chl[0] = 32 = ZoeDepth's out_conv feature)
+_ZOE_L = {**ZOE_DA["zcfg"], "midas_model_type": "vitl", "img_size": [112, 224]}
+E2E_V2Z = dict(
+    raw=[256, 512], split=[2, 2], pps=[112, 224], max_depth=80.0, seed=0, modes=["m1", "r4"], zcfg=_ZOE_L,
+    fusion=dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64, 96, 960],
+                fine_chl_after_coarse2fine=[32, 256, 256, 256, 256, 256], temp_chl=[32, 64, 64, 128, 256, 512],
+                dec_chl=[512, 256, 128, 64, 32]),
+)
+E2E_V2Z["ref_config"] = {**E2E_V2["ref_config"], "coarse_branch": dict(type="DA-ZoeDepth", **_ZOE_L),
+                         "refiner": dict(fine_branch=E2E_V2["ref_config"]["refiner"]["fine_branch"],
+                                         fusion_model=dict(type="BiDirectionalFusion",
+                                                           encoder_name="mobilenetv4_conv_small.e2400_r224_in1k",
+                                                           coarse2fine=True, coarse2fine_type="coarse-gated",
+                                                           **E2E_V2Z["fusion"]))}
+
+
+def e2e_v2z_sd(seed: int = 47):
+    spec = OrderedDict()
+    spec.update(W.zoedepth_spec("coarse_branch.", _ZOE_L))
+    spec.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
+    f = E2E_V2Z["fusion"]
+    spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
+                                    f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
+    return W.synth_state_dict(spec, seed=seed)

@@ -24,8 +24,9 @@ from oracle import refharness  # noqa: E402
 refharness.install()
 
 from oracle import dav2 as o_dav2, fusion as o_fusion, mnv4 as o_mnv4, ops as o_ops, tiling as o_tiling  # noqa: E402
-from oracle.cases import (TINY_DAV2, TINY_FUSION_UNET, TINY_BIDIR, E2E_V1, E2E_V2, rand_image, tiny_dav2_sd,  # noqa: E402
-                          e2e_v1_sd, e2e_v2_sd)
+from oracle import zoe as o_zoe  # noqa: E402
+from oracle.cases import (TINY_DAV2, TINY_FUSION_UNET, TINY_BIDIR, E2E_V1, E2E_V2, E2E_V2Z, rand_image, tiny_dav2_sd,  # noqa: E402
+                          e2e_v1_sd, e2e_v2_sd, e2e_v2z_sd)
 from patchrefinerv2_amd import weights as W  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -271,6 +272,41 @@ def g_tiling():
     save("tiling", **res)
 
 
+def build_ref_zoedepth(zcfg, sd, prefix=""):
+    """Reference ZoeDepth over the DepthAnything core, built by the reference's own ZoeDepth.build
+    (type='DA-ZoeDepth' path, zoedepth_v1.py:296-311 -> DepthAnythingCore.build), strict-loaded from ``sd``."""
+    zmod = refharness.ref_module("external.zoedepth.models.zoedepth.zoedepth_v1")
+    m = zmod.ZoeDepth.build(**zcfg)
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    m.load_state_dict(sub, strict=True)
+    return m.eval()
+
+
+def g_zoedepth():
+    print("[zoedepth]")
+    from oracle.cases import ZOE_DA
+    c = ZOE_DA
+    sd = W.synth_state_dict(W.zoedepth_spec("", c["zcfg"]), seed=c["seed"])
+    m = build_ref_zoedepth(dict(c["zcfg"]), sd)
+    z = W.zoedepth_cfg(c["zcfg"])
+    res = {}
+    for tag, (h, w) in c["inputs"].items():
+        x = rand_image(c["seed"], 2, h, w)
+        ref = m(x, return_final_centers=True)
+        ora = o_zoe.zoedepth_forward(sd, "", x, z)
+        d = maxdiff(ref["metric_depth"], ora["metric_depth"])
+        print(f"  {tag}: depth range [{float(ref['metric_depth'].min()):.3f}, {float(ref['metric_depth'].max()):.3f}] "
+              f"oracle-vs-ref max|d| {d:.2e}")
+        assert d < 1e-4 * float(ref["metric_depth"].max()), d
+        for k in ("x_d0", "x_blocks_feat_0", "x_blocks_feat_3", "midas_final_feat"):
+            dd = maxdiff(ref["temp_features"][k], ora["temp_features"][k])
+            assert dd < 1e-4 * max(1.0, float(ref["temp_features"][k].abs().max())), (k, dd)
+        res[f"{tag}_depth"] = ref["metric_depth"]
+        res[f"{tag}_x_d0"] = ref["temp_features"]["x_d0"]
+        res[f"{tag}_final_feat_mean"] = ref["temp_features"]["midas_final_feat"].mean(dim=1)
+    save("zoedepth_da", **res)
+
+
 def _patch_torch_load(sd_for):
     real = torch.load
 
@@ -335,10 +371,8 @@ def g_e2e_v1():
     save("e2e_v1", **res)
 
 
-def g_e2e_v2():
-    print("[e2e_v2]")
-    c = E2E_V2
-    sd = e2e_v2_sd()
+def _g_e2e_v2(tag, c, sd, zoe=False):
+    print(f"[{tag}]")
     import timm
 
     class Enc(torch.nn.Module):
@@ -361,7 +395,8 @@ def g_e2e_v2():
     refharness.ref_module("estimator.models.blocks.lightweight_refiner")
     refharness.ref_module("estimator.models.blocks.bi_directional_fusion_model")
     orig = prp.DepthAnythingV2
-    prp.DepthAnythingV2 = lambda **kw: build_ref_dav2({**c["da2_cfg"], "max_depth": kw["max_depth"]}, sd, "coarse_branch.")
+    if not zoe:
+        prp.DepthAnythingV2 = lambda **kw: build_ref_dav2({**c["da2_cfg"], "max_depth": kw["max_depth"]}, sd, "coarse_branch.")
     prp.Conv2dSame = torch.nn.Conv2d
     orig_lsd = torch.nn.Module.load_state_dict
     real = _patch_torch_load({"dummy_da2": lambda: None})
@@ -379,8 +414,14 @@ def g_e2e_v2():
     assert all(k.startswith(ep) for k in res_load.unexpected_keys)
     m.refiner_fine_branch.refiner_encoder.sd = {k[len(ep):]: v for k, v in sd.items() if k.startswith(ep)}
     assert tuple(m.refiner_fine_branch.refiner_encoder.conv_stem.weight.shape) == (32, 4, 3, 3)
-    ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
-                                          patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+    if zoe:
+        zc = W.zoedepth_cfg(c["zcfg"])
+        ora = o_tiling.OraclePatchRefinerPlus(
+            sd, None, coarse_fn=lambda lr: o_dav2.coarse_features(o_zoe.zoedepth_forward(sd, "coarse_branch.", lr, zc)),
+            patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+    else:
+        ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                              patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
     image_hr = rand_image(c["seed"], 1, *c["raw"])
     image_lr = m.resizer(image_hr)
     res = {}
@@ -395,11 +436,20 @@ def g_e2e_v2():
         print(f"  {mode}: out {tuple(ref.shape)} range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {d:.2e}")
         assert d < 2e-4, d
         res[mode] = ref
-    save("e2e_v2", **res)
+    save(tag, **res)
+
+
+def g_e2e_v2():
+    _g_e2e_v2("e2e_v2", E2E_V2, e2e_v2_sd())
+
+
+def g_e2e_v2z():
+    """PatchRefinerPlus with the reference's own 'DA-ZoeDepth' coarse branch (ZoeDepth.build -> DepthAnythingCore vitl)."""
+    _g_e2e_v2("e2e_v2z", E2E_V2Z, e2e_v2z_sd(), zoe=True)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2"]
+    which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2", "zoedepth", "e2e_v2z"]
     for w in which:
         globals()["g_" + w]()
     print("done")

@@ -255,6 +255,74 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
   }
 }
 
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                  int ldb, int64_t rows, int C, float* __restrict__ y, int ldy) {
+  int64_t total = rows * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(idx % C);
+    int64_t r = idx / C;
+    y[r * ldy + c] = a[r * lda + c] + b[r * ldb + c];
+  }
+}
+
+// one thread per (pixel, bin): the pixel's attractor points are re-read from L1 by its n_bins threads
+__global__ void __launch_bounds__(256) zoe_attractor_kernel(const float* __restrict__ attr, int ld_attr, int n_attr,
+                                                            const float* __restrict__ bins, int ld_bins, int n_bins,
+                                                            float alpha, int64_t rows, float* __restrict__ out,
+                                                            int ld_out) {
+  int64_t total = rows * n_bins;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int j = (int)(idx % n_bins);
+    int64_t r = idx / n_bins;
+    const float c = bins[r * ld_bins + j];
+    const float* a = attr + r * ld_attr;
+    float s = 0.f;
+    for (int i = 0; i < n_attr; ++i) {
+      float dx = a[i] - c;
+      s += dx / (1.0f + alpha * (dx * dx));
+    }
+    out[r * ld_out + j] = c + s / (float)n_attr;
+  }
+}
+
+// one thread per pixel: log-binomial logits over the bins, softmax at temperature t, expectation of the centres
+__global__ void __launch_bounds__(256) zoe_logbinom_depth_kernel(const float* __restrict__ pt, int ld_pt,
+                                                                 const float* __restrict__ centers, int ld_c, int K,
+                                                                 float min_temp, float max_temp, int64_t rows,
+                                                                 float* __restrict__ depth) {
+  const float p_eps = 1e-4f, eps = 1e-4f, sb = 1e-7f;  // ConditionalLogBinomial.p_eps, LogBinomial eps, log_binom eps
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const float* q = pt + r * ld_pt;
+    float p0 = q[0] + p_eps, p1 = q[1] + p_eps, t0 = q[2] + p_eps, t1 = q[3] + p_eps;
+    float p = p0 / (p0 + p1);
+    float t = (max_temp - min_temp) * (t0 / (t0 + t1)) + min_temp;
+    float omp = fminf(fmaxf(1.0f - p, eps), 1.0f);
+    p = fminf(fmaxf(p, eps), 1.0f);
+    const float lp = logf(p), lomp = logf(omp);
+    const float n = (float)(K - 1) + sb;
+    const float nlogn = n * logf(n);
+    const float* c = centers + r * ld_c;
+    // pass 1: max logit; pass 2: softmax-weighted sum
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float kk = (float)k + sb;
+      float lb = nlogn - kk * logf(kk) - (n - kk) * logf(n - kk + sb);
+      float y = (lb + (float)k * lp + (float)(K - 1 - k) * lomp) / t;
+      mx = fmaxf(mx, y);
+    }
+    float den = 0.f, num = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float kk = (float)k + sb;
+      float lb = nlogn - kk * logf(kk) - (n - kk) * logf(n - kk + sb);
+      float y = (lb + (float)k * lp + (float)(K - 1 - k) * lomp) / t;
+      float e = expf(y - mx);
+      den += e;
+      num += e * c[k];
+    }
+    depth[r] = num / den;
+  }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace prv2
@@ -339,5 +407,34 @@ extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, in
   hipLaunchKernelGGL(dwconv_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt,
                      bias, k, stride, relu, oh, ow, y, ldy);
   PRV2_LAUNCH_CHECK("dwconv2d");
+  return 0;
+}
+
+extern "C" int prv2_add(const float* a, int32_t lda, const float* b, int32_t ldb, int64_t rows, int32_t c, float* y,
+                        int32_t ldy, void* stream) {
+  PRV2_REQUIRE(a && b && y && rows > 0 && c > 0 && lda >= c && ldb >= c && ldy >= c, "add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(flat_grid(rows * c, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, rows, c,
+                     y, ldy);
+  PRV2_LAUNCH_CHECK("add");
+  return 0;
+}
+
+extern "C" int prv2_zoe_attractor(const float* attr, int32_t ld_attr, int32_t n_attr, const float* bins, int32_t ld_bins,
+                                  int32_t n_bins, float alpha, int64_t rows, float* out, int32_t ld_out, void* stream) {
+  PRV2_REQUIRE(attr && bins && out && rows > 0 && n_attr > 0 && n_bins > 0 && ld_attr >= n_attr && ld_bins >= n_bins &&
+                   ld_out >= n_bins, "zoe_attractor: bad arguments");
+  hipLaunchKernelGGL(zoe_attractor_kernel, dim3(flat_grid(rows * n_bins, 256)), dim3(256), 0, (hipStream_t)stream, attr,
+                     ld_attr, n_attr, bins, ld_bins, n_bins, alpha, rows, out, ld_out);
+  PRV2_LAUNCH_CHECK("zoe_attractor");
+  return 0;
+}
+
+extern "C" int prv2_zoe_logbinom_depth(const float* pt, int32_t ld_pt, const float* centers, int32_t ld_c, int32_t n_bins,
+                                       float min_temp, float max_temp, int64_t rows, float* depth, void* stream) {
+  PRV2_REQUIRE(pt && centers && depth && rows > 0 && n_bins > 1 && ld_pt >= 4 && ld_c >= n_bins,
+               "zoe_logbinom_depth: bad arguments");
+  hipLaunchKernelGGL(zoe_logbinom_depth_kernel, dim3(flat_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, pt, ld_pt,
+                     centers, ld_c, n_bins, min_temp, max_temp, rows, depth);
+  PRV2_LAUNCH_CHECK("zoe_logbinom_depth");
   return 0;
 }

@@ -114,8 +114,12 @@ def interpolate_pos_encoding(pos_embed: torch.Tensor, h: int, w: int, patch: int
 
 class DepthAnythingV2(StateDictModule):
     def __init__(self, encoder="vitl", features=256, out_channels=(256, 512, 1024, 1024), use_bn=False,
-                 use_clstoken=False, max_depth=20.0, vit=None, device="cuda", prec="f32"):
+                 use_clstoken=False, max_depth=20.0, vit=None, device="cuda", prec="f32", variant="v2"):
+        """variant='v2': DepthAnythingV2 (sigmoid * max_depth head, taps dpt.py:165-170);
+        variant='v1': DPT_DINOv2 of external/depth_anything/dpt.py:133-165 (last-4-blocks taps, ReLU head),
+        the core of the 'DA-ZoeDepth' coarse branch."""
         super().__init__()
+        self.variant = variant
         if use_bn or use_clstoken:
             raise NotImplementedError("use_bn / use_clstoken are never set on the inference path")
         self.cfg = W.dav2_cfg(dict(encoder=encoder, features=features, out_channels=list(out_channels),
@@ -123,6 +127,9 @@ class DepthAnythingV2(StateDictModule):
         if self.cfg["vit"]["dim"] != 64 * self.cfg["vit"]["heads"]:
             raise NotImplementedError("the attention kernel is built for head_dim 64 (every DINOv2 size: "
                                       "384/6, 768/12, 1024/16)")
+        if variant == "v1":
+            d = self.cfg["vit"]["depth"]
+            self.cfg["vit"]["taps"] = list(range(d - 4, d))  # get_intermediate_layers(x, 4, ...) (depth_anything/dpt.py:152)
         self.max_depth = float(max_depth)
         self.encoder = encoder
         self.device = torch.device(device)
@@ -206,7 +213,7 @@ class DepthAnythingV2(StateDictModule):
         # sum to one, so the order commutes up to rounding: conv at low resolution = 4x fewer FLOPs
         return ops.upsample_bilinear(ops.conv2d(out, p["out_conv"]), size[0], size[1])
 
-    def forward_nhwc(self, xn: Feat) -> dict:
+    def forward_nhwc(self, xn: Feat, out_conv_dest: Optional[Feat] = None) -> dict:
         """xn: ImageNet-normalised NHWC input [B, H, W, >=3]; H, W multiples of 14."""
         P = self._packed
         if P is None:
@@ -256,7 +263,11 @@ class DepthAnythingV2(StateDictModule):
         path1 = self._fusion_block(R[1], [path2, rn[0]], (rn[0].h * 2, rn[0].w * 2))
         o = ops.conv2d(path1, P["out1"])
         out_feat = ops.upsample_bilinear(o, gh * 14, gw * 14)
-        o = ops.conv2d(out_feat, P["out2_0"], act=ACT_RELU)
+        o = ops.conv2d(out_feat, P["out2_0"], out_conv_dest, act=ACT_RELU)
+        if self.variant == "v1":
+            # ReLU(conv1x1) ; the interpolate to (h, w) is the identity for 14-multiples; ReLU again is idempotent
+            rel = ops.conv2d_cout1(o, P["out2_2_w"], P["out2_2_b"], 1, act=ACT_RELU)
+            return dict(rel_depth=rel, feats=[o, rn[3], path4, path3, path2, path1])
         depth = ops.conv2d_cout1(o, P["out2_2_w"], P["out2_2_b"], 1, act=ACT_SIGMOID, scale=self.max_depth)
         return dict(metric_depth=depth,
                     temp_features=dict(x_d0=rn[3], x_blocks_feat_0=path4, x_blocks_feat_1=path3,

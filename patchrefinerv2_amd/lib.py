@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprv2_hip.so")
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
@@ -47,6 +47,9 @@ SIGNATURES = {
     "prv2_patchify": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_assemble_tokens": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "prv2_attention": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "prv2_add": (_I, [_P, _I, _P, _I, _L, _I, _P, _I, _P]),
+    "prv2_zoe_attractor": (_I, [_P, _I, _I, _P, _I, _I, _F, _L, _P, _I, _P]),
+    "prv2_zoe_logbinom_depth": (_I, [_P, _I, _P, _I, _I, _F, _F, _L, _P, _P]),
     "prv2_crop_resize": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _I, _P]),
     "prv2_roi_align": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P, _I, _P]),
     "prv2_upsample_bilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -328,10 +328,15 @@ class _PatchModel(StateDictModule):
         if ctype == "DA2":
             self.coarse_branch = self._make_da2(config.coarse_branch, config.max_depth)
             self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
+        elif ctype in ("DA-ZoeDepth", "ZoeDepth"):
+            # ZoeDepth.build(**coarse_branch) (patchrefinerplus.py:102-116); only the vendored DepthAnything cores
+            # exist here -- W.zoedepth_cfg raises for the torch.hub MiDaS DPT-BEiT-L core of type='ZoeDepth'
+            from .zoedepth import ZoeDepth
+            zc = {k: v for k, v in config.coarse_branch.to_dict().items() if k != "type"}
+            self.coarse_branch = ZoeDepth(device=self.device, prec=self.prec, **zc)
+            self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
         else:
-            raise NotImplementedError(
-                f"coarse_branch type {ctype!r}: the ZoeDepth metric-bins head over the MiDaS DPT-BEiT-L core "
-                "(torch.hub, un-vendored in the reference) is not built yet; use type='DA2'")
+            raise NotImplementedError(f"coarse_branch type {ctype!r}")
         if self.strategy_refiner_target != "offset_coarse":
             raise NotImplementedError("strategy_refiner_target: every shipped config uses 'offset_coarse'")
         return config

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as L
-from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, PREC_F32  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS, PREC_F32  # noqa: F401
 
 
 def _stream():
@@ -339,3 +339,27 @@ def blend_resize(avg, cnt, oh, ow):
     L.check(L.load().prv2_blend_resize(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], a.data_ptr(),
                                        c.data_ptr(), oh, ow, _stream()), "blend_resize")
     return a, c
+
+
+def add(a: Feat, b: Feat, out: Optional[Feat] = None) -> Feat:
+    assert (a.n, a.h, a.w, a.c) == (b.n, b.h, b.w, b.c)
+    if out is None:
+        out = Feat.alloc(a.n, a.h, a.w, a.c, a.device)
+    L.check(L.load().prv2_add(a.ptr, a.ld, b.ptr, b.ld, a.n * a.h * a.w, a.c, out.ptr, out.ld, _stream()), "add")
+    return out
+
+
+def zoe_attractor(attr: Feat, bins: Feat, alpha: float = 300.0) -> Feat:
+    assert (attr.n, attr.h, attr.w) == (bins.n, bins.h, bins.w)
+    out = Feat.alloc(bins.n, bins.h, bins.w, bins.c, bins.device)
+    L.check(L.load().prv2_zoe_attractor(attr.ptr, attr.ld, attr.c, bins.ptr, bins.ld, bins.c, alpha,
+                                        bins.n * bins.h * bins.w, out.ptr, out.ld, _stream()), "zoe_attractor")
+    return out
+
+
+def zoe_logbinom_depth(pt: Feat, centers: Feat, min_temp: float, max_temp: float) -> torch.Tensor:
+    assert pt.c == 4 and (pt.n, pt.h, pt.w) == (centers.n, centers.h, centers.w)
+    depth = torch.empty((pt.n, 1, pt.h, pt.w), device=pt.device, dtype=torch.float32)
+    L.check(L.load().prv2_zoe_logbinom_depth(pt.ptr, pt.ld, centers.ptr, centers.ld, centers.c, min_temp, max_temp,
+                                             pt.n * pt.h * pt.w, depth.data_ptr(), _stream()), "zoe_logbinom_depth")
+    return depth

@@ -132,6 +132,67 @@ def dav2_cfg(model_cfg: dict) -> dict:
     )
 
 
+DA_CORE = {  # DepthAnythingCore.build (external/zoedepth/models/base_models/depth_anything.py:340-365)
+    "vits": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384]),
+    "vitb": dict(encoder="vitb", features=128, out_channels=[96, 192, 384, 768]),
+    "vitl": dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024]),
+}
+
+
+def zoedepth_cfg(cfg: dict) -> dict:
+    """Normalise a reference ZoeDepth config dict (configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py:10-66)
+    for the DepthAnything-core flavour (type='DA-ZoeDepth')."""
+    mt = cfg.get("midas_model_type", "vitl")
+    if mt not in DA_CORE:
+        raise NotImplementedError(
+            f"midas_model_type={mt!r}: only the vendored DepthAnything cores (vits/vitb/vitl) are built; the MiDaS "
+            "DPT-BEiT-L core is fetched by torch.hub in the reference (midas.py:342-347) and is not vendored")
+    if cfg.get("bin_centers_type", "softplus") != "softplus" or cfg.get("attractor_type", "inv") != "inv" or \
+            cfg.get("attractor_kind", "mean") != "mean":
+        raise NotImplementedError("only bin_centers_type='softplus', attractor_type='inv', attractor_kind='mean' "
+                                  "(every shipped config)")
+    core = dav2_cfg({**DA_CORE[mt], "vit": cfg.get("vit", {})})
+    return dict(core=core, core_type=mt, n_bins=int(cfg.get("n_bins", 64)),
+                bin_embedding_dim=int(cfg.get("bin_embedding_dim", 128)),
+                n_attractors=list(cfg.get("n_attractors", [16, 8, 4, 1])), min_temp=float(cfg.get("min_temp", 5)),
+                max_temp=float(cfg.get("max_temp", 50)), min_depth=float(cfg.get("min_depth", 1e-3)),
+                max_depth=float(cfg.get("max_depth", 10)))
+
+
+def zoedepth_spec(prefix: str, cfg: dict) -> Spec:
+    """ZoeDepth(core=DepthAnythingCore) parameter table (zoedepth_v1.py:39-123)."""
+    z = zoedepth_cfg(cfg)
+    F_ = z["core"]["features"]
+    nb, emb = z["n_bins"], z["bin_embedding_dim"]
+    s: Spec = OrderedDict()
+    s.update(dinov2_spec(prefix + "core.core.pretrained.", z["core"]["vit"]))
+    s.update(dpt_head_spec(prefix + "core.core.depth_head.", z["core"]["vit"]["dim"], F_, z["core"]["out_channels"]))
+
+    def mlp(name, cin, mid, cout):
+        s[f"{prefix}{name}._net.0.weight"] = (mid, cin, 1, 1)
+        s[f"{prefix}{name}._net.0.bias"] = (mid,)
+        s[f"{prefix}{name}._net.2.weight"] = (cout, mid, 1, 1)
+        s[f"{prefix}{name}._net.2.bias"] = (cout,)
+
+    s[prefix + "conv2.weight"] = (F_, F_, 1, 1)
+    s[prefix + "conv2.bias"] = (F_,)
+    mlp("seed_bin_regressor", F_, 256, nb)
+    mlp("seed_projector", F_, 128, emb)
+    for i in range(4):
+        mlp(f"projectors.{i}", F_, 128, emb)
+    for i in range(4):
+        mlp(f"attractors.{i}", emb, 128, z["n_attractors"][i])
+    last_in = 32 + 1
+    bott = (last_in + emb) // 2
+    s[prefix + "conditional_log_binomial.log_binomial_transform.k_idx"] = (1, nb, 1, 1)
+    s[prefix + "conditional_log_binomial.log_binomial_transform.K_minus_1"] = (1, 1, 1, 1)
+    s[prefix + "conditional_log_binomial.mlp.0.weight"] = (bott, last_in + emb, 1, 1)
+    s[prefix + "conditional_log_binomial.mlp.0.bias"] = (bott,)
+    s[prefix + "conditional_log_binomial.mlp.2.weight"] = (4, bott, 1, 1)
+    s[prefix + "conditional_log_binomial.mlp.2.bias"] = (4,)
+    return s
+
+
 def fusion_unet_spec(prefix: str, input_chl, temp_chl, dec_chl) -> Spec:
     s: Spec = OrderedDict()
     for l, (ic, tc) in enumerate(zip(input_chl, temp_chl)):
@@ -314,6 +375,10 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
     the sigmoid depth head nor the clamp saturates."""
     g = _rng(name, seed)
     leaf = name.rsplit(".", 1)[-1]
+    if leaf == "k_idx":  # LogBinomial buffers (dist_layers.py:45-48): fixed values, not random
+        return torch.arange(0, shape[1]).view(shape)
+    if leaf == "K_minus_1":  # filled from its sibling k_idx by synth_state_dict
+        return torch.zeros(shape)
     n = int(np.prod(shape)) if len(shape) else 1
     z = g.standard_normal(n).astype(np.float32).reshape(shape)
     if leaf == "gamma":  # LayerScale
@@ -327,7 +392,10 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
     elif leaf == "mask_token":
         v = 0.0 * z
     elif leaf == "bias":
-        v = (0.1 if len(shape) == 1 and _is_norm(name) else 0.02) * z
+        if "seed_bin_regressor._net.2" in name:
+            v = 1.5 * z  # spread the 64 seed bin centres (softplus) over ~0.1 .. 5
+        else:
+            v = (0.1 if len(shape) == 1 and _is_norm(name) else 0.02) * z
     elif len(shape) == 1:  # norm weight
         v = 1.0 + 0.1 * z
     else:
@@ -337,6 +405,8 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
             fan_in = int(np.prod(shape[1:]))
         if name.endswith("final_conv.weight"):
             gain = 0.5  # offset head: O(1) metres on top of the coarse depth
+        elif "seed_bin_regressor._net.2" in name or "conditional_log_binomial.mlp.2" in name:
+            gain = 3.0
         elif "output_conv2.2." in name:
             gain = 1.5  # pre-sigmoid logits O(1): the depth head must not saturate
         elif re.search(r"resConfUnit\d\.conv2\.|GateresConfUnit\d\.conv\.", name):
@@ -352,4 +422,8 @@ def _is_norm(name: str) -> bool:
 
 
 def synth_state_dict(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    return OrderedDict((k, synth_tensor(k, tuple(shp), seed)) for k, shp in spec.items())
+    sd = OrderedDict((k, synth_tensor(k, tuple(shp), seed)) for k, shp in spec.items())
+    for k in sd:
+        if k.endswith("K_minus_1"):
+            sd[k] = torch.tensor([float(sd[k[:-len("K_minus_1")] + "k_idx"].numel() - 1)]).view(sd[k].shape)
+    return sd

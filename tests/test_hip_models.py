@@ -10,8 +10,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import dav2 as o_dav2, fusion as o_fusion, mnv4 as o_mnv4, tiling as o_tiling  # noqa: E402
-from oracle.cases import (E2E_V1, E2E_V2, TINY_BIDIR, TINY_DAV2, TINY_FUSION_UNET, e2e_v1_sd, e2e_v2_sd, rand_image,  # noqa: E402
-                          tiny_dav2_sd)
+from oracle.cases import (E2E_V1, E2E_V2, E2E_V2Z, TINY_BIDIR, TINY_DAV2, TINY_FUSION_UNET, ZOE_DA, e2e_v1_sd,  # noqa: E402
+                          e2e_v2_sd, e2e_v2z_sd, rand_image, tiny_dav2_sd)
+from oracle import zoe as o_zoe  # noqa: E402
 from patchrefinerv2_amd import weights as W  # noqa: E402
 
 DEV = "cuda"
@@ -199,3 +200,36 @@ def test_e2e_bf16x3_meets_absrel_target(P, golden):
         print(kind, mode, "bf16x3 AbsRel", ar, "max|d|", mx)
         assert ar < ABSREL_TOL, (kind, ar)
         assert ar > 1e-8  # really the split path
+
+
+def test_zoedepth_da_core(P, golden):
+    """ZoeDepth metric-bins head over the DepthAnything ViT-S core vs the reference's ZoeDepth.build output"""
+    from patchrefinerv2_amd.zoedepth import ZoeDepth
+    c, g = ZOE_DA, golden("zoedepth_da")
+    sd = W.synth_state_dict(W.zoedepth_spec("", c["zcfg"]), seed=c["seed"])
+    m = ZoeDepth.build(**c["zcfg"])
+    res = m.load_state_dict(sd, strict=True)
+    assert not res["missing_keys"]
+    z = W.zoedepth_cfg(c["zcfg"])
+    for tag, (h, w) in c["inputs"].items():
+        x = rand_image(c["seed"], 2, h, w)
+        out = m(x.to(DEV), return_final_centers=True)
+        ref = o_zoe.zoedepth_forward(sd, "", x, z)
+        close(out["metric_depth"], g[f"{tag}_depth"], 3e-5, f"{tag} depth vs golden")
+        for k, v in ref["temp_features"].items():
+            close(out["temp_features"][k].to_nchw(), v, 3e-5, f"{tag} {k}")
+    with pytest.raises(NotImplementedError):
+        ZoeDepth.build(midas_model_type="DPT_BEiT_L_384")
+
+
+def test_e2e_v2_zoedepth_coarse_vs_reference_golden(P, golden):
+    c, g = E2E_V2Z, golden("e2e_v2z")
+    from patchrefinerv2_amd.registry import build_model
+    import patchrefinerv2_amd.models  # noqa: F401
+    m = build_model(dict(type="PatchRefinerPlus", config=dict(c["ref_config"])))
+    res = m.load_state_dict(e2e_v2z_sd(), strict=True)
+    assert not res["missing_keys"] and not res["unexpected_keys"]
+    for mode in c["modes"]:
+        depth, _ = _run(m, c, mode)
+        ar, mx = absrel(depth, g[mode])
+        assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)

@@ -311,3 +311,32 @@ def test_conv3x3_halo_equals_generic(P, prec):
     g = P.conv2d(xf, cw, act=P.ACT_RELU, force_generic=True).to_nchw()
     close(a, g.cpu(), 2e-6 if prec == "f32" else 2e-5)
     assert not torch.equal(a, g) or prec != "f32"  # really two different kernels
+
+
+def test_zoe_head_ops(P):
+    """softplus epilogue, add, inverse attractor (alpha=300, gamma=2) and the log-binomial expectation"""
+    from oracle import zoe as o_zoe
+    x = rnd(1, 2, 48, 9, 11)
+    w, b = rnd(2, 16, 48, 1, 1) / 5, rnd(3, 16)
+    y = P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(w.to(DEV), b.to(DEV)), act=P.ACT_SOFTPLUS)
+    close(y.to_nchw(), F.softplus(F.conv2d(x * 1.0, w, b)), 2e-5)
+    big = P.conv2d(P.Feat.from_nchw((x * 50).to(DEV)), P.pack_conv(w.to(DEV), b.to(DEV)), act=P.ACT_SOFTPLUS)
+    close(big.to_nchw(), F.softplus(F.conv2d(x * 50, w, b)), 2e-5)   # threshold=20 branch
+    a2, b2 = rnd(4, 2, 12, 9, 11), rnd(5, 2, 12, 9, 11)
+    close(P.add(P.Feat.from_nchw(a2.to(DEV)), P.Feat.from_nchw(b2.to(DEV))).to_nchw(), a2 + b2, 0)
+    A = F.softplus(rnd(6, 2, 16, 9, 11))
+    bins = F.softplus(rnd(7, 2, 64, 9, 11)) * 3
+    ref = bins + torch.mean(o_zoe.inv_attractor(A.unsqueeze(2) - bins.unsqueeze(1)), dim=1)
+    got = P.zoe_attractor(P.Feat.from_nchw(A.to(DEV)), P.Feat.from_nchw(bins.to(DEV)), 300.0)
+    close(got.to_nchw(), ref, 2e-6)
+    pt = F.softplus(rnd(8, 2, 4, 9, 11) * 2)
+    centers = F.softplus(rnd(9, 2, 64, 9, 11)) * 10
+    pp = (pt[:, 0] + 1e-4) / (pt[:, 0] + pt[:, 1] + 2e-4)
+    tt = ((pt[:, 2] + 1e-4) / (pt[:, 2] + pt[:, 3] + 2e-4)).unsqueeze(1) * (50 - 0.0212) + 0.0212
+    xx = pp.unsqueeze(1)
+    k = torch.arange(0, 64).view(1, -1, 1, 1)
+    yy = o_zoe.log_binom(torch.Tensor([63.]).view(1, 1, 1, 1), k) + k * torch.log(xx.clamp(1e-4, 1)) + \
+        (63 - k) * torch.log((1 - xx).clamp(1e-4, 1))
+    refd = (torch.softmax(yy / tt, dim=1) * centers).sum(1, keepdim=True)
+    gotd = P.zoe_logbinom_depth(P.Feat.from_nchw(pt.to(DEV)), P.Feat.from_nchw(centers.to(DEV)), 0.0212, 50.0)
+    close(gotd, refd, 2e-5)
