@@ -142,7 +142,7 @@ DA_CORE = {  # DepthAnythingCore.build (external/zoedepth/models/base_models/dep
 def zoedepth_cfg(cfg: dict) -> dict:
     """Normalise a reference ZoeDepth config dict (configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py:10-66)
     for the DepthAnything-core flavour (type='DA-ZoeDepth')."""
-    mt = cfg.get("midas_model_type", "vitl")
+    mt = cfg.get("midas_model_type", "DPT_BEiT_L_384")  # ZoeDepth.build default (zoedepth_v1.py:297)
     if mt not in DA_CORE:
         raise NotImplementedError(
             f"midas_model_type={mt!r}: only the vendored DepthAnything cores (vits/vitb/vitl) are built; the MiDaS "

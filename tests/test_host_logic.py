@@ -87,3 +87,30 @@ def test_state_dict_contract_and_loud_failures():
     bad["coarse_branch"] = dict(type="ZoeDepth")
     with pytest.raises(NotImplementedError):
         build_model(dict(type="PatchRefinerPlus", config=bad))
+
+
+def test_png16_and_read_image(tmp_path):
+    from patchrefinerv2_amd.tester import ImageDataset, read_image, write_png16
+    a = (np.arange(6 * 5).reshape(6, 5) * 1000).astype(np.uint16)
+    write_png16(str(tmp_path / "x.png"), a)
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / "x.png"))), a)
+    except ImportError:
+        pass
+    img = np.random.RandomState(0).rand(20, 30, 3).astype(np.float32)
+    np.save(str(tmp_path / "f.npy"), img)
+    out = read_image(str(tmp_path / "f.npy"), "", (40, 60))
+    import torch
+    import torch.nn.functional as F
+    ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], (40, 60), mode="bicubic", align_corners=True)
+    assert np.allclose(out, ref[0].permute(1, 2, 0).numpy())
+    os.remove(str(tmp_path / "x.png"))
+    ds = ImageDataset(str(tmp_path), image_resolution=(40, 60))
+    assert len(ds) == 1 and tuple(ds[0]["image_hr"].shape) == (3, 40, 60) and ds[0]["img_file_basename"] == "f"
+
+
+def test_shipped_config_builds():
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "v2_dav2_mobile_u4k.py"))
+    m = build_model(cfg.model)
+    assert m.tile_cfg["patch_raw_shape"] == (540, 960) and len(m.spec()) > 500

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""User inference CLI with the reference's flags (README.md:51-76, docs/user_infer.md:113-130):
+
+  python tools/test.py CONFIG --ckp-path CKP --cai-mode r32 --cfg-option general_dataloader.dataset.rgb_image_dir=DIR \\
+      [--save] --work-dir OUT --test-type general [--gray-scale] --image-raw-shape H W --patch-split-num h w
+
+CONFIG is an MMEngine-style python config (``model=dict(type=..., config=dict(...))``, ``_base_`` supported).
+Extras: ``--synthetic-weights`` (the reference has not released checkpoints), ``--prec``, ``--process-num``.
+Multi-GPU: launch with torch.distributed.run; frames are sharded over ranks like the reference's dist_test.sh.
+"""
+import argparse
+import ast
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from patchrefinerv2_amd import models, weights as W  # noqa: E402,F401
+from patchrefinerv2_amd.registry import DATASETS, Config, build_model  # noqa: E402
+from patchrefinerv2_amd.tester import RunnerInfo, Tester  # noqa: E402,F401
+
+
+def parse_opts(opts):
+    out = {}
+    for o in opts or []:
+        k, v = o.split("=", 1)
+        try:
+            v = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            pass
+        out[k] = v
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--ckp-path", default=None)
+    ap.add_argument("--cai-mode", default="m1")
+    ap.add_argument("--cfg-option", nargs="+", default=None)
+    ap.add_argument("--save", action="store_true")
+    ap.add_argument("--work-dir", default="./work_dir/predictions")
+    ap.add_argument("--test-type", default="general")
+    ap.add_argument("--gray-scale", action="store_true")
+    ap.add_argument("--image-raw-shape", nargs=2, type=int, default=[2160, 3840])
+    ap.add_argument("--patch-split-num", nargs=2, type=int, default=[4, 4])
+    ap.add_argument("--process-num", type=int, default=4)
+    ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--synthetic-weights", action="store_true")
+    ap.add_argument("--seed", type=int, default=621)
+    args = ap.parse_args()
+    if args.test_type != "general":
+        raise SystemExit("only --test-type general (folder of images) is built; dataset metrics are out of scope")
+
+    cfg = Config.fromfile(args.config)
+    cfg.merge_from_dict(parse_opts(args.cfg_option))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+
+    mcfg = cfg.model.to_dict()
+    mcfg["config"]["prec"] = args.prec
+    model = build_model(mcfg)
+    if args.ckp_path:
+        sd = torch.load(args.ckp_path, map_location="cpu")
+        print(model.load_dict(sd.get("model_state_dict", sd)))
+    elif args.synthetic_weights:
+        model.load_state_dict(W.synth_state_dict(model.spec(), seed=0), strict=True)
+    else:
+        raise SystemExit("give --ckp-path or --synthetic-weights")
+
+    ds_cfg = cfg.general_dataloader.dataset.to_dict()
+    ds_cfg["image_resolution"] = args.image_raw_shape
+    dataset = DATASETS.build(ds_cfg)
+    runner = RunnerInfo(rank=rank, world_size=world, save=args.save, gray_scale=args.gray_scale, work_dir=args.work_dir)
+    for name, shape, mean in Tester(cfg, runner, dataset, model).run(
+            cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
+            patch_split_num=args.patch_split_num, seed=args.seed):
+        print(f"[rank {rank}] {name}: depth {shape} mean {mean:.4f}")
+
+
+if __name__ == "__main__":
+    main()
