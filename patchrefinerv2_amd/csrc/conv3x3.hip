@@ -28,11 +28,11 @@ constexpr int A_IT = (HALO * 8 + 511) / 512;  // float4 loads per thread per sla
 template <int BN, int PREC>
 __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams p) {
   constexpr int NJ = BN / 64;
-  constexpr int NB = BN / 64;                      // weight float4 per thread per step
   constexpr int A_STAGE = HALO * LDS_LD;           // floats
-  constexpr int B_STAGE = BN * LDS_LD;
+  constexpr int B_STAGE = BN * 32;                 // floats: unpadded 128-byte rows, XOR-swizzled (LDS-DMA image)
   constexpr int CLD = BN + 4;
-  constexpr int SMEM_MAIN = 2 * A_STAGE + 2 * B_STAGE;
+  constexpr int NBUF = 2;                          // weight tile of this step + the one landing for the next
+  constexpr int SMEM_MAIN = 2 * A_STAGE + NBUF * B_STAGE;
   constexpr int SMEM_EPI = TH * TW * CLD;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
   float* const As = smem;
@@ -72,12 +72,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
     a_off[it] = ok ? (iy * p.W + ix) * p.ldx : -1;
   }
   const long long w_row_stride = 9LL * p.Cin_pad;
-  const float* wbase = reinterpret_cast<const float*>(p.w) + ((long long)tile_n * BN + prow) * w_row_stride + chunk * 4;
   const int cchunks = p.Cin_pad / BK;
   const int nsteps = 9 * cchunks;
   const int cin4 = (p.Cin + 3) & ~3;
 
-  f32x4 ra[A_IT], rb[NB];
+  f32x4 ra[A_IT];
   const float x_floor = p.relu_in ? 0.f : -INFINITY;  // fused input ReLU without a branch next to the loads
 
   // halo item `it` (one float4 per thread) of slab cc: issued at tap `it`, stored after that tap's MFMAs.
@@ -92,16 +91,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
     const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
     if (hp < HALO) stage_a<PREC>(As + abuf * A_STAGE + hp * LDS_LD, chunk, floor4(zero_unless(ra[it], ok), x_floor));
   };
-  auto load_b = [&](int s) {
+  // Weight tile of step s via LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B = 8 rows x 128 B land
+  // contiguously in LDS, no VGPRs and no ds_write.  The packed weights are pre-swizzled in HBM
+  // (prv2_pack_conv_weight) so that the linear copy IS the conflict-free XOR image.
+  const int dma_row = lane >> 3, dma_slot = lane & 7;
+  const float* wdma = reinterpret_cast<const float*>(p.w) + ((long long)tile_n * BN + dma_row) * w_row_stride + dma_slot * 4;
+  auto dma_b = [&](int s, int bbuf) {
     const int cc = s / 9, tap = s - cc * 9;
-    const float* wsrc = wbase + (long long)tap * p.Cin_pad + cc * BK;
+    const float* wsrc = wdma + (long long)tap * p.Cin_pad + cc * BK;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wsrc + (long long)(64 * i) * w_row_stride);
-  };
-  auto store_b = [&](int bbuf) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<f32x4*>(Bs + bbuf * B_STAGE + (prow + 64 * i) * LDS_LD + chunk * 4) = rb[i];
+    for (int i = 0; i < BN / 64; ++i) {
+      const int piece = wave * (BN / 64) + i;  // 8 rows each
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wsrc + (long long)(piece * 8) * w_row_stride),
+          (__attribute__((address_space(3))) void*)(Bs + bbuf * B_STAGE + piece * 256), 16, 0, 0);
+    }
   };
 
   f32x16 acc[2][NJ];
@@ -117,34 +121,42 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
   auto compute = [&](int abuf, int bbuf, int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const char* Ab = reinterpret_cast<const char*>(As + abuf * A_STAGE + (a_pix0 + ky * HW_ + kx) * LDS_LD) + half * 16;
-    const char* Bb = reinterpret_cast<const char*>(Bs + bbuf * B_STAGE + (wn * (BN / 2) + r32) * LDS_LD) + half * 16;
+    const char* Bb = reinterpret_cast<const char*>(Bs + bbuf * B_STAGE + (wn * (BN / 2) + r32) * 32);
     const char* a_row[2] = {Ab, Ab + HW_ * LDS_LD * 4};
     const char* b_row[NJ];
+    int b_swz[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) b_row[j] = Bb + j * 32 * LDS_LD * 4;
-    mma_slab<NJ, PREC>(acc, a_row, b_row);
+    for (int j = 0; j < NJ; ++j) {
+      b_row[j] = Bb + j * 32 * 128;
+      b_swz[j] = ((wn * (BN / 2) + j * 32 + r32) >> 1) & 7;
+    }
+    mma_slab<NJ, PREC, true>(acc, a_row, b_row, b_swz, half * 16);
   };
 
+  // ---- pipeline: one barrier per (slab, tap) step -------------------------------------------------
+  // Measured alternatives that did NOT pay on MI355X (tools/ab_conv.sh, same box, 512->256 @224^2 x27):
+  //   weights through registers + ds_write instead of LDS-DMA: equal within 1 %;
+  //   3 weight buffers, DMA two steps ahead, hand-counted vmcnt + raw s_barrier: +1 %;
+  //   fragment reads issued before the VMEM instructions: -1.5 %;  s_setprio around the MFMAs: 0.
+  // Ablation: without any global->LDS traffic the same loop reaches 607 TF (73 % of the bf16x3 peak).
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) load_a(0, it);
-  load_b(0);
+  dma_b(0, 0);
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) store_a(0, 0, it);
-  store_b(0);
-  __syncthreads();
+  __syncthreads();  // (also drains the LDS-DMA: with a DMA in flight the barrier's fence waits vmcnt(0))
   for (int cc = 0; cc < cchunks; ++cc) {
-    // No uniform branches around the loads: hipcc would drain vmcnt at each one.  The last slab / last
-    // step simply re-load clamped (already cached) data into buffers nobody reads afterwards.
+    // No uniform branches around the loads (hipcc would drain vmcnt at each one): the last slab / last step
+    // simply re-load clamped (already cached) data into buffers nobody reads afterwards.
     const int ccn = cc + 1 < cchunks ? cc + 1 : cc;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      load_b(s + 1 < nsteps ? s + 1 : s);
+      dma_b(s + 1 < nsteps ? s + 1 : s, (s + 1) & 1);  // lands during the MFMAs below
       if (tap < A_IT) load_a(ccn, tap);
-      __builtin_amdgcn_sched_barrier(0);  // keep the global loads above the MFMAs (hipcc sinks them to their use)
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMAs (hipcc sinks them to their use)
       compute(cc & 1, s & 1, tap);
       __builtin_amdgcn_sched_barrier(0);
-      store_b((s + 1) & 1);
       // the other halo buffer was last read in slab cc-1: free since this slab's first barrier
       if (tap < A_IT) store_a(ccn, (cc + 1) & 1, tap);
       __syncthreads();

@@ -63,57 +63,77 @@ __device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo
 }
 
 
-// One BK=32 slab of MFMAs for a wave: 2 row sub-tiles (32 rows each) x NJ column sub-tiles.
-// a_row[i] / b_row[j] point at the lane's LDS row (144-byte rows: 32 fp32, or [32 bf16 hi | 32 bf16 lo]),
-// already offset by the lane half (half*16 bytes).
+// ---- MFMA fragments of one k-step for a wave: 2 row sub-tiles (32 rows each) x NJ column sub-tiles ----------
+// a_row[i] / b_row[j] point at the lane's LDS row (A: 144-byte rows already offset by the lane half;
+// B: either the same, or -- BSWZ -- unpadded 128-byte rows whose 16-byte slots are XOR-swizzled: slot c of
+// the row lives at c ^ b_swz[j]; that is the image an LDS-DMA, which can only write linearly, produces from
+// the pre-swizzled packed weights).  PREC_F32: k-step = 8 channels (4 MFMAs of k=2: lane half h takes channels
+// 8ks+4h..+3 so MFMA e multiplies channel 8ks+4h+e on both operands); bf16 modes: k-step = 16 channels
+// (v_mfma_f32_32x32x16_bf16: lane (r32, half) holds A[row r32][k = 8*half + j]).
 template <int NJ, int PREC>
-__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NJ], const char* const (&a_row)[2], const char* const (&b_row)[NJ]) {
+struct Frags {
+  f32x4 a[2], b[NJ];
+  bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+};
+template <int PREC>
+constexpr int ksteps() { return PREC == PRV2_PREC_F32 ? 4 : 2; }
+
+template <int NJ, int PREC, bool BSWZ>
+__device__ __forceinline__ void read_frags(Frags<NJ, PREC>& f, int ks, const char* const (&a_row)[2],
+                                           const char* const (&b_row)[NJ], const int (&b_swz)[NJ], int half16) {
+  auto b_at = [&](int j, int byte_off) -> const char* {
+    if constexpr (BSWZ) return b_row[j] + ((((byte_off + half16) >> 4) ^ b_swz[j]) << 4);
+    else return b_row[j] + byte_off;
+  };
   if constexpr (PREC == PRV2_PREC_F32) {
-    // v_mfma_f32_32x32x2_f32: lane half h takes channels 8ks+4h..+3; MFMA e multiplies channel 8ks+4h+e
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      f32x4 a[2], b[NJ];
+    for (int i = 0; i < 2; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(a_row[i] + ks * 32);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_row[i] + ks * 32);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_row[j] + ks * 32);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+    for (int j = 0; j < NJ; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(b_at(j, ks * 32));
   } else {
-    // v_mfma_f32_32x32x16_bf16: lane (r32, half) holds A[row r32][k = 8*half + j], B[k = 8*half + j][col r32];
-    // k-step ks covers channels 16*ks..+15 -> byte offset 32*ks inside the hi (or +64: lo) half-row
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + ks * 32);
-        if constexpr (PREC == PRV2_PREC_BF16X3) al[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + 64 + ks * 32);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        bh[j] = *reinterpret_cast<const bf16x8*>(b_row[j] + ks * 32);
-        if constexpr (PREC == PRV2_PREC_BF16X3) bl[j] = *reinterpret_cast<const bf16x8*>(b_row[j] + 64 + ks * 32);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if constexpr (PREC == PRV2_PREC_BF16X3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+    for (int i = 0; i < 2; ++i) {
+      f.ah[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + ks * 32);
+      if constexpr (PREC == PRV2_PREC_BF16X3) f.al[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + 64 + ks * 32);
     }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f.bh[j] = *reinterpret_cast<const bf16x8*>(b_at(j, ks * 32));
+      if constexpr (PREC == PRV2_PREC_BF16X3) f.bl[j] = *reinterpret_cast<const bf16x8*>(b_at(j, 64 + ks * 32));
+    }
+  }
+}
+
+template <int NJ, int PREC>
+__device__ __forceinline__ void mma_frags(f32x16 (&acc)[2][NJ], const Frags<NJ, PREC>& f) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if constexpr (PREC == PRV2_PREC_F32) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].x, f.b[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].y, f.b[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].z, f.b[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].w, f.b[j].w, acc[i][j], 0, 0, 0);
+      } else {
+        if constexpr (PREC == PRV2_PREC_BF16X3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+}
+
+// One BK=32 slab (all k-steps), fragments read on the fly
+template <int NJ, int PREC, bool BSWZ = false>
+__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NJ], const char* const (&a_row)[2], const char* const (&b_row)[NJ],
+                                         const int (&b_swz)[NJ] = {}, int half16 = 0) {
+#pragma unroll
+  for (int ks = 0; ks < ksteps<PREC>(); ++ks) {
+    Frags<NJ, PREC> f;
+    read_frags<NJ, PREC, BSWZ>(f, ks, a_row, b_row, b_swz, half16);
+    mma_frags<NJ, PREC>(acc, f);
   }
 }
 

@@ -112,8 +112,12 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
       stage_a<PREC>(&smem[buf * STAGE + (row0 + 32 * i) * LDS_LD], chunk,
                     floor4(zero_unless(ra[i], (okmask >> i) & 1u), x_floor));
 #pragma unroll
-    for (int i = 0; i < NB; ++i)  // packed weights already are the LDS row image: plain 16-byte copy
-      *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (BM + row0 + 32 * i) * LDS_LD + chunk * 4]) = rb[i];
+    for (int i = 0; i < NB; ++i) {
+      // packed weights are the LDS row image with XOR-swizzled 16-byte slots (for the LDS-DMA of conv3x3.hip):
+      // physical slot `chunk` of row r holds logical slot chunk ^ ((r >> 1) & 7)
+      const int r = row0 + 32 * i;
+      *reinterpret_cast<f32x4*>(&smem[buf * STAGE + (BM + r) * LDS_LD + ((chunk ^ ((r >> 1) & 7)) << 2)]) = rb[i];
+    }
   };
 
   f32x16 acc[2][NJ];
@@ -209,15 +213,21 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
         if (scale) v *= scale[r];
       }
     }
+    // 128-byte row image of this (row, tap, 32-channel chunk); its eight 16-byte slots are stored XOR-swizzled
+    // by ((row >> 1) & 7) so that a LINEAR LDS-DMA copy of 8 rows x 128 B is bank-conflict free for ds_read_b128
+    float* rowp = dst + (idx - (c & 31));
+    const int key = (r >> 1) & 7;
     if (prec == PRV2_PREC_F32) {
-      dst[idx] = v;
+      const int e = c & 31;  // element e lives in logical slot e/4
+      rowp[(((e >> 2) ^ key) << 2) + (e & 3)] = v;
     } else {
-      // per 32-channel chunk: [32 x bf16 hi][32 x bf16 lo] -- the LDS row image of the bf16 modes
+      // logical image: [32 x bf16 hi][32 x bf16 lo]; element e of hi in slot e/8, of lo in slot 4 + e/8
       __bf16 hi = (__bf16)v;
       __bf16 lo = (__bf16)(v - (float)hi);
-      __bf16* d16 = reinterpret_cast<__bf16*>(dst + (idx - (c & 31)));
-      d16[c & 31] = hi;
-      d16[32 + (c & 31)] = prec == PRV2_PREC_BF16X3 ? lo : (__bf16)0.0f;
+      __bf16* d16 = reinterpret_cast<__bf16*>(rowp);
+      const int e = c & 31;
+      d16[(((e >> 3) ^ key) << 3) + (e & 7)] = hi;
+      d16[((((e >> 3) + 4) ^ key) << 3) + (e & 7)] = prec == PRV2_PREC_BF16X3 ? lo : (__bf16)0.0f;
     }
   }
 }
