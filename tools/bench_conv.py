@@ -6,13 +6,16 @@ from patchrefinerv2_amd import ops, lib as L
 
 prec = L.PREC_NAMES[sys.argv[1] if len(sys.argv) > 1 else "bf16x3"]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ONLY = [int(i) for i in sys.argv[3].split(",")] if len(sys.argv) > 3 else None  # shape indices (PMC runs)
 SHAPES = [  # (cin, cout, k, h, w)  -- the heavy layers of BiDirectionalFusion, dav2 cfg (SURVEY.md A.1 rescaled to 448^2)
     (512, 256, 3, 224, 224), (256, 256, 3, 224, 224), (256, 128, 3, 448, 448), (512, 256, 3, 112, 112),
     (98, 98, 3, 448, 448), (194, 194, 3, 224, 224), (512, 64, 3, 224, 224), (256, 256, 1, 448, 448),
     (322, 322, 3, 112, 112), (642, 642, 3, 56, 56), (128, 128, 3, 448, 448), (98, 32, 3, 448, 448), (770, 770, 3, 28, 28),
     (1024, 4096, 1, 1025, 1), (4096, 1024, 1, 1025, 1),
 ]
-for (cin, cout, k, h, w) in SHAPES:
+for si, (cin, cout, k, h, w) in enumerate(SHAPES):
+    if ONLY is not None and si not in ONLY:
+        continue
     b = 1 if w == 1 else B
     x = ops.Feat.alloc(b, h, w, cin, "cuda")
     x.buf.normal_()
