@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="matrix-kernel arithmetic (DESIGN.md 3): bf16x3 = split-bf16, AbsRel ~5e-6; f32 = exact fp32 MFMA")
     ap.add_argument("--shard", default="frames", choices=["frames", "patches"])
-    ap.add_argument("--max-batch", type=int, default=27, help="patches per launch batch (results are batch independent)")
+    ap.add_argument("--max-batch", type=int, default=14, help="patches per launch batch (results are batch independent)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layer-report", default=None, help="write a per-layer-shape timing table (extra instrumented frame)")
@@ -125,7 +126,7 @@ def main():
 
     name = args.workload or DEFAULT_WORKLOAD
     w = WORKLOADS[name]
-    mc = model_config(name, prec=args.prec, max_batch=args.max_batch)
+    mc = model_config(name, prec=args.prec, max_batch=args.max_batch, n_streams=args.streams)
     mc["config"]["device"] = str(dev)
     model = build_model(mc)
     sd = W.synth_state_dict(state_spec(name), seed=0)
@@ -176,7 +177,7 @@ def main():
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
                     coarse_branch=w["coarse"]["encoder"], shard=args.shard if world > 1 else "none",
-                    max_batch=args.max_batch, out_shape=list(out.shape)))
+                    max_batch=args.max_batch, streams=args.streams, out_shape=list(out.shape)))
 
     if rank == 0 and not args.no_roofline:
         # one extra, instrumented frame: HIP events on the launch stream around every matrix-kernel launch

@@ -256,11 +256,26 @@ class _PatchModel(StateDictModule):
             idx = idx[rank::world]
         bs = max(1, int(getattr(self, "max_batch", None) or process_num))
         preds = torch.empty((len(idx), 1, ph, pw), device=dev)  # this rank's predictions, in tile order
-        for s in range(0, len(idx), bs):
+        # Tile batches are independent: they are issued round-robin on ``n_streams`` HIP streams so that the
+        # HBM-bound kernels of one batch (gathers, LayerNorm, gate 1x1s) run beside the MFMA-bound convs of another.
+        n_streams = max(1, int(getattr(self, "n_streams", None) or 1))
+        main = torch.cuda.current_stream(dev)
+        streams = [main] if n_streams == 1 else self._streams(dev, n_streams)
+        if n_streams > 1:
+            ready = torch.cuda.Event()
+            ready.record(main)
+        for bi, s in enumerate(range(0, len(idx), bs)):
             sel = idx[s:s + bs]
-            crops, rois, depth_roi = self._prepare_batch(image_chw, [flat[i] for i in sel], tile_cfg, coarse_feats,
-                                                         coarse_depth)
-            self.infer_forward(crops, rois, depth_roi, out=preds[s:s + len(sel)])
+            st = streams[bi % len(streams)]
+            with torch.cuda.stream(st):
+                if n_streams > 1 and bi < len(streams):
+                    st.wait_event(ready)
+                crops, rois, depth_roi = self._prepare_batch(image_chw, [flat[i] for i in sel], tile_cfg, coarse_feats,
+                                                             coarse_depth)
+                self.infer_forward(crops, rois, depth_roi, out=preds[s:s + len(sel)])
+        if n_streams > 1:
+            for st in streams:
+                main.wait_stream(st)
         if shard is not None and shard[1] > 1:
             preds = self._gather_predictions(preds, len(flat), shard)
         preds = preds.view(len(flat), ph, pw)
@@ -302,6 +317,12 @@ class _PatchModel(StateDictModule):
         allp = allp.view((world, per) + tuple(mine.shape[1:]))
         return allp.transpose(0, 1).reshape((per * world,) + tuple(preds.shape[1:]))[:n_total].contiguous()
 
+    def _streams(self, dev, n):
+        cache = self.__dict__.setdefault("_stream_cache", {})
+        if (str(dev), n) not in cache:
+            cache[(str(dev), n)] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        return cache[(str(dev), n)]
+
     # -- checkpoint contract (patchrefinerplus.py:212-216) ------------------------------------------
     def load_dict(self, sd):
         return self.load_state_dict(sd, strict=False)
@@ -322,6 +343,7 @@ class _PatchModel(StateDictModule):
         self.prec = ops.L.PREC_NAMES[config.get("prec", "f32")]
         self.device = torch.device(config.get("device", "cuda"))
         self.max_batch = config.get("max_batch", None)
+        self.n_streams = config.get("n_streams", 1)
         self.strategy_refiner_target = config.strategy_refiner_target
         self.fusion_feat_level = config.fusion_feat_level
         ctype = config.coarse_branch["type"]

@@ -38,14 +38,14 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "v2_dav2l_4k_r32"
 
 
-def model_config(name: str, prec: str = "f32", max_batch=None) -> dict:
+def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> dict:
     w = WORKLOADS[name]
     raw, split = w["raw"], w["split"]
     cfg = dict(
         image_raw_shape=raw, patch_process_shape=w["pps"], patch_raw_shape=[raw[0] // split[0], raw[1] // split[1]],
         patch_split_num=split, fusion_feat_level=6, min_depth=1e-3, max_depth=80.0, pretrain_coarse_model=None,
         strategy_refiner_target="offset_coarse", coarse_branch=dict(type="DA2", pretrained=None, model_cfg=w["coarse"]),
-        sigloss=dict(type="SILogLoss"), pretrained=None, pre_norm_bbox=True, prec=prec, max_batch=max_batch)
+        sigloss=dict(type="SILogLoss"), pretrained=None, pre_norm_bbox=True, prec=prec, max_batch=max_batch, n_streams=n_streams)
     if w["kind"] == "PatchRefinerPlus":
         cfg.update(e2e_training=True, pretrain_stage=False, gmloss=dict(type="GradMatchLoss"), sigweight=1,
                    whole_pretrained=None,

@@ -175,6 +175,10 @@ def test_batching_independence(P):
     m.max_batch = 7
     b, _ = _run(m, c, "r8")
     assert torch.equal(a, b)
+    m.max_batch, m.n_streams = 3, 3  # batches spread over 3 HIP streams
+    for _ in range(3):
+        d, _ = _run(m, c, "r8")
+        assert torch.equal(a, d)
 
 
 def test_rejects_cpu_inputs_and_bad_shapes(P):
