@@ -181,10 +181,12 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # one extra, instrumented frame: HIP events on the launch stream around every matrix-kernel launch
+        model.n_streams = 1  # per-launch durations must not include kernels of other streams
         ops.PROFILER.start(timed=True)
         step(0)
         torch.cuda.synchronize()
         ops.PROFILER.stop()
+        model.n_streams = args.streams
         summ = ops.PROFILER.summary()
         tot_ms = sum(d["ms"] for d in summ.values())
         dom = max(summ, key=lambda k: summ[k]["ms"])
@@ -202,6 +204,7 @@ def main():
                                                                                   if v["ms"] > 0 else None))
                      for k, v in summ.items()})
     if rank == 0 and args.layer_report:
+        model.n_streams = 1
         ops.PROFILER.start(timed=True, by_shape=True)
         step(0)
         torch.cuda.synchronize()
