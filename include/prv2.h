@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 1
+#define PRV2_ABI_VERSION 2
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4 };
 
@@ -46,8 +46,11 @@ const char* prv2_last_error(void);
  *   ViT linears      external/depth_anything_v2/dinov2_layers/attention.py:44,46; mlp.py:30,32
  *
  *   y[m, n] = epilogue( sum_{ky,kx,c} pre(x[pix(m) + (ky,kx), c]) * w[n, ky, kx, c] )
- *   epilogue: v = acc + bias[n]; v = act(v); v *= gamma[n]; v = mul[m,n] * v; v += res[m,n] + res2[m,n]
+ *   epilogue: v = acc + bias[n]; [v = LN_row(v) * ln_weight[n] + ln_bias[n]]; v = act(v); v *= gamma[n];
+ *             v = mul[m,n] * v; v += res[m,n] + res2[m,n]
  *   (every pointer optional).  pre = ReLU when relu_in != 0.  Zero padding.
+ *   LN_row = the channels-first LayerNorm of the fusion convs (convs.py:21-29, biased variance, eps ln_eps) over the
+ *   cout channels of the pixel, fused when cout <= 128 (the whole row sits in one workgroup tile).
  *
  * Weights are pre-packed by prv2_pack_conv_weight(): [cout_pad][kh*kw][cin_pad] with
  * cin_pad = roundup(cin, 32), cout_pad = roundup(cout, 128), zero filled.
@@ -67,6 +70,8 @@ typedef struct prv2_conv_desc {
   int32_t convt_k;       /* 0, or k for ConvTranspose2d(k, stride=k)                     */
   int32_t ld_mul, ld_res, ld_res2;
   int32_t prec;          /* enum prv2_prec                                               */
+  int32_t force_generic; /* != 0: never use the LDS-halo 3x3 kernel (tests / A-B)        */
+  float ln_eps;          /* epsilon of the fused LayerNorm (used when ln_weight != NULL) */
   int32_t reserved;
 } prv2_conv_desc;
 
@@ -79,7 +84,8 @@ int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, void* w_pac
                           int32_t kh, int32_t kw, int32_t convt_k, int32_t prec, void* stream);
 
 int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
-                const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream);
+                const float* ln_weight, const float* ln_bias, const float* gamma, const float* mul, const float* res,
+                const float* res2, float* y, void* stream);
 
 /* Convolution with ONE output channel (direct, HBM-bound):
  *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
   constexpr int CLD = BN + 4;
   constexpr int NBUF = 2;                          // weight tile of this step + the one landing for the next
   constexpr int SMEM_MAIN = 2 * A_STAGE + NBUF * B_STAGE;
-  constexpr int SMEM_EPI = TH * TW * CLD;
+  constexpr int SMEM_EPI = TH * TW * CLD + 2 * TH * TW;  // C tile + LN row statistics
   __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
   float* const As = smem;
   float* const Bs = smem + 2 * A_STAGE;
@@ -175,6 +175,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
         smem[row * CLD + wn * (BN / 2) + j * 32 + r32] = acc[i][j][reg];
       }
   __syncthreads();
+  float* const ln_stats = smem + TH * TW * CLD;
+  if (p.ln_w) {  // block-uniform
+    ln_row_stats(p, smem, CLD, TH * TW, tid, ln_stats);
+    __syncthreads();
+  }
 
   constexpr int C4 = BN / 4;
   constexpr int RPP = 512 / C4;
@@ -189,7 +194,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
     const long long pix = (long long)oy * p.W + ox;
     const long long m = (long long)n_img * p.H * p.W + pix;
     const long long o = (long long)n_img * p.y_bstride + pix * p.ldy + ec.co;
-    epi_store(p, ec, cv, m, o);
+    epi_store(p, ec, cv, m, o, ln_stats[rr], ln_stats[TH * TW + rr]);
   }
 }
 

@@ -17,6 +17,9 @@ struct IgemmParams {
   const float* mul;
   const float* res;
   const float* res2;
+  const float* ln_w;   // fused channels-first LayerNorm (weight, bias) or null
+  const float* ln_b;
+  float ln_eps;
   float* y;
   int N, H, W, OH, OW;
   int Cin, Cin_pad, Cout, Ncols;  // Ncols = GEMM columns (= Cout, or k*k*Cout for convT)
@@ -154,7 +157,7 @@ __device__ __forceinline__ void stage_a(float* row, int chunk, const f32x4 v) {
 struct EpiCols {
   int co, sub_y, sub_x, nvalid;
   bool vec;
-  float bias[4], gam[4];
+  float bias[4], gam[4], lnw[4], lnb[4];
 };
 
 __device__ __forceinline__ bool epi_cols(const IgemmParams& p, int ncol, EpiCols& c) {
@@ -175,12 +178,15 @@ __device__ __forceinline__ bool epi_cols(const IgemmParams& p, int ncol, EpiCols
   for (int e = 0; e < 4; ++e) {
     c.bias[e] = (e < c.nvalid && p.bias) ? p.bias[c.co + e] : 0.f;
     c.gam[e] = (e < c.nvalid && p.gamma) ? p.gamma[c.co + e] : 1.f;
+    c.lnw[e] = (e < c.nvalid && p.ln_w) ? p.ln_w[c.co + e] : 1.f;
+    c.lnb[e] = (e < c.nvalid && p.ln_b) ? p.ln_b[c.co + e] : 0.f;
   }
   return true;
 }
 
 // m = dense output pixel index (for mul/res/res2), o = element offset of y[m, co]
-__device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c, const f32x4 cv, long long m, long long o) {
+__device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c, const f32x4 cv, long long m, long long o,
+                                          float ln_mean = 0.f, float ln_rstd = 1.f) {
   float v[4] = {cv.x, cv.y, cv.z, cv.w};
   float mulv[4] = {1.f, 1.f, 1.f, 1.f}, resv[4] = {0.f, 0.f, 0.f, 0.f}, res2v[4] = {0.f, 0.f, 0.f, 0.f};
   if (c.vec) {
@@ -197,7 +203,9 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float t = act_apply(v[e] + c.bias[e], p.act);
+    float t = v[e] + c.bias[e];
+    if (p.ln_w) t = (t - ln_mean) * ln_rstd * c.lnw[e] + c.lnb[e];
+    t = act_apply(t, p.act);
     if (p.gamma) t *= c.gam[e];
     if (p.mul) t = mulv[e] * t;
     if (p.res) t += resv[e];
@@ -211,6 +219,25 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (e < c.nvalid) p.y[o + e] = v[e];
+  }
+}
+
+// Row statistics for the fused LayerNorm: the C tile sits in LDS as [rows][cld]; thread t (< rows) owns row t.
+// Two passes (mean, then biased variance of the centred values) exactly like convs.py:25-27.
+__device__ __forceinline__ void ln_row_stats(const IgemmParams& p, const float* ctile, int cld, int rows, int tid,
+                                             float* stats /* [2*rows] in LDS */) {
+  if (tid < rows) {
+    const float* r = ctile + tid * cld;
+    float s = 0.f;
+    for (int c = 0; c < p.Cout; ++c) s += r[c] + (p.bias ? p.bias[c] : 0.f);
+    const float mean = s / (float)p.Cout;
+    float q = 0.f;
+    for (int c = 0; c < p.Cout; ++c) {
+      float d = r[c] + (p.bias ? p.bias[c] : 0.f) - mean;
+      q += d * d;
+    }
+    stats[tid] = mean;
+    stats[rows + tid] = 1.0f / sqrtf(q / (float)p.Cout + p.ln_eps);
   }
 }
 

@@ -33,7 +33,7 @@ template <int BN, int PREC>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
   constexpr int NJ = BN / 64;  // 32-wide column sub-tiles per wave
   constexpr int NB = BN / 32;  // B rows loaded per thread per step (float4 each)
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD + 2 * BM];  // + LN row statistics
   constexpr int STAGE = (BM + BN) * LDS_LD;  // A rows then B rows
 
   // ---- XCD-aware, bijective block -> tile map -------------------------------------------
@@ -168,6 +168,11 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         smem[row * CLD + wn * (BN / 2) + j * 32 + r32] = acc[i][j][reg];
       }
   __syncthreads();
+  float* const ln_stats = smem + 2 * (BM + BN) * LDS_LD;
+  if (p.ln_w) {  // block-uniform
+    ln_row_stats(p, smem, CLD, BM, tid, ln_stats);
+    __syncthreads();
+  }
 
   constexpr int C4 = BN / 4;          // float4 per tile row
   constexpr int RPP = 256 / C4;       // rows per pass
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     } else {
       o = (long long)n_img * p.y_bstride + (long long)rem * p.ldy + ec.co;
     }
-    epi_store(p, ec, cv, m, o);
+    epi_store(p, ec, cv, m, o, ln_stats[rr], ln_stats[BM + rr]);
   }
 }
 
@@ -261,8 +266,8 @@ extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, 
 }
 
 extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
-                           const float* gamma, const float* mul, const float* res, const float* res2, float* y,
-                           void* stream) {
+                           const float* ln_weight, const float* ln_bias, const float* gamma, const float* mul,
+                           const float* res, const float* res2, float* y, void* stream) {
   PRV2_REQUIRE(d && x && w_packed && y, "conv2d: null pointer");
   PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -272,6 +277,9 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
+  p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps;
+  PRV2_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "conv2d: ln_weight and ln_bias go together");
+  PRV2_REQUIRE(!ln_weight || (d->cout <= 128 && d->convt_k == 0), "conv2d: fused LayerNorm needs cout <= 128 (got %d)", d->cout);
   p.N = d->n; p.H = d->h; p.W = d->w;
   p.Cin = d->cin; p.Cin_pad = (int)roundup(d->cin, BK); p.Cout = d->cout;
   p.convt_k = d->convt_k;
@@ -310,7 +318,7 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   }
   p.tiles_m = (int)cdiv(p.M, BM);
   hipStream_t s = (hipStream_t)stream;
-  if (conv3x3_halo_supported(p) && !d->reserved) {  // reserved != 0 forces the generic kernel (tests / A-B)
+  if (conv3x3_halo_supported(p) && !d->force_generic) {
     launch_conv3x3_halo(p, d->prec, s);
     PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
     return 0;

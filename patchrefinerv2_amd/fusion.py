@@ -82,8 +82,7 @@ class _EncDec(StateDictModule):
             pairs[l](cat1)
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
             cat2 = Feat.alloc(B, h, w, tc + 2, dev)
-            f = ops.conv2d(cat1, conv, cat2.slice(0, tc))
-            ops.layernorm_feat(f, lnw, lnb, 1e-6, ACT_GELU)
+            ops.conv2d(cat1, conv, cat2.slice(0, tc), act=ACT_GELU, ln=(lnw, lnb))  # conv -> LN -> GELU (convs.py:67-72)
             place(pred1, cat2.slice(tc, 1))
             place(pred2, cat2.slice(tc + 1, 1))
             conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
@@ -94,8 +93,7 @@ class _EncDec(StateDictModule):
                 dst = dec_bufs[j].slice(c1, c2)
             else:
                 dst = Feat.alloc(B, h, w, tc, dev)
-            temps[l] = ops.conv2d(cat2, conv, dst)
-            ops.layernorm_feat(temps[l], lnw, lnb, 1e-6, ACT_GELU)
+            temps[l] = ops.conv2d(cat2, conv, dst, act=ACT_GELU, ln=(lnw, lnb))
         feat = temps[L_ - 1] if nd > 0 else temps[0]
         for j, (c1, c2, dc) in enumerate(self.dec_in):
             buf = dec_bufs[j]
@@ -195,8 +193,7 @@ class BiDirectionalFusion(_EncDec):
         """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
         half already holds the coarse feature; the lower half receives ``out``."""
         out = ops.conv2d(x, u["conv"], cat.slice(0, F_), relu_in=True, res=x)            # conv(relu(x)) + x
-        fused = ops.conv2d(cat, u["f0"])
-        ops.layernorm_feat(fused, u["lnw"], u["lnb"], 1e-6, ACT_RELU)
+        fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
         return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])
 
     def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True, dest=None) -> Feat:

@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(C.Structure):
@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("x_bstride", C.c_int64), ("y_bstride", C.c_int64),
         ("relu_in", C.c_int32), ("act", C.c_int32), ("convt_k", C.c_int32),
         ("ld_mul", C.c_int32), ("ld_res", C.c_int32), ("ld_res2", C.c_int32),
-        ("prec", C.c_int32), ("reserved", C.c_int32),
+        ("prec", C.c_int32), ("force_generic", C.c_int32), ("ln_eps", C.c_float), ("reserved", C.c_int32),
     ]
 
 
@@ -40,7 +40,7 @@ SIGNATURES = {
     "prv2_last_error": (C.c_char_p, []),
     "prv2_packed_weight_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "prv2_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prv2_conv2d_cout1": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _P]),
     "prv2_dwconv2d": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "prv2_layernorm": (_I, [_P, _L, _I, _I, _P, _P, _F, _I, _P, _I, _P]),

@@ -187,8 +187,14 @@ def conv_out_hw(cw: ConvW, h: int, w: int):
 
 def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = False, act: int = ACT_NONE,
            gamma: Optional[torch.Tensor] = None, mul: Optional[Feat] = None, res: Optional[Feat] = None,
-           res2: Optional[Feat] = None, x_bstride: int = 0, force_generic: bool = False) -> Feat:
-    """y = epilogue(conv(x)); see include/prv2.h::prv2_conv2d."""
+           res2: Optional[Feat] = None, x_bstride: int = 0, force_generic: bool = False, ln=None,
+           ln_eps: float = 1e-6) -> Feat:
+    """y = epilogue(conv(x)); see include/prv2.h::prv2_conv2d.  ``ln`` = (weight, bias) of a channels-first
+    LayerNorm applied between the bias and the activation (fused when cout <= 128, else a separate row-LN pass)."""
+    if ln is not None and cw.cout > 128:
+        y = conv2d(x, cw, out, relu_in=relu_in, x_bstride=x_bstride, force_generic=force_generic)
+        assert gamma is None and mul is None and res is None and res2 is None
+        return layernorm_feat(y, ln[0], ln[1], ln_eps, act)
     assert x.c == cw.cin, (x.c, cw.cin)
     oh, ow = conv_out_hw(cw, x.h, x.w)
     if out is None:
@@ -197,7 +203,8 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad,
                    ldx=x.ld, ldy=out.ld, x_bstride=x_bstride, y_bstride=0, relu_in=int(relu_in), act=act,
                    convt_k=cw.convt_k, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0,
-                   ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, reserved=int(force_generic))
+                   ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, force_generic=int(force_generic),
+                   ln_eps=ln_eps, reserved=0)
     for aux in (mul, res, res2):
         if aux is not None:
             assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
@@ -208,7 +215,9 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
             and not force_generic)  # mirrors conv3x3_halo_supported() in csrc/conv3x3.hip
     kname = "conv3x3_halo_kernel" if halo else "igemm_kernel"
     PROFILER.launch(f"{kname}<{128 if ncols > 64 else 64},{L.PREC_LABEL[cw.prec]}>", 2.0 * m_rows * ncols * cw.cin * taps,
-                    lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(gamma),
+                    lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias),
+                                                         _ptr(ln[0]) if ln is not None else None,
+                                                         _ptr(ln[1]) if ln is not None else None, _ptr(gamma),
                                                          _ptr(mul), _ptr(res), _ptr(res2), out.ptr, _stream()), "conv2d"),
                     shape=f"{cw.cin}->{cw.cout} k{cw.kh}s{cw.stride}{'T' if cw.convt_k else ''} {x.n}x{x.h}x{x.w}")
     return out

@@ -32,10 +32,10 @@ def test_conv_desc_layout_matches_header():
     body = txt[txt.index("typedef struct prv2_conv_desc {"):txt.index("} prv2_conv_desc;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
-    for decl in re.findall(r"int(?:32|64)_t\s+([^;]+);", body):
+    for decl in re.findall(r"(?:int(?:32|64)_t|float)\s+([^;]+);", body):
         fields += [f.strip() for f in decl.split(",")]
     assert fields == [f[0] for f in L.ConvDesc._fields_]
-    assert ctypes.sizeof(L.ConvDesc) == 96
+    assert ctypes.sizeof(L.ConvDesc) == 104
 
 
 def test_rejects_bad_arguments_without_gpu():

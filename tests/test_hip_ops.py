@@ -340,3 +340,22 @@ def test_zoe_head_ops(P):
     refd = (torch.softmax(yy / tt, dim=1) * centers).sum(1, keepdim=True)
     gotd = P.zoe_logbinom_depth(P.Feat.from_nchw(pt.to(DEV)), P.Feat.from_nchw(centers.to(DEV)), 0.0212, 50.0)
     close(gotd, refd, 2e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 20, 40, 66, 32, 3), (1, 9, 33, 130, 128, 3), (1, 12, 16, 64, 64, 3), (2, 7, 5, 48, 96, 1)])
+def test_conv_fused_layernorm(P, case):
+    """conv -> channels-first LayerNorm -> GELU in one launch (cout <= 128) == the unfused sequence"""
+    from oracle.fusion import ln_cf
+    n, h, w, cin, cout, k = case
+    x = rnd(1, n, cin, h, w)
+    wt, b = rnd(2, cout, cin, k, k) / np.sqrt(cin * k * k), rnd(3, cout)
+    lw, lb = 1 + 0.1 * rnd(4, cout), 0.1 * rnd(5, cout)
+    ref = F.gelu(ln_cf(F.conv2d(x, wt, b, padding=k // 2), lw, lb))
+    y = P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(wt.to(DEV), b.to(DEV)), act=P.ACT_GELU, ln=(lw.to(DEV), lb.to(DEV)))
+    close(y.to_nchw(), ref, 2e-5, f"fused LN {case}")
+    # cout > 128 falls back to conv + row-LN pass
+    wt2 = rnd(6, 160, cin, k, k) / np.sqrt(cin * k * k)
+    lw2, lb2 = 1 + 0.1 * rnd(7, 160), 0.1 * rnd(8, 160)
+    ref2 = F.relu(ln_cf(F.conv2d(x, wt2, None, padding=k // 2), lw2, lb2))
+    y2 = P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(wt2.to(DEV), None), act=P.ACT_RELU, ln=(lw2.to(DEV), lb2.to(DEV)))
+    close(y2.to_nchw(), ref2, 2e-5)
