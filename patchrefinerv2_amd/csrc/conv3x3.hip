@@ -27,7 +27,12 @@ constexpr int A_IT = (HALO * 8 + 511) / 512;  // float4 loads per thread per sla
 
 template <int BN, int PREC>
 __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams p) {
-  constexpr int NJ = BN / 64;
+  // wave grid: BN >= 64: 4 (pixel rows pairs) x 2 (channel halves), a wave owns 2 rows x BN/2 channels;
+  //            BN == 32 (cout <= 32 layers): 8 x 1, a wave owns 1 row x 32 channels -- no MFMA work on padding columns
+  constexpr int WN = BN >= 64 ? 2 : 1;
+  constexpr int NI = BN >= 64 ? 2 : 1;             // 32-pixel rows per wave
+  constexpr int NJ = BN / (32 * WN);               // 32-channel column tiles per wave
+  constexpr int ND = BN >= 64 ? BN / 64 : 1;       // LDS-DMA pieces (8 rows x 128 B) per wave per weight tile
   constexpr int A_STAGE = HALO * LDS_LD;           // floats
   constexpr int B_STAGE = BN * 32;                 // floats: unpadded 128-byte rows, XOR-swizzled (LDS-DMA image)
   constexpr int CLD = BN + 4;
@@ -56,7 +61,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int r32 = lane & 31, half = lane >> 5;
   const int chunk = tid & 7, prow = tid >> 3;  // loader role: float4 `chunk` of rows prow + 64*i
 
@@ -99,38 +104,41 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
   auto dma_b = [&](int s, int bbuf) {
     const int cc = s / 9, tap = s - cc * 9;
     const float* wsrc = wdma + (long long)tap * p.Cin_pad + cc * BK;
+    if (BN == 32 && wave >= 4) return;  // 32 rows = 4 pieces
 #pragma unroll
-    for (int i = 0; i < BN / 64; ++i) {
-      const int piece = wave * (BN / 64) + i;  // 8 rows each
+    for (int i = 0; i < ND; ++i) {
+      const int piece = wave * ND + i;  // 8 rows each
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(wsrc + (long long)(piece * 8) * w_row_stride),
           (__attribute__((address_space(3))) void*)(Bs + bbuf * B_STAGE + piece * 256), 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // lane's halo pixel for its two output rows at tap (0,0): row 2*wm + i, column r32
-  const int a_pix0 = (2 * wm) * HW_ + r32;
+  const int a_pix0 = (NI * wm) * HW_ + r32;
   auto compute = [&](int abuf, int bbuf, int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const char* Ab = reinterpret_cast<const char*>(As + abuf * A_STAGE + (a_pix0 + ky * HW_ + kx) * LDS_LD) + half * 16;
-    const char* Bb = reinterpret_cast<const char*>(Bs + bbuf * B_STAGE + (wn * (BN / 2) + r32) * 32);
-    const char* a_row[2] = {Ab, Ab + HW_ * LDS_LD * 4};
+    const char* Bb = reinterpret_cast<const char*>(Bs + bbuf * B_STAGE + (wn * (BN / WN) + r32) * 32);
+    const char* a_row[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a_row[i] = Ab + i * HW_ * LDS_LD * 4;
     const char* b_row[NJ];
     int b_swz[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       b_row[j] = Bb + j * 32 * 128;
-      b_swz[j] = ((wn * (BN / 2) + j * 32 + r32) >> 1) & 7;
+      b_swz[j] = ((wn * (BN / WN) + j * 32 + r32) >> 1) & 7;
     }
-    mma_slab<NJ, PREC, true>(acc, a_row, b_row, b_swz, half * 16);
+    mma_slab<NJ, PREC, true, NI>(acc, a_row, b_row, b_swz, half * 16);
   };
 
   // ---- pipeline: one barrier per (slab, tap) step -------------------------------------------------
@@ -165,14 +173,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
 
   // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int col = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // pixel column inside the 32-wide row
-        const int row = (2 * wm + i) * TW + col;
-        smem[row * CLD + wn * (BN / 2) + j * 32 + r32] = acc[i][j][reg];
+        const int row = (NI * wm + i) * TW + col;
+        smem[row * CLD + wn * (BN / WN) + j * 32 + r32] = acc[i][j][reg];
       }
   __syncthreads();
   float* const ln_stats = smem + TH * TW * CLD;
@@ -212,11 +220,20 @@ void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t s) {
     if (prec == PRV2_PREC_F32) PRV2_LAUNCH_HALO(128, PRV2_PREC_F32);
     else if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO(128, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_HALO(128, PRV2_PREC_BF16);
-  } else {
+#ifdef PRV2_NO_BN32
+  } else if (true) {
+#else
+  } else if (p.Ncols > 32) {
+#endif
     p.tiles_n = 1;
     if (prec == PRV2_PREC_F32) PRV2_LAUNCH_HALO(64, PRV2_PREC_F32);
     else if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO(64, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_HALO(64, PRV2_PREC_BF16);
+  } else {
+    p.tiles_n = 1;
+    if (prec == PRV2_PREC_F32) PRV2_LAUNCH_HALO(32, PRV2_PREC_F32);
+    else if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO(32, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_HALO(32, PRV2_PREC_BF16);
   }
 #undef PRV2_LAUNCH_HALO
 }

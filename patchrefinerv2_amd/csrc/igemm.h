@@ -73,16 +73,16 @@ __device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo
 // the pre-swizzled packed weights).  PREC_F32: k-step = 8 channels (4 MFMAs of k=2: lane half h takes channels
 // 8ks+4h..+3 so MFMA e multiplies channel 8ks+4h+e on both operands); bf16 modes: k-step = 16 channels
 // (v_mfma_f32_32x32x16_bf16: lane (r32, half) holds A[row r32][k = 8*half + j]).
-template <int NJ, int PREC>
+template <int NJ, int PREC, int NI = 2>
 struct Frags {
-  f32x4 a[2], b[NJ];
-  bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+  f32x4 a[NI], b[NJ];
+  bf16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
 };
 template <int PREC>
 constexpr int ksteps() { return PREC == PRV2_PREC_F32 ? 4 : 2; }
 
-template <int NJ, int PREC, bool BSWZ>
-__device__ __forceinline__ void read_frags(Frags<NJ, PREC>& f, int ks, const char* const (&a_row)[2],
+template <int NJ, int PREC, bool BSWZ, int NI = 2>
+__device__ __forceinline__ void read_frags(Frags<NJ, PREC, NI>& f, int ks, const char* const (&a_row)[NI],
                                            const char* const (&b_row)[NJ], const int (&b_swz)[NJ], int half16) {
   auto b_at = [&](int j, int byte_off) -> const char* {
     if constexpr (BSWZ) return b_row[j] + ((((byte_off + half16) >> 4) ^ b_swz[j]) << 4);
@@ -90,12 +90,12 @@ __device__ __forceinline__ void read_frags(Frags<NJ, PREC>& f, int ks, const cha
   };
   if constexpr (PREC == PRV2_PREC_F32) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(a_row[i] + ks * 32);
+    for (int i = 0; i < NI; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(a_row[i] + ks * 32);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(b_at(j, ks * 32));
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       f.ah[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + ks * 32);
       if constexpr (PREC == PRV2_PREC_BF16X3) f.al[i] = *reinterpret_cast<const bf16x8*>(a_row[i] + 64 + ks * 32);
     }
@@ -107,10 +107,10 @@ __device__ __forceinline__ void read_frags(Frags<NJ, PREC>& f, int ks, const cha
   }
 }
 
-template <int NJ, int PREC>
-__device__ __forceinline__ void mma_frags(f32x16 (&acc)[2][NJ], const Frags<NJ, PREC>& f) {
+template <int NJ, int PREC, int NI = 2>
+__device__ __forceinline__ void mma_frags(f32x16 (&acc)[NI][NJ], const Frags<NJ, PREC, NI>& f) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if constexpr (PREC == PRV2_PREC_F32) {
@@ -129,14 +129,14 @@ __device__ __forceinline__ void mma_frags(f32x16 (&acc)[2][NJ], const Frags<NJ, 
 }
 
 // One BK=32 slab (all k-steps), fragments read on the fly
-template <int NJ, int PREC, bool BSWZ = false>
-__device__ __forceinline__ void mma_slab(f32x16 (&acc)[2][NJ], const char* const (&a_row)[2], const char* const (&b_row)[NJ],
-                                         const int (&b_swz)[NJ] = {}, int half16 = 0) {
+template <int NJ, int PREC, bool BSWZ = false, int NI = 2>
+__device__ __forceinline__ void mma_slab(f32x16 (&acc)[NI][NJ], const char* const (&a_row)[NI],
+                                         const char* const (&b_row)[NJ], const int (&b_swz)[NJ] = {}, int half16 = 0) {
 #pragma unroll
   for (int ks = 0; ks < ksteps<PREC>(); ++ks) {
-    Frags<NJ, PREC> f;
-    read_frags<NJ, PREC, BSWZ>(f, ks, a_row, b_row, b_swz, half16);
-    mma_frags<NJ, PREC>(acc, f);
+    Frags<NJ, PREC, NI> f;
+    read_frags<NJ, PREC, BSWZ, NI>(f, ks, a_row, b_row, b_swz, half16);
+    mma_frags<NJ, PREC, NI>(acc, f);
   }
 }
 

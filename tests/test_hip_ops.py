@@ -47,6 +47,8 @@ CONV_CASES = [
     (1, 19, 75, 258, 256, 3, 1, dict(bias=True, relu_in=True, res=True)),
     (3, 7, 24, 98, 40, 3, 1, dict(res=True, res2=True, gamma=True, bias=True)),
     (1, 56, 56, 512, 256, 3, 1, dict(bias=True)),
+    (2, 21, 45, 98, 32, 3, 1, dict(bias=True, act="gelu")),   # cout <= 32: 8x1 wave grid variant
+    (1, 40, 64, 34, 20, 3, 1, dict(res=True)),
 ]
 
 

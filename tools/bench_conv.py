@@ -11,6 +11,7 @@ SHAPES = [  # (cin, cout, k, h, w)  -- the heavy layers of BiDirectionalFusion, 
     (512, 256, 3, 224, 224), (256, 256, 3, 224, 224), (256, 128, 3, 448, 448), (512, 256, 3, 112, 112),
     (98, 98, 3, 448, 448), (194, 194, 3, 224, 224), (512, 64, 3, 224, 224), (256, 256, 1, 448, 448),
     (322, 322, 3, 112, 112), (642, 642, 3, 56, 56), (128, 128, 3, 448, 448), (98, 32, 3, 448, 448), (770, 770, 3, 28, 28),
+    (256, 32, 3, 448, 448), (34, 32, 3, 448, 448),
     (1024, 4096, 1, 1025, 1), (4096, 1024, 1, 1025, 1),
 ]
 for si, (cin, cout, k, h, w) in enumerate(SHAPES):
