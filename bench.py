@@ -64,9 +64,14 @@ def cpu_baseline(name, sd, frame_seed):
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     sd_cpu = {k: v.float() for k, v in sd.items()}
-    ccfg = W.dav2_cfg({**w["coarse"], "max_depth": 80.0})
     kw = dict(patch_process_shape=w["pps"], image_raw_shape=w["raw"], patch_split_num=w["split"])
-    if w["kind"] == "PatchRefinerPlus":
+    ccfg = W.dav2_cfg({**w["coarse"], "max_depth": 80.0}) if w.get("coarse") else None
+    if w.get("zoe"):
+        from oracle import dav2 as o_dav2, zoe as o_zoe
+        zc = W.zoedepth_cfg(w["zoe"])
+        m = o_tiling.OraclePatchRefinerPlus(
+            sd_cpu, None, coarse_fn=lambda lr: o_dav2.coarse_features(o_zoe.zoedepth_forward(sd_cpu, "coarse_branch.", lr, zc)), **kw)
+    elif w["kind"] == "PatchRefinerPlus":
         m = o_tiling.OraclePatchRefinerPlus(sd_cpu, ccfg, **kw)
     else:
         m = o_tiling.OraclePatchRefiner(sd_cpu, ccfg, W.dav2_cfg({**w["fine"], "max_depth": 80.0}), **kw)
@@ -176,7 +181,7 @@ def main():
         vs_baseline=None, dtype=args.prec, data="synthetic",
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
-                    coarse_branch=w["coarse"]["encoder"], shard=args.shard if world > 1 else "none",
+                    coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else "DA-ZoeDepth/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
                     max_batch=args.max_batch, streams=args.streams, out_shape=list(out.shape)))
 
     if rank == 0 and not args.no_roofline:

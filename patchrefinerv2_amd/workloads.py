@@ -35,6 +35,19 @@ WORKLOADS = {
                             fusion=dict(input_chl=[256, 512, 512, 512, 512, 512], temp_chl=[128, 256, 256, 256, 256, 256],
                                         dec_chl=[256, 256, 256, 256, 128]), patches=81),
 }
+# BASELINE config[2] in its fully vendored form (SURVEY.md 8d C3 "pinned sibling"): configs/patchrefinerv2_zoedepth/
+# v2_mobile_u4k.py (BiDirectionalFusion zoe cfg: coarse_chl[0] = 32) with the ZoeDepth metric-bins head over the
+# DepthAnything ViT-L core (type='DA-ZoeDepth') instead of the un-vendored MiDaS DPT-BEiT-L; P must be a
+# multiple of 14 -> 392 x 518.
+ZOE_DA_L = dict(midas_model_type="vitl", min_depth=1e-3, max_depth=80, do_resize=False, attractor_alpha=1000,
+                attractor_gamma=2, attractor_kind="mean", attractor_type="inv", bin_centers_type="softplus",
+                bin_embedding_dim=128, img_size=[392, 518], max_temp=50.0, min_temp=0.0212, n_attractors=[16, 8, 4, 1],
+                n_bins=64)
+BIDIR_ZOE = dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64, 96, 960],
+                 fine_chl_after_coarse2fine=[32, 256, 256, 256, 256, 256], temp_chl=[32, 64, 64, 128, 256, 512],
+                 dec_chl=[512, 256, 128, 64, 32])
+WORKLOADS["v2_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 518], mode="r32",
+                                    coarse=None, zoe=ZOE_DA_L, fusion=BIDIR_ZOE, patches=81)
 DEFAULT_WORKLOAD = "v2_dav2l_4k_r32"
 
 
@@ -44,7 +57,9 @@ def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> d
     cfg = dict(
         image_raw_shape=raw, patch_process_shape=w["pps"], patch_raw_shape=[raw[0] // split[0], raw[1] // split[1]],
         patch_split_num=split, fusion_feat_level=6, min_depth=1e-3, max_depth=80.0, pretrain_coarse_model=None,
-        strategy_refiner_target="offset_coarse", coarse_branch=dict(type="DA2", pretrained=None, model_cfg=w["coarse"]),
+        strategy_refiner_target="offset_coarse",
+        coarse_branch=(dict(type="DA-ZoeDepth", **w["zoe"]) if w.get("zoe") else
+                       dict(type="DA2", pretrained=None, model_cfg=w["coarse"])),
         sigloss=dict(type="SILogLoss"), pretrained=None, pre_norm_bbox=True, prec=prec, max_batch=max_batch, n_streams=n_streams)
     if w["kind"] == "PatchRefinerPlus":
         cfg.update(e2e_training=True, pretrain_stage=False, gmloss=dict(type="GradMatchLoss"), sigweight=1,
@@ -64,7 +79,10 @@ def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> d
 def state_spec(name: str) -> "OrderedDict[str, tuple]":
     w = WORKLOADS[name]
     s = OrderedDict()
-    s.update(W.dav2_spec("coarse_branch.", w["coarse"]))
+    if w.get("zoe"):
+        s.update(W.zoedepth_spec("coarse_branch.", w["zoe"]))
+    else:
+        s.update(W.dav2_spec("coarse_branch.", w["coarse"]))
     if w["kind"] == "PatchRefinerPlus":
         s.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
         f = w["fusion"]
