@@ -97,10 +97,10 @@ def cpu_baseline(name, sd, frame_seed):
 
 def pmc_traffic(kernel_tag, workload, prec):
     """HBM bytes per launch of ``kernel_tag`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_<prec>_pmc_frame.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, per-launch averages in KB).
+    (profiles/r01_<prec>_pmc_frame_<workload>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, per-launch averages in KB).
     gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads."""
-    path = os.path.join(ROOT, "profiles", f"r01_{prec}_pmc_frame.json")
-    if workload != "v2_dav2l_4k_r32" or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", f"r01_{prec}_pmc_frame_{workload}.json")
+    if not os.path.exists(path):
         return None
     name, _, targs = kernel_tag.partition("<")
     bn, pr = targs.rstrip(">").split(",")

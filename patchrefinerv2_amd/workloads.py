@@ -48,7 +48,7 @@ BIDIR_ZOE = dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64,
                  dec_chl=[512, 256, 128, 64, 32])
 WORKLOADS["v2_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 518], mode="r32",
                                     coarse=None, zoe=ZOE_DA_L, fusion=BIDIR_ZOE, patches=81)
-DEFAULT_WORKLOAD = "v2_dav2l_4k_r32"
+DEFAULT_WORKLOAD = "v2_zoeda_4k_r32"
 
 
 def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> dict:
