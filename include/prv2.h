@@ -124,7 +124,10 @@ int prv2_assemble_tokens(const float* emb, const float* cls, const float* pos, i
 /* softmax((q*scale) k^T) v per (batch, head); qkv rows are [3][heads][hd] as produced by the qkv
  * Linear (attention.py:49-62).  hd must be 64.  out rows are [heads][hd]. */
 int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out, int32_t prec,
-                   void* stream);
+                   void* workspace, int64_t workspace_bytes, void* stream);
+/* device scratch the split-bf16 attention needs (pre-split q/k rows + transposed v planes); 0 for PRV2_PREC_F32.
+ * The workspace must be 256-byte aligned; its contents are dead when the call returns (stream order). */
+int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32_t heads, int32_t prec);
 
 /* ------------------------------------------------------------------------------------------
  * ZoeDepth metric-bins head, elementwise parts (the 1x1 MLPs go through prv2_conv2d)

@@ -154,15 +154,270 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
 
 using namespace prv2;
 
+int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, float* out, void* workspace,
+                            int64_t workspace_bytes, hipStream_t s);
+
 extern "C" int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out,
-                              int32_t prec, void* stream) {
+                              int32_t prec, void* workspace, int64_t workspace_bytes, void* stream) {
   PRV2_REQUIRE(qkv && out, "attention: null pointer");
   PRV2_REQUIRE(b > 0 && ntok > 0 && heads > 0 && hd == 64, "attention: head_dim must be 64 (got %d)", hd);
-  // every precision mode currently runs the exact fp32-MFMA kernel (attention is ~1% of a V2 frame)
   PRV2_REQUIRE(prec >= PRV2_PREC_F32 && prec <= PRV2_PREC_BF16, "attention: unknown precision mode %d", prec);
   PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attention: qkv must be 16-byte aligned");
+  if (prec != PRV2_PREC_F32) {  // bf16 mode also runs the bf16x3 kernel (attention is never the bottleneck there)
+    int rc = launch_attention_bf16x3(qkv, b, ntok, heads, out, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    PRV2_LAUNCH_CHECK("attention(bf16x3)");
+    return 0;
+  }
   dim3 grid((unsigned)cdiv(ntok, AT_BQ), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, b, ntok, heads, 0.125f, out);
   PRV2_LAUNCH_CHECK("attention");
+  return 0;
+}
+
+// =================================================================================================
+// Split-bf16 (bf16x3) attention.
+//
+// Pre-pass (qkv_split_kernel): q (pre-scaled by 1/8 -- exact), k -> rows [64 x bf16 hi | 64 x bf16 lo];
+// v -> transposed planes Vt[b, head, d, key] (hi, lo), keys zero-padded to a multiple of 64.  One pass
+// over qkv; afterwards every operand of the attention kernel is a plain 16-byte copy away from its
+// MFMA fragment (no conversion arithmetic in the hot loop).
+//
+// attention_bf16x3_kernel: one workgroup = 128 queries of one (batch, head), 4 waves x 32 queries.
+// S^T = K Q^T is computed (keys on accumulator rows, queries on lanes), so
+//   * the online softmax of a query is a per-LANE reduction over its 32 accumulator registers plus one
+//     cross-half shuffle (instead of 16 five-step butterflies), and the O rescale is a per-lane scalar;
+//   * P^T in accumulator layout IS the B operand of O^T = V^T P^T (cdna_hip_programming.md section 3,
+//     "an accumulator tile as the next MFMA's operand"): registers 8s..8s+7 -> k-step s, no LDS round trip.
+// V^T fragments follow the permuted k order of that trick: element j of lane half h is key
+// 16s + 8(j>>2) + 4h + (j&3) -> two ds_read_b64 per fragment from the [d][key] LDS image.
+// All products are hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 softmax.
+// =================================================================================================
+namespace prv2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+  hi = __builtin_convertvector(v, bf16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+}
+
+// grid (ceil(N/64), heads, B), 256 threads
+__global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict__ qkv, int N, int heads, int Npad,
+                                                        __bf16* __restrict__ Qs, __bf16* __restrict__ Ks,
+                                                        __bf16* __restrict__ VtH, __bf16* __restrict__ VtL) {
+  __shared__ float vt[64][65];
+  const int t0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
+  const int D3 = 3 * heads * 64;
+  const int tid = threadIdx.x, d4 = (tid & 15) * 4;
+  const long long bh = (long long)b * heads + head;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tl = (tid >> 4) + 16 * i, tok = t0 + tl;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
+    if (tok < N) {
+      const float* src = qkv + ((long long)b * N + tok) * D3 + head * 64 + d4;
+      q = *reinterpret_cast<const f32x4*>(src) * 0.125f;
+      k = *reinterpret_cast<const f32x4*>(src + heads * 64);
+      v = *reinterpret_cast<const f32x4*>(src + 2 * heads * 64);
+      bf16x4 hi, lo;
+      __bf16* qd = Qs + (bh * N + tok) * 128 + d4;
+      split4(q, hi, lo);
+      *reinterpret_cast<bf16x4*>(qd) = hi;
+      *reinterpret_cast<bf16x4*>(qd + 64) = lo;
+      __bf16* kd = Ks + (bh * N + tok) * 128 + d4;
+      split4(k, hi, lo);
+      *reinterpret_cast<bf16x4*>(kd) = hi;
+      *reinterpret_cast<bf16x4*>(kd + 64) = lo;
+    }
+    vt[tl][d4] = v.x; vt[tl][d4 + 1] = v.y; vt[tl][d4 + 2] = v.z; vt[tl][d4 + 3] = v.w;
+  }
+  __syncthreads();
+  // transposed write: thread = (d, 16-key group); padded keys (tok >= N) carry zeros
+  const int d = tid >> 2, kg = (tid & 3) * 16;
+  __bf16* oh = VtH + (bh * 64 + d) * Npad + t0 + kg;
+  __bf16* ol = VtL + (bh * 64 + d) * Npad + t0 + kg;
+#pragma unroll
+  for (int j = 0; j < 16; j += 4) {
+    f32x4 v = {vt[kg + j][d], vt[kg + j + 1][d], vt[kg + j + 2][d], vt[kg + j + 3][d]};
+    bf16x4 hi, lo;
+    split4(v, hi, lo);
+    *reinterpret_cast<bf16x4*>(oh + j) = hi;
+    *reinterpret_cast<bf16x4*>(ol + j) = lo;
+  }
+}
+
+constexpr int AB_KP = 272;  // K tile row pitch (bytes): 128 hi + 128 lo + 16 pad -> conflict-free ds_read_b128
+constexpr int AB_VP = 264;  // V^T tile row pitch (bytes): conflict-free ds_read_b64 (66 dwords: 2r mod 64)
+
+__device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
+                                                                  const __bf16* __restrict__ Ks,
+                                                                  const __bf16* __restrict__ VtH,
+                                                                  const __bf16* __restrict__ VtL, int N, int Npad,
+                                                                  int heads, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AB_VP];  // 34304 B; reused for the output strips
+  char* const Kt = smem;
+  char* const Vt = smem + 64 * AB_KP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const long long bh = (long long)b * heads + head;
+
+  // Q fragments (B operand of S^T): lane (q = r32, half) holds Q[q][16ks + 8half + j]
+  const int q_row = qt * AT_BQ + wave * 32 + r32;
+  bf16x8 qh[4], ql[4];
+  {
+    const __bf16* qp = Qs + (bh * N + (q_row < N ? q_row : 0)) * 128 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+      ql[ks] = *reinterpret_cast<const bf16x8*>(qp + 64 + ks * 16);
+    }
+  }
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o_acc[0][e] = 0.f; o_acc[1][e] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ld_row = tid >> 2, ld_q = tid & 3;  // staging: 64 rows x 4 quarters (64 B each) per plane
+  for (int k0 = 0; k0 < N; k0 += AT_BK) {
+    __syncthreads();
+    {
+      // K rows: [hi 128 B | lo 128 B] (256 B contiguous in Ks); V^T rows: 128 B from each plane
+      const int key = k0 + ld_row;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const char* ksrc = reinterpret_cast<const char*>(Ks + (bh * N + (key < N ? key : 0)) * 128) + ld_q * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ksrc + i * 16);
+        *reinterpret_cast<f32x4*>(Kt + ld_row * AB_KP + ld_q * 64 + i * 16) = key < N ? v : z;
+      }
+      const long long vrow = (bh * 64 + ld_row) * Npad + k0;
+      const char* vsrc = reinterpret_cast<const char*>((ld_q < 2 ? VtH : VtL) + vrow) + (ld_q & 1) * 64;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)  // 8-byte stores: the 264-byte pitch is only 8-byte aligned
+        *reinterpret_cast<uint2*>(Vt + ld_row * AB_VP + ld_q * 64 + i * 8) = *reinterpret_cast<const uint2*>(vsrc + i * 8);
+    }
+    __syncthreads();
+
+    // S^T tiles: rows = keys (t*32 + row), cols = this wave's 32 queries
+    f32x16 st[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const char* kr = Kt + (t * 32 + r32) * AB_KP + ks * 32 + half * 16;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kr);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kr + 128);
+        st[t] = mfma3(kh, kl, qh[ks], ql[ks], st[t]);
+      }
+    // online softmax of this lane's query column (keys live in the registers of both lane halves)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = k0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        st[t][e] = key < N ? st[t][e] : -INFINITY;
+        mx = fmaxf(mx, st[t][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        st[t][e] = expf(st[t][e] - m_new);  // exp(-inf) = 0 for masked keys
+        rs += st[t][e];
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * corr + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o_acc[0][e] *= corr; o_acc[1][e] *= corr; }
+
+    // O^T += V^T P^T : B fragments straight from the P^T accumulators, A = V^T rows from LDS
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 p0 = {st[t][8 * s], st[t][8 * s + 1], st[t][8 * s + 2], st[t][8 * s + 3]};
+        f32x4 p1 = {st[t][8 * s + 4], st[t][8 * s + 5], st[t][8 * s + 6], st[t][8 * s + 7]};
+        bf16x4 h0, l0, h1, l1;
+        split4(p0, h0, l0);
+        split4(p1, h1, l1);
+        const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int koff = (t * 32 + s * 16 + half * 4) * 2;  // bytes; element j -> key + 8*(j>>2) + (j&3)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vr = Vt + (dt * 32 + r32) * AB_VP + koff;
+          const bf16x4 va = *reinterpret_cast<const bf16x4*>(vr), vb = *reinterpret_cast<const bf16x4*>(vr + 16);
+          const bf16x4 wa = *reinterpret_cast<const bf16x4*>(vr + 128), wb = *reinterpret_cast<const bf16x4*>(vr + 144);
+          const bf16x8 vh = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vl = __builtin_shufflevector(wa, wb, 0, 1, 2, 3, 4, 5, 6, 7);
+          o_acc[dt] = mfma3(vh, vl, ph, pl, o_acc[dt]);
+        }
+      }
+  }
+
+  // O^T accumulators: col = query (lane), row = d.  Transpose through a per-wave LDS strip [32 q][64 d + pad]
+  __syncthreads();
+  float* strip = reinterpret_cast<float*>(smem) + wave * 32 * 66;
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) strip[r32 * 66 + dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = o_acc[dt][e] * inv;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  const int D = heads * 64;
+  for (int i = lane; i < 32 * 16; i += 64) {  // 32 rows x 16 float4
+    const int qr = i >> 4, c4 = (i & 15) * 4;
+    const int q = qt * AT_BQ + wave * 32 + qr;
+    if (q < N) {
+      const float* sp = strip + qr * 66 + c4;
+      f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
+      *reinterpret_cast<f32x4*>(out + ((long long)b * N + q) * D + head * 64 + c4) = v;
+    }
+  }
+}
+
+}  // namespace prv2
+
+extern "C" int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32_t heads, int32_t prec) {
+  if (prec == PRV2_PREC_F32) return 0;
+  const int64_t npad = prv2::roundup(ntok, 64);
+  return (int64_t)b * heads * (2 * (int64_t)ntok * 128 + 2 * 64 * npad) * 2 + 256;
+}
+
+int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, float* out, void* workspace,
+                            int64_t workspace_bytes, hipStream_t s) {
+  using namespace prv2;
+  const int64_t need = prv2_attention_workspace_bytes(b, ntok, heads, PRV2_PREC_BF16X3);
+  PRV2_REQUIRE(workspace && workspace_bytes >= need, "attention: workspace too small (%lld < %lld bytes)",
+               (long long)workspace_bytes, (long long)need);
+  PRV2_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "attention: workspace must be 256-byte aligned");
+  const int npad = (int)roundup(ntok, 64);
+  __bf16* Qs = reinterpret_cast<__bf16*>(workspace);
+  __bf16* Ks = Qs + (int64_t)b * heads * ntok * 128;
+  __bf16* VtH = Ks + (int64_t)b * heads * ntok * 128;
+  __bf16* VtL = VtH + (int64_t)b * heads * 64 * npad;
+  dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
+  hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
+  dim3 g2((unsigned)cdiv(ntok, AT_BQ), (unsigned)heads, (unsigned)b);
+  hipLaunchKernelGGL(attention_bf16x3_kernel, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, out);
   return 0;
 }

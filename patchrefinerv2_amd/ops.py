@@ -294,9 +294,13 @@ def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: 
 
 def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32) -> torch.Tensor:
     out = torch.empty((b * ntok, heads * 64), device=qkv.device, dtype=torch.float32)
-    PROFILER.launch("attention_f32_kernel", 4.0 * b * heads * ntok * ntok * 64,
-                    lambda: L.check(L.load().prv2_attention(qkv.data_ptr(), b, ntok, heads, 64, out.data_ptr(), prec,
-                                                            _stream()), "attention"))
+    lib = L.load()
+    nbytes = lib.prv2_attention_workspace_bytes(b, ntok, heads, prec)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device) if nbytes else None
+    PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel",
+                    4.0 * b * heads * ntok * ntok * 64,
+                    lambda: L.check(lib.prv2_attention(qkv.data_ptr(), b, ntok, heads, 64, out.data_ptr(), prec, _ptr(ws),
+                                                       nbytes, _stream()), "attention"))
     return out
 
 

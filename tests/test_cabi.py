@@ -18,7 +18,7 @@ def _declared():
 def test_library_exports_header_symbols():
     from patchrefinerv2_amd import lib as L
     names = _declared()
-    assert len(names) >= 22
+    assert len(names) >= 23
     assert set(names) == set(L.SIGNATURES), set(names) ^ set(L.SIGNATURES)
     lib = ctypes.CDLL(L.LIB_PATH)
     for n in names:
@@ -44,7 +44,7 @@ def test_rejects_bad_arguments_without_gpu():
     assert lib.prv2_layernorm(None, 4, 8, 8, None, None, 1e-6, 0, None, 8, None) != 0
     assert b"null" in lib.prv2_last_error()
     with pytest.raises(RuntimeError):
-        L.check(lib.prv2_attention(None, 1, 1, 1, 64, None, 0, None), "attention")
+        L.check(lib.prv2_attention(None, 1, 1, 1, 64, None, 0, None, 0, None), "attention")
     assert lib.prv2_packed_weight_bytes(256, 514, 3, 3, 0, 0) == 256 * 9 * 544 * 4
 
 

@@ -148,8 +148,10 @@ def test_layernorm(P, c):
     close(out.to_nchw(), ref, 1e-5, f"ln c={c}")
 
 
-@pytest.mark.parametrize("shape", [(1, 1025, 6), (2, 197, 2), (1, 64, 1)])
-def test_attention(P, shape):
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("shape", [(1, 1025, 6), (2, 197, 2), (1, 64, 1), (3, 130, 1)])
+def test_attention(P, shape, prec):
+    from patchrefinerv2_amd import lib as L
     b, n, heads = shape
     D = heads * 64
     x = rnd(1, b, n, D)
@@ -157,8 +159,8 @@ def test_attention(P, shape):
           "proj.weight": torch.eye(D), "proj.bias": torch.zeros(D)}
     ref = o_attention(sd, "", x, heads)
     qkv = F.linear(x, sd["qkv.weight"], sd["qkv.bias"]).reshape(b * n, 3 * D)
-    out = P.attention(qkv.to(DEV).contiguous(), b, n, heads)
-    close(out.view(b, n, D), ref, 1e-5, f"attention {shape}")
+    out = P.attention(qkv.to(DEV).contiguous(), b, n, heads, L.PREC_NAMES[prec])
+    close(out.view(b, n, D), ref, 1e-5 if prec == "f32" else 4e-5, f"attention {shape} {prec}")
 
 
 def test_attention_spiky(P):
@@ -174,6 +176,9 @@ def test_attention_spiky(P):
     att = ((q * 0.125) @ k.t()).softmax(-1) @ v
     out = P.attention(qkv.to(DEV).contiguous(), b, n, heads)
     close(out, att, 1e-5)
+    from patchrefinerv2_amd import lib as L
+    out3 = P.attention(qkv.to(DEV).contiguous(), b, n, heads, L.PREC_BF16X3)
+    close(out3, att, 1e-4)  # logits up to ~100: the 2^-17 product error is amplified by exp()
 
 
 def test_patchify_tokens(P):
