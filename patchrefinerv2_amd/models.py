@@ -185,6 +185,10 @@ class _PatchModel(StateDictModule):
             for off, offp in (((0, rw // 2), (0, pw // 2)), ((rh // 2, 0), (ph // 2, 0)),
                               ((rh // 2, rw // 2), (ph // 2, pw // 2))):
                 r, p = grid(off, offp)
+                if not r:
+                    # the reference dies here too (torch.stack of an empty crop list, baseline_pretrain.py:280)
+                    raise RuntimeError(f"cai_mode {cai_mode!r} needs patch_split_num >= 2 on both axes (got "
+                                       f"{tile_cfg['patch_split_num']}): a half-offset pass would be empty")
                 passes.append(dict(kind="grid", raw=r, proc=p))
         elif cai_mode != "m1":
             raise ValueError(f"unknown cai_mode {cai_mode!r} (expected m1, m2 or r<N>)")

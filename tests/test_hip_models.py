@@ -237,3 +237,41 @@ def test_e2e_v2_zoedepth_coarse_vs_reference_golden(P, golden):
         depth, _ = _run(m, c, mode)
         ar, mx = absrel(depth, g[mode])
         assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)
+
+
+@pytest.mark.parametrize("raw,split,mode,pn", [
+    ([216, 384], [2, 2], "r8", 4),      # the golden case, against a freshly run oracle
+    ([168, 504], [1, 3], "m1", 4),      # single tile row
+    ([224, 336], [2, 3], "r6", 3),      # process_num 3: two random calls of 3 tiles sharing a column each
+    ([112, 168], [1, 1], "m1", 4),      # one tile == whole frame
+    ([240, 400], [2, 2], "r7", 4),      # N // process_num = 1 random call (7 // 4)
+])
+def test_tiling_variants_vs_oracle(P, raw, split, mode, pn):
+    """frame driver on ragged / degenerate tilings: product == oracle run on the same seed (tile plan, ROI boxes,
+    nearest/bilinear resizes of the blend, order-dependent running mean)"""
+    c = dict(E2E_V1)
+    c["raw"], c["split"] = raw, split
+    sd = e2e_v1_sd()
+    m = _build("PatchRefiner", c, sd, image_raw_shape=raw, patch_split_num=split)
+    cfg = W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]})
+    ora = o_tiling.OraclePatchRefiner(sd, cfg, cfg, patch_process_shape=c["pps"], image_raw_shape=raw, patch_split_num=split)
+    hr = rand_image(3, 1, *raw)
+    tc = dict(image_raw_shape=raw, patch_split_num=split)
+    random.seed(99)
+    ref, _ = ora(mode="infer", cai_mode=mode, process_num=pn, tile_cfg=tc, image_lr=ora.resizer(hr), image_hr=hr)
+    random.seed(99)
+    hr_d = hr.to(DEV)
+    got, _ = m(mode="infer", cai_mode=mode, process_num=pn, tile_cfg=tc, image_lr=m.resizer(hr_d), image_hr=hr_d)
+    assert tuple(got.shape) == tuple(ref.shape)
+    ar, mx = absrel(got, ref)
+    assert ar < 1e-5 and mx < 1e-3, (ar, mx)
+
+
+def test_single_row_split_rejects_overlap_modes(P):
+    """the reference cannot run m2 / r<N> with a 1-tile axis (empty half-offset pass): same loud failure"""
+    c = dict(E2E_V1)
+    m = _build("PatchRefiner", c, e2e_v1_sd(), image_raw_shape=[168, 504], patch_split_num=[1, 3])
+    hr = rand_image(3, 1, 168, 504).to(DEV)
+    with pytest.raises(RuntimeError):
+        m(mode="infer", cai_mode="m2", process_num=4, tile_cfg=dict(image_raw_shape=[168, 504], patch_split_num=[1, 3]),
+          image_lr=m.resizer(hr), image_hr=hr)
