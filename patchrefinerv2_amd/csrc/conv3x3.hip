@@ -7,15 +7,20 @@
 // zero padding / ReLU / hi-lo bf16 split -> LDS) and reused by all nine taps: tap (ky, kx) is just
 // a different LDS base address for the A fragments.  Compared with the generic kernel this
 // removes 9x of the activation traffic and of the split arithmetic; what is left per step is the
-// 16 KB (BN=128) weight tile of that tap, double buffered like the halo.
+// 16 KB (BN=128) weight tile of that tap.
 //
-// LDS rows are 144 bytes (32 fp32, or 32 bf16 hi | 32 bf16 lo, + 16 B pad).  A lane's A row is the
-// halo pixel under its output pixel: the 32 lanes of a wave half walk 32 consecutive halo pixels,
-// so every 16-lane ds_read_b128 group touches 16 distinct 16-byte bank slots (rows distinct
-// mod 16) -- conflict free for every tap shift.
+// Halo rows in LDS are 144 bytes (32 fp32, or 32 bf16 hi | 32 bf16 lo, + 16 B pad).  A lane's A row is the
+// halo pixel under its output pixel: the lanes of a ds_read_b128 group walk consecutive halo pixels, so
+// every group touches 16 distinct 16-byte bank slots -- conflict free for every tap shift, and a tap is
+// an immediate offset on one address register.  Weight rows are unpadded 128 bytes whose 16-byte slots
+// are XOR-swizzled (slot q of row r at q ^ ((r >> 1) & 7)), the image a linear LDS-DMA can produce.
+// 2 halo buffers + 4 weight buffers = 159.6 KB of the 160 KB.
 //
-// Sync: one barrier per (slab, tap) step.  Weights of step s+1 and (at tap 0) the halo of the
-// next slab are in flight in registers under the MFMAs of step s.
+// Sync: one barrier per (slab, tap) step, and every dependency is at least one whole step old when it is
+// waited for: global -> LDS traffic is issued 2-3 steps ahead (s_waitcnt vmcnt(N) counts only the current
+// step's loads as outstanding), fragment reads one k-step ahead, also across the barrier.
+#include <type_traits>
+
 #include "igemm.h"
 
 namespace prv2 {
@@ -34,9 +39,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
   constexpr int NJ = BN / (32 * WN);               // 32-channel column tiles per wave
   constexpr int ND = BN >= 64 ? BN / 64 : 1;       // LDS-DMA pieces (8 rows x 128 B) per wave per weight tile
   constexpr int A_STAGE = HALO * LDS_LD;           // floats
+  constexpr int A_BYTES = A_STAGE * 4;
   constexpr int B_STAGE = BN * 32;                 // floats: unpadded 128-byte rows, XOR-swizzled (LDS-DMA image)
   constexpr int CLD = BN + 4;
-  constexpr int NBUF = 2;                          // weight tile of this step + the one landing for the next
+  constexpr int NBUF = 4;                          // weight tiles of steps s (read), s+1 (read ahead), s+2, s+3 (landing)
   constexpr int SMEM_MAIN = 2 * A_STAGE + NBUF * B_STAGE;
   constexpr int SMEM_EPI = TH * TW * CLD + 2 * TH * TW;  // C tile + LN row statistics
   __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
@@ -83,35 +89,57 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
 
   f32x4 ra[A_IT];
   const float x_floor = p.relu_in ? 0.f : -INFINITY;  // fused input ReLU without a branch next to the loads
+  char* const As_b = reinterpret_cast<char*>(As);
+  char* const Bs_b = reinterpret_cast<char*>(Bs);
 
-  // halo item `it` (one float4 per thread) of slab cc: issued at tap `it`, stored after that tap's MFMAs.
+  // halo item `it` (one float4 per thread) of the next slab: issued at tap `it`, stored two taps later.
   // Loads are unconditional (padding lanes re-read the image's first float4); zeroing + the fused
   // input ReLU happen at store time so that nothing forces an early s_waitcnt next to the load.
   auto load_a = [&](int cc, int it) {
     const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
     ra[it] = *reinterpret_cast<const f32x4*>(ok ? img + a_off[it] + cc * BK : img);
   };
+  // Same load as inline asm for the main loop, where hipcc's own bookkeeping cannot be used: with LDS-DMAs in
+  // flight it treats vmcnt as unordered and waits vmcnt(0) in front of the first use -- draining the weight
+  // DMAs issued since.  The register is handed back by wait_a() (the "+v" ties the value to the wait).
+  auto load_a_async = [&](int cc, int it) {
+    const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
+    const float* src = ok ? img + a_off[it] + cc * BK : img;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(src) : "memory");
+  };
   auto store_a = [&](int cc, int abuf, int it) {
     const int hp = prow + 64 * it;
     const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
-    if (hp < HALO) stage_a<PREC>(As + abuf * A_STAGE + hp * LDS_LD, chunk, floor4(zero_unless(ra[it], ok), x_floor));
+    if (hp >= HALO) return;
+    const f32x4 v = floor4(zero_unless(ra[it], ok), x_floor);
+    // The LDS stores are inline asm on purpose: for a compiler-visible ds_write hipcc drains ALL in-flight
+    // LDS-DMAs first (s_waitcnt vmcnt(0): it cannot tell the weight buffers from the halo buffers), which
+    // would put the DMA latency this pipeline hides right back.  lgkmcnt is settled at the step barrier.
+    const unsigned addr = (unsigned)(size_t)(As_b + abuf * A_BYTES + hp * (LDS_LD * 4)) + chunk * (PREC == PRV2_PREC_F32 ? 16 : 8);
+    if constexpr (PREC == PRV2_PREC_F32) {
+      asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+    } else {
+      bf16x4 hi, lo;
+      split_bf16(v, hi, lo);
+      const unsigned long long h = __builtin_bit_cast(unsigned long long, hi), l = __builtin_bit_cast(unsigned long long, lo);
+      if constexpr (PREC == PRV2_PREC_BF16X3) asm volatile("ds_write2_b64 %0, %1, %2 offset1:8" ::"v"(addr), "v"(h), "v"(l) : "memory");
+      else asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(h) : "memory");
+    }
   };
   // Weight tile of step s via LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 B = 8 rows x 128 B land
   // contiguously in LDS, no VGPRs and no ds_write.  The packed weights are pre-swizzled in HBM
-  // (prv2_pack_conv_weight) so that the linear copy IS the conflict-free XOR image.
+  // (prv2_pack_conv_weight) so that the linear copy IS the conflict-free XOR image.  Every wave issues
+  // ND DMAs per step (BN = 32: waves 4-7 repeat pieces 0-3 -- same bytes, same place) so that the vmcnt
+  // bookkeeping below is the same number in all waves.
   const int dma_row = lane >> 3, dma_slot = lane & 7;
   const float* wdma = reinterpret_cast<const float*>(p.w) + ((long long)tile_n * BN + dma_row) * w_row_stride + dma_slot * 4;
-  auto dma_b = [&](int s, int bbuf) {
+  auto dma_b = [&](int s, int bbuf, int i) {  // piece i (of ND) of this wave
     const int cc = s / 9, tap = s - cc * 9;
     const float* wsrc = wdma + (long long)tap * p.Cin_pad + cc * BK;
-    if (BN == 32 && wave >= 4) return;  // 32 rows = 4 pieces
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const int piece = wave * ND + i;  // 8 rows each
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wsrc + (long long)(piece * 8) * w_row_stride),
-          (__attribute__((address_space(3))) void*)(Bs + bbuf * B_STAGE + piece * 256), 16, 0, 0);
-    }
+    const int piece = (wave * ND + i) % (BN / 8);  // 8 rows each
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(wsrc + (long long)(piece * 8) * w_row_stride),
+        (__attribute__((address_space(3))) void*)(Bs + bbuf * B_STAGE + piece * 256), 16, 0, 0);
   };
 
   f32x16 acc[NI][NJ];
@@ -122,54 +150,112 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // lane's halo pixel for its two output rows at tap (0,0): row 2*wm + i, column r32
+  // lane's halo pixel for its output rows at tap (0,0): row NI*wm + i, column r32
   const int a_pix0 = (NI * wm) * HW_ + r32;
-  auto compute = [&](int abuf, int bbuf, int tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const char* Ab = reinterpret_cast<const char*>(As + abuf * A_STAGE + (a_pix0 + ky * HW_ + kx) * LDS_LD) + half * 16;
-    const char* Bb = reinterpret_cast<const char*>(Bs + bbuf * B_STAGE + (wn * (BN / WN) + r32) * 32);
-    const char* a_row[NI];
+  int b_key[NJ];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) a_row[i] = Ab + i * HW_ * LDS_LD * 4;
-    const char* b_row[NJ];
-    int b_swz[NJ];
+  for (int j = 0; j < NJ; ++j) b_key[j] = (((wn * (BN / WN) + j * 32 + r32) >> 1) & 7) ^ half;
+  // Fragments of k-step `ks` of (halo buffer, weight buffer, tap); tap (ky, kx) is only an LDS base address.
+  // Lane (r32, half) wants slot 2*ks + half (bf16 modes: + 4 for the lo plane) of its row.
+  auto read_step = [&](Frags<NJ, PREC, NI>& f, int abuf, int bbuf, int tap, int ks) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const char* row = As_b + abuf * A_BYTES + (a_pix0 + (ky + i) * HW_ + kx) * (LDS_LD * 4) + half * 16;
+      if constexpr (PREC == PRV2_PREC_F32) {
+        f.a[i] = *reinterpret_cast<const f32x4*>(row + ks * 32);
+      } else {
+        f.ah[i] = *reinterpret_cast<const bf16x8*>(row + ks * 32);
+        if constexpr (PREC == PRV2_PREC_BF16X3) f.al[i] = *reinterpret_cast<const bf16x8*>(row + 64 + ks * 32);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      b_row[j] = Bb + j * 32 * 128;
-      b_swz[j] = ((wn * (BN / WN) + j * 32 + r32) >> 1) & 7;
+      const char* row = Bs_b + bbuf * (B_STAGE * 4) + (wn * (BN / WN) + j * 32 + r32) * 128;
+      if constexpr (PREC == PRV2_PREC_F32) {
+        f.b[j] = *reinterpret_cast<const f32x4*>(row + (((2 * ks) ^ b_key[j]) << 4));
+      } else {
+        f.bh[j] = *reinterpret_cast<const bf16x8*>(row + (((2 * ks) ^ b_key[j]) << 4));
+        if constexpr (PREC == PRV2_PREC_BF16X3) f.bl[j] = *reinterpret_cast<const bf16x8*>(row + (((2 * ks + 4) ^ b_key[j]) << 4));
+      }
     }
-    mma_slab<NJ, PREC, true, NI>(acc, a_row, b_row, b_swz, half * 16);
   };
 
-  // ---- pipeline: one barrier per (slab, tap) step -------------------------------------------------
-  // Measured alternatives that did NOT pay on MI355X (tools/ab_conv.sh, same box, 512->256 @224^2 x27):
-  //   weights through registers + ds_write instead of LDS-DMA: equal within 1 %;
-  //   3 weight buffers, DMA two steps ahead, hand-counted vmcnt + raw s_barrier: +1 %;
-  //   fragment reads issued before the VMEM instructions: -1.5 %;  s_setprio around the MFMAs: 0.
-  // Ablation: without any global->LDS traffic the same loop reaches 607 TF (73 % of the bf16x3 peak).
+  // ---- pipeline ----------------------------------------------------------------------------------------
+  // step s = (slab cc, tap).  In step s a wave issues: halo item `tap` of slab cc+1 (taps 0..5) and the
+  // weight DMA of step s+3 (into the buffer step s-1 read); it consumes: the halo item issued two taps ago
+  // (-> LDS, second halo buffer) and, at the closing barrier, the DMA issued in step s-1, i.e. only this
+  // step's own loads may still be in flight: s_waitcnt vmcnt(#loads of this step).  That DMA (step s+2's
+  // weights) is first read at the end of step s+1, when the fragments of step s+2 / k-step 0 are pulled
+  // one k-step ahead of their MFMAs.  Before this (loads waited for within their own step, fragments read
+  // right after the barrier) the same loop ran at 380-420 TF on the big layers; the history of what did
+  // NOT pay: weights through registers + ds_write instead of LDS-DMA (equal), s_setprio around MFMAs (0).
+  constexpr int KS = ksteps<PREC>();
+  Frags<NJ, PREC, NI> fr[2];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) load_a(0, it);
-  dma_b(0, 0);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    dma_b(0, 0, i);
+    dma_b(1, 1, i);
+    dma_b(2, 2, i);
+  }
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) store_a(0, 0, it);
-  __syncthreads();  // (also drains the LDS-DMA: with a DMA in flight the barrier's fence waits vmcnt(0))
+  __syncthreads();  // full fence: drains the LDS-DMAs too (vmcnt(0))
+  read_step(fr[0], 0, 0, 0, 0);
   for (int cc = 0; cc < cchunks; ++cc) {
-    // No uniform branches around the loads (hipcc would drain vmcnt at each one): the last slab / last step
+    // No uniform branches around the loads (hipcc would drain vmcnt at each one): the last slab / last steps
     // simply re-load clamped (already cached) data into buffers nobody reads afterwards.
     const int ccn = cc + 1 < cchunks ? cc + 1 : cc;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    auto step = [&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
       const int s = cc * 9 + tap;
-      dma_b(s + 1 < nsteps ? s + 1 : s, (s + 1) & 1);  // lands during the MFMAs below
-      if (tap < A_IT) load_a(ccn, tap);
-      __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMAs (hipcc sinks them to their use)
-      compute(cc & 1, s & 1, tap);
-      __builtin_amdgcn_sched_barrier(0);
-      // the other halo buffer was last read in slab cc-1: free since this slab's first barrier
-      if (tap < A_IT) store_a(ccn, (cc + 1) & 1, tap);
-      __syncthreads();
-    }
+      const int s3 = s + 3 < nsteps ? s + 3 : nsteps - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        // Between the three MFMA portions of a k-step go (a) the fragment reads of the NEXT k-step -- after the
+        // first MFMAs, so the wait in front of those sees only reads a whole k-step old, and 2/3 of a k-step
+        // before their use -- and (b) one global / LDS-store instruction group at a time: all 8 waves leave the
+        // barrier together, and a burst of 3 VMEM + 2 DS-store instructions per wave in one place backs up the
+        // address pipes with both waves of a SIMD queued behind it, MFMA pipe idle.  The sched_barriers pin
+        // the order (hipcc would sink loads and reads to their uses).
+        mma_frags<NJ, PREC, NI, 1>(acc, fr[ks & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KS) read_step(fr[(ks + 1) & 1], cc & 1, s & 3, tap, ks + 1);
+        else read_step(fr[0], tap == 8 ? (cc + 1) & 1 : cc & 1, (s + 1) & 3, (tap + 1) % 9, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags<NJ, PREC, NI, 3>(acc, fr[ks & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) dma_b(s3, (s + 3) & 3, 0);
+        if (ks == KS - 1 && ND > 1) dma_b(s3, (s + 3) & 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_frags<NJ, PREC, NI, 4>(acc, fr[ks & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (tap < A_IT) if (ks == 0) load_a_async(ccn, tap);
+        // the other halo buffer was last read in slab cc-1: free since this slab's first barrier
+        if constexpr (tap >= 2 && tap - 2 < A_IT) if (ks == KS - 1) {
+          // VMEM instructions issued since load_a_async(tap - 2): the rest of its step, steps tap-1 and tap
+          constexpr int newer = (ND - 1) + ND + (tap - 1 < A_IT ? 1 : 0) + ND + (tap < A_IT ? 1 : 0);
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
+          store_a(ccn, (cc + 1) & 1, tap - 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // LDS writes/reads of this step done; of the global loads only this step's may still fly
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((tap < A_IT ? 1 : 0) + ND) : "memory");
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
   }
+  __syncthreads();  // clamped tail DMAs must have landed before the C tile overwrites the buffers
 
   // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
 #pragma unroll

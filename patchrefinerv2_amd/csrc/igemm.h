@@ -107,23 +107,31 @@ __device__ __forceinline__ void read_frags(Frags<NJ, PREC, NI>& f, int ks, const
   }
 }
 
-template <int NJ, int PREC, int NI = 2>
+// PART: 0 = all MFMAs of the k-step; 1 / 3 / 4 = its three portions (2 = 3 and 4 together).  bf16x3: the lo*hi,
+// hi*lo and hi*hi products; other modes: row sub-tile 0, the rest, nothing.  Lets a caller drop other
+// instructions (next fragment reads, global loads, LDS stores) between the portions.
+template <int NJ, int PREC, int NI = 2, int PART = 0>
 __device__ __forceinline__ void mma_frags(f32x16 (&acc)[NI][NJ], const Frags<NJ, PREC, NI>& f) {
+  constexpr bool P1 = PART == 0 || PART == 1, P3 = PART == 0 || PART == 2 || PART == 3,
+                 P4 = PART == 0 || PART == 2 || PART == 4;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      const bool mine = (i == 0 && NI > 1) ? P1 : P3;  // single-product modes
       if constexpr (PREC == PRV2_PREC_F32) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].x, f.b[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].y, f.b[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].z, f.b[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].w, f.b[j].w, acc[i][j], 0, 0, 0);
-      } else {
-        if constexpr (PREC == PRV2_PREC_BF16X3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        if (mine) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].x, f.b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].y, f.b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].z, f.b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].w, f.b[j].w, acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      } else if constexpr (PREC == PRV2_PREC_BF16X3) {
+        if (P1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        if (P3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        if (P4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      } else {
+        if (mine) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
       }
     }
 }

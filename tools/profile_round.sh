@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): regenerates the profiles/ evidence of the default
+# bench workload into gpurun_out/profiles/ (copy what should be judged into profiles/ afterwards).
+set -u
+TAG=${1:-r01}; PREC=${2:-bf16x3}
+R=$(pwd); O=$R/gpurun_out/profiles; mkdir -p $O
+WL=$(python3 -c "from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD as w; print(w)")
+export TMPDIR=/tmp
+python3 bench.py --steps 5 --warmup 2 > $O/${TAG}_${PREC}_bench.json 2> $O/bench.err
+python3 bench.py --layer-report $O/${TAG}_${PREC}_layers_${WL}.csv --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/bench.err
+# kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline > /tmp/kt.log 2>&1
+cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $O/${TAG}_${PREC}_kernel_stats_${WL}.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python3 $R/bench.py --steps 1 --warmup 0 --streams 1 --no-roofline --no-cpu-baseline > /tmp/pmc_$C.log 2>&1
+done
+python3 $R/tools/pmc_to_json.py $O/${TAG}_${PREC}_pmc_frame_${WL}.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
+ls -la $O
