@@ -19,6 +19,8 @@
 // Sync: one barrier per (slab, tap) step, and every dependency is at least one whole step old when it is
 // waited for: global -> LDS traffic is issued 2-3 steps ahead (s_waitcnt vmcnt(N) counts only the current
 // step's loads as outstanding), fragment reads one k-step ahead, also across the barrier.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "igemm.h"
@@ -297,7 +299,13 @@ bool conv3x3_halo_supported(const IgemmParams& p) {
          (long long)p.H * p.W * p.ldx < (1LL << 31);
 }
 
+void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s);  // conv3x3_m16.hip
+
 void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t s) {
+  // bf16 modes run on the 16x16x32 MFMA shape (conv3x3_m16.hip); PRV2_HALO_MFMA32=1 keeps them on this file's
+  // 32x32x16 kernel (A/B knob for tools/ab_conv.sh, read once)
+  static const bool force32 = [] { const char* e = getenv("PRV2_HALO_MFMA32"); return e && e[0] == '1'; }();
+  if (prec != PRV2_PREC_F32 && !force32) return launch_conv3x3_halo16(p, prec, s);
   const int tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
 #define PRV2_LAUNCH_HALO(BN_, PREC_) \
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, PREC_>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p)

@@ -1,0 +1,326 @@
+// 3x3 / stride 1 / pad 1 convolution, LDS halo tile, bf16 modes on v_mfma_f32_16x16x32_bf16.
+//
+// Same decomposition as conv3x3.hip (8 x 32 output pixels x BN channels per 512-thread workgroup, a
+// 32-channel slab of the (8+2) x (32+2) halo staged once and reused by the nine taps, weight tile of each
+// tap by LDS-DMA), but the MFMA is the 16x16x32 shape: one instruction spans the whole 32-channel slab of a
+// tap, and on MI355X the chip holds a higher clock on this shape than on 32x32x16 for the same FLOPs
+// (MI355X_MICROARCH.md, DVFS give-back (7)); the 3x3 convs are MFMA-dense enough to be clock-limited
+// (profiles/: 1.66 GHz effective, MFMA pipe 72 % busy, on the 32x32x16 kernel).
+//
+// Fragment layout (lane = 16*g + m): A operand = halo pixel m of a 16-pixel run, channels 8g..8g+7;
+// B operand = output channel m of a 16-channel column, input channels 8g..8g+7; accumulator = pixels
+// 4g..4g+3 x channel m.  A wave owns NI image rows x 32 pixels (NA = 2*NI pixel runs) x NJ columns.
+//
+// LDS: halo rows are 160 bytes (32 bf16 hi | 32 bf16 lo | 32 B pad): with a 10-slot row stride the 16 lanes
+// of every ds_read_b128 group (pixels p..p+15 at slot g, mixed g) hit 16 distinct 16-byte bank slots for
+// every tap shift (exhaustive check in tests/test_host_logic.py).  Weight rows are the same unpadded,
+// XOR-swizzled 128-byte rows as in conv3x3.hip (slot q of row r at q ^ ((r >> 1) & 7)) -- also conflict
+// free for this access pattern.  2 halo buffers (106 KB) + 3 weight buffers (48 KB).
+//
+// Pipeline per (slab, tap) step, NJ column phases of NA*3 MFMAs each:
+//   phase j < NJ-1 : read column j+1's weights, then the MFMAs of column j
+//   barrier        : before the last phase (everything in LDS that the rest needs is now a step old)
+//   last phase     : read column 0 of the NEXT step's weights; MFMAs of the last column, and as each pixel
+//                    run retires, its fragment registers are refilled with the NEXT tap's run.
+// Global traffic is two steps ahead of its first use: the weight DMA of step s+3 goes out right after the
+// barrier of step s (all waves have read step s's tile by then) and has to have landed at the barrier of
+// step s+2; the halo item loaded at tap t is stored at tap t+2.  All waits are counted (s_waitcnt vmcnt(N)).
+#include <type_traits>
+
+#include "igemm.h"
+
+namespace prv2 {
+
+namespace m16 {
+constexpr int TH = 8, TW = 32;
+constexpr int HW_ = TW + 2, HH_ = TH + 2;
+constexpr int HALO = HH_ * HW_;                 // 340 pixels
+constexpr int A_IT = (HALO * 8 + 511) / 512;    // float4 loads per thread per slab (6)
+constexpr int AROW = 160;                       // bytes per halo pixel in LDS
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+}  // namespace m16
+
+template <int BN, int PREC>
+__global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParams p) {
+  using namespace m16;
+  static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
+  constexpr int WN = BN >= 64 ? 2 : 1;
+  constexpr int NI = BN >= 64 ? 2 : 1;             // image rows per wave
+  constexpr int NA = 2 * NI;                       // 16-pixel runs per wave
+  constexpr int NJ = BN / (16 * WN);               // 16-channel columns per wave
+  constexpr int ND = BN >= 64 ? BN / 64 : 1;       // LDS-DMA pieces (8 rows x 128 B) per wave per weight tile
+  constexpr int A_BYTES = HALO * AROW;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int CLD = BN + 4;
+  constexpr int NBUF = 3;
+  constexpr int SMEM_MAIN = (2 * A_BYTES + NBUF * B_BYTES) / 4;
+  constexpr int SMEM_EPI = TH * TW * CLD + 2 * TH * TW;  // C tile + LN row statistics
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
+  char* const As_b = reinterpret_cast<char*>(smem);
+  char* const Bs_b = As_b + 2 * A_BYTES;
+
+  // ---- XCD-aware block -> (pixel tile, channel tile) ----------------------------------------
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n;
+  int tm = bid / p.tiles_n;
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int tx = tm % tiles_x;
+  tm /= tiles_x;
+  const int ty = tm % tiles_y;
+  const int n_img = tm / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  const int m16 = lane & 15, g = lane >> 4;
+  const int chunk = tid & 7, prow = tid >> 3;  // loader role: float4 `chunk` of halo pixels prow + 64*i
+
+  // ---- halo loader (constant over the K loop) -----------------------------------------------------
+  const float* img = p.x + (long long)n_img * p.x_bstride + chunk * 4;
+  int a_off[A_IT];  // element offset of halo pixel (prow + 64*it), or -1 when it is zero padding / unused
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int hp = prow + 64 * it;
+    const int hy = hp / HW_, hx = hp - hy * HW_;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    a_off[it] = ok ? (iy * p.W + ix) * p.ldx : -1;
+  }
+  const long long w_row_stride = 9LL * p.Cin_pad;
+  const int cchunks = p.Cin_pad / BK;
+  const int nsteps = 9 * cchunks;
+  const int cin4 = (p.Cin + 3) & ~3;
+  const float x_floor = p.relu_in ? 0.f : -INFINITY;  // fused input ReLU without a branch next to the loads
+
+  f32x4 ra[A_IT];
+  auto a_src = [&](int cc, int it) {
+    const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
+    return ok ? img + a_off[it] + cc * BK : img;  // padding lanes re-read the image's first float4 (zeroed at store)
+  };
+  auto load_a = [&](int cc, int it) { ra[it] = *reinterpret_cast<const f32x4*>(a_src(cc, it)); };
+  // inline asm in the main loop: with LDS-DMAs in flight hipcc treats vmcnt as unordered and would wait
+  // vmcnt(0) in front of the first use; the value is handed back by the counted wait (its "+v" operand)
+  auto load_a_async = [&](int cc, int it) {
+    const float* src = a_src(cc, it);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(src) : "memory");
+  };
+  auto store_a = [&](int cc, int abuf, int it) {
+    const int hp = prow + 64 * it;
+    const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
+    if (hp >= HALO) return;
+    const f32x4 v = floor4(zero_unless(ra[it], ok), x_floor);
+    bf16x4 hi, lo;
+    split_bf16(v, hi, lo);
+    const unsigned addr = (unsigned)(size_t)(As_b + abuf * A_BYTES + hp * AROW) + chunk * 8;
+    const unsigned long long h = __builtin_bit_cast(unsigned long long, hi), l = __builtin_bit_cast(unsigned long long, lo);
+    // asm for the same reason: a compiler-visible ds_write waits for ALL in-flight LDS-DMAs first
+    if constexpr (PREC == PRV2_PREC_BF16X3) asm volatile("ds_write2_b64 %0, %1, %2 offset1:8" ::"v"(addr), "v"(h), "v"(l) : "memory");
+    else asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(h) : "memory");
+  };
+  // weight tile of step s: 64 lanes x 16 B = 8 rows x 128 B per DMA, linear in LDS (pre-swizzled in HBM)
+  const int dma_row = lane >> 3, dma_slot = lane & 7;
+  const float* wdma = reinterpret_cast<const float*>(p.w) + ((long long)tile_n * BN + dma_row) * w_row_stride + dma_slot * 4;
+  auto dma_src = [&](int s, int i) {
+    const int cc = s / 9, tap = s - cc * 9;
+    const int piece = (wave * ND + i) % (BN / 8);  // BN = 32: waves 4-7 repeat pieces 0-3 (uniform vmcnt bookkeeping)
+    return wdma + (long long)tap * p.Cin_pad + cc * BK + (long long)(piece * 8) * w_row_stride;
+  };
+  auto dma_dst = [&](int bbuf, int i) { return Bs_b + bbuf * B_BYTES + ((wave * ND + i) % (BN / 8)) * 1024; };
+  auto dma_b = [&](int s, int bbuf, int i) {  // prologue: compiler-visible
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dma_src(s, i),
+                                     (__attribute__((address_space(3))) void*)dma_dst(bbuf, i), 16, 0, 0);
+  };
+  // Main loop: the same instruction as inline asm.  While hipcc sees an LDS-DMA in flight it degrades every
+  // s_waitcnt lgkmcnt(N) in front of an MFMA to lgkmcnt(0) (a flat-LDS access makes the counter "unordered"
+  // in its model), which drains the fragment reads issued a few instructions earlier for the NEXT phase.
+  auto dma_b_async = [&](int s, int bbuf, int i) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dma_dst(bbuf, i));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(dma_src(s, i)) : "memory");  // (m0 is not live anywhere else in the loop)
+  };
+
+  f32x4 acc[NA][NJ];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addressing ---------------------------------------------------------------------------
+  // pixel run a = (image row a / 2 of the wave, half a % 2): halo pixel of lane m at tap (ky, kx)
+  const char* const a_lane = As_b + ((NI * wm) * HW_ + m16) * AROW + g * 16;
+  const int b_key = (m16 >> 1) & 7;  // rows wn*(BN/WN) + 16 j + m: the key only depends on m
+  const char* const b_lane_hi = Bs_b + (wn * (BN / WN) + m16) * 128 + ((g ^ b_key) << 4);
+  const char* const b_lane_lo = Bs_b + (wn * (BN / WN) + m16) * 128 + (((4 + g) ^ b_key) << 4);
+  bf16x8 ah[NA], al[NA], bh[2], bl[2];
+  auto read_a = [&](int a, int abuf, int tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const char* q = a_lane + abuf * A_BYTES + ((a / 2 + ky) * HW_ + (a % 2) * 16 + kx) * AROW;
+    ah[a] = *reinterpret_cast<const bf16x8*>(q);
+    if constexpr (PREC == PRV2_PREC_BF16X3) al[a] = *reinterpret_cast<const bf16x8*>(q + 64);
+  };
+  auto read_b = [&](int slot, int bbuf, int j) {
+    bh[slot] = *reinterpret_cast<const bf16x8*>(b_lane_hi + bbuf * B_BYTES + j * 16 * 128);
+    if constexpr (PREC == PRV2_PREC_BF16X3) bl[slot] = *reinterpret_cast<const bf16x8*>(b_lane_lo + bbuf * B_BYTES + j * 16 * 128);
+  };
+  // product pr of the split (bf16x3: lo*hi, hi*lo, hi*hi -- smallest terms first; bf16: the single product)
+  constexpr int NP = PREC == PRV2_PREC_BF16X3 ? 3 : 1;
+  auto mma = [&](int a, int j, int slot, int pr) {
+    if constexpr (PREC == PRV2_PREC_BF16X3) {
+      if (pr == 0) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bh[slot], acc[a][j], 0, 0, 0);
+      if (pr == 1) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bl[slot], acc[a][j], 0, 0, 0);
+      if (pr == 2) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh[slot], acc[a][j], 0, 0, 0);
+    } else {
+      acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh[slot], acc[a][j], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) load_a(0, it);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    dma_b(0, 0, i);
+    dma_b(1, 1, i);
+    dma_b(2, 2, i);
+  }
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) store_a(0, 0, it);
+  __syncthreads();  // full fence: lgkmcnt for the asm stores, vmcnt(0) for the DMAs
+#pragma unroll
+  for (int a = 0; a < NA; ++a) read_a(a, 0, 0);
+  read_b(0, 0, 0);
+
+  for (int cc = 0; cc < cchunks; ++cc) {
+    const int ccn = cc + 1 < cchunks ? cc + 1 : cc;  // last slab: re-load clamped data nobody reads (no branches)
+    auto step = [&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      constexpr int L0 = tap < A_IT ? 1 : 0, Lm1 = (tap >= 1 && tap - 1 < A_IT) ? 1 : 0;
+      const int s = cc * 9 + tap;
+      const int s3 = s + 3 < nsteps ? s + 3 : nsteps - 1;
+      constexpr int bb = tap % 3;  // 9 taps per slab: step mod 3 == tap mod 3
+#pragma unroll
+      for (int j = 0; j < NJ - 1; ++j) {
+        read_b((j + 1) & 1, bb, j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // two pixel runs at a time, products outer: consecutive MFMAs never share an accumulator, and the runs
+        // refilled last (end of the previous step) are needed last
+#pragma unroll
+        for (int a = 0; a < NA; a += 2) {
+#pragma unroll
+          for (int pr = 0; pr < NP; ++pr) {
+            mma(a, j, j & 1, pr);
+            mma(a + 1, j, j & 1, pr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (j == 0 && a == 0) {
+            if constexpr (tap < A_IT) load_a_async(ccn, tap);
+          }
+          if (j == (NJ > 2 ? 1 : 0) && a == NA - 2) {
+            if constexpr (tap >= 2 && tap - 2 < A_IT) {
+              // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
+              constexpr int newer = 2 * ND + Lm1 + L0;
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
+              store_a(ccn, (cc + 1) & 1, tap - 2);  // other halo buffer: last read in slab cc-1
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // Barrier: every wave has issued (and, lgkmcnt(0), received) its reads of this step's weight tile and, at
+      // tap 8, of this slab's halo; the DMA of step s+1 (issued two barriers ago) has landed: newer than it are
+      // the halo loads of steps s-1 and s and the DMA issued at the previous barrier.
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ND + Lm1 + L0) : "memory");
+      read_b(NJ & 1, (tap + 1) % 3, 0);  // column 0 of the next step (the last column sits in slot (NJ-1)&1)
+      __builtin_amdgcn_sched_barrier(0);
+      // last column, two pixel runs at a time; as a pair retires its registers take the NEXT tap's runs
+#pragma unroll
+      for (int a = 0; a < NA; a += 2) {
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+          mma(a, NJ - 1, (NJ - 1) & 1, pr);
+          mma(a + 1, NJ - 1, (NJ - 1) & 1, pr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(a, tap == 8 ? (cc + 1) & 1 : cc & 1, (tap + 1) % 9);
+        read_a(a + 1, tap == 8 ? (cc + 1) & 1 : cc & 1, (tap + 1) % 9);
+        if (a / 2 < ND) dma_b_async(s3, tap % 3, a / 2);  // this step's tile buffer is free since the barrier
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr ((NJ & 1) != 0) {  // (not instantiated: NJ is 2 or 4, so next step's column 0 sits in slot 0)
+        bh[0] = bh[1];
+        bl[0] = bl[1];
+      }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+  }
+  __syncthreads();  // clamped tail DMAs must have landed before the C tile overwrites the buffers
+
+  // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = (NI * wm + a / 2) * TW + (a % 2) * 16 + 4 * g + e;
+        smem[row * CLD + wn * (BN / WN) + j * 16 + m16] = acc[a][j][e];
+      }
+  __syncthreads();
+  float* const ln_stats = smem + TH * TW * CLD;
+  if (p.ln_w) {  // block-uniform
+    ln_row_stats(p, smem, CLD, TH * TW, tid, ln_stats);
+    __syncthreads();
+  }
+
+  constexpr int C4 = BN / 4;
+  constexpr int RPP = 512 / C4;
+  const int col4 = tid % C4;
+  EpiCols ec;
+  if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
+  for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+    const int py = rr / TW, px = rr - py * TW;
+    const int oy = y0 + py, ox = x0 + px;
+    if (oy >= p.H || ox >= p.W) continue;
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
+    const long long pix = (long long)oy * p.W + ox;
+    const long long m = (long long)n_img * p.H * p.W + pix;
+    const long long o = (long long)n_img * p.y_bstride + pix * p.ldy + ec.co;
+    epi_store(p, ec, cv, m, o, ln_stats[rr], ln_stats[TH * TW + rr]);
+  }
+}
+
+void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
+  using namespace m16;
+  const int tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+#define PRV2_LAUNCH_HALO16(BN_, PREC_) \
+  hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p)
+  if (p.Ncols > 64) {
+    p.tiles_n = (int)cdiv(p.Ncols, 128);
+    if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(128, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_HALO16(128, PRV2_PREC_BF16);
+  } else if (p.Ncols > 32) {
+    p.tiles_n = 1;
+    if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(64, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_HALO16(64, PRV2_PREC_BF16);
+  } else {
+    p.tiles_n = 1;
+    if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(32, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_HALO16(32, PRV2_PREC_BF16);
+  }
+#undef PRV2_LAUNCH_HALO16
+}
+
+}  // namespace prv2

@@ -213,7 +213,8 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
     halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and cw.pad == 1 and not cw.convt_k and x.w >= 24 and x.h >= 4
             and not force_generic)  # mirrors conv3x3_halo_supported() in csrc/conv3x3.hip
-    kname = "conv3x3_halo_kernel" if halo else "igemm_kernel"
+    # bf16 modes of the halo conv run on the 16x16x32 MFMA kernel (csrc/conv3x3_m16.hip), f32 on csrc/conv3x3.hip
+    kname = ("conv3x3_halo_kernel" if cw.prec == PREC_F32 else "conv3x3_halo16_kernel") if halo else "igemm_kernel"
     bn = 128 if ncols > 64 else (32 if (halo and ncols <= 32) else 64)
     PROFILER.launch(f"{kname}<{bn},{L.PREC_LABEL[cw.prec]}>", 2.0 * m_rows * ncols * cw.cin * taps,
                     lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias),
