@@ -25,6 +25,10 @@
 // Global traffic is two steps ahead of its first use: the weight DMA of step s+3 goes out right after the
 // barrier of step s (all waves have read step s's tile by then) and has to have landed at the barrier of
 // step s+2; the halo item loaded at tap t is stored at tap t+2.  All waits are counted (s_waitcnt vmcnt(N)).
+//
+// PRV2_ABL_NOA / _NOB / _NOBAR compile out the halo stream / the weight DMA / the barrier for timing ablations
+// (tools/ab_conv.sh; results are wrong with any of them, and stale LDS data raises the clock by itself --
+// compare cycles via tools/pmc_conv.sh, not only wall time).
 #include <type_traits>
 
 #include "igemm.h"
@@ -79,7 +83,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int m16 = lane & 15, g = lane >> 4;
-  const int chunk = tid & 7, prow = tid >> 3;  // loader role: float4 `chunk` of halo pixels prow + 64*i
+  // loader role: float4 `chunk` of halo pixels prow + 64*i.  A 16-lane ds_write_b64 group covers two pixels: with
+  // 160-byte rows neighbours p, p+1 share 8 of the 32 store banks, p and p+2 none -> swap bits 0/1 of the pixel index
+  const int chunk = tid & 7, prow_lin = tid >> 3;
+  const int prow = (prow_lin & ~3) | ((prow_lin & 1) << 1) | ((prow_lin >> 1) & 1);
 
   // ---- halo loader (constant over the K loop) -----------------------------------------------------
   const float* img = p.x + (long long)n_img * p.x_bstride + chunk * 4;
@@ -114,10 +121,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
     const int hp = prow + 64 * it;
     const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
     if (hp >= HALO) return;
+    const unsigned addr = (unsigned)(size_t)(As_b + abuf * A_BYTES + hp * AROW) + chunk * 8;
     const f32x4 v = floor4(zero_unless(ra[it], ok), x_floor);
     bf16x4 hi, lo;
     split_bf16(v, hi, lo);
-    const unsigned addr = (unsigned)(size_t)(As_b + abuf * A_BYTES + hp * AROW) + chunk * 8;
     const unsigned long long h = __builtin_bit_cast(unsigned long long, hi), l = __builtin_bit_cast(unsigned long long, lo);
     // asm for the same reason: a compiler-visible ds_write waits for ALL in-flight LDS-DMAs first
     if constexpr (PREC == PRV2_PREC_BF16X3) asm volatile("ds_write2_b64 %0, %1, %2 offset1:8" ::"v"(addr), "v"(h), "v"(l) : "memory");
@@ -218,15 +225,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
           }
           __builtin_amdgcn_sched_barrier(0);
           if (j == 0 && a == 0) {
+#ifndef PRV2_ABL_NOA
             if constexpr (tap < A_IT) load_a_async(ccn, tap);
+#endif
           }
           if (j == (NJ > 2 ? 1 : 0) && a == NA - 2) {
+#ifndef PRV2_ABL_NOA
             if constexpr (tap >= 2 && tap - 2 < A_IT) {
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
               constexpr int newer = 2 * ND + Lm1 + L0;
               asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
               store_a(ccn, (cc + 1) & 1, tap - 2);  // other halo buffer: last read in slab cc-1
             }
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -234,7 +245,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
       // Barrier: every wave has issued (and, lgkmcnt(0), received) its reads of this step's weight tile and, at
       // tap 8, of this slab's halo; the DMA of step s+1 (issued two barriers ago) has landed: newer than it are
       // the halo loads of steps s-1 and s and the DMA issued at the previous barrier.
+#ifdef PRV2_ABL_NOBAR
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ND + Lm1 + L0) : "memory");
+#else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ND + Lm1 + L0) : "memory");
+#endif
       read_b(NJ & 1, (tap + 1) % 3, 0);  // column 0 of the next step (the last column sits in slot (NJ-1)&1)
       __builtin_amdgcn_sched_barrier(0);
       // last column, two pixel runs at a time; as a pair retires its registers take the NEXT tap's runs
@@ -248,7 +263,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
         __builtin_amdgcn_sched_barrier(0);
         read_a(a, tap == 8 ? (cc + 1) & 1 : cc & 1, (tap + 1) % 9);
         read_a(a + 1, tap == 8 ? (cc + 1) & 1 : cc & 1, (tap + 1) % 9);
-        if (a / 2 < ND) dma_b_async(s3, tap % 3, a / 2);  // this step's tile buffer is free since the barrier
+#ifndef PRV2_ABL_NOB
+        if (a / 2 < ND) dma_b_async(s3, tap % 3, a / 2);
+#endif  // this step's tile buffer is free since the barrier
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr ((NJ & 1) != 0) {  // (not instantiated: NJ is 2 or 4, so next step's column 0 sits in slot 0)
