@@ -44,7 +44,7 @@ constexpr int AROW = 160;                       // bytes per halo pixel in LDS
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 }  // namespace m16
 
-template <int BN, int PREC>
+template <int BN, int PREC, bool TAIL>
 __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParams p) {
   using namespace m16;
   static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
@@ -100,8 +100,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
     a_off[it] = ok ? (iy * p.W + ix) * p.ldx : -1;
   }
   const long long w_row_stride = 9LL * p.Cin_pad;
-  const int cchunks = p.Cin_pad / BK;
-  const int nsteps = 9 * cchunks;
+  // With a tail tile (igemm.h: has_tail_tile) the last slab -- 2 real channels -- is not walked tap by tap: its
+  // 9 taps x 2 channels are ONE extra step (k = 2*tap + c) after the full slabs.
+  constexpr bool tail = TAIL;  // a template flag: the regular layers pay nothing for it
+  const int cslabs = p.Cin_pad / BK;            // slabs staged through the halo buffers
+  const int cchunks = cslabs - (tail ? 1 : 0);  // slabs walked by the 9-tap loop
+  const int nsteps = 9 * cchunks + (tail ? 1 : 0);
   const int cin4 = (p.Cin + 3) & ~3;
   const float x_floor = p.relu_in ? 0.f : -INFINITY;  // fused input ReLU without a branch next to the loads
 
@@ -133,10 +137,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   // weight tile of step s: 64 lanes x 16 B = 8 rows x 128 B per DMA, linear in LDS (pre-swizzled in HBM)
   const int dma_row = lane >> 3, dma_slot = lane & 7;
   const float* wdma = reinterpret_cast<const float*>(p.w) + ((long long)tile_n * BN + dma_row) * w_row_stride + dma_slot * 4;
+  const float* wdma_tail = reinterpret_cast<const float*>(p.w_tail) + ((long long)tile_n * BN + dma_row) * 32 + dma_slot * 4;
   auto dma_src = [&](int s, int i) {
     const int cc = s / 9, tap = s - cc * 9;
     const int piece = (wave * ND + i) % (BN / 8);  // BN = 32: waves 4-7 repeat pieces 0-3 (uniform vmcnt bookkeeping)
-    return wdma + (long long)tap * p.Cin_pad + cc * BK + (long long)(piece * 8) * w_row_stride;
+    const float* main = wdma + (long long)tap * p.Cin_pad + cc * BK + (long long)(piece * 8) * w_row_stride;
+    return (tail && s == nsteps - 1) ? wdma_tail + piece * 8 * 32 : main;
   };
   auto dma_dst = [&](int bbuf, int i) { return Bs_b + bbuf * B_BYTES + ((wave * ND + i) % (BN / 8)) * 1024; };
   auto dma_b = [&](int s, int bbuf, int i) {  // prologue: compiler-visible
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   read_b(0, 0, 0);
 
   for (int cc = 0; cc < cchunks; ++cc) {
-    const int ccn = cc + 1 < cchunks ? cc + 1 : cc;  // last slab: re-load clamped data nobody reads (no branches)
+    const int ccn = cc + 1 < cslabs ? cc + 1 : cc;  // last slab: re-load clamped data nobody reads (no branches)
     auto step = [&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
       constexpr int L0 = tap < A_IT ? 1 : 0, Lm1 = (tap >= 1 && tap - 1 < A_IT) ? 1 : 0;
@@ -283,6 +289,38 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
     step(std::integral_constant<int, 7>{});
     step(std::integral_constant<int, 8>{});
   }
+  if (tail) {
+    // ---- tail step: A operand gathered from the staged last slab, k = 2*tap + c: lane group g covers taps
+    // 4g..4g+3 (channels 0,1 of the slab = the first 4 bytes of the pixel's hi / lo plane).  The weight tile sits
+    // in buffer 0 (step index 9*cchunks), column 0 already in slot 0; the fragments refilled by the last
+    // regular step are replaced.
+    const int abuf = cchunks & 1;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tp = 4 * g + i;
+        const int tpc = tp < 9 ? tp : 0;
+        const int ky = tpc / 3, kx = tpc - ky * 3;
+        const char* q = a_lane - g * 16 + abuf * A_BYTES + ((a / 2 + ky) * HW_ + (a % 2) * 16 + kx) * AROW;
+        const unsigned hv = *reinterpret_cast<const unsigned*>(q), lv = *reinterpret_cast<const unsigned*>(q + 64);
+        h[i] = tp < 9 ? hv : 0u;
+        l[i] = tp < 9 ? lv : 0u;
+      }
+      ah[a] = __builtin_bit_cast(bf16x8, h);
+      al[a] = __builtin_bit_cast(bf16x8, l);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j + 1 < NJ) read_b((j + 1) & 1, 0, j + 1);
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) mma(a, j, j & 1, pr);
+    }
+  }
   __syncthreads();  // clamped tail DMAs must have landed before the C tile overwrites the buffers
 
   // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
@@ -322,8 +360,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   using namespace m16;
   const int tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-#define PRV2_LAUNCH_HALO16(BN_, PREC_) \
-  hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p)
+#define PRV2_LAUNCH_HALO16(BN_, PREC_)                                                                             \
+  do {                                                                                                             \
+    if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, true>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p); \
+    else hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, false>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p);       \
+  } while (0)
   if (p.Ncols > 64) {
     p.tiles_n = (int)cdiv(p.Ncols, 128);
     if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(128, PRV2_PREC_BF16X3);

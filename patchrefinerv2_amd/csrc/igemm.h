@@ -29,7 +29,16 @@ struct IgemmParams {
   long long M;
   int relu_in, act, convt_k, vec_ok, vec_epi;
   int tiles_m, tiles_n;
+  const void* w_tail;  // im2col tile of the last (Cin % 32 == 2) channels for the 16x16x32 halo kernel, or null
 };
+
+// 3x3 convs whose Cin is a multiple of 32 plus the two appended depth maps ([feat | pred1 | pred2] concats:
+// Cin = 34, 66, 98, 194, 322, 642, 770) carry one extra 128-byte tile per output row behind the regular packed
+// weights: the 9 taps x 2 stray channels as ONE k = 32 slab (k = 2*tap + c, 18 used).  The 16x16x32 halo kernel
+// then spends one MFMA step on them instead of nine steps of a 94 % empty slab (conv3x3_m16.hip).
+static inline bool has_tail_tile(int cin, int kh, int kw, int convt_k, int prec) {
+  return kh == 3 && kw == 3 && convt_k == 0 && prec != PRV2_PREC_F32 && cin > 32 && cin % 32 == 2;
+}
 
 constexpr int BM = 128;
 constexpr int BK = 32;

@@ -237,6 +237,25 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
   }
 }
 
+// tail tile (igemm.h: has_tail_tile): row r, k = 2*tap + c for the last two input channels, same 128-byte image
+__global__ void __launch_bounds__(256) pack_tail_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                        float* __restrict__ dst, int Cout, int Cin, int rows_pad, int prec) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows_pad * 32) return;
+  const int r = idx >> 5, e = idx & 31;
+  float v = 0.f;
+  if (r < Cout && e < 18) {
+    v = src[((long long)r * Cin + (Cin - 2 + (e & 1))) * 9 + (e >> 1)];
+    if (scale) v *= scale[r];
+  }
+  const int key = (r >> 1) & 7;
+  __bf16 hi = (__bf16)v;
+  __bf16 lo = (__bf16)(v - (float)hi);
+  __bf16* d16 = reinterpret_cast<__bf16*>(dst + (long long)r * 32);
+  d16[(((e >> 3) ^ key) << 3) + (e & 7)] = hi;
+  d16[((((e >> 3) + 4) ^ key) << 3) + (e & 7)] = prec == PRV2_PREC_BF16X3 ? lo : (__bf16)0.0f;
+}
+
 static inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace prv2
@@ -247,9 +266,9 @@ static inline int gemm_rows(int cout, int convt_k) { return convt_k > 0 ? convt_
 
 extern "C" int64_t prv2_packed_weight_bytes(int32_t cout, int32_t cin, int32_t kh, int32_t kw, int32_t convt_k,
                                             int32_t prec) {
-  (void)prec;
   int64_t taps = convt_k > 0 ? 1 : (int64_t)kh * kw;
-  return roundup(gemm_rows(cout, convt_k), 128) * taps * roundup(cin, BK) * 4;
+  const int64_t rows_pad = roundup(gemm_rows(cout, convt_k), 128);
+  return rows_pad * taps * roundup(cin, BK) * 4 + (has_tail_tile(cin, kh, kw, convt_k, prec) ? rows_pad * 128 : 0);
 }
 
 extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, void* w_packed, int32_t cout, int32_t cin,
@@ -262,6 +281,11 @@ extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, 
   hipLaunchKernelGGL(pack_weight_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w_src, bn_scale,
                      (float*)w_packed, cout, cin, kh, kw, convt_k, rows, rows_pad, cin_pad, prec);
   PRV2_LAUNCH_CHECK("pack_conv_weight");
+  if (has_tail_tile(cin, kh, kw, convt_k, prec)) {
+    hipLaunchKernelGGL(pack_tail_kernel, dim3((rows_pad * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_src, bn_scale,
+                       (float*)w_packed + total, cout, cin, rows_pad, prec);
+    PRV2_LAUNCH_CHECK("pack_conv_weight(tail)");
+  }
   return 0;
 }
 
@@ -319,6 +343,8 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   p.tiles_m = (int)cdiv(p.M, BM);
   hipStream_t s = (hipStream_t)stream;
   if (conv3x3_halo_supported(p) && !d->force_generic) {
+    if (has_tail_tile(d->cin, d->kh, d->kw, d->convt_k, d->prec))
+      p.w_tail = (const float*)w_packed + roundup(p.Ncols, 128) * 9 * p.Cin_pad;
     launch_conv3x3_halo(p, d->prec, s);
     PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
     return 0;
