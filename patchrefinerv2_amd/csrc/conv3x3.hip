@@ -305,7 +305,8 @@ void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t s) {
   // bf16 modes run on the 16x16x32 MFMA shape (conv3x3_m16.hip); PRV2_HALO_MFMA32=1 keeps them on this file's
   // 32x32x16 kernel (A/B knob for tools/ab_conv.sh, read once)
   static const bool force32 = [] { const char* e = getenv("PRV2_HALO_MFMA32"); return e && e[0] == '1'; }();
-  if (prec != PRV2_PREC_F32 && !force32) return launch_conv3x3_halo16(p, prec, s);
+  // (its buffer-addressed halo loads need the image extent below 2^31 bytes)
+  if (prec != PRV2_PREC_F32 && !force32 && (long long)p.H * p.W * p.ldx < (1LL << 29)) return launch_conv3x3_halo16(p, prec, s);
   const int tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
 #define PRV2_LAUNCH_HALO(BN_, PREC_) \
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, PREC_>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p)

@@ -89,15 +89,28 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   const int prow = (prow_lin & ~3) | ((prow_lin & 1) << 1) | ((prow_lin >> 1) & 1);
 
   // ---- halo loader (constant over the K loop) -----------------------------------------------------
-  const float* img = p.x + (long long)n_img * p.x_bstride + chunk * 4;
-  int a_off[A_IT];  // element offset of halo pixel (prow + 64*it), or -1 when it is zero padding / unused
+  // The image is read through a buffer resource (base = this image, num_records = its extent): a lane whose
+  // halo pixel is zero padding, or whose 4 channels lie beyond Cin, gets the out-of-range offset 2^31 and the
+  // hardware returns zeros -- no select on the loaded data.  (conv3x3_halo16_usable: extent < 2^31 bytes.)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)n_img * p.x_bstride);
+  i32x4 rsrc;
+  rsrc.x = (int)(unsigned)img_base;
+  rsrc.y = (int)(unsigned)((img_base >> 32) & 0xffffu);  // stride 0: raw buffer
+  rsrc.z = (int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + ((p.Cin + 3) & ~3)) * 4);  // bytes up to the last channel read
+  rsrc.w = 0x00020000;
+  rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x);
+  rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
+  rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_off[A_IT];  // byte offset of (halo pixel prow + 64*it, channel chunk*4), or OOB
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int hp = prow + 64 * it;
     const int hy = hp / HW_, hx = hp - hy * HW_;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    a_off[it] = ok ? (iy * p.W + ix) * p.ldx : -1;
+    a_off[it] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + chunk * 4) * 4) : OOB;
   }
   const long long w_row_stride = 9LL * p.Cin_pad;
   // With a tail tile (igemm.h: has_tail_tile) the last slab -- 2 real channels -- is not walked tap by tap: its
@@ -107,28 +120,39 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   const int cchunks = cslabs - (tail ? 1 : 0);  // slabs walked by the 9-tap loop
   const int nsteps = 9 * cchunks + (tail ? 1 : 0);
   const int cin4 = (p.Cin + 3) & ~3;
-  const float x_floor = p.relu_in ? 0.f : -INFINITY;  // fused input ReLU without a branch next to the loads
+  const int relu_floor = p.relu_in ? 0 : (int)0x80000000;  // fused input ReLU as an integer max on the float bits
 
   f32x4 ra[A_IT];
-  auto a_src = [&](int cc, int it) {
-    const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
-    return ok ? img + a_off[it] + cc * BK : img;  // padding lanes re-read the image's first float4 (zeroed at store)
+  auto a_voff = [&](int cc, int it) {  // (2^31 + cc*128 stays out of range: no wrap)
+    return cc * BK + chunk * 4 < cin4 ? a_off[it] + (unsigned)(cc * BK * 4) : OOB;
   };
-  auto load_a = [&](int cc, int it) { ra[it] = *reinterpret_cast<const f32x4*>(a_src(cc, it)); };
-  // inline asm in the main loop: with LDS-DMAs in flight hipcc treats vmcnt as unordered and would wait
-  // vmcnt(0) in front of the first use; the value is handed back by the counted wait (its "+v" operand)
+  // Inline asm: (a) hipcc has no counted wait once LDS-DMAs are in flight -- it treats vmcnt as unordered and
+  // waits vmcnt(0) in front of the first use; the value is handed back by the counted wait (its "+v" operand);
+  // (b) the buffer form with hardware range checking.
   auto load_a_async = [&](int cc, int it) {
-    const float* src = a_src(cc, it);
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(src) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it]) : "v"(a_voff(cc, it)), "s"(rsrc) : "memory");
   };
-  auto store_a = [&](int cc, int abuf, int it) {
+  auto store_a = [&](int abuf, int it) {
     const int hp = prow + 64 * it;
-    const bool ok = cc * BK + chunk * 4 < cin4 && a_off[it] >= 0;
     if (hp >= HALO) return;
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    i32x4v vi = __builtin_bit_cast(i32x4v, ra[it]);
+    vi.x = max(vi.x, relu_floor);  // ReLU on the bits: negative floats are negative ints; floor INT_MIN = identity
+    vi.y = max(vi.y, relu_floor);
+    vi.z = max(vi.z, relu_floor);
+    vi.w = max(vi.w, relu_floor);
+    const f32x4 v = __builtin_bit_cast(f32x4, vi);
+    // hi = RNE bf16 of v (2 x v_cvt_pk), back to fp32 by shift / mask of the packed pairs, lo = RNE bf16 of v - hi
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+    const u32x2 hw = __builtin_bit_cast(u32x2, hi);
+    f32x4 hf;
+    hf.x = __builtin_bit_cast(float, hw.x << 16);
+    hf.y = __builtin_bit_cast(float, hw.x & 0xffff0000u);
+    hf.z = __builtin_bit_cast(float, hw.y << 16);
+    hf.w = __builtin_bit_cast(float, hw.y & 0xffff0000u);
+    const bf16x4 lo = __builtin_convertvector(v - hf, bf16x4);
     const unsigned addr = (unsigned)(size_t)(As_b + abuf * A_BYTES + hp * AROW) + chunk * 8;
-    const f32x4 v = floor4(zero_unless(ra[it], ok), x_floor);
-    bf16x4 hi, lo;
-    split_bf16(v, hi, lo);
     const unsigned long long h = __builtin_bit_cast(unsigned long long, hi), l = __builtin_bit_cast(unsigned long long, lo);
     // asm for the same reason: a compiler-visible ds_write waits for ALL in-flight LDS-DMAs first
     if constexpr (PREC == PRV2_PREC_BF16X3) asm volatile("ds_write2_b64 %0, %1, %2 offset1:8" ::"v"(addr), "v"(h), "v"(l) : "memory");
@@ -194,7 +218,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
 
   // ---- prologue ------------------------------------------------------------------------------------------
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) load_a(0, it);
+  for (int it = 0; it < A_IT; ++it) load_a_async(0, it);
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     dma_b(0, 0, i);
@@ -202,7 +226,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
     dma_b(2, 2, i);
   }
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) store_a(0, 0, it);
+  for (int it = 0; it < A_IT; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[it])::"memory");
+    store_a(0, it);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // full fence: lgkmcnt for the asm stores, vmcnt(0) for the DMAs
 #pragma unroll
   for (int a = 0; a < NA; ++a) read_a(a, 0, 0);
@@ -241,7 +269,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
               constexpr int newer = 2 * ND + Lm1 + L0;
               asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
-              store_a(ccn, (cc + 1) & 1, tap - 2);  // other halo buffer: last read in slab cc-1
+              store_a((cc + 1) & 1, tap - 2);  // other halo buffer: last read in slab cc-1
             }
 #endif
           }
