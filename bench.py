@@ -217,7 +217,7 @@ def main():
         rows = sorted(ops.PROFILER.summary().items(), key=lambda kv: -kv[1]["ms"])
         tot = sum(v["ms"] for _, v in rows)
         with open(args.layer_report, "w") as f:
-            f.write(f"# per-layer matrix-kernel time, one frame, {name}, {args.prec}; total {tot:.1f} ms\n")
+            f.write(f"# per-layer kernel time (matrix kernels with TFLOP/s; gathers / LayerNorm with their byte volume in the tag), one frame, {name}, {args.prec}; total {tot:.1f} ms\n")
             f.write("ms,pct,launches,TFLOP/s,kernel shape\n")
             for k, v in rows:
                 f.write(f"{v['ms']:.3f},{100 * v['ms'] / tot:.1f},{v['launches']},{v['flops'] / max(v['ms'], 1e-9) / 1e9:.1f},{k}\n")

@@ -1,6 +1,9 @@
 // HBM-bound gather kernels: crop+resize, ROI pyramid gather, bilinear upsample, layout changes.
 // One work item = one output pixel x one 16-byte channel group; consecutive lanes walk the
 // channel dimension first (NHWC), so every load/store instruction covers whole 64-1024 B runs.
+// Grid = (chunks of one output row, output row, image): the row / image coordinates are scalar
+// (blockIdx) and the only per-thread index arithmetic is one 32-bit divide -- the flat 64-bit
+// index decomposition these kernels started with cost more ALU time than the memory traffic.
 #include "common.h"
 
 namespace prv2 {
@@ -17,23 +20,21 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const float* __restric
                                                           const int* __restrict__ tiles, int K, int ch, int cw, int oh,
                                                           int ow, float sy, float sx, Norm3 nrm, float* __restrict__ out,
                                                           int ldo) {
-  int64_t total = (int64_t)K * oh * ow;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int ox = (int)(idx % ow);
-    int oy = (int)((idx / ow) % oh);
-    int k = (int)(idx / ((int64_t)ow * oh));
-    int h0 = tiles[2 * k], w0 = tiles[2 * k + 1];
-    AxisTap ty = ac_tap(oy, sy, ch), tx = ac_tap(ox, sx, cw);
-    const float* base = img + (int64_t)(h0)*W + w0;
-    float* o = out + idx * ldo;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y, k = blockIdx.z;
+  if (ox >= ow) return;
+  const int64_t idx = ((int64_t)k * oh + oy) * ow + ox;
+  int h0 = tiles[2 * k], w0 = tiles[2 * k + 1];
+  AxisTap ty = ac_tap(oy, sy, ch), tx = ac_tap(ox, sx, cw);
+  const float* base = img + (int64_t)(h0)*W + w0;
+  float* o = out + idx * ldo;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float* p = base + (int64_t)c * H * W;
-      float v00 = p[(int64_t)ty.i0 * W + tx.i0], v01 = p[(int64_t)ty.i0 * W + tx.i1];
-      float v10 = p[(int64_t)ty.i1 * W + tx.i0], v11 = p[(int64_t)ty.i1 * W + tx.i1];
-      float v = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
-      o[c] = (v - nrm.mean[c]) / nrm.std[c];
-    }
+  for (int c = 0; c < 3; ++c) {
+    const float* p = base + (int64_t)c * H * W;
+    float v00 = p[(int64_t)ty.i0 * W + tx.i0], v01 = p[(int64_t)ty.i0 * W + tx.i1];
+    float v10 = p[(int64_t)ty.i1 * W + tx.i0], v11 = p[(int64_t)ty.i1 * W + tx.i1];
+    float v = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
+    o[c] = (v - nrm.mean[c]) / nrm.std[c];
   }
 }
 
@@ -79,14 +80,13 @@ __global__ void __launch_bounds__(256) roi_align_kernel(const float* __restrict_
                                                         const float* __restrict__ boxes, int K, float scale, int oh,
                                                         int ow, float* __restrict__ out, int ldo) {
   using V = typename VecT<VEC>::type;
-  const int cg = C / VEC;
-  int64_t total = (int64_t)K * oh * ow * cg;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(idx % cg) * VEC;
-    int64_t pix = idx / cg;
-    int px = (int)(pix % ow);
-    int py = (int)((pix / ow) % oh);
-    int k = (int)(pix / ((int64_t)ow * oh));
+  const unsigned cg = C / VEC;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)ow * cg) return;
+  const int px = (int)(t / cg), c = (int)(t - (unsigned)px * cg) * VEC;
+  const int py = blockIdx.y, k = blockIdx.z;
+  const int64_t pix = ((int64_t)k * oh + py) * ow + px;
+  {
     const float* b = boxes + 4 * k;
     // torchvision roi_align_forward_kernel_impl, aligned=True
     float rsw = b[0] * scale - 0.5f, rsh = b[1] * scale - 0.5f;
@@ -135,14 +135,13 @@ __global__ void __launch_bounds__(256) upsample_bilinear_kernel(const float* __r
                                                                 int ldx, int oh, int ow, float sy, float sx,
                                                                 float* __restrict__ y, int ldy) {
   using V = typename VecT<VEC>::type;
-  const int cg = C / VEC;
-  int64_t total = (int64_t)N * oh * ow * cg;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(idx % cg) * VEC;
-    int64_t pix = idx / cg;
-    int ox = (int)(pix % ow);
-    int oy = (int)((pix / ow) % oh);
-    int n = (int)(pix / ((int64_t)ow * oh));
+  const unsigned cg = C / VEC;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)ow * cg) return;
+  const int ox = (int)(t / cg), c = (int)(t - (unsigned)ox * cg) * VEC;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  const int64_t pix = ((int64_t)n * oh + oy) * ow + ox;
+  {
     AxisTap ty = ac_tap(oy, sy, H), tx = ac_tap(ox, sx, W);
     const float* p = x + (int64_t)n * H * W * ldx + c;
     const V v00 = *reinterpret_cast<const V*>(p + ((int64_t)ty.i0 * W + tx.i0) * ldx);
@@ -201,8 +200,8 @@ extern "C" int prv2_crop_resize(const float* img, int32_t H, int32_t W, const in
     n.mean[i] = mean3 ? mean3[i] : 0.f;
     n.std[i] = std3 ? std3[i] : 1.f;
   }
-  int64_t total = (int64_t)K * oh * ow;
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, img, H, W, tiles,
+  PRV2_REQUIRE(oh <= 65535 && K <= 65535, "crop_resize: grid too large");
+  hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)cdiv(ow, 256), oh, K), dim3(256), 0, (hipStream_t)stream, img, H, W, tiles,
                      K, ch, cw, oh, ow, ac_scale(ch, oh), ac_scale(cw, ow), n, out, ldo);
   PRV2_LAUNCH_CHECK("crop_resize");
   return 0;
@@ -214,12 +213,13 @@ extern "C" int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c
   PRV2_REQUIRE(feat && boxes && out, "roi_align: null pointer");
   PRV2_REQUIRE(h > 0 && w > 0 && c > 0 && k > 0 && oh > 0 && ow > 0 && ldf >= c && ldo >= c, "roi_align: bad geometry");
   bool vec = (c % 4 == 0) && (ldf % 4 == 0) && (ldo % 4 == 0) && aligned16(feat) && aligned16(out);
-  int64_t total = (int64_t)k * oh * ow * (vec ? c / 4 : c);
+  PRV2_REQUIRE(oh <= 65535 && k <= 65535, "roi_align: grid too large");
+  const dim3 grid((unsigned)cdiv((int64_t)ow * (vec ? c / 4 : c), 256), oh, k);
   if (vec)
-    hipLaunchKernelGGL(roi_align_kernel<4>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, h, w,
+    hipLaunchKernelGGL(roi_align_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, feat, h, w,
                        c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo);
   else
-    hipLaunchKernelGGL(roi_align_kernel<1>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, feat, h, w,
+    hipLaunchKernelGGL(roi_align_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, feat, h, w,
                        c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo);
   PRV2_LAUNCH_CHECK("roi_align");
   return 0;
@@ -231,12 +231,13 @@ extern "C" int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int3
   PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0 && ldx >= c && ldy >= c,
                "upsample_bilinear: bad geometry");
   bool vec = (c % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y);
-  int64_t total = (int64_t)n * oh * ow * (vec ? c / 4 : c);
+  PRV2_REQUIRE(oh <= 65535 && n <= 65535, "upsample_bilinear: grid too large");
+  const dim3 grid((unsigned)cdiv((int64_t)ow * (vec ? c / 4 : c), 256), oh, n);
   if (vec)
-    hipLaunchKernelGGL(upsample_bilinear_kernel<4>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+    hipLaunchKernelGGL(upsample_bilinear_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, n,
                        h, w, c, ldx, oh, ow, ac_scale(h, oh), ac_scale(w, ow), y, ldy);
   else
-    hipLaunchKernelGGL(upsample_bilinear_kernel<1>, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n,
+    hipLaunchKernelGGL(upsample_bilinear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, n,
                        h, w, c, ldx, oh, ow, ac_scale(h, oh), ac_scale(w, ow), y, ldy);
   PRV2_LAUNCH_CHECK("upsample_bilinear");
   return 0;

@@ -51,6 +51,12 @@ class Profiler:
             fn()
             self.records.append((tag, flops, None, None))
 
+    def launch_aux(self, tag, nbytes, fn, shape):
+        """memory-bound kernels: only itemised in the per-layer report (by_shape); bytes go into the tag"""
+        if not (self.enabled and self.by_shape):
+            return fn()
+        return self.launch(tag, 0.0, fn, f"{shape} {nbytes / 1e6:.0f}MB")
+
     def summary(self):
         """{tag: dict(launches, flops, ms)} (call after torch.cuda.synchronize())."""
         out = {}
@@ -274,8 +280,10 @@ def layernorm_feat(x: Feat, weight, bias, eps: float = 1e-6, act: int = ACT_NONE
     """channels-first LayerNorm of the reference == row LayerNorm in NHWC (convs.py:21-29)."""
     if out is None:
         out = x
-    L.check(L.load().prv2_layernorm(x.ptr, x.n * x.h * x.w, x.c, x.ld, weight.data_ptr(), bias.data_ptr(), eps, act,
-                                    out.ptr, out.ld, _stream()), "layernorm")
+    PROFILER.launch_aux("layernorm", 8.0 * x.n * x.h * x.w * x.c,
+                        lambda: L.check(L.load().prv2_layernorm(x.ptr, x.n * x.h * x.w, x.c, x.ld, weight.data_ptr(),
+                                                                 bias.data_ptr(), eps, act, out.ptr, out.ld, _stream()),
+                                        "layernorm"), f"{x.c}ch {x.n}x{x.h}x{x.w}")
     return out
 
 
@@ -322,8 +330,10 @@ def roi_align(feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow
     k = boxes.shape[0]
     if out is None:
         out = Feat.alloc(k, oh, ow, feat.c, feat.device)
-    L.check(L.load().prv2_roi_align(feat.ptr, feat.h, feat.w, feat.c, feat.ld, boxes.data_ptr(), k, spatial_scale, oh,
-                                    ow, out.ptr, out.ld, _stream()), "roi_align")
+    PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
+                        lambda: L.check(L.load().prv2_roi_align(feat.ptr, feat.h, feat.w, feat.c, feat.ld, boxes.data_ptr(), k,
+                                                                 spatial_scale, oh, ow, out.ptr, out.ld, _stream()), "roi_align"),
+                        f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}")
     return out
 
 
@@ -331,8 +341,10 @@ def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> 
     if out is None:
         out = Feat.alloc(x.n, oh, ow, x.c, x.device)
     assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, x.c)
-    L.check(L.load().prv2_upsample_bilinear(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, out.ptr, out.ld, _stream()),
-            "upsample_bilinear")
+    PROFILER.launch_aux("upsample_bilinear", 4.0 * x.n * x.c * (x.h * x.w + oh * ow),
+                        lambda: L.check(L.load().prv2_upsample_bilinear(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, out.ptr,
+                                                                         out.ld, _stream()), "upsample_bilinear"),
+                        f"{x.c}ch {x.n}x{x.h}x{x.w}->{oh}x{ow}")
     return out
 
 
