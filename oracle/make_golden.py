@@ -448,6 +448,54 @@ def g_e2e_v2z():
     _g_e2e_v2("e2e_v2z", E2E_V2Z, e2e_v2z_sd(), zoe=True)
 
 
+def g_output_stage():
+    """Tester output stage: colour maps and evaluation metrics of the reference (estimator/utils/color.py, metric.py)."""
+    print("[output_stage]")
+    import types
+    refharness.install()
+    for name, attrs in (("skimage", {}), ("skimage.feature", {"canny": None}), ("kornia", {}), ("imageio", {})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    u = types.ModuleType("estimator.utils")
+    u.__path__ = [os.path.join(refharness.REF, "estimator/utils")]
+    sys.modules["estimator.utils"] = u
+    import importlib
+    color = importlib.import_module("estimator.utils.color")
+    metric = importlib.import_module("estimator.utils.metric")
+    import matplotlib
+    if not hasattr(matplotlib.cm, "get_cmap"):  # removed in matplotlib 3.9; the reference pins an older one
+        matplotlib.cm.get_cmap = lambda name: matplotlib.colormaps[name]
+    g = torch.Generator().manual_seed(77)
+    h, w = 40, 56
+    gt = torch.rand(1, 1, h, w, generator=g) * 12 + 0.05          # some pixels outside (min, max) = (0.1, 10)
+    pred = (gt * (1 + 0.2 * torch.randn(1, 1, h, w, generator=g))).clamp(min=-0.5)
+    pred[0, 0, 3, 5] = float("nan")
+    pred[0, 0, 4, 6] = float("inf")
+    pred_lo = torch.nn.functional.interpolate(pred, (20, 28), mode="bilinear")  # resized inside compute_metrics
+    disp = 1.0 / gt.squeeze().numpy()
+    edges = metric.get_boundaries(disp * 40, th=1, dilation=0)
+    out = dict(gt=gt.numpy(), pred=pred.numpy(), pred_lo=pred_lo.numpy(), edges=edges)
+    c1 = color.colorize(pred.clone(), cmap="Spectral", vminp=0, vmaxp=100)
+    vv = gt.clone()
+    vv[0, 0, :4, :4] = -99
+    c2 = color.colorize(vv, cmap="gray_r")
+    out.update(color_spectral=c1, color_gray=c2)
+    e = metric.compute_errors(gt.squeeze().numpy()[2:30, 2:40], np.abs(pred.squeeze().numpy()[2:30, 2:40]) + 0.01)
+    out.update({f"err_{k}": np.float64(v) for k, v in e.items()})
+    m1 = metric.compute_metrics(gt, pred.clone(), garg_crop=False, eigen_crop=False, dataset="u4k", min_depth_eval=0.1,
+                                max_depth_eval=10, disp_gt_edges=torch.from_numpy(edges))
+    out.update({f"m1_{k}": np.float64(float(v)) for k, v in m1.items()})
+    m2 = metric.compute_metrics(gt, pred_lo.clone(), garg_crop=True, eigen_crop=False, dataset="kitti", min_depth_eval=0.1,
+                                max_depth_eval=10)
+    out.update({f"m2_{k}": np.float64(float(v)) for k, v in m2.items()})
+    see = metric.soft_edge_error(np.abs(pred.squeeze().numpy()), gt.squeeze().numpy(), radius=2)
+    out.update(see_r2=see)
+    np.savez_compressed(os.path.join(OUT, "output_stage.npz"), **out)
+    print("  wrote output_stage.npz", {k: float(v) for k, v in m1.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2", "zoedepth", "e2e_v2z"]
     for w in which:

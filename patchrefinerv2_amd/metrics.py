@@ -1,0 +1,120 @@
+"""Depth-evaluation metrics and colour maps of the reference's Tester (host side, numpy).
+
+compute_errors      estimator/utils/metric.py:11-50   (delta1-3, AbsRel, RMSE, log10, RMSE-log, SILog, SqRel)
+soft_edge_error     estimator/utils/metric.py:53-72   (min |gt shifted - pred| over a (2r+1)^2 window)
+get_boundaries      estimator/utils/metric.py:74-85   (disparity jumps > th; dilation needs cv2 -> dilation=0 only)
+compute_metrics     estimator/utils/metric.py:87-149  (resize, clamp, valid / crop masks, optional SEE on gt edges)
+colorize            estimator/utils/color.py:95-158   (percentile normalisation + matplotlib colour map, RGBA uint8)
+
+Pinned by tests/golden/output_stage.npz (the reference functions imported by oracle/make_golden.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def compute_errors(gt: np.ndarray, pred: np.ndarray) -> dict:
+    thresh = np.maximum(gt / pred, pred / gt)
+    d = gt - pred
+    err = np.log(pred) - np.log(gt)
+    return dict(a1=(thresh < 1.25).mean(), a2=(thresh < 1.25 ** 2).mean(), a3=(thresh < 1.25 ** 3).mean(),
+                abs_rel=np.mean(np.abs(d) / gt), rmse=np.sqrt((d ** 2).mean()),
+                log_10=np.abs(np.log10(gt) - np.log10(pred)).mean(),
+                rmse_log=np.sqrt(((np.log(gt) - np.log(pred)) ** 2).mean()),
+                silog=np.sqrt(np.mean(err ** 2) - np.mean(err) ** 2) * 100, sq_rel=np.mean(d ** 2 / gt))
+
+
+def _shift(data: np.ndarray, dx: int, dy: int, fill=0) -> np.ndarray:
+    out = np.roll(data, dx, axis=1)
+    if dx < 0:
+        out[:, dx:] = fill
+    elif dx > 0:
+        out[:, :dx] = fill
+    out = np.roll(out, dy, axis=0)
+    if dy < 0:
+        out[dy:, :] = fill
+    elif dy > 0:
+        out[:dy, :] = fill
+    return out
+
+
+def soft_edge_error(pred: np.ndarray, gt: np.ndarray, radius: int = 1) -> np.ndarray:
+    diffs = [np.abs(_shift(gt, i, j, 0) - pred) for i in range(-radius, radius + 1) for j in range(-radius, radius + 1)]
+    return np.minimum.reduce(diffs)
+
+
+def get_boundaries(disp: np.ndarray, th: float = 1.0, dilation: int = 0) -> np.ndarray:
+    if dilation > 0:
+        raise NotImplementedError("get_boundaries(dilation > 0) uses cv2.dilate (un-vendored); every dataset branch of the "
+                                  "reference calls it with dilation=0 (general_dataset.py:88-143)")
+    dy = np.abs(disp[1:, :] - disp[:-1, :]) > th
+    dx = np.abs(disp[:, 1:] - disp[:, :-1]) > th
+    ey = np.logical_or(np.pad(dy, ((1, 0), (0, 0))), np.pad(dy, ((0, 1), (0, 0))))
+    ex = np.logical_or(np.pad(dx, ((0, 0), (1, 0))), np.pad(dx, ((0, 0), (0, 1))))
+    return np.logical_or(ey, ex).astype(np.float32)
+
+
+def compute_metrics(gt, pred, interpolate=True, garg_crop=False, eigen_crop=True, dataset="nyu", min_depth_eval=0.1,
+                    max_depth_eval=10, disp_gt_edges=None, additional_mask=None) -> dict:
+    if gt.shape[-2:] != pred.shape[-2:] and interpolate:
+        pred = F.interpolate(pred, gt.shape[-2:], mode="bilinear", align_corners=False).squeeze()
+    pred = pred.squeeze().cpu().numpy().copy()
+    pred[pred < min_depth_eval] = min_depth_eval
+    pred[pred > max_depth_eval] = max_depth_eval
+    pred[np.isinf(pred)] = max_depth_eval
+    pred[np.isnan(pred)] = min_depth_eval
+    gt_depth = gt.squeeze().cpu().numpy()
+    valid = np.logical_and(gt_depth > min_depth_eval, gt_depth < max_depth_eval)
+    eval_mask = np.ones(valid.shape)
+    if garg_crop or eigen_crop:
+        h, w = gt_depth.shape
+        eval_mask = np.zeros(valid.shape)
+        if garg_crop:
+            eval_mask[int(0.40810811 * h):int(0.99189189 * h), int(0.03594771 * w):int(0.96405229 * w)] = 1
+        elif dataset == "kitti":
+            eval_mask[int(0.3324324 * h):int(0.91351351 * h), int(0.0359477 * w):int(0.96405229 * w)] = 1
+        else:
+            eval_mask[45:471, 41:601] = 1
+    valid = np.logical_and(valid, eval_mask)
+    if additional_mask is not None:
+        valid = np.logical_and(valid, additional_mask.squeeze().detach().cpu().numpy())
+    metrics = compute_errors(gt_depth[valid], pred[valid])
+    if disp_gt_edges is not None:
+        edges = disp_gt_edges.squeeze().numpy() if isinstance(disp_gt_edges, torch.Tensor) else np.squeeze(disp_gt_edges)
+        mask = np.logical_and(valid.squeeze(), edges)
+        see = torch.tensor([0])
+        if mask.sum() > 0:
+            see = soft_edge_error(pred, gt_depth)[mask].mean()
+        metrics["see"] = see
+    return metrics
+
+
+def evaluate(per_frame: list) -> dict:
+    """mean of every metric over the frames (general_dataset.py evaluate / mmengine-style collect)."""
+    keys = per_frame[0].keys()
+    return {k: float(np.mean([float(m[k]) for m in per_frame])) for k in keys}
+
+
+def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, invalid_mask=None,
+             background_color=(128, 128, 128, 255), gamma_corrected=False, value_transform=None, vminp=2, vmaxp=95):
+    """[H,W] / [1,1,H,W] depth -> RGBA uint8 [H,W,4]."""
+    import matplotlib
+    if isinstance(value, torch.Tensor):
+        value = value.detach().cpu().numpy()
+    value = value.squeeze()
+    if invalid_mask is None:
+        invalid_mask = value == invalid_val
+    mask = np.logical_not(invalid_mask)
+    vmin = np.percentile(value[mask], vminp) if vmin is None else vmin
+    vmax = np.percentile(value[mask], vmaxp) if vmax is None else vmax
+    value = (value - vmin) / (vmax - vmin) if vmin != vmax else value * 0.0
+    value[invalid_mask] = np.nan
+    if value_transform:
+        value = value_transform(value)
+    img = matplotlib.colormaps[cmap](value, bytes=True)
+    img[invalid_mask] = background_color
+    if gamma_corrected:
+        img = (np.power(img / 255, 2.2) * 255).astype(np.uint8)
+    return img

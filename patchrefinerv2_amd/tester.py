@@ -3,8 +3,10 @@
 Tester.run          estimator/tester/tester.py:52-127 (frame loop, model call contract, uint16 PNG x256)
 ImageDataset        estimator/datasets/general_dataset.py:161-234 (folder of images -> image_hr / image_lr)
 read_image          estimator/datasets/general_dataset.py:22-62 (RGB/255 -> bicubic, align_corners=True)
-Metrics, colour maps and edge maps of the reference's Tester are out of scope:
-only the 16-bit depth PNG (the on-disk format downstream tools read) is written, with a dependency-free encoder.
+With ``--save``: <name>.png (colour map, tester.py:72-87), <name>_uint16.png (depth x 256, :89-91), <name>_coarse.png
+(coarse prediction resized to the raw shape, :93-96) -- colour maps and metrics in metrics.py, PNGs through a
+dependency-free encoder.  Not built: <name>_edge.png (cv2.Canny + kornia blur, both un-vendored, :98-106) and the
+dataset-specific ground-truth decoders (general_dataset.py:74-150); ground truth is accepted as metric depth .npy files.
 """
 from __future__ import annotations
 
@@ -37,6 +39,26 @@ def write_png16(path: str, arr_u16: np.ndarray):
         f.write(chunk(b"IEND", b""))
 
 
+def write_png8(path: str, arr_u8: np.ndarray):
+    """8-bit RGB / RGBA / gray PNG (== cv2.imwrite of the BGR-swapped array the reference builds)."""
+    assert arr_u8.dtype == np.uint8 and arr_u8.ndim in (2, 3)
+    h, w = arr_u8.shape[:2]
+    ch = 1 if arr_u8.ndim == 2 else arr_u8.shape[2]
+    ctype = {1: 0, 3: 2, 4: 6}[ch]
+    raw = np.zeros((h, 1 + w * ch), dtype=np.uint8)
+    raw[:, 1:] = arr_u8.reshape(h, w * ch)
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)))
+        f.write(chunk(b"IEND", b""))
+
+
 def read_image(path, dataset_name="", image_resolution=(2160, 3840)) -> np.ndarray:
     """general_dataset.py:22-62, generic branch: decode, RGB/255, bicubic(align_corners=True) to the raw shape."""
     if path.endswith(".npy"):
@@ -58,10 +80,12 @@ def read_image(path, dataset_name="", image_resolution=(2160, 3840)) -> np.ndarr
 class ImageDataset:
     def __init__(self, rgb_image_dir, mode="", min_depth=1e-3, max_depth=80, gt_dir=None, image_resolution=(2160, 3840),
                  dataset_name="", network_process_size=(384, 512), resize_mode="zoe"):
-        if gt_dir is not None:
-            raise NotImplementedError("ground-truth metrics are out of scope (SURVEY.md 8f rank 4)")
         self.rgb_image_dir = rgb_image_dir
         self.files = sorted(os.listdir(rgb_image_dir))
+        # ground truth: metric depth as <gt_dir>/<basename>.npy (the reference's per-dataset decoders -- u4k disparity +
+        # factor files, gta exr, middlebury pfm ... general_dataset.py:74-150 -- are not built)
+        self.gt_dir = gt_dir
+        self.min_depth, self.max_depth = min_depth, max_depth
         self.dataset_name = dataset_name
         self.image_resolution = tuple(image_resolution)
         self.network_process_size = tuple(network_process_size)
@@ -74,7 +98,19 @@ class ImageDataset:
         name = self.files[i]
         img = read_image(os.path.join(self.rgb_image_dir, name), self.dataset_name, self.image_resolution)
         # image_lr is produced on the device by model.resizer (same bilinear align_corners arithmetic)
-        return dict(image_hr=torch.from_numpy(img).permute(2, 0, 1).float(), img_file_basename=os.path.splitext(name)[0])
+        item = dict(image_hr=torch.from_numpy(img).permute(2, 0, 1).float(), img_file_basename=os.path.splitext(name)[0])
+        if self.gt_dir is not None:
+            from .metrics import get_boundaries
+            gt = np.load(os.path.join(self.gt_dir, item["img_file_basename"] + ".npy")).astype(np.float32)
+            item["depth_gt"] = torch.from_numpy(gt)[None, None]
+            item["boundary"] = torch.from_numpy(get_boundaries(gt, th=1, dilation=0))
+        return item
+
+    def get_metrics(self, depth_gt, result, disp_gt_edges=None, **kw):
+        """general_dataset.py:236-245"""
+        from .metrics import compute_metrics
+        return compute_metrics(depth_gt, result, disp_gt_edges=disp_gt_edges, min_depth_eval=self.min_depth,
+                               max_depth_eval=self.max_depth, garg_crop=False, eigen_crop=False, dataset=self.dataset_name)
 
 
 class RunnerInfo:
@@ -108,7 +144,20 @@ class Tester:
                 base = os.path.join(self.runner_info.work_dir, item["img_file_basename"])
                 # raw depth as 16-bit PNG, multiplier 256 (tester.py:89-91)
                 write_png16(base + "_uint16.png", (result.squeeze().numpy() * 256).astype("uint16"))
+                from .metrics import colorize
+                if getattr(self.runner_info, "gray_scale", False):
+                    color = colorize(result, cmap="gray_r")
+                else:  # every dataset branch of tester.py:76-84 but cityscapes maps to Spectral, 0..100 percentiles
+                    cmap = "magma_r" if getattr(self.dataloader, "dataset_name", "") == "cityscapes" else "Spectral"
+                    color = colorize(result, cmap=cmap, vminp=0, vmaxp=100)
+                write_png8(base + ".png", np.ascontiguousarray(color[:, :, :3]))
                 coarse = F.interpolate(log["coarse_prediction"].cpu(), tuple(image_raw_shape), mode="bilinear")
-                write_png16(base + "_coarse_uint16.png", (coarse.squeeze().numpy() * 256).astype("uint16"))
-            results.append((item["img_file_basename"], tuple(result.shape), float(result.mean())))
+                write_png8(base + "_coarse.png", np.ascontiguousarray(colorize(coarse, cmap="Spectral", vminp=0, vmaxp=100)[:, :, :3]))
+            entry = dict(name=item["img_file_basename"], shape=tuple(result.shape), mean=float(result.mean()))
+            if item.get("depth_gt") is not None:
+                entry["metrics"] = self.dataloader.get_metrics(item["depth_gt"], result, disp_gt_edges=item.get("boundary"))
+            results.append(entry)
+        if results and "metrics" in results[0]:
+            from .metrics import evaluate
+            self.last_eval = evaluate([r["metrics"] for r in results])
         return results

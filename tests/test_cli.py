@@ -10,16 +10,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cli_writes_uint16_depth(tmp_path):
+def test_cli_writes_depth_pngs_and_metrics(tmp_path):
     (tmp_path / "imgs").mkdir()
+    (tmp_path / "gts").mkdir()
     np.save(str(tmp_path / "imgs" / "frame0.npy"), np.random.RandomState(1).rand(90, 160, 3).astype(np.float32))
+    np.save(str(tmp_path / "gts" / "frame0.npy"), (np.random.RandomState(2).rand(256, 512) * 20 + 0.5).astype(np.float32))
     cfg = tmp_path / "cfg.py"
     cfg.write_text(f"_base_ = ['{os.path.join(ROOT, 'configs', 'v2_dav2_mobile_u4k.py')}']\n"
                    "model = dict(config=dict(patch_process_shape=[112, 224], image_raw_shape=[256, 512], patch_split_num=[2, 2],\n"
                    "    coarse_branch=dict(model_cfg=dict(encoder='vits', features=256, out_channels=[48, 96, 192, 384]))))\n")
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "test.py"), str(cfg), "--synthetic-weights", "--cai-mode", "r4",
-                        "--cfg-option", f"general_dataloader.dataset.rgb_image_dir={tmp_path / 'imgs'}", "--save", "--work-dir",
+                        "--cfg-option", f"general_dataloader.dataset.rgb_image_dir={tmp_path / 'imgs'}",
+                        f"general_dataloader.dataset.gt_dir={tmp_path / 'gts'}", "--save", "--work-dir",
                         str(out), "--test-type", "general", "--image-raw-shape", "256", "512", "--patch-split-num", "2", "2"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -27,4 +30,7 @@ def test_cli_writes_uint16_depth(tmp_path):
     from PIL import Image
     d = np.asarray(Image.open(str(out / "frame0_uint16.png")))
     assert d.dtype == np.uint16 and d.shape == (256, 512) and d.max() > 0
-    assert os.path.exists(str(out / "frame0_coarse_uint16.png"))
+    for name in ("frame0.png", "frame0_coarse.png"):   # colour maps (Spectral, 0..100 percentile)
+        c = np.asarray(Image.open(str(out / name)))
+        assert c.dtype == np.uint8 and c.shape == (256, 512, 3) and c.std() > 0
+    assert "abs_rel" in r.stdout and "see" in r.stdout

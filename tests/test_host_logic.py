@@ -136,3 +136,30 @@ def test_m16_lds_layout_is_bank_conflict_free():
                     row, g = n0 + (l & 15), l >> 4
                     slots.add((row * 128 + (((g + plane) ^ ((row >> 1) & 7)) << 4)) // 16 % 16)
                 assert len(slots) == 16
+
+
+def test_output_stage_matches_reference():
+    """colour maps + evaluation metrics (patchrefinerv2_amd/metrics.py) vs the reference's own functions
+    (estimator/utils/color.py, metric.py -> tests/golden/output_stage.npz by oracle/make_golden.py)."""
+    import torch
+    from patchrefinerv2_amd import metrics as M
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "output_stage.npz"))
+    gt, pred, pred_lo, edges = (torch.from_numpy(g[k]) for k in ("gt", "pred", "pred_lo", "edges"))
+    np.testing.assert_array_equal(M.colorize(pred.clone(), cmap="Spectral", vminp=0, vmaxp=100), g["color_spectral"])
+    vv = gt.clone()
+    vv[0, 0, :4, :4] = -99
+    np.testing.assert_array_equal(M.colorize(vv, cmap="gray_r"), g["color_gray"])
+    np.testing.assert_array_equal(M.get_boundaries(1.0 / gt.squeeze().numpy() * 40, th=1, dilation=0), g["edges"])
+    e = M.compute_errors(gt.squeeze().numpy()[2:30, 2:40], np.abs(pred.squeeze().numpy()[2:30, 2:40]) + 0.01)
+    for k, v in e.items():   # (the slice contains the NaN / inf pixels on purpose: NaN must propagate identically)
+        np.testing.assert_equal(float(v), float(g[f"err_{k}"]), k)
+    m1 = M.compute_metrics(gt, pred.clone(), garg_crop=False, eigen_crop=False, dataset="u4k", min_depth_eval=0.1,
+                           max_depth_eval=10, disp_gt_edges=edges)
+    m2 = M.compute_metrics(gt, pred_lo.clone(), garg_crop=True, eigen_crop=False, dataset="kitti", min_depth_eval=0.1,
+                           max_depth_eval=10)
+    for tag, m in (("m1", m1), ("m2", m2)):
+        for k, v in m.items():
+            np.testing.assert_equal(float(v), float(g[f"{tag}_{k}"]), f"{tag} {k}")
+    np.testing.assert_array_equal(M.soft_edge_error(np.abs(pred.squeeze().numpy()), gt.squeeze().numpy(), radius=2), g["see_r2"])
+    with pytest.raises(NotImplementedError):
+        M.get_boundaries(gt.squeeze().numpy(), dilation=3)

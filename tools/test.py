@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--seed", type=int, default=621)
     args = ap.parse_args()
     if args.test_type != "general":
-        raise SystemExit("only --test-type general (folder of images) is built; dataset metrics are out of scope")
+        raise SystemExit("only --test-type general (folder of images, optional .npy ground truth via dataset gt_dir) is built")
 
     cfg = Config.fromfile(args.config)
     cfg.merge_from_dict(parse_opts(args.cfg_option))
@@ -74,10 +74,12 @@ def main():
     ds_cfg["image_resolution"] = args.image_raw_shape
     dataset = DATASETS.build(ds_cfg)
     runner = RunnerInfo(rank=rank, world_size=world, save=args.save, gray_scale=args.gray_scale, work_dir=args.work_dir)
-    for name, shape, mean in Tester(cfg, runner, dataset, model).run(
-            cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
-            patch_split_num=args.patch_split_num, seed=args.seed):
-        print(f"[rank {rank}] {name}: depth {shape} mean {mean:.4f}")
+    tester = Tester(cfg, runner, dataset, model)
+    for r in tester.run(cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
+                        patch_split_num=args.patch_split_num, seed=args.seed):
+        print(f"[rank {rank}] {r['name']}: depth {r['shape']} mean {r['mean']:.4f}")
+    if getattr(tester, "last_eval", None):  # frames that came with ground truth (dataset gt_dir)
+        print(f"[rank {rank}] " + ", ".join(f"{k} {v:.4f}" for k, v in tester.last_eval.items()))
 
 
 if __name__ == "__main__":
