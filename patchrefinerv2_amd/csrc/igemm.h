@@ -261,5 +261,8 @@ __device__ __forceinline__ void ln_row_stats(const IgemmParams& p, const float* 
 // conv3x3.hip: LDS-halo kernel for 3x3 / stride 1 / pad 1; returns false when the shape is not covered
 bool conv3x3_halo_supported(const IgemmParams& p);
 void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t stream);
+// gemm_m16.hip: dense 1x1 / linear layers in the bf16 modes
+bool gemm16_supported(const IgemmParams& p, int prec);
+void launch_gemm16(IgemmParams& p, int prec, hipStream_t stream);
 
 }  // namespace prv2

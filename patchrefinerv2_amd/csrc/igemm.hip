@@ -349,6 +349,11 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
     PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
     return 0;
   }
+  if (gemm16_supported(p, d->prec) && !d->force_generic) {
+    launch_gemm16(p, d->prec, s);
+    PRV2_LAUNCH_CHECK("conv2d(1x1 gemm16)");
+    return 0;
+  }
 #define PRV2_LAUNCH_IGEMM(BN_, PREC_) \
   hipLaunchKernelGGL((igemm_kernel<BN_, PREC_>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p)
   if (p.Ncols > 64) {

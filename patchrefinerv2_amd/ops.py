@@ -222,6 +222,9 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     # bf16 modes of the halo conv run on the 16x16x32 MFMA kernel (csrc/conv3x3_m16.hip), f32 on csrc/conv3x3.hip
     kname = ("conv3x3_halo_kernel" if cw.prec == PREC_F32 else "conv3x3_halo16_kernel") if halo else "igemm_kernel"
     bn = 128 if ncols > 64 else (32 if (halo and ncols <= 32) else 64)
+    if (cw.kh == 1 and cw.kw == 1 and cw.stride == 1 and cw.pad == 0 and not cw.convt_k and cw.prec != PREC_F32
+            and m_rows >= 512 and ncols > 64 and not x_bstride and not force_generic):
+        kname = "gemm16_kernel"  # mirrors gemm16_supported() in csrc/gemm_m16.hip (dense 1x1 / linear)
     PROFILER.launch(f"{kname}<{bn},{L.PREC_LABEL[cw.prec]}>", 2.0 * m_rows * ncols * cw.cin * taps,
                     lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias),
                                                          _ptr(ln[0]) if ln is not None else None,
