@@ -258,6 +258,70 @@ __global__ void __launch_bounds__(256) pack_tail_kernel(const float* __restrict_
 
 static inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// ---------------------------------------------------------------------------------------------
+// small 1x1 convs (Cin, Cout <= 64: the 32->32 gates / out_convs at full resolution).  A GEMM tile would be 3/4
+// padding and the layer is HBM-bound anyway: one thread = one pixel x 8 output channels on the fp32 VALU, the
+// weights decoded once per block from the packed image (fp32, or bf16 hi + lo = 16 mantissa bits) into LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv1x1_small_kernel(const IgemmParams p, int prec) {
+  __shared__ __attribute__((aligned(16))) float wl[64 * 64];  // [cin][cout_pad8]
+  const int ng = (p.Cout + 7) >> 3, ncp = ng * 8;
+  for (int i = threadIdx.x; i < p.Cin_pad * ncp; i += blockDim.x) {
+    const int co = i % ncp, c = i / ncp;
+    float v = 0.f;
+    if (co < p.Cout && c < p.Cin) {
+      const char* row = reinterpret_cast<const char*>(p.w) + ((long long)co * p.Cin_pad + (c & ~31)) * 4;
+      const int key = (co >> 1) & 7, e = c & 31;
+      if (prec == PRV2_PREC_F32) {
+        v = reinterpret_cast<const float*>(row)[(((e >> 2) ^ key) << 2) + (e & 3)];
+      } else {
+        const __bf16* d16 = reinterpret_cast<const __bf16*>(row);
+        v = (float)d16[(((e >> 3) ^ key) << 3) + (e & 7)] + (float)d16[((((e >> 3) + 4) ^ key) << 3) + (e & 7)];
+      }
+    }
+    wl[c * ncp + co] = v;
+  }
+  __syncthreads();
+  const int ppb = 256 / ng;  // pixels per block
+  const int grp = threadIdx.x % ng, pl = threadIdx.x / ng;
+  if (pl >= ppb) return;
+  const float x_floor = p.relu_in ? 0.f : -INFINITY;
+  EpiCols ec0, ec1;
+  const bool v0 = epi_cols(p, grp * 8, ec0), v1 = epi_cols(p, grp * 8 + 4, ec1);
+  for (long long m = (long long)blockIdx.x * ppb + pl; m < p.M; m += (long long)gridDim.x * ppb) {
+    const float* px = p.x + m * p.ldx;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < p.Cin; c += 4) {
+      const f32x4 xv = floor4(*reinterpret_cast<const f32x4*>(px + c), x_floor);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c + e < p.Cin) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[(c + e) * ncp + grp * 8]);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wl[(c + e) * ncp + grp * 8 + 4]);
+          a0.x = __builtin_fmaf(xs[e], w0.x, a0.x);  // (explicit FMAs: the build runs with -ffp-contract=off)
+          a0.y = __builtin_fmaf(xs[e], w0.y, a0.y);
+          a0.z = __builtin_fmaf(xs[e], w0.z, a0.z);
+          a0.w = __builtin_fmaf(xs[e], w0.w, a0.w);
+          a1.x = __builtin_fmaf(xs[e], w1.x, a1.x);
+          a1.y = __builtin_fmaf(xs[e], w1.y, a1.y);
+          a1.z = __builtin_fmaf(xs[e], w1.z, a1.z);
+          a1.w = __builtin_fmaf(xs[e], w1.w, a1.w);
+        }
+      }
+    }
+    if (v0) epi_store(p, ec0, a0, m, m * p.ldy + ec0.co);
+    if (v1) epi_store(p, ec1, a1, m, m * p.ldy + ec1.co);
+  }
+}
+
+static bool conv1x1_small_supported(const IgemmParams& p) {
+  return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 && p.Cin <= 64 && p.Cout <= 64 &&
+         p.Cout >= 8 && !p.ln_w && p.x_bstride == (long long)p.H * p.W * p.ldx &&
+         p.y_bstride == (long long)p.OH * p.OW * p.ldy && p.M >= 4096;
+}
+
+
 }  // namespace prv2
 
 using namespace prv2;
@@ -347,6 +411,12 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
       p.w_tail = (const float*)w_packed + roundup(p.Ncols, 128) * 9 * p.Cin_pad;
     launch_conv3x3_halo(p, d->prec, s);
     PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
+    return 0;
+  }
+  if (conv1x1_small_supported(p) && !d->force_generic) {
+    const int ng = (p.Cout + 7) >> 3;
+    hipLaunchKernelGGL(conv1x1_small_kernel, dim3(flat_grid(p.M * ng, 256)), dim3(256), 0, s, p, (int)d->prec);
+    PRV2_LAUNCH_CHECK("conv2d(1x1 small)");
     return 0;
   }
   if (gemm16_supported(p, d->prec) && !d->force_generic) {

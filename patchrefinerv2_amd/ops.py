@@ -225,6 +225,9 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     if (cw.kh == 1 and cw.kw == 1 and cw.stride == 1 and cw.pad == 0 and not cw.convt_k and cw.prec != PREC_F32
             and m_rows >= 512 and ncols > 64 and not x_bstride and not force_generic):
         kname = "gemm16_kernel"  # mirrors gemm16_supported() in csrc/gemm_m16.hip (dense 1x1 / linear)
+    if (cw.kh == 1 and cw.kw == 1 and cw.stride == 1 and cw.pad == 0 and not cw.convt_k and cw.cin <= 64 and 8 <= cw.cout <= 64
+            and ln is None and m_rows >= 4096 and not x_bstride and not force_generic):
+        kname, bn = "conv1x1_small_kernel", 64  # mirrors conv1x1_small_supported() in csrc/igemm.hip (fp32 VALU)
     PROFILER.launch(f"{kname}<{bn},{L.PREC_LABEL[cw.prec]}>", 2.0 * m_rows * ncols * cw.cin * taps,
                     lambda: L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias),
                                                          _ptr(ln[0]) if ln is not None else None,
