@@ -366,3 +366,66 @@ def test_conv_fused_layernorm(P, case):
     ref2 = F.relu(ln_cf(F.conv2d(x, wt2, None, padding=k // 2), lw2, lb2))
     y2 = P.conv2d(P.Feat.from_nchw(x.to(DEV)), P.pack_conv(wt2.to(DEV), None), act=P.ACT_RELU, ln=(lw2.to(DEV), lb2.to(DEV)))
     close(y2.to_nchw(), ref2, 2e-5)
+
+
+ONE_BY_ONE_CASES = [
+    # n, h, w, cin, cout, opts   -- M = n*h*w >= 512 rows: gemm_m16.hip (cout > 64) / conv1x1_small (cin, cout <= 64, M >= 4096)
+    (1, 24, 40, 256, 256, dict(bias=True, act="sigmoid", mul=True, res=True)),          # GatedConvUnit f3 gate
+    (2, 20, 25, 98, 130, dict(bias=True, relu_in=True)),                                  # ragged K (98) and N (130), last tile 232 rows
+    (1, 33, 31, 512, 96, dict(bias=True, act="gelu", ln=True)),                           # fused channels-first LayerNorm (cout <= 128)
+    (1, 1025, 1, 160, 192, dict(bias=True, gamma=True, res=True, res2=True)),             # ViT-style linear, 5 slabs
+    (3, 40, 40, 32, 32, dict(bias=True, act="sigmoid", mul=True)),                        # small-channel gate (fp32 VALU kernel)
+    (2, 48, 48, 64, 40, dict(bias=True, relu_in=True, res=True, gamma=True)),
+    (1, 70, 70, 36, 8, dict(act="gelu")),
+]
+
+
+@pytest.mark.parametrize("case", ONE_BY_ONE_CASES)
+def test_conv1x1_split_precision_kernels(P, case):
+    """the bf16x3 1x1 paths (rows straight into MFMA operand registers; fp32 VALU for few channels) vs fp64, and vs the
+    generic kernel; input and output are channel slices of wider buffers (ldx > cin, ldy > cout)"""
+    from patchrefinerv2_amd import lib as L
+    n, h, w, cin, cout, o = case
+    pr = L.PREC_NAMES["bf16x3"]
+    x = rnd(1, n, cin, h, w) * 2
+    wt = rnd(2, cout, cin, 1, 1) / np.sqrt(cin)
+    bias = rnd(3, cout) if o.get("bias") else None
+    ref = F.conv2d((F.relu(x) if o.get("relu_in") else x).double(), wt.double(), bias.double() if bias is not None else None)
+    lnw = lnb = None
+    if o.get("ln"):
+        lnw, lnb = rnd(8, cout).abs() + 0.5, rnd(9, cout)
+        u = ref.mean(1, keepdim=True)
+        s = (ref - u).pow(2).mean(1, keepdim=True)
+        ref = (ref - u) / torch.sqrt(s + 1e-6) * lnw.double().view(1, -1, 1, 1) + lnb.double().view(1, -1, 1, 1)
+    if o.get("act") == "gelu":
+        ref = F.gelu(ref)
+    if o.get("act") == "sigmoid":
+        ref = torch.sigmoid(ref)
+    gamma = rnd(4, cout) if o.get("gamma") else None
+    if gamma is not None:
+        ref = ref * gamma.double().view(1, -1, 1, 1)
+    mul, res, res2 = (rnd(s_, n, cout, h, w) if o.get(k_) else None for s_, k_ in ((5, "mul"), (6, "res"), (7, "res2")))
+    if mul is not None:
+        ref = mul.double() * ref
+    if res is not None:
+        ref = ref + res.double()
+    if res2 is not None:
+        ref = ref + res2.double()
+    ref = ref.float()
+    act = {"gelu": P.ACT_GELU, "sigmoid": P.ACT_SIGMOID, None: P.ACT_NONE}[o.get("act")]
+    cw = P.pack_conv(wt.to(DEV), bias.to(DEV) if bias is not None else None, prec=pr)
+    f = lambda t: P.Feat.from_nchw(t.to(DEV)) if t is not None else None  # noqa: E731
+    xcat = P.Feat.alloc(n, h, w, cin + 8, DEV)      # x lives in channels [4, 4 + cin) of a wider buffer
+    xcat.buf.fill_(7.0)
+    P.add(f(x), f(torch.zeros_like(x)), out=xcat.slice(4, cin))
+    kw = dict(relu_in=bool(o.get("relu_in")), act=act, gamma=gamma.to(DEV) if gamma is not None else None, mul=f(mul),
+              res=f(res), res2=f(res2), ln=(lnw.to(DEV), lnb.to(DEV)) if lnw is not None else None)
+    outs = []
+    for force in (False, True):
+        ycat = P.Feat.alloc(n, h, w, cout + 12, DEV)
+        ycat.buf.fill_(-3.0)
+        y = P.conv2d(xcat.slice(4, cin), cw, ycat.slice(8, cout), force_generic=force, **kw)
+        outs.append(y.to_nchw())
+        assert float(ycat.buf[..., :8].min()) == -3.0 and float(ycat.buf[..., 8 + cout:].max()) == -3.0  # neighbours untouched
+    close(outs[0], ref, 3e-5, f"1x1 {case}")
+    close(outs[0], outs[1].cpu(), 2e-5, f"1x1 vs generic {case}")
