@@ -104,11 +104,13 @@ def pmc_traffic(kernel_tag, workload, prec):
         return None
     name, _, targs = kernel_tag.partition("<")
     bn, pr = targs.rstrip(">").split(",")
-    key = f"prv2::{name}<{bn}, {dict(f32=0, bf16x3=1, bf16=2)[pr]}>"
-    d = json.load(open(path)).get(key)
-    if not d:
+    # the tag covers every instantiation "prv2::<name><bn, prec[, ...]>" (e.g. the im2col-tail variant): launch-weighted mean
+    prefix = f"prv2::{name}<{bn}, {dict(f32=0, bf16x3=1, bf16=2)[pr]}"
+    rows = [d for k, d in json.load(open(path)).items() if k.startswith(prefix + ">") or k.startswith(prefix + ",")]
+    n = sum(d["launches"] for d in rows)
+    if not n:
         return None
-    return (2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    return sum((2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * d["launches"] for d in rows) / n * 1024.0
 
 
 def main():
