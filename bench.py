@@ -106,7 +106,8 @@ def pmc_traffic(kernel_tag, workload, prec):
     bn, pr = targs.rstrip(">").split(",")
     # the tag covers every instantiation "prv2::<name><bn, prec[, ...]>" (e.g. the im2col-tail variant): launch-weighted mean
     prefix = f"prv2::{name}<{bn}, {dict(f32=0, bf16x3=1, bf16=2)[pr]}"
-    rows = [d for k, d in json.load(open(path)).items() if k.startswith(prefix + ">") or k.startswith(prefix + ",")]
+    rows = [d for k, d in json.load(open(path)).items()
+            if k.startswith(prefix + ">") or k.startswith(prefix + ",")]
     n = sum(d["launches"] for d in rows)
     if not n:
         return None

@@ -72,7 +72,9 @@ typedef struct prv2_conv_desc {
   int32_t prec;          /* enum prv2_prec                                               */
   int32_t force_generic; /* != 0: never use the LDS-halo 3x3 kernel (tests / A-B)        */
   float ln_eps;          /* epsilon of the fused LayerNorm (used when ln_weight != NULL) */
-  int32_t reserved;
+  int32_t part;          /* f32 mode: 3x3 halo convs whose width is 32k + (1..8) run as 32-pixel tiles + a remainder strip
+                          * (generic kernel): 0 = both (default), 1 = the tiles only, 2 = the strip only (per-kernel timing).
+                          * The bf16 modes do tiles and strip in one launch: part must be 0.                             */
 } prv2_conv_desc;
 
 /* host-side helpers: sizes of the packed weight buffers (in bytes) */

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
   }
   const int tile_n = bid % p.tiles_n;
   int tm = bid / p.tiles_n;
-  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int tiles_x = p.tiles_x, tiles_y = (p.H + TH - 1) / TH;  // (tiles_x may exclude a remainder strip: igemm.hip)
   const int tx = tm % tiles_x;
   tm /= tiles_x;
   const int ty = tm % tiles_y;
@@ -301,13 +301,16 @@ bool conv3x3_halo_supported(const IgemmParams& p) {
 
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s);  // conv3x3_m16.hip
 
-void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t s) {
-  // bf16 modes run on the 16x16x32 MFMA shape (conv3x3_m16.hip); PRV2_HALO_MFMA32=1 keeps them on this file's
-  // 32x32x16 kernel (A/B knob for tools/ab_conv.sh, read once)
+// bf16 modes run on the 16x16x32 MFMA shape (conv3x3_m16.hip; its buffer-addressed halo loads need the image extent
+// below 2^31 bytes); PRV2_HALO_MFMA32=1 keeps them on this file's 32x32x16 kernel (A/B knob for tools/ab_conv.sh)
+bool conv3x3_halo16_usable(const IgemmParams& p, int prec) {
   static const bool force32 = [] { const char* e = getenv("PRV2_HALO_MFMA32"); return e && e[0] == '1'; }();
-  // (its buffer-addressed halo loads need the image extent below 2^31 bytes)
-  if (prec != PRV2_PREC_F32 && !force32 && (long long)p.H * p.W * p.ldx < (1LL << 29)) return launch_conv3x3_halo16(p, prec, s);
-  const int tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+  return prec != PRV2_PREC_F32 && !force32 && (long long)p.H * p.W * p.ldx < (1LL << 29);
+}
+
+void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t s) {
+  if (conv3x3_halo16_usable(p, prec)) return launch_conv3x3_halo16(p, prec, s);  // (with its strip, if any)
+  const int tiles = p.N * ((p.H + TH - 1) / TH) * p.tiles_x;
 #define PRV2_LAUNCH_HALO(BN_, PREC_) \
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, PREC_>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p)
   if (p.Ncols > 64) {

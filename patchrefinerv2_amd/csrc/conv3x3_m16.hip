@@ -36,17 +36,25 @@
 namespace prv2 {
 
 namespace m16 {
-constexpr int TH = 8, TW = 32;
-constexpr int HW_ = TW + 2, HH_ = TH + 2;
-constexpr int HALO = HH_ * HW_;                 // 340 pixels
+constexpr int HALO = 10 * 34;                   // halo pixels of an 8 x 32 tile -- and of a 32 x 8 one
 constexpr int A_IT = (HALO * 8 + 511) / 512;    // float4 loads per thread per slab (6)
 constexpr int AROW = 160;                       // bytes per halo pixel in LDS
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 }  // namespace m16
 
-template <int BN, int PREC, bool TAIL>
-__global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParams p) {
+template <int BN>
+constexpr int halo16_smem_floats() {
+  constexpr int main_ = (2 * m16::HALO * m16::AROW + 3 * BN * 128) / 4, epi = 256 * (BN + 4) + 2 * 256;
+  return main_ > epi ? main_ : epi;
+}
+
+// one workgroup; `bid` of `nwg` = its index among the workgroups of its tile shape
+template <int BN, int PREC, bool TAIL, bool TALL>
+__device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, int bid, const int nwg) {
   using namespace m16;
+  // Tile = 8 rows x 32 pixels, or (TALL) 32 rows x 8 pixels for the remainder strip of images whose width is
+  // 32k + (1..8): same pixel count, same halo size, a pixel run of 16 is then 2 rows x 8 pixels.
+  constexpr int TH = TALL ? 32 : 8, TW = TALL ? 8 : 32, HW_ = TW + 2;
   static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
   constexpr int WN = BN >= 64 ? 2 : 1;
   constexpr int NI = BN >= 64 ? 2 : 1;             // image rows per wave
@@ -57,27 +65,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   constexpr int B_BYTES = BN * 128;
   constexpr int CLD = BN + 4;
   constexpr int NBUF = 3;
-  constexpr int SMEM_MAIN = (2 * A_BYTES + NBUF * B_BYTES) / 4;
-  constexpr int SMEM_EPI = TH * TW * CLD + 2 * TH * TW;  // C tile + LN row statistics
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
+  static_assert(NBUF == 3 && (2 * A_BYTES + NBUF * B_BYTES) / 4 <= halo16_smem_floats<BN>() &&
+                TH * TW * CLD + 2 * TH * TW <= halo16_smem_floats<BN>(), "LDS budget");  // main loop / C tile + LN statistics
   char* const As_b = reinterpret_cast<char*>(smem);
   char* const Bs_b = As_b + 2 * A_BYTES;
 
   // ---- XCD-aware block -> (pixel tile, channel tile) ----------------------------------------
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
   {
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tile_n = bid % p.tiles_n;
   int tm = bid / p.tiles_n;
-  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int tiles_x = TALL ? 1 : p.tiles_x, tiles_y = (p.H + TH - 1) / TH;  // (tiles_x excludes the strip columns [rx0, W))
   const int tx = tm % tiles_x;
   tm /= tiles_x;
   const int ty = tm % tiles_y;
   const int n_img = tm / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW;
+  const int y0 = ty * TH, x0 = TALL ? p.rx0 : tx * TW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -189,14 +194,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
 
   // ---- fragment addressing ---------------------------------------------------------------------------
   // pixel run a = (image row a / 2 of the wave, half a % 2): halo pixel of lane m at tap (ky, kx)
-  const char* const a_lane = As_b + ((NI * wm) * HW_ + m16) * AROW + g * 16;
+  // halo pixel of lane m at tap (0,0) of run 0, and the pixel offset of (run a, tap ky,kx) from it
+  const char* const a_lane = As_b + (TALL ? (wm * NA * 2 + (m16 >> 3)) * HW_ + (m16 & 7) : (NI * wm) * HW_ + m16) * AROW + g * 16;
+  auto run_off = [](int a, int ky, int kx) { return TALL ? (2 * a + ky) * HW_ + kx : (a / 2 + ky) * HW_ + (a % 2) * 16 + kx; };
   const int b_key = (m16 >> 1) & 7;  // rows wn*(BN/WN) + 16 j + m: the key only depends on m
   const char* const b_lane_hi = Bs_b + (wn * (BN / WN) + m16) * 128 + ((g ^ b_key) << 4);
   const char* const b_lane_lo = Bs_b + (wn * (BN / WN) + m16) * 128 + (((4 + g) ^ b_key) << 4);
   bf16x8 ah[NA], al[NA], bh[2], bl[2];
   auto read_a = [&](int a, int abuf, int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
-    const char* q = a_lane + abuf * A_BYTES + ((a / 2 + ky) * HW_ + (a % 2) * 16 + kx) * AROW;
+    const char* q = a_lane + abuf * A_BYTES + run_off(a, ky, kx) * AROW;
     ah[a] = *reinterpret_cast<const bf16x8*>(q);
     if constexpr (PREC == PRV2_PREC_BF16X3) al[a] = *reinterpret_cast<const bf16x8*>(q + 64);
   };
@@ -332,7 +339,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
         const int tp = 4 * g + i;
         const int tpc = tp < 9 ? tp : 0;
         const int ky = tpc / 3, kx = tpc - ky * 3;
-        const char* q = a_lane - g * 16 + abuf * A_BYTES + ((a / 2 + ky) * HW_ + (a % 2) * 16 + kx) * AROW;
+        const char* q = a_lane - g * 16 + abuf * A_BYTES + run_off(a, ky, kx) * AROW;
         const unsigned hv = *reinterpret_cast<const unsigned*>(q), lv = *reinterpret_cast<const unsigned*>(q + 64);
         h[i] = tp < 9 ? hv : 0u;
         l[i] = tp < 9 ? lv : 0u;
@@ -358,7 +365,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = (NI * wm + a / 2) * TW + (a % 2) * 16 + 4 * g + e;
+        const int row = TALL ? ((wm * NA + a) * 2 + ((4 * g + e) >> 3)) * TW + ((4 * g + e) & 7)
+                             : (NI * wm + a / 2) * TW + (a % 2) * 16 + 4 * g + e;
         smem[row * CLD + wn * (BN / WN) + j * 16 + m16] = acc[a][j][e];
       }
   __syncthreads();
@@ -385,24 +393,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   }
 }
 
+// One launch = the 32-pixel tile columns [0, tiles_x) as 8 x 32 tiles + (strip_blocks > 0) the remainder strip
+// [rx0, W) as 32 x 8 tiles.  The strip workgroups come first in the grid: they are ordinary workgroups of the same
+// duration, so the strip costs its share of workgroups (3-5 %) instead of an under-filled launch of its own.
+template <int BN, int PREC, bool TAIL>
+__global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<BN>()];
+  const int strip = p.strip_blocks;  // block-uniform
+  if ((int)blockIdx.x < strip) halo16_body<BN, PREC, TAIL, true>(p, smem, blockIdx.x, strip);
+  else halo16_body<BN, PREC, TAIL, false>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+}
+
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   using namespace m16;
-  const int tiles = p.N * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-#define PRV2_LAUNCH_HALO16(BN_, PREC_)                                                                             \
-  do {                                                                                                             \
-    if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, true>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p); \
-    else hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, false>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p);       \
+  p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;
+  p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) * p.tiles_n : 0;
+  const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x * p.tiles_n + p.strip_blocks;
+#define PRV2_LAUNCH_HALO16(BN_, PREC_)                                                                                 \
+  do {                                                                                                                 \
+    if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, true>), dim3(blocks), dim3(512), 0, s, p);     \
+    else hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, false>), dim3(blocks), dim3(512), 0, s, p);             \
   } while (0)
   if (p.Ncols > 64) {
-    p.tiles_n = (int)cdiv(p.Ncols, 128);
     if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(128, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_HALO16(128, PRV2_PREC_BF16);
   } else if (p.Ncols > 32) {
-    p.tiles_n = 1;
     if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(64, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_HALO16(64, PRV2_PREC_BF16);
   } else {
-    p.tiles_n = 1;
     if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_HALO16(32, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_HALO16(32, PRV2_PREC_BF16);
   }

@@ -29,6 +29,9 @@ struct IgemmParams {
   long long M;
   int relu_in, act, convt_k, vec_ok, vec_epi;
   int tiles_m, tiles_n;
+  int tiles_x;         // halo kernels: 32-pixel tile columns to process (the rest is the remainder strip)
+  int strip_blocks;    // conv3x3_m16: leading workgroups of the grid that take the strip (32 x 8 tiles)
+  int rx0, rw;         // remainder strip = output columns [rx0, rx0 + rw): tall halo tiles, or the generic kernel's window (rw = 0: none)
   const void* w_tail;  // im2col tile of the last (Cin % 32 == 2) channels for the 16x16x32 halo kernel, or null
 };
 
@@ -261,6 +264,8 @@ __device__ __forceinline__ void ln_row_stats(const IgemmParams& p, const float* 
 // conv3x3.hip: LDS-halo kernel for 3x3 / stride 1 / pad 1; returns false when the shape is not covered
 bool conv3x3_halo_supported(const IgemmParams& p);
 void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t stream);
+bool conv3x3_halo16_usable(const IgemmParams& p, int prec);
+void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t stream);  // tiles [0, tiles_x) + strip [rx0, rx0 + rw)
 // gemm_m16.hip: dense 1x1 / linear layers in the bf16 modes
 bool gemm16_supported(const IgemmParams& p, int prec);
 void launch_gemm16(IgemmParams& p, int prec, hipStream_t stream);

@@ -54,7 +54,9 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
   // ---- per-thread A rows (pixels) ---------------------------------------------------------
   const int chunk = tid & 7;   // which float4 of the 32-channel slab
   const int row0 = tid >> 3;   // 0..31, rows row0 + 32*i
-  const long long ohw = (long long)p.OH * p.OW;
+  // rows = output pixels of the column window [rx0, rx0 + rw) of every image row (rw = OW unless a strip was split off)
+  const int rw = p.rw > 0 ? p.rw : p.OW;
+  const long long ohw = (long long)p.OH * rw;
   const float* a_ptr[4];  // &x[n, iy0, ix0, chunk*4]; may point outside the image -- only dereferenced when in range
   int a_iy0[4], a_ix0[4];
 #pragma unroll
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     if (m < p.M) {
       int n = (int)(m / ohw);
       int rem = (int)(m - (long long)n * ohw);
-      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      int oy = rem / rw, ox = rem - oy * rw + p.rx0;
       a_iy0[i] = oy * p.stride - p.pad;
       a_ix0[i] = ox * p.stride - p.pad;
       a_ptr[i] = p.x + (long long)n * p.x_bstride + ((long long)a_iy0[i] * p.W + a_ix0[i]) * p.ldx + chunk * 4;
@@ -186,14 +188,15 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
     const int n_img = (int)(m / ohw);
     const int rem = (int)(m - (long long)n_img * ohw);
+    const int oy = rem / rw, ox = rem - oy * rw + p.rx0;
+    const long long pix = (long long)oy * p.OW + ox;  // dense pixel index of the image (== rem without a window)
     long long o;
     if (p.convt_k > 0) {
-      const int iy = rem / p.OW, ix = rem - iy * p.OW;
-      o = (long long)n_img * p.y_bstride + ((long long)(iy * kk + ec.sub_y) * (p.OW * kk) + ix * kk + ec.sub_x) * p.ldy + ec.co;
+      o = (long long)n_img * p.y_bstride + ((long long)(oy * kk + ec.sub_y) * (p.OW * kk) + ox * kk + ec.sub_x) * p.ldy + ec.co;
     } else {
-      o = (long long)n_img * p.y_bstride + (long long)rem * p.ldy + ec.co;
+      o = (long long)n_img * p.y_bstride + pix * p.ldy + ec.co;
     }
-    epi_store(p, ec, cv, m, o, ln_stats[rr], ln_stats[BM + rr]);
+    epi_store(p, ec, cv, (long long)n_img * p.OH * p.OW + pix, o, ln_stats[rr], ln_stats[BM + rr]);
   }
 }
 
@@ -409,10 +412,33 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   if (conv3x3_halo_supported(p) && !d->force_generic) {
     if (has_tail_tile(d->cin, d->kh, d->kw, d->convt_k, d->prec))
       p.w_tail = (const float*)w_packed + roundup(p.Ncols, 128) * 9 * p.Cin_pad;
-    launch_conv3x3_halo(p, d->prec, s);
-    PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
-    return 0;
-  }
+    // The fusion pyramid is 392x518, 196x259, 98x130, 49x65, 25x33: every width is 32k + {6, 3, 2, 1, 1}, i.e. the
+    // last 32-pixel tile column of the halo kernel would be 81-97 % padding.  A remainder of <= 8 columns goes to
+    // a second launch instead: the same kernel with 32-row x 8-pixel tiles (bf16 modes), or the generic kernel's
+    // column window (f32 mode); disjoint outputs, same stream.
+    const int rem = p.W % 32;
+    const bool strip = rem != 0 && rem <= 8 && p.W >= 64;
+    p.tiles_x = strip ? p.W / 32 : (int)cdiv(p.W, 32);
+    if (strip && conv3x3_halo16_usable(p, d->prec)) {  // bf16 modes: tiles and strip are one launch
+      PRV2_REQUIRE(d->part == 0, "conv2d: part=%d is only meaningful when the strip is a launch of its own (f32 mode)", d->part);
+      p.rx0 = p.W - rem;
+      p.rw = rem;
+      launch_conv3x3_halo(p, d->prec, s);
+      PRV2_LAUNCH_CHECK("conv2d(3x3 halo + strip)");
+      return 0;
+    }
+    PRV2_REQUIRE(d->part >= 0 && d->part <= 2 && (d->part == 0 || strip), "conv2d: part=%d but this conv has no remainder strip", d->part);
+    if (d->part != 2) {
+      launch_conv3x3_halo(p, d->prec, s);
+      PRV2_LAUNCH_CHECK("conv2d(3x3 halo)");
+    }
+    if (!strip || d->part == 1) return 0;
+    p.w_tail = nullptr;  // f32 mode: the strip goes through the generic kernel's column window
+    p.rx0 = p.W - rem;
+    p.rw = rem;
+    p.M = (long long)d->n * p.OH * rem;
+    p.tiles_m = (int)cdiv(p.M, BM);
+  } else
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;
     hipLaunchKernelGGL(conv1x1_small_kernel, dim3(flat_grid(p.M * ng, 256)), dim3(256), 0, s, p, (int)d->prec);

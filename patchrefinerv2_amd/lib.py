@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("x_bstride", C.c_int64), ("y_bstride", C.c_int64),
         ("relu_in", C.c_int32), ("act", C.c_int32), ("convt_k", C.c_int32),
         ("ld_mul", C.c_int32), ("ld_res", C.c_int32), ("ld_res2", C.c_int32),
-        ("prec", C.c_int32), ("force_generic", C.c_int32), ("ln_eps", C.c_float), ("reserved", C.c_int32),
+        ("prec", C.c_int32), ("force_generic", C.c_int32), ("ln_eps", C.c_float), ("part", C.c_int32),
     ]
 
 
