@@ -137,6 +137,11 @@ int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32_t heads, i
 /* y = a + b over [rows, c] with row strides (x + prev_b_embedding, external/zoedepth/models/layers/attractor.py:178) */
 int prv2_add(const float* a, int32_t lda, const float* b, int32_t ldb, int64_t rows, int32_t c, float* y, int32_t ldy,
              void* stream);
+
+/* Zero the pad channels [c, ld) of every pixel of an NHWC buffer (rows = n*h*w).  Buffers whose channel count is
+ * not a multiple of 4 (the [feat | pred1 | pred2] concats of fusion_model.py:91-118: 34, 66, 98 ...) carry pad
+ * channels up to ld; the conv loaders read them against zero weights, so they must be finite. */
+int prv2_zero_pad_channels(float* y, int64_t rows, int32_t c, int32_t ld, void* stream);
 /* AttractorLayerUnnormed, kind='mean', type='inv' (attractor.py:45-57,186-206):
  *   out[r, j] = bins[r, j] + mean_i( dx / (1 + alpha * dx^2) ),  dx = attr[r, i] - bins[r, j]               */
 int prv2_zoe_attractor(const float* attr, int32_t ld_attr, int32_t n_attr, const float* bins, int32_t ld_bins,

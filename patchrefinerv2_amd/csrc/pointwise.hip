@@ -265,6 +265,13 @@ __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, i
   }
 }
 
+// zero the pad channels [c, ld) of an NHWC buffer (they are read by the conv loaders against zero weights and must be
+// finite); one thread per pixel -- a full-buffer memset for 2 of 100 channels costs 50x the traffic
+__global__ void __launch_bounds__(256) zero_pad_kernel(float* __restrict__ y, int64_t rows, int c, int ld) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x)
+    for (int k = c; k < ld; ++k) y[r * ld + k] = 0.f;
+}
+
 // one thread per (pixel, bin): the pixel's attractor points are re-read from L1 by its n_bins threads
 __global__ void __launch_bounds__(256) zoe_attractor_kernel(const float* __restrict__ attr, int ld_attr, int n_attr,
                                                             const float* __restrict__ bins, int ld_bins, int n_bins,
@@ -416,6 +423,14 @@ extern "C" int prv2_add(const float* a, int32_t lda, const float* b, int32_t ldb
   hipLaunchKernelGGL(add_kernel, dim3(flat_grid(rows * c, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, rows, c,
                      y, ldy);
   PRV2_LAUNCH_CHECK("add");
+  return 0;
+}
+
+extern "C" int prv2_zero_pad_channels(float* y, int64_t rows, int32_t c, int32_t ld, void* stream) {
+  PRV2_REQUIRE(y && rows > 0 && c > 0 && ld >= c, "zero_pad_channels: bad arguments");
+  if (ld == c) return 0;
+  hipLaunchKernelGGL(zero_pad_kernel, dim3(flat_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, y, rows, c, ld);
+  PRV2_LAUNCH_CHECK("zero_pad_channels");
   return 0;
 }
 

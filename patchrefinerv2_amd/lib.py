@@ -49,6 +49,7 @@ SIGNATURES = {
     "prv2_attention": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _L, _P]),
     "prv2_attention_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "prv2_add": (_I, [_P, _I, _P, _I, _L, _I, _P, _I, _P]),
+    "prv2_zero_pad_channels": (_I, [_P, _L, _I, _I, _P]),
     "prv2_zoe_attractor": (_I, [_P, _I, _I, _P, _I, _I, _F, _L, _P, _I, _P]),
     "prv2_zoe_logbinom_depth": (_I, [_P, _I, _P, _I, _I, _F, _F, _L, _P, _P]),
     "prv2_crop_resize": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _I, _P]),

@@ -107,9 +107,10 @@ class Feat:
     @staticmethod
     def alloc(n, h, w, c, device, pad_to: int = 4) -> "Feat":
         ld = roundup(c, pad_to)
-        # pad channels are read by the conv loader (x zero weights): they must be finite
-        buf = torch.zeros((n, h, w, ld), device=device, dtype=torch.float32) if ld != c else \
-            torch.empty((n, h, w, ld), device=device, dtype=torch.float32)
+        # pad channels are read by the conv loader (x zero weights): they must be finite -- zero just those
+        buf = torch.empty((n, h, w, ld), device=device, dtype=torch.float32)
+        if ld != c:
+            L.check(L.load().prv2_zero_pad_channels(buf.data_ptr(), n * h * w, c, ld, _stream()), "zero_pad_channels")
         return Feat(buf, c)
 
     @property
