@@ -381,16 +381,18 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   const int col4 = tid % C4;
   EpiCols ec;
   if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
-  for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
-    const int py = rr / TW, px = rr - py * TW;
-    const int oy = y0 + py, ox = x0 + px;
-    if (oy >= p.H || ox >= p.W) continue;
-    const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
-    const long long pix = (long long)oy * p.W + ox;
-    const long long m = (long long)n_img * p.H * p.W + pix;
-    const long long o = (long long)n_img * p.y_bstride + pix * p.ldy + ec.co;
-    epi_store(p, ec, cv, m, o, ln_stats[rr], ln_stats[TH * TW + rr]);
-  }
+  const long long img_m = (long long)n_img * p.H * p.W, img_o = (long long)n_img * p.y_bstride + ec.co;
+  dispatch_act(p.act, [&](auto act_c) {
+    for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+      const int py = rr / TW, px = rr - py * TW;
+      const int oy = y0 + py, ox = x0 + px;
+      if (oy >= p.H || ox >= p.W) continue;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
+      const int pix = oy * p.W + ox;
+      epi_store<decltype(act_c)::value>(p, ec, cv, img_m + pix, img_o + (long long)pix * p.ldy, ln_stats[rr],
+                                        ln_stats[TH * TW + rr]);
+    }
+  });
 }
 
 // One launch = the 32-pixel tile columns [0, tiles_x) as 8 x 32 tiles + (strip_blocks > 0) the remainder strip

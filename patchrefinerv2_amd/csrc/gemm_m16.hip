@@ -242,12 +242,13 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
   const int col4 = tid % C4;
   EpiCols ec;
   if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
-  for (int rr = tid / C4; rr < TM; rr += RPP) {
-    if (rr >= rows_here) break;
-    const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
-    const long long m = row0 + rr;
-    epi_store(p, ec, cv, m, m * p.ldy + ec.co, ln_stats[rr], ln_stats[TM + rr]);
-  }
+  dispatch_act(p.act, [&](auto act_c) {
+    for (int rr = tid / C4; rr < TM && rr < rows_here; rr += RPP) {
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
+      const long long m = row0 + rr;
+      epi_store<decltype(act_c)::value>(p, ec, cv, m, m * p.ldy + ec.co, ln_stats[rr], ln_stats[TM + rr]);
+    }
+  });
 }
 
 // dense row-major operands only (every 1x1 / linear call of the path): otherwise the generic kernel takes it

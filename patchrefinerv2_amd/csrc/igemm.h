@@ -1,5 +1,7 @@
 // Shared pieces of the implicit-GEMM kernels (igemm.hip: generic; conv3x3.hip: LDS-halo 3x3).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace prv2 {
@@ -204,7 +206,22 @@ __device__ __forceinline__ bool epi_cols(const IgemmParams& p, int ncol, EpiCols
   return true;
 }
 
-// m = dense output pixel index (for mul/res/res2), o = element offset of y[m, co]
+// Runs f(integral_constant<int, act>) for the layer's activation.  The store loops of the kernels go through this:
+// with the activation a runtime value inside the loop, every iteration carried all five variants (erff, expf,
+// log1pf expansions x 4 channels) -- ~30 KB of epilogue code per kernel against an 8 KB main loop.
+template <class F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+  switch (act) {
+    case PRV2_ACT_RELU: f(std::integral_constant<int, PRV2_ACT_RELU>{}); break;
+    case PRV2_ACT_GELU: f(std::integral_constant<int, PRV2_ACT_GELU>{}); break;
+    case PRV2_ACT_SIGMOID: f(std::integral_constant<int, PRV2_ACT_SIGMOID>{}); break;
+    case PRV2_ACT_SOFTPLUS: f(std::integral_constant<int, PRV2_ACT_SOFTPLUS>{}); break;
+    default: f(std::integral_constant<int, PRV2_ACT_NONE>{}); break;
+  }
+}
+
+// m = dense output pixel index (for mul/res/res2), o = element offset of y[m, co]; ACT >= 0: compile-time activation
+template <int ACT = -1>
 __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c, const f32x4 cv, long long m, long long o,
                                           float ln_mean = 0.f, float ln_rstd = 1.f) {
   float v[4] = {cv.x, cv.y, cv.z, cv.w};
@@ -225,7 +242,7 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
   for (int e = 0; e < 4; ++e) {
     float t = v[e] + c.bias[e];
     if (p.ln_w) t = (t - ln_mean) * ln_rstd * c.lnw[e] + c.lnb[e];
-    t = act_apply(t, p.act);
+    t = act_apply(t, ACT >= 0 ? ACT : p.act);
     if (p.gamma) t *= c.gam[e];
     if (p.mul) t = mulv[e] * t;
     if (p.res) t += resv[e];

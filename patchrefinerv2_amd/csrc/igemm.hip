@@ -182,22 +182,24 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
   EpiCols ec;
   if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
   const int kk = p.convt_k > 0 ? p.convt_k : 1;
-  for (int rr = tid / C4; rr < BM; rr += RPP) {
-    const long long m = (long long)tile_m * BM + rr;
-    if (m >= p.M) break;
-    const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
-    const int n_img = (int)(m / ohw);
-    const int rem = (int)(m - (long long)n_img * ohw);
-    const int oy = rem / rw, ox = rem - oy * rw + p.rx0;
-    const long long pix = (long long)oy * p.OW + ox;  // dense pixel index of the image (== rem without a window)
-    long long o;
-    if (p.convt_k > 0) {
-      o = (long long)n_img * p.y_bstride + ((long long)(oy * kk + ec.sub_y) * (p.OW * kk) + ox * kk + ec.sub_x) * p.ldy + ec.co;
-    } else {
-      o = (long long)n_img * p.y_bstride + pix * p.ldy + ec.co;
+  dispatch_act(p.act, [&](auto act_c) {
+    for (int rr = tid / C4; rr < BM; rr += RPP) {
+      const long long m = (long long)tile_m * BM + rr;
+      if (m >= p.M) break;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
+      const int n_img = (int)(m / ohw);
+      const int rem = (int)(m - (long long)n_img * ohw);
+      const int oy = rem / rw, ox = rem - oy * rw + p.rx0;
+      const long long pix = (long long)oy * p.OW + ox;  // dense pixel index of the image (== rem without a window)
+      long long o;
+      if (p.convt_k > 0) {
+        o = (long long)n_img * p.y_bstride + ((long long)(oy * kk + ec.sub_y) * (p.OW * kk) + ox * kk + ec.sub_x) * p.ldy + ec.co;
+      } else {
+        o = (long long)n_img * p.y_bstride + pix * p.ldy + ec.co;
+      }
+      epi_store<decltype(act_c)::value>(p, ec, cv, (long long)n_img * p.OH * p.OW + pix, o, ln_stats[rr], ln_stats[BM + rr]);
     }
-    epi_store(p, ec, cv, (long long)n_img * p.OH * p.OW + pix, o, ln_stats[rr], ln_stats[BM + rr]);
-  }
+  });
 }
 
 // ---- weight packing: [cout][cin][kh][kw] (or ConvT [cin][cout][k][k]) -> [cout_pad][taps][cin_pad] ----
