@@ -243,7 +243,10 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
   EpiCols ec;
   if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
   dispatch_act(p.act, [&](auto act_c) {
-    for (int rr = tid / C4; rr < TM && rr < rows_here; rr += RPP) {
+#pragma unroll  // (no back-edge: see conv3x3_m16.hip)
+    for (int k = 0; k < TM / RPP; ++k) {
+      const int rr = tid / C4 + k * RPP;
+      if (rr >= rows_here) continue;
       const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
       const long long m = row0 + rr;
       epi_store<decltype(act_c)::value>(p, ec, cv, m, m * p.ldy + ec.co, ln_stats[rr], ln_stats[TM + rr]);
