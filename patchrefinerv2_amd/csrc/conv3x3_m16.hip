@@ -382,6 +382,46 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   EpiCols ec;
   if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
   const long long img_m = (long long)n_img * p.H * p.W, img_o = (long long)n_img * p.y_bstride + ec.co;
+  // The store loop is VALU-bound (16 rows per thread, 2 waves per SIMD): the general epilogue costs ~100 instructions a
+  // row -- every optional stage as a select -- which was 14 k of the 280 k cycles of a 512->256 tile.
+  // Lean paths for the three common shapes: bias + act; bias + LN + act (fusion encoders); bias + act + one residual
+  // (GatedConvUnit.conv).  Everything else (gates, gamma, two residuals, ragged channels) takes the general loop below.
+  const bool simple = ec.vec && !p.gamma && !p.mul && !p.res2 && !(p.ln_w && p.res);  // block-uniform
+  if (simple) {
+    float* const ybase = p.y + img_o;
+    const float* const rbase = p.res ? p.res + img_m * p.ld_res + ec.co : nullptr;
+    auto lean = [&](auto act_c, auto ln_c, auto res_c) {
+      constexpr bool LN = decltype(ln_c)::value, RES = decltype(res_c)::value;
+      for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+        const int py = rr / TW, px = rr - py * TW;
+        const int oy = y0 + py, ox = x0 + px;
+        if (oy >= p.H || ox >= p.W) continue;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
+        const int pix = oy * p.W + ox;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES) rv = *reinterpret_cast<const f32x4*>(rbase + (unsigned)(pix * p.ld_res));
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = cv[e] + ec.bias[e];
+          if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[TH * TW + rr] * ec.lnw[e] + ec.lnb[e];
+          t = act_apply(t, decltype(act_c)::value);
+          if constexpr (RES) t += rv[e];
+          ov[e] = t;
+        }
+        float* dst = ybase + (unsigned)(pix * p.ldy);
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+      }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    dispatch_act(p.act, [&](auto act_c) {
+      if (p.ln_w) lean(act_c, T_{}, F_{});
+      else if (p.res) lean(act_c, F_{}, T_{});
+      else lean(act_c, F_{}, F_{});
+    });
+    return;
+  }
   dispatch_act(p.act, [&](auto act_c) {
     for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
       const int py = rr / TW, px = rr - py * TW;

@@ -251,7 +251,12 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
   }
   if (c.vec) {
     f32x4 ov = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(p.y + o) = ov;
+    // Inline asm: hipcc puts s_waitcnt vmcnt(0) at the header of a loop that contains a store it knows about, i.e.
+    // every iteration of the kernels' store loops waited ~900 cycles for the previous row's store to be acknowledged
+    // (14 k of the 280 k cycles of a 512->256 tile: tools/probes/halo_phase_stamps.py).  A store needs no wait at all
+    // (s_nop 1: the data registers are read right after issue); hidden stores only make hipcc's counted waits for the
+    // gate / residual loads wait longer, never shorter (vmcnt retires in issue order).
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p.y + o), "v"(ov) : "memory");
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
