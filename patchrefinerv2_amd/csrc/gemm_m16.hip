@@ -242,11 +242,44 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
   const int col4 = tid % C4;
   EpiCols ec;
   if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
+  // lean store paths (the general epilogue is ~100 VALU instructions a row, every optional stage a select):
+  // bias + act [+ gate] [+ one residual] -- the GatedConvUnit gate sigmoid(.) * out + x and the plain 1x1 / linear layers
+  const bool simple = ec.vec && !p.gamma && !p.res2 && !p.ln_w;  // block-uniform
+  if (simple) {
+    float* const ybase = p.y + row0 * p.ldy + ec.co;
+    const float* const mbase = p.mul ? p.mul + row0 * p.ld_mul + ec.co : nullptr;
+    const float* const rbase = p.res ? p.res + row0 * p.ld_res + ec.co : nullptr;
+    auto lean = [&](auto act_c, auto mul_c, auto res_c) {
+      constexpr bool MUL = decltype(mul_c)::value, RES = decltype(res_c)::value;
+      for (int rr = tid / C4; rr < TM && rr < rows_here; rr += RPP) {
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
+        f32x4 mv = {1.f, 1.f, 1.f, 1.f}, rv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MUL) mv = *reinterpret_cast<const f32x4*>(mbase + (unsigned)(rr * p.ld_mul));
+        if constexpr (RES) rv = *reinterpret_cast<const f32x4*>(rbase + (unsigned)(rr * p.ld_res));
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = act_apply(cv[e] + ec.bias[e], decltype(act_c)::value);
+          if constexpr (MUL) t = mv[e] * t;
+          if constexpr (RES) t += rv[e];
+          ov[e] = t;
+        }
+        float* dst = ybase + (unsigned)(rr * p.ldy);
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+      }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    dispatch_act(p.act, [&](auto act_c) {
+      if (p.mul && p.res) lean(act_c, T_{}, T_{});
+      else if (p.mul) lean(act_c, T_{}, F_{});
+      else if (p.res) lean(act_c, F_{}, T_{});
+      else lean(act_c, F_{}, F_{});
+    });
+    return;
+  }
   dispatch_act(p.act, [&](auto act_c) {
-#pragma unroll  // (no back-edge: see conv3x3_m16.hip)
-    for (int k = 0; k < TM / RPP; ++k) {
-      const int rr = tid / C4 + k * RPP;
-      if (rr >= rows_here) continue;
+    for (int rr = tid / C4; rr < TM && rr < rows_here; rr += RPP) {
       const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
       const long long m = row0 + rr;
       epi_store<decltype(act_c)::value>(p, ec, cv, m, m * p.ldy + ec.co, ln_stats[rr], ln_stats[TM + rr]);
