@@ -429,3 +429,63 @@ def test_conv1x1_split_precision_kernels(P, case):
         assert float(ycat.buf[..., :8].min()) == -3.0 and float(ycat.buf[..., 8 + cout:].max()) == -3.0  # neighbours untouched
     close(outs[0], ref, 3e-5, f"1x1 {case}")
     close(outs[0], outs[1].cpu(), 2e-5, f"1x1 vs generic {case}")
+
+
+STRIP_CASES = [
+    # n, h, w, cin, cout, opts -- widths 32k + (1..8): 32-pixel tile columns + a remainder strip (32 x 8 tiles in the bf16
+    # modes, the generic kernel's column window in f32 mode); heights that are not multiples of 8 / 32
+    (2, 37, 67, 64, 128, dict(bias=True, act="gelu")),
+    (1, 50, 65, 98, 130, dict(bias=True, relu_in=True, res=True)),          # rem 1, tail tile (cin = 96 + 2), 2 channel tiles
+    (3, 19, 72, 34, 40, dict(bias=True, ln=True, act="gelu")),              # rem 8, BN = 64, fused LayerNorm, tail tile
+    (2, 33, 130, 66, 32, dict(bias=True, act="sigmoid", mul=True)),         # rem 2, BN = 32, gate
+    (1, 64, 100, 256, 256, dict(res=True, res2=True, gamma=True, bias=True)),  # rem 4
+]
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16x3", 3e-5)])
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_conv3x3_remainder_strip(P, case, prec, tol):
+    from patchrefinerv2_amd import lib as L
+    n, h, w, cin, cout, o = case
+    x = rnd(1, n, cin, h, w)
+    wt = rnd(2, cout, cin, 3, 3) / np.sqrt(cin * 9)
+    bias = rnd(3, cout) if o.get("bias") else None
+    ref = F.conv2d((F.relu(x) if o.get("relu_in") else x).double(), wt.double(), bias.double() if bias is not None else None,
+                   padding=1)
+    lnw = lnb = None
+    if o.get("ln"):
+        lnw, lnb = rnd(8, cout).abs() + 0.5, rnd(9, cout)
+        u = ref.mean(1, keepdim=True)
+        s = (ref - u).pow(2).mean(1, keepdim=True)
+        ref = (ref - u) / torch.sqrt(s + 1e-6) * lnw.double().view(1, -1, 1, 1) + lnb.double().view(1, -1, 1, 1)
+    if o.get("act") == "gelu":
+        ref = F.gelu(ref)
+    if o.get("act") == "sigmoid":
+        ref = torch.sigmoid(ref)
+    gamma = rnd(4, cout) if o.get("gamma") else None
+    if gamma is not None:
+        ref = ref * gamma.double().view(1, -1, 1, 1)
+    mul, res, res2 = (rnd(s_, n, cout, h, w) if o.get(k_) else None for s_, k_ in ((5, "mul"), (6, "res"), (7, "res2")))
+    if mul is not None:
+        ref = mul.double() * ref
+    if res is not None:
+        ref = ref + res.double()
+    if res2 is not None:
+        ref = ref + res2.double()
+    ref = ref.float()
+    act = {"gelu": P.ACT_GELU, "sigmoid": P.ACT_SIGMOID, None: P.ACT_NONE}[o.get("act")]
+    cw = P.pack_conv(wt.to(DEV), bias.to(DEV) if bias is not None else None, prec=L.PREC_NAMES[prec])
+    f = lambda t: P.Feat.from_nchw(t.to(DEV)) if t is not None else None  # noqa: E731
+    kw = dict(relu_in=bool(o.get("relu_in")), act=act, gamma=gamma.to(DEV) if gamma is not None else None, mul=f(mul),
+              res=f(res), res2=f(res2), ln=(lnw.to(DEV), lnb.to(DEV)) if lnw is not None else None)
+    ycat = P.Feat.alloc(n, h, w, cout + 8, DEV)
+    ycat.buf.fill_(-3.0)
+    y = P.conv2d(f(x), cw, ycat.slice(4, cout), **kw)
+    close(y.to_nchw(), ref, tol, f"strip {case} {prec}")
+    assert float(ycat.buf[..., :4].min()) == -3.0 and float(ycat.buf[..., 4 + cout:].max()) == -3.0
+    close(y.to_nchw(), P.conv2d(f(x), cw, force_generic=True, **kw).to_nchw().cpu(), tol, f"strip vs generic {case} {prec}")
+    # timed (profiled) launches issue tiles and strip separately in f32 mode (prv2_conv_desc.part): same result
+    P.PROFILER.start(timed=True)
+    y2 = P.conv2d(f(x), cw, **kw)
+    P.PROFILER.stop()
+    assert torch.equal(y2.to_nchw(), y.to_nchw())
