@@ -407,7 +407,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[TH * TW + rr] * ec.lnw[e] + ec.lnb[e];
           t = act_apply(t, decltype(act_c)::value);
           if constexpr (RES) t += rv[e];
-          ov[e] = t;
+          ov[e] = e < ec.nvalid ? t : 0.f;  // pad channels behind cout stay zero
         }
         float* dst = ybase + (unsigned)(pix * p.ldy);
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");

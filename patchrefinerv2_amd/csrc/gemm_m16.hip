@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
           float t = act_apply(cv[e] + ec.bias[e], decltype(act_c)::value);
           if constexpr (MUL) t = mv[e] * t;
           if constexpr (RES) t += rv[e];
-          ov[e] = t;
+          ov[e] = e < ec.nvalid ? t : 0.f;  // pad channels behind cout stay zero
         }
         float* dst = ybase + (unsigned)(rr * p.ldy);
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");

@@ -195,7 +195,7 @@ __device__ __forceinline__ bool epi_cols(const IgemmParams& p, int ncol, EpiCols
     c.sub_x = t - c.sub_y * kk;
   }
   c.nvalid = min(4, (p.convt_k > 0 ? p.Cout - c.co : p.Ncols - ncol));
-  c.vec = p.vec_epi && c.nvalid == 4;
+  c.vec = p.vec_epi;  // (nvalid < 4 only with pad channels behind cout: written as zeros)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     c.bias[e] = (e < c.nvalid && p.bias) ? p.bias[c.co + e] : 0.f;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
     if (p.mul) t = mulv[e] * t;
     if (p.res) t += resv[e];
     if (p.res2) t += res2v[e];
-    v[e] = t;
+    v[e] = e < c.nvalid ? t : 0.f;
   }
   if (c.vec) {
     f32x4 ov = {v[0], v[1], v[2], v[3]};

@@ -403,10 +403,15 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
                "conv2d: x must be 16-byte aligned with ldx %% 4 == 0 and ldx >= roundup(cin,4) (ldx=%d cin=%d)", d->ldx, d->cin);
   p.vec_ok = 1;
   {
-    bool ve = (d->ldy % 4 == 0) && aligned16(y) && (p.y_bstride % 4 == 0) && (d->cout % 4 == 0);
-    if (mul) ve = ve && (d->ld_mul % 4 == 0) && aligned16(mul);
-    if (res) ve = ve && (d->ld_res % 4 == 0) && aligned16(res);
-    if (res2) ve = ve && (d->ld_res2 % 4 == 0) && aligned16(res2);
+    // 16-byte epilogue: cout a multiple of 4 -- or (the 98 / 194 / 322 / 642 / 770-channel layers) rows whose only
+    // bytes behind cout are the pad channels up to the pixel stride: those are then written too, as zeros
+    const int c4 = (int)roundup(d->cout, 4);
+    const bool padded = d->cout % 4 != 0 && d->convt_k == 0;
+    bool ve = (d->ldy % 4 == 0) && aligned16(y) && (p.y_bstride % 4 == 0) && (!padded || d->ldy == c4);
+    if (mul) ve = ve && (d->ld_mul % 4 == 0) && aligned16(mul) && (!padded || d->ld_mul == c4);
+    if (res) ve = ve && (d->ld_res % 4 == 0) && aligned16(res) && (!padded || d->ld_res == c4);
+    if (res2) ve = ve && (d->ld_res2 % 4 == 0) && aligned16(res2) && (!padded || d->ld_res2 == c4);
+    if (d->convt_k > 0) ve = ve && (d->cout % 4 == 0);
     p.vec_epi = ve;
   }
   p.tiles_m = (int)cdiv(p.M, BM);
