@@ -155,6 +155,12 @@ int prv2_zoe_logbinom_depth(const float* pt, int32_t ld_pt, const float* centers
 /* ------------------------------------------------------------------------------------------
  * Gathers
  * ------------------------------------------------------------------------------------------ */
+/* Input stage of the image dataset (estimator/datasets/general_dataset.py:22-62, generic branch): RGB image, HWC, uint8
+ * (src_is_u8) or fp32, device memory -> v / 255 (uint8 only) -> F.interpolate(mode='bicubic', align_corners=True) to H x W ->
+ * CHW fp32 image_hr.  Evaluated in float64 like the reference (its cv2-image / 255.0 is a float64 array), rounded once. */
+int prv2_bicubic_resize(const void* src_hwc, int32_t src_is_u8, int32_t h, int32_t w, float* dst_chw, int32_t H, int32_t W,
+                        void* stream);
+
 /* Crop + bilinear(align_corners=True) resize of K tiles of a CHW image into NHWC patches, with the
  * (v - mean[c]) / std[c] input normalisation fused.
  *   baseline_pretrain.py:169-170,274-275 -> external/depth_anything/transform.py:127-129 (ResizeDA)

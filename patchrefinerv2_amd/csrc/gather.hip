@@ -39,6 +39,48 @@ __global__ void __launch_bounds__(256) crop_resize_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// image input stage: HWC uint8 (or fp32) RGB -> /255 -> bicubic(align_corners=True, A = -0.75) -> CHW fp32.
+// The reference does this on the CPU in float64 (cv2 image / 255.0 is a float64 array; general_dataset.py:55-60), so the
+// arithmetic here is double as well and rounded to fp32 once, tap order as in ATen's separable kernel (x then y).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(double t, double (&c)[4]) {
+  const double A = -0.75;
+  const double x0 = t + 1.0, x3 = (1.0 - t) + 1.0, x2 = 1.0 - t;
+  c[0] = ((A * x0 - 5.0 * A) * x0 + 8.0 * A) * x0 - 4.0 * A;
+  c[1] = ((A + 2.0) * t - (A + 3.0)) * t * t + 1.0;
+  c[2] = ((A + 2.0) * x2 - (A + 3.0)) * x2 * x2 + 1.0;
+  c[3] = ((A * x3 - 5.0 * A) * x3 + 8.0 * A) * x3 - 4.0 * A;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bicubic_resize_kernel(const T* __restrict__ src, int h, int w, float* __restrict__ dst,
+                                                             int H, int W, double sy, double sx, double norm) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+  if (ox >= W) return;
+  const double ry = sy * oy, rx = sx * ox;
+  const int iy = (int)floor(ry), ix = (int)floor(rx);
+  double cy[4], cx[4];
+  cubic_coeffs(ry - iy, cy);
+  cubic_coeffs(rx - ix, cx);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yy = min(max(iy - 1 + i, 0), h - 1);
+      double row = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xx = min(max(ix - 1 + j, 0), w - 1);
+        row += cx[j] * ((double)src[((int64_t)yy * w + xx) * 3 + c] / norm);
+      }
+      acc += cy[i] * row;
+    }
+    dst[((int64_t)c * H + oy) * W + ox] = (float)acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // roi_align(aligned=True, sampling_ratio=-1) from ONE feature map to K outputs (no repeat(K))
 // ---------------------------------------------------------------------------------------------
 template <int VEC>
@@ -204,6 +246,21 @@ extern "C" int prv2_crop_resize(const float* img, int32_t H, int32_t W, const in
   hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)cdiv(ow, 256), oh, K), dim3(256), 0, (hipStream_t)stream, img, H, W, tiles,
                      K, ch, cw, oh, ow, ac_scale(ch, oh), ac_scale(cw, ow), n, out, ldo);
   PRV2_LAUNCH_CHECK("crop_resize");
+  return 0;
+}
+
+extern "C" int prv2_bicubic_resize(const void* src_hwc, int32_t src_is_u8, int32_t h, int32_t w, float* dst_chw, int32_t H,
+                                   int32_t W, void* stream) {
+  PRV2_REQUIRE(src_hwc && dst_chw && h > 0 && w > 0 && H > 0 && W > 0 && H <= 65535, "bicubic_resize: bad arguments");
+  const double sy = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0, sx = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
+  const dim3 grid((unsigned)cdiv(W, 256), H);
+  if (src_is_u8)
+    hipLaunchKernelGGL(bicubic_resize_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_hwc, h, w,
+                       dst_chw, H, W, sy, sx, 255.0);
+  else
+    hipLaunchKernelGGL(bicubic_resize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src_hwc, h, w, dst_chw,
+                       H, W, sy, sx, 1.0);
+  PRV2_LAUNCH_CHECK("bicubic_resize");
   return 0;
 }
 

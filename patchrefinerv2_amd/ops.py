@@ -345,6 +345,19 @@ def crop_resize(img_chw: torch.Tensor, tiles: torch.Tensor, ch: int, cw: int, oh
                                       cw, oh, ow, m, s, out.ptr, out.ld, _stream()), "crop_resize")
 
 
+def bicubic_resize(img_hwc: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
+    """[h, w, 3] uint8 (-> /255) or fp32 RGB image on the device -> [3, oh, ow] fp32 (bicubic, align_corners=True);
+    general_dataset.py:55-60."""
+    if not img_hwc.is_cuda or img_hwc.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("bicubic_resize needs a uint8 or float32 image on the GPU (no CPU fallback exists)")
+    assert img_hwc.dim() == 3 and img_hwc.shape[2] == 3
+    img_hwc = img_hwc.contiguous()
+    out = torch.empty((3, oh, ow), device=img_hwc.device, dtype=torch.float32)
+    L.check(L.load().prv2_bicubic_resize(img_hwc.data_ptr(), int(img_hwc.dtype == torch.uint8), img_hwc.shape[0], img_hwc.shape[1],
+                                         out.data_ptr(), oh, ow, _stream()), "bicubic_resize")
+    return out
+
+
 def roi_align(feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow: int, out: Optional[Feat] = None) -> Feat:
     assert feat.n == 1 and boxes.dtype == torch.float32 and boxes.is_cuda and boxes.shape[1] == 4
     k = boxes.shape[0]

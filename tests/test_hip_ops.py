@@ -489,3 +489,22 @@ def test_conv3x3_remainder_strip(P, case, prec, tol):
     y2 = P.conv2d(f(x), cw, **kw)
     P.PROFILER.stop()
     assert torch.equal(y2.to_nchw(), y.to_nchw())
+
+
+@pytest.mark.parametrize("case", [(54, 96, 216, 384, "u8"), (45, 80, 90, 160, "u8"), (64, 48, 33, 97, "f32"), (30, 40, 30, 40, "u8"),
+                                  (120, 200, 61, 77, "f32")])
+def test_bicubic_input_stage(P, case):
+    """device read_image: RGB / 255 -> bicubic(align_corners=True) -> CHW, vs the reference's float64 F.interpolate
+    (general_dataset.py:55-60: cv2 image / 255.0 is a float64 array)"""
+    h, w, H, W, kind = case
+    g = torch.Generator().manual_seed(5)
+    if kind == "u8":
+        img = torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8)
+        src = img.double() / 255.0
+    else:
+        img = torch.rand(h, w, 3, generator=g)
+        src = img.double()
+    ref = F.interpolate(src.unsqueeze(0).permute(0, 3, 1, 2), (H, W), mode="bicubic", align_corners=True)[0].float()
+    out = P.bicubic_resize(img.to(DEV), H, W).cpu()
+    assert out.shape == (3, H, W)
+    assert float((out - ref).abs().max()) <= 2.4e-7, float((out - ref).abs().max())   # <= 2 ulp at 1.0
