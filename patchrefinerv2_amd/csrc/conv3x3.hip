@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo_kernel(const IgemmParams 
     step(std::integral_constant<int, 7>{});
     step(std::integral_constant<int, 8>{});
   }
-  __syncthreads();  // clamped tail DMAs must have landed before the C tile overwrites the buffers
+  // clamped tail DMAs must have landed before the C tile overwrites the buffers (explicit: see conv3x3_m16.hip)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
 #pragma unroll

@@ -356,7 +356,10 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         for (int a = 0; a < NA; ++a) mma(a, j, j & 1, pr);
     }
   }
-  __syncthreads();  // clamped tail DMAs must have landed before the C tile overwrites the buffers
+  // The clamped DMAs of the last two steps are still in flight and hipcc does not know it (they are inline asm, so
+  // __syncthreads() alone emits NO vmcnt wait): drain them by hand before the C tile overwrites the buffers.  Without
+  // this a late DMA (HBM contention from kernels on other streams) lands on top of the C tile.
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
 #pragma unroll

