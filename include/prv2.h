@@ -99,9 +99,9 @@ int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w, int32_t c
                       int32_t k, const float* bias, int32_t act, float scale, const float* res, int32_t clamp0,
                       float* y, void* stream);
 
-/* Depthwise kxk convolution (+folded BatchNorm bias, optional ReLU) for the MobileNetV4 refiner
- * encoder (timm, un-vendored; lightweight_refiner.py:260-262,296).  w: device, TAP-MAJOR [k*k][c] with
- * the BN scale already folded (so that a lane's 4 channels are one float4); bias [c]. */
+/* Depthwise kxk convolution, k in {3, 5, 7}, pad k/2 (+folded BatchNorm bias, optional ReLU) for the refiner encoders
+ * (timm, un-vendored; lightweight_refiner.py:260-262,296): MobileNetV4 (3x3 / 5x5) and ConvNeXt (7x7, conv_dw).
+ * w: device, TAP-MAJOR [k*k][c] with the BN scale already folded (so that a lane's 4 channels are one float4); bias [c]. */
 int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
                   const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy, void* stream);
 

@@ -168,3 +168,45 @@ def e2e_v2z_sd(seed: int = 47):
     spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                     f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
     return W.synth_state_dict(spec, seed=seed)
+
+
+# -- LightWeightRefiner with a ConvNeXt encoder (reduced dims; real cfg: configs/patchrefinerv2_zoedepth/v2_convx_u4k.py:90-97) ----
+CONVNEXT_REFINER = dict(arch=W.CONVNEXT_TINY_TEST, seed=53, in_seed=540, b=2, h=64, w=96)
+
+
+def convnext_refiner_sd(arch=None, seed=None, prefix=""):
+    arch = arch or CONVNEXT_REFINER["arch"]
+    spec = W.convnext_spec(prefix + "refiner_encoder.", arch, in_chans=4)
+    spec[prefix + "upsample_convx.0.weight"] = (arch["dims"][0], arch["dims"][0] // 2, 2, 2)
+    spec[prefix + "upsample_convx.0.bias"] = (arch["dims"][0] // 2,)
+    return W.synth_state_dict(spec, seed=CONVNEXT_REFINER["seed"] if seed is None else seed)
+
+
+def convnext_refiner_inputs(c=None):
+    c = c or CONVNEXT_REFINER
+    crop = rand_image(c["in_seed"], c["b"], c["h"], c["w"])
+    depth = torch.rand(c["b"], 1, c["h"], c["w"], generator=torch.Generator().manual_seed(c["in_seed"] + 1)) * 10
+    return crop, depth
+
+
+# -- end-to-end V2 with the ConvNeXt refiner encoder (configs/patchrefinerv2_zoedepth/v2_convx_u4k.py:90-104), reduced dims
+_CX = W.CONVNEXT_TINY_TEST
+E2E_V2CX = dict(E2E_V2, arch=_CX, modes=["m1", "r4"],
+                fusion=dict(E2E_V2["fusion"], fine_chl=[_CX["dims"][0] // 2] + list(_CX["dims"])))
+E2E_V2CX["ref_config"] = {**E2E_V2["ref_config"], "refiner": dict(
+    fine_branch=dict(type="LightWeightRefiner", coarse_condition=True, with_decoder=False, encoder_name="convnext_large",
+                     encoder_channels=[_CX["dims"][0] // 2] + list(_CX["dims"]), arch=_CX),
+    fusion_model=dict(type="BiDirectionalFusion", encoder_name="convnext_large", coarse2fine=True,
+                      coarse2fine_type="coarse-gated", **E2E_V2CX["fusion"]))}
+
+
+def e2e_v2cx_sd(seed: int = 59):
+    spec = OrderedDict()
+    spec.update(W.dav2_spec("coarse_branch.", _E2E2_DA2))
+    spec.update(W.convnext_spec("refiner_fine_branch.refiner_encoder.", _CX, in_chans=4))
+    spec["refiner_fine_branch.upsample_convx.0.weight"] = (_CX["dims"][0], _CX["dims"][0] // 2, 2, 2)
+    spec["refiner_fine_branch.upsample_convx.0.bias"] = (_CX["dims"][0] // 2,)
+    f = E2E_V2CX["fusion"]
+    spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
+                                    f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
+    return W.synth_state_dict(spec, seed=seed)

@@ -10,6 +10,7 @@ from __future__ import annotations
 import json
 import os
 import random
+import re
 import sys
 
 import numpy as np
@@ -494,6 +495,58 @@ def g_output_stage():
     out.update(see_r2=see)
     np.savez_compressed(os.path.join(OUT, "output_stage.npz"), **out)
     print("  wrote output_stage.npz", {k: float(v) for k, v in m1.items()})
+
+
+def g_convnext():
+    """LightWeightRefiner (reference class, convnext branch) over HuggingFace transformers' ConvNext as the stand-in for
+    timm.create_model('convnext_large', features_only=True): pins the block arithmetic of oracle/convnext.py against an
+    independent implementation of the published architecture and the wrapper (upsample_convx, 2x copy, order) against
+    the reference's own code."""
+    print("[convnext]")
+    import timm
+    from transformers import ConvNextConfig, ConvNextModel
+    from oracle import convnext as o_cx
+    from oracle.cases import CONVNEXT_REFINER, convnext_refiner_sd, convnext_refiner_inputs
+    arch = CONVNEXT_REFINER["arch"]
+    sd = convnext_refiner_sd()
+
+    class Enc(torch.nn.Module):
+        default_cfg = dict(mean=arch["mean"], std=arch["std"])
+
+        def __init__(self):
+            super().__init__()
+            self.hf = ConvNextModel(ConvNextConfig(num_channels=4, hidden_sizes=list(arch["dims"]), depths=list(arch["depths"])))
+
+        def forward(self, x):
+            return list(self.hf(x, output_hidden_states=True).hidden_states[1:])  # the four stage outputs, no final norm
+
+    timm.create_model = lambda name, pretrained=True, features_only=True: Enc()
+    lwr = refharness.ref_module("estimator.models.blocks.lightweight_refiner")
+    d0 = arch["dims"][0]
+    m = lwr.LightWeightRefiner("convnext_large", True, encoder_channels=[d0 // 2] + list(arch["dims"])).eval()
+
+    def hf_name(k):  # timm (flattened features_only) -> transformers
+        k = k.replace("stem_0.", "embeddings.patch_embeddings.").replace("stem_1.", "embeddings.layernorm.")
+        k = re.sub(r"stages_(\d)\.downsample\.", r"encoder.stages.\1.downsampling_layer.", k)
+        k = re.sub(r"stages_(\d)\.blocks\.(\d+)\.", r"encoder.stages.\1.layers.\2.", k)
+        return (k.replace(".gamma", ".layer_scale_parameter").replace("conv_dw.", "dwconv.").replace(".norm.", ".layernorm.")
+                .replace("mlp.fc1.", "pwconv1.").replace("mlp.fc2.", "pwconv2."))
+
+    ep = "refiner_encoder."
+    hf_sd = {hf_name(k[len(ep):]): v for k, v in sd.items() if k.startswith(ep)}
+    res = m.refiner_encoder.hf.load_state_dict(hf_sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("layernorm.") for k in res.missing_keys), res  # final norm: unused
+    m.upsample_convx[0].weight.data.copy_(sd["upsample_convx.0.weight"])
+    m.upsample_convx[0].bias.data.copy_(sd["upsample_convx.0.bias"])
+    crop, depth = convnext_refiner_inputs()
+    feats, out_depth = m(crop, depth)
+    o_feats, o_out = o_cx.lightweight_refiner_convnext(sd, "", crop, depth, arch)
+    assert len(feats) == len(o_feats) == 6 and float(out_depth.abs().max()) == 0.0 and o_out.shape == out_depth.shape
+    for i, (a, b) in enumerate(zip(feats, o_feats)):
+        d = maxdiff(a, b)
+        print(f"  feat {i}: {tuple(a.shape)} |x|max {float(a.abs().max()):.2f} oracle-vs-ref max|d| {d:.2e}")
+        assert a.shape == b.shape and d < 1e-4 * max(1.0, float(a.abs().max())), d
+    save("convnext_refiner", **{f"feat{i}": f for i, f in enumerate(feats)})
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ import random
 
 import torch
 
-from . import dav2, fusion, mnv4
+from . import convnext, dav2, fusion, mnv4
 from .ops import bilinear_ac, generatemask, nearest, resize_da, resize_zoe, roi_align
 
 
@@ -218,10 +218,11 @@ class OraclePatchRefinerPlus(OracleRefiner):
     """V2: DA2 coarse + LightWeightRefiner(MNv4-S) + BiDirectionalFusion
     (configs/patchrefinerv2_dav2/plus_mobile_u4k_base_coarse_e2e_c2f_pretrain.py)."""
 
-    def __init__(self, sd, coarse_cfg, coarse_fn=None, **kw):
+    def __init__(self, sd, coarse_cfg, coarse_fn=None, convnext_arch=None, **kw):
         super().__init__(sd, **kw)
         self.coarse_cfg = coarse_cfg
         self.coarse_fn = coarse_fn
+        self.convnext_arch = convnext_arch  # set: the v2_convx_u4k.py variant (ConvNeXt refiner encoder)
 
     def coarse_forward(self, image_lr):
         if self.coarse_fn is not None:
@@ -229,8 +230,12 @@ class OraclePatchRefinerPlus(OracleRefiner):
         return dav2.coarse_features(dav2.dav2_forward(self.sd, "coarse_branch.", image_lr, self.coarse_cfg))
 
     def infer_forward(self, imgs_crop, post):
-        r_feats, r_depth = mnv4.lightweight_refiner(self.sd, "refiner_fine_branch.", imgs_crop,
-                                                    post["coarse_depth_roi"])
+        if self.convnext_arch is not None:
+            r_feats, r_depth = convnext.lightweight_refiner_convnext(self.sd, "refiner_fine_branch.", imgs_crop,
+                                                                     post["coarse_depth_roi"], self.convnext_arch)
+        else:
+            r_feats, r_depth = mnv4.lightweight_refiner(self.sd, "refiner_fine_branch.", imgs_crop,
+                                                        post["coarse_depth_roi"])
         return fusion.bidirectional_fusion(self.sd, "refiner_fusion_model.", post["coarse_feats_roi"][::-1],
                                            r_feats[::-1], post["coarse_depth_roi"], r_depth,
                                            update_base=post["coarse_depth_roi"])

@@ -406,7 +406,7 @@ extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, in
                              void* stream) {
   PRV2_REQUIRE(x && wgt && y, "dwconv2d: null pointer");
   PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= c && ldy >= c &&
-                   (k == 3 || k == 5) && (stride == 1 || stride == 2),
+                   (k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2),
                "dwconv2d: bad geometry c=%d k=%d stride=%d", c, k, stride);
   PRV2_REQUIRE(aligned16(x) && aligned16(y) && aligned16(wgt), "dwconv2d: pointers must be 16-byte aligned");
   int oh = (h + 2 * (k / 2) - k) / stride + 1, ow = (w + 2 * (k / 2) - k) / stride + 1;

@@ -1,4 +1,4 @@
-"""LightWeightRefiner (V2 per-patch encoder) on the HIP kernels.
+"""LightWeightRefiner (V2 per-patch encoder) on the HIP kernels: MobileNetV4-conv-small and ConvNeXt-L encoders.
 
 Host-side mirror of ``LightWeightRefiner`` (estimator/models/blocks/lightweight_refiner.py:242-322)
 with ``with_decoder=False`` and the ``mobilenetv4_conv_small`` encoder after the reference's
@@ -8,6 +8,10 @@ The encoder arithmetic is timm's (``timm.create_model(..., features_only=True)``
 lightweight_refiner.py:260-262) -- timm is not vendored in the reference: the architecture
 is restated from the public MobileNetV4 definition (weights.py::MNV4_SMALL) and is PARITY
 UNPINNED.  BatchNorm (eval) is folded into the preceding convolution at load time.
+
+``convnext_large`` (configs/patchrefinerv2_zoedepth/v2_convx_u4k.py:90-101; stem surgery patchrefinerplus.py:194-200;
+``upsample_convx`` lightweight_refiner.py:277-283,307-313): block arithmetic pinned against HuggingFace transformers'
+ConvNext through the reference's own LightWeightRefiner class (tests/golden/convnext_refiner.npz).
 """
 from __future__ import annotations
 
@@ -21,32 +25,43 @@ from .dav2 import StateDictModule
 from .ops import ACT_NONE, ACT_RELU, Feat
 
 BN_EPS = 1e-5
-SUPPORTED_ENCODERS = {"mobilenetv4_conv_small.e2400_r224_in1k": W.MNV4_SMALL, "mobilenetv4_conv_small": W.MNV4_SMALL}
+SUPPORTED_ENCODERS = {"mobilenetv4_conv_small.e2400_r224_in1k": W.MNV4_SMALL, "mobilenetv4_conv_small": W.MNV4_SMALL,
+                      "convnext_large": W.CONVNEXT_LARGE}
+LN_EPS = 1e-6
 
 
 class LightWeightRefiner(StateDictModule):
     def __init__(self, encoder_name, coarse_condition=True, with_decoder=False, cls_pretrain=True, device="cuda",
-                 prec="f32", **_unused):
+                 prec="f32", arch=None, **_unused):
         super().__init__()
         if encoder_name not in SUPPORTED_ENCODERS:
             raise NotImplementedError(
-                f"refiner encoder '{encoder_name}': only mobilenetv4_conv_small is built (EfficientNet-B5-AP / "
-                "ConvNeXt-L are timm models not vendored in the reference; SURVEY.md 8f rank 3)")
+                f"refiner encoder '{encoder_name}': mobilenetv4_conv_small and convnext_large are built "
+                "(EfficientNet-B5-AP is a timm model not vendored in the reference; SURVEY.md 8f rank 3)")
         if with_decoder or not coarse_condition:
             raise NotImplementedError("with_decoder=True / coarse_condition=False are not used by any V2 config")
         self.encoder_name = encoder_name
-        self.arch = SUPPORTED_ENCODERS[encoder_name]
+        self.arch = arch or SUPPORTED_ENCODERS[encoder_name]  # ``arch``: reduced dims for the parity tests
         self.coarse_condition = True
         self.device = torch.device(device)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
-        self.layers, self.taps = W.mnv4_layers(self.arch, in_chans=4)
-        self._spec = W.mnv4_spec("refiner_encoder.", self.arch, in_chans=4)
         self.mean, self.std = self.arch["mean"], self.arch["std"]
         self._packed = None
+        self.convnext = "convnext" in encoder_name
+        if self.convnext:
+            d0 = self.arch["dims"][0]
+            self._spec = W.convnext_spec("refiner_encoder.", self.arch, in_chans=4)
+            self._spec["upsample_convx.0.weight"] = (d0, d0 // 2, 2, 2)
+            self._spec["upsample_convx.0.bias"] = (d0 // 2,)
+            return
+        self.layers, self.taps = W.mnv4_layers(self.arch, in_chans=4)
+        self._spec = W.mnv4_spec("refiner_encoder.", self.arch, in_chans=4)
 
     def _pack(self):
         if len(self._sd) < len(self._spec):
             return
+        if self.convnext:
+            return self._pack_convnext()
         P = []
         for Lr in self.layers:
             b = "refiner_encoder." + Lr["bn"] + "."
@@ -69,6 +84,8 @@ class LightWeightRefiner(StateDictModule):
         [None(2x copy placeholder), /2, /4, /8, /16, /32], sizes) -- out_depth is zeros (:320)."""
         if self._packed is None:
             raise RuntimeError("LightWeightRefiner: weights not loaded")
+        if self.convnext:
+            return self._forward_convnext(crop)
         x = crop
         feats: List[Feat] = []
         skip = None
@@ -87,5 +104,51 @@ class LightWeightRefiner(StateDictModule):
                 feats.append(x)
         sizes = [(feats[0].h * 2, feats[0].w * 2)] + [(f.h, f.w) for f in feats]
         return [None] + feats, sizes
+
+    # -- ConvNeXt ------------------------------------------------------------------------------------------
+    def _pack_convnext(self):
+        sd, dev, e = self._sd, self.device, "refiner_encoder."
+        pk = lambda w, b, **kw: ops.pack_conv(w, b, device=dev, prec=self.prec, **kw)  # noqa: E731
+        v = lambda k: sd[k].to(dev).contiguous()  # noqa: E731
+        P = dict(stem=pk(sd[e + "stem_0.weight"], sd[e + "stem_0.bias"], stride=4, pad=0),
+                 stem_ln=(v(e + "stem_1.weight"), v(e + "stem_1.bias")), stages=[])
+        for i, (c, n) in enumerate(zip(self.arch["dims"], self.arch["depths"])):
+            st = f"{e}stages_{i}."
+            S = dict(blocks=[])
+            if i > 0:
+                S["down_ln"] = (v(st + "downsample.0.weight"), v(st + "downsample.0.bias"))
+                S["down"] = pk(sd[st + "downsample.1.weight"], sd[st + "downsample.1.bias"], stride=2, pad=0)
+            for j in range(n):
+                b = f"{st}blocks.{j}."
+                S["blocks"].append(dict(
+                    dw=sd[b + "conv_dw.weight"].view(c, 49).t().contiguous().to(dev), dw_b=v(b + "conv_dw.bias"),
+                    ln=(v(b + "norm.weight"), v(b + "norm.bias")),
+                    fc1=pk(sd[b + "mlp.fc1.weight"].view(4 * c, c, 1, 1), sd[b + "mlp.fc1.bias"]),
+                    fc2=pk(sd[b + "mlp.fc2.weight"].view(c, 4 * c, 1, 1), sd[b + "mlp.fc2.bias"]), gamma=v(b + "gamma")))
+            P["stages"].append(S)
+        P["up"] = ops.pack_conv(sd["upsample_convx.0.weight"], sd["upsample_convx.0.bias"], convt_k=2, device=dev, prec=self.prec)
+        self._packed = P
+
+    def _forward_convnext(self, crop: Feat):
+        """dw 7x7 -> LN -> fc1 + GELU -> fc2, * gamma, + x: the dw conv and the LN are HBM-bound row kernels, the two
+        linears run on the 1x1 GEMM kernel with GELU / layer-scale / residual fused into their epilogues."""
+        P = self._packed
+        x = ops.conv2d(crop, P["stem"])
+        ops.layernorm_feat(x, *P["stem_ln"], eps=LN_EPS)
+        feats: List[Feat] = []
+        for S in P["stages"]:
+            if "down" in S:
+                t = ops.layernorm_feat(x, *S["down_ln"], eps=LN_EPS, out=Feat.alloc(x.n, x.h, x.w, x.c, x.device))
+                x = ops.conv2d(t, S["down"])
+            for B in S["blocks"]:
+                t = ops.dwconv2d(x, B["dw"], B["dw_b"], 7, 1, False)
+                ops.layernorm_feat(t, *B["ln"], eps=LN_EPS)
+                u = ops.conv2d(t, B["fc1"], act=ops.ACT_GELU)
+                x = ops.conv2d(u, B["fc2"], gamma=B["gamma"], res=x)
+            feats.append(x)
+        up = ops.conv2d(feats[0], P["up"], act=ACT_RELU)  # upsample_convx: ConvTranspose2d(k=2, s=2) + ReLU
+        feats = [up] + feats
+        sizes = [(up.h * 2, up.w * 2)] + [(f.h, f.w) for f in feats]
+        return [None] + feats, sizes  # the stride-1 bilinear copy of ``up`` is dropped by the fusion model
 
     __call__ = forward

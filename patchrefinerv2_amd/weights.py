@@ -359,6 +359,43 @@ def mnv4_spec(prefix: str, arch: dict = MNV4_SMALL, in_chans: int = 4) -> Spec:
         _bn_spec(s, prefix + L["bn"] + ".", L["cout"])
     return s
 
+# ConvNeXt-L (timm ``convnext_large``, features_only): stem = Conv 4x4 stride 4 + LayerNorm2d, four stages of
+# [LayerNorm2d + Conv 2x2 stride 2 (stages 1..3)] + depth x block(dw 7x7 -> LN -> Linear 4C -> GELU -> Linear C ->
+# gamma -> + x), every LayerNorm with eps 1e-6, feature taps = the four stage outputs (no final norm).  timm is not
+# vendored in the reference: the arithmetic is pinned against the independent implementation in HuggingFace
+# ``transformers`` (oracle/make_golden.py::g_convnext); the flattened timm key names (``stem_0`` is confirmed by the
+# reference's stem surgery, patchrefinerplus.py:194-200; the rest follows timm's FeatureListNet) are unpinned.
+CONVNEXT_LARGE = dict(dims=(192, 384, 768, 1536), depths=(3, 3, 27, 3), mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
+CONVNEXT_TINY_TEST = dict(dims=(16, 32, 64, 128), depths=(1, 1, 2, 1), mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
+
+
+def convnext_spec(prefix: str, arch: dict = CONVNEXT_LARGE, in_chans: int = 4) -> Spec:
+    s: Spec = OrderedDict()
+    d = arch["dims"]
+    s[prefix + "stem_0.weight"] = (d[0], in_chans, 4, 4)
+    s[prefix + "stem_0.bias"] = (d[0],)
+    s[prefix + "stem_1.weight"] = (d[0],)
+    s[prefix + "stem_1.bias"] = (d[0],)
+    for i, (c, n) in enumerate(zip(d, arch["depths"])):
+        st = f"{prefix}stages_{i}."
+        if i > 0:
+            s[st + "downsample.0.weight"] = (d[i - 1],)
+            s[st + "downsample.0.bias"] = (d[i - 1],)
+            s[st + "downsample.1.weight"] = (c, d[i - 1], 2, 2)
+            s[st + "downsample.1.bias"] = (c,)
+        for j in range(n):
+            b = f"{st}blocks.{j}."
+            s[b + "gamma"] = (c,)
+            s[b + "conv_dw.weight"] = (c, 1, 7, 7)
+            s[b + "conv_dw.bias"] = (c,)
+            s[b + "norm.weight"] = (c,)
+            s[b + "norm.bias"] = (c,)
+            s[b + "mlp.fc1.weight"] = (4 * c, c)
+            s[b + "mlp.fc1.bias"] = (4 * c,)
+            s[b + "mlp.fc2.weight"] = (c, 4 * c)
+            s[b + "mlp.fc2.bias"] = (c,)
+    return s
+
 
 # ----------------------------------------------------------------------------
 # synthetic weights
@@ -381,7 +418,9 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
         return torch.zeros(shape)
     n = int(np.prod(shape)) if len(shape) else 1
     z = g.standard_normal(n).astype(np.float32).reshape(shape)
-    if leaf == "gamma":  # LayerScale
+    if leaf == "gamma" and ".stages_" in name:  # ConvNeXt layer scale: 36 residual blocks deep -- keep the trunk O(1)
+        v = 0.15 + 0.02 * z
+    elif leaf == "gamma":  # LayerScale
         v = 1.0 + 0.05 * z
     elif leaf == "running_var":
         v = 1.0 + 0.1 * np.abs(z)
@@ -418,7 +457,7 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
 
 
 def _is_norm(name: str) -> bool:
-    return any(t in name for t in (".norm", "norm1", "norm2", "single_conv.1", "fusion_conv.1", ".bn"))
+    return any(t in name for t in (".norm", "norm1", "norm2", "single_conv.1", "fusion_conv.1", ".bn", "stem_1.", "downsample.0."))
 
 
 def synth_state_dict(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":

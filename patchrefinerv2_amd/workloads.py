@@ -48,7 +48,15 @@ BIDIR_ZOE = dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64,
                  dec_chl=[512, 256, 128, 64, 32])
 WORKLOADS["v2_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 518], mode="r32",
                                     coarse=None, zoe=ZOE_DA_L, fusion=BIDIR_ZOE, patches=81)
+# configs/patchrefinerv2_zoedepth/v2_convx_u4k.py: the same model with the ConvNeXt-L refiner encoder (fine_chl :101).
+# The 4x4-stride-4 stem needs P % 4 == 0 on top of the ViT's P % 14 == 0 (the prediction is 4 * floor(P / 4) wide, in the
+# reference as well) -> 392 x 504.
+BIDIR_ZOE_CONVX = dict(BIDIR_ZOE, fine_chl=[96, 192, 384, 768, 1536])
+WORKLOADS["v2_convx_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 504], mode="r32",
+                                          coarse=None, zoe=dict(ZOE_DA_L, img_size=[392, 504]), fusion=BIDIR_ZOE_CONVX, patches=81,
+                                          refiner_encoder="convnext_large")
 DEFAULT_WORKLOAD = "v2_zoeda_4k_r32"
+MNV4_NAME = "mobilenetv4_conv_small.e2400_r224_in1k"
 
 
 def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> dict:
@@ -65,9 +73,9 @@ def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> d
         cfg.update(e2e_training=True, pretrain_stage=False, gmloss=dict(type="GradMatchLoss"), sigweight=1,
                    whole_pretrained=None,
                    refiner=dict(fine_branch=dict(type="LightWeightRefiner", coarse_condition=True, with_decoder=False,
-                                                 encoder_name="mobilenetv4_conv_small.e2400_r224_in1k"),
+                                                 encoder_name=w.get("refiner_encoder", MNV4_NAME)),
                                 fusion_model=dict(type="BiDirectionalFusion",
-                                                  encoder_name="mobilenetv4_conv_small.e2400_r224_in1k",
+                                                  encoder_name=w.get("refiner_encoder", MNV4_NAME),
                                                   coarse2fine=True, coarse2fine_type="coarse-gated", **w["fusion"])))
     else:
         cfg.update(pretrain_fine_model=None,
@@ -84,7 +92,13 @@ def state_spec(name: str) -> "OrderedDict[str, tuple]":
     else:
         s.update(W.dav2_spec("coarse_branch.", w["coarse"]))
     if w["kind"] == "PatchRefinerPlus":
-        s.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
+        if "convnext" in w.get("refiner_encoder", ""):
+            s.update(W.convnext_spec("refiner_fine_branch.refiner_encoder.", W.CONVNEXT_LARGE, in_chans=4))
+            d0 = W.CONVNEXT_LARGE["dims"][0]
+            s["refiner_fine_branch.upsample_convx.0.weight"] = (d0, d0 // 2, 2, 2)
+            s["refiner_fine_branch.upsample_convx.0.bias"] = (d0 // 2,)
+        else:
+            s.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
         f = w["fusion"]
         s.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                      f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))

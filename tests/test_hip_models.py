@@ -121,6 +121,47 @@ def test_lightweight_refiner(P):
         close(got.to_nchw(), ref, 3e-5, f"mnv4 {tuple(ref.shape)}")
 
 
+def _convnext_input(arch, img, depth):
+    mean = torch.tensor(arch["mean"]).view(1, 3, 1, 1)
+    std = torch.tensor(arch["std"]).view(1, 3, 1, 1)
+    return torch.cat([(img - mean) / std, depth], dim=1)
+
+
+def test_lightweight_refiner_convnext_golden(P, golden):
+    """reduced-width ConvNeXt encoder + upsample_convx against the reference's LightWeightRefiner (over transformers' ConvNext)."""
+    from oracle.cases import CONVNEXT_REFINER, convnext_refiner_inputs, convnext_refiner_sd
+    from patchrefinerv2_amd.refiner import LightWeightRefiner
+    arch = CONVNEXT_REFINER["arch"]
+    m = LightWeightRefiner("convnext_large", coarse_condition=True, arch=arch)
+    m.load_state_dict(convnext_refiner_sd(), strict=True)
+    img, depth = convnext_refiner_inputs()
+    feats, sizes = m(P.Feat.from_nchw(_convnext_input(arch, img, depth).to(DEV)))
+    g = golden("convnext_refiner")  # feat0 = stride 32 ... feat4 = stride 2 (upsample_convx), feat5 = its 2x copy (dropped)
+    assert feats[0] is None and sizes[0] == tuple(g["feat5"].shape[-2:])
+    for i, got in enumerate(feats[1:]):
+        ref = g[f"feat{4 - i}"]
+        assert sizes[i + 1] == tuple(ref.shape[-2:])
+        close(got.to_nchw(), ref, 3e-5, f"convnext feat{4 - i}")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_lightweight_refiner_convnext_large_width(P, prec):
+    """real ConvNeXt-L widths (192..1536), depths cut to (2,2,3,2), a 128x160 patch: every kernel shape of the full encoder."""
+    from oracle import convnext as o_cx
+    from oracle.cases import convnext_refiner_sd
+    from patchrefinerv2_amd.refiner import LightWeightRefiner
+    arch = dict(W.CONVNEXT_LARGE, depths=(2, 2, 3, 2))
+    sd = convnext_refiner_sd(arch, seed=11)
+    m = LightWeightRefiner("convnext_large", coarse_condition=True, arch=arch, prec=prec)
+    m.load_state_dict(sd, strict=True)
+    img = rand_image(12, 2, 128, 160)
+    depth = torch.rand(2, 1, 128, 160, generator=torch.Generator().manual_seed(13)) * 40
+    ref_feats, _ = o_cx.lightweight_refiner_convnext(sd, "", img, depth, arch)
+    feats, _ = m(P.Feat.from_nchw(_convnext_input(arch, img, depth).to(DEV)))
+    for got, ref in zip(feats[1:], ref_feats[::-1][1:]):
+        close(got.to_nchw(), ref, 5e-5, f"convnext-L {tuple(ref.shape)}")
+
+
 def _build(kind, c, sd, **extra):
     from patchrefinerv2_amd.models import PatchRefiner, PatchRefinerPlus  # noqa: F401
     from patchrefinerv2_amd.registry import build_model
@@ -165,6 +206,24 @@ def test_e2e_v2_vs_reference_golden(P, golden):
         assert tuple(depth.shape) == tuple(g[mode].shape)
         ar, mx = absrel(depth, g[mode])
         assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)
+
+
+def test_e2e_v2_convnext_refiner_vs_oracle(P):
+    """PatchRefinerPlus with the ConvNeXt refiner encoder (v2_convx_u4k.py) end to end; the encoder itself is pinned by
+    test_lightweight_refiner_convnext_golden, everything around it by the e2e_v2 goldens."""
+    from oracle.cases import E2E_V2CX, e2e_v2cx_sd
+    c, sd = E2E_V2CX, e2e_v2cx_sd()
+    m = _build("PatchRefinerPlus", c, sd)
+    ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}), convnext_arch=c["arch"],
+                                          patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+    hr = rand_image(c["seed"], 1, *c["raw"])
+    tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+    for mode in c["modes"]:
+        random.seed(621)
+        ref, _ = ora(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tc, image_lr=ora.resizer(hr), image_hr=hr)
+        depth, _ = _run(m, c, mode)
+        ar, mx = absrel(depth, ref)
+        assert ar < 1e-5 and mx < 1e-3, (mode, ar, mx)
 
 
 def test_batching_independence(P):
