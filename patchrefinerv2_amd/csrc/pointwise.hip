@@ -255,6 +255,64 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
   }
 }
 
+// depthwise KxK, stride 1: one thread = 4 channels x PX consecutive output pixels of a row.  The naive kernel above issues
+// 2*K*K 16-byte loads per output float4 (load-issue bound: 7 TFLOP/s on the 7x7 ConvNeXt layers); here a row of PX + K - 1
+// inputs serves PX outputs and a weight is loaded once per PX outputs.  Same summation order per output (bias, then
+// taps row-major), out-of-image taps contribute +0.
+template <int K, int PX>
+__global__ void __launch_bounds__(256) dwconv_strip_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                           const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                           int relu, float* __restrict__ y, int ldy) {
+  constexpr int PAD = K / 2;
+  const int cg = C >> 2;
+  const int strips = (W + PX - 1) / PX;
+  const int64_t total = (int64_t)N * H * strips * cg;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % cg) * 4;
+  int64_t t = idx / cg;
+  const int sx = (int)(t % strips);
+  t /= strips;
+  const int oy = (int)(t % H), n = (int)(t / H);
+  const int ox0 = sx * PX;
+  float4 acc[PX];
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < PX; ++i) acc[i] = b4;
+#pragma unroll 1  // (fully unrolled hipcc hoists all K rows of loads: 512 VGPRs and spills)
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy + ky - PAD;
+    const bool rok = (unsigned)iy < (unsigned)H;
+    const float* row = x + (((int64_t)n * H + (rok ? iy : 0)) * W) * ldx + c;
+    float4 in[PX + K - 1];
+#pragma unroll
+    for (int i = 0; i < PX + K - 1; ++i) {
+      const int ix = ox0 + i - PAD;
+      in[i] = (rok && (unsigned)ix < (unsigned)W) ? *reinterpret_cast<const float4*>(row + (int64_t)ix * ldx)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float4 ww = *reinterpret_cast<const float4*>(wgt + (int64_t)(ky * K + kx) * C + c);
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        acc[i].x += in[i + kx].x * ww.x;
+        acc[i].y += in[i + kx].y * ww.y;
+        acc[i].z += in[i + kx].z * ww.z;
+        acc[i].w += in[i + kx].w * ww.w;
+      }
+    }
+  }
+  float* out = y + (((int64_t)n * H + oy) * W + ox0) * ldy + c;
+#pragma unroll
+  for (int i = 0; i < PX; ++i) {
+    if (ox0 + i >= W) break;
+    float4 v = acc[i];
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    *reinterpret_cast<float4*>(out + (int64_t)i * ldy) = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
                                                   int ldb, int64_t rows, int C, float* __restrict__ y, int ldy) {
   int64_t total = rows * C;
@@ -411,6 +469,17 @@ extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, in
   PRV2_REQUIRE(aligned16(x) && aligned16(y) && aligned16(wgt), "dwconv2d: pointers must be 16-byte aligned");
   int oh = (h + 2 * (k / 2) - k) / stride + 1, ow = (w + 2 * (k / 2) - k) / stride + 1;
   int64_t total = (int64_t)n * oh * ow * (c / 4);
+  if (stride == 1 && w >= 8) {  // strip kernel: 8 output pixels per thread
+    constexpr int PX = 8;
+    const int64_t threads = (int64_t)n * h * ((w + PX - 1) / PX) * (c / 4);
+    PRV2_REQUIRE((threads + 255) / 256 < (1LL << 31), "dwconv2d: too large");
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<3, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, relu, y, ldy);
+    else if (k == 5) hipLaunchKernelGGL((dwconv_strip_kernel<5, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, relu, y, ldy);
+    else hipLaunchKernelGGL((dwconv_strip_kernel<7, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, relu, y, ldy);
+    PRV2_LAUNCH_CHECK("dwconv2d");
+    return 0;
+  }
   hipLaunchKernelGGL(dwconv_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt,
                      bias, k, stride, relu, oh, ow, y, ldy);
   PRV2_LAUNCH_CHECK("dwconv2d");

@@ -177,3 +177,68 @@ class Tester:
             from .metrics import evaluate
             self.last_eval = evaluate([r["metrics"] for r in results])
         return results
+
+    @torch.no_grad()
+    def benchmark(self, cai_mode="m1", process_num=4, image_raw_shape=(2160, 3840), patch_split_num=(4, 4), repeat_times=10,
+                  log_interval=10, num_warmup=20, total_iters=50, seed=None):
+        """The reference's own throughput protocol (estimator/tester/tester.py:325-406): ``repeat_times`` passes over the
+        dataloader, each timing frames ``num_warmup`` .. ``total_iters`` one by one (synchronize, perf_counter, model(...),
+        synchronize), fps = frames / summed time; reports the mean and variance over the passes plus the model's FLOPs and
+        parameter count (mmengine's get_model_complexity_info there; here the per-launch algorithmic 2*MAC accounting of
+        ops.PROFILER and the state-dict spec) and writes ``<work_dir>/benchmark.txt``.  The dataset is cycled when it holds
+        fewer than ``total_iters`` frames (the reference simply stops early and divides by zero)."""
+        import random
+        import time
+        from . import ops
+        n = len(self.dataloader)
+        if n == 0:
+            raise ValueError("benchmark: empty dataset")
+        tile_cfg = dict(image_raw_shape=list(image_raw_shape), patch_split_num=list(patch_split_num))
+        items = {}
+
+        def frame(i):
+            if i % n not in items:  # decode + device resize once per file: the reference times model(...) only
+                hr = self.dataloader[i % n]["image_hr"].unsqueeze(0).cuda()
+                items[i % n] = (hr, self.model.resizer(hr))
+            return items[i % n]
+
+        bench = dict(unit="img / s")
+        fps_list = []
+        for rep in range(repeat_times):
+            pure = 0.0
+            for i in range(total_iters):
+                hr, lr = frame(i)
+                if seed is not None:
+                    random.seed(seed)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                self.model(mode="infer", cai_mode=cai_mode, process_num=process_num, tile_cfg=tile_cfg, image_lr=lr, image_hr=hr)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                if i >= num_warmup:
+                    pure += dt
+                    if (i + 1) % log_interval == 0 and self.runner_info.rank == 0:
+                        print(f"Done image [{i + 1:<3}/ {total_iters}], fps: {(i + 1 - num_warmup) / pure:.3f} img / s")
+            fps = (total_iters - num_warmup) / pure
+            bench[f"overall_fps_{rep + 1}"] = round(fps, 2)
+            fps_list.append(fps)
+        bench["average_fps"] = round(float(np.mean(fps_list)), 2)
+        bench["fps_variance"] = round(float(np.var(fps_list)), 4)
+        hr, lr = frame(0)
+        ops.PROFILER.start()
+        self.model(mode="infer", cai_mode=cai_mode, process_num=process_num, tile_cfg=tile_cfg, image_lr=lr, image_hr=hr)
+        torch.cuda.synchronize()
+        ops.PROFILER.stop()
+        summ = ops.PROFILER.summary()
+        bench["flops"] = float(sum(d["flops"] for d in summ.values()))
+        bench["params"] = int(sum(int(np.prod(shp)) for shp in self.model.spec().values()))
+        if self.runner_info.rank == 0:
+            os.makedirs(self.runner_info.work_dir, exist_ok=True)
+            with open(os.path.join(self.runner_info.work_dir, "benchmark.txt"), "w") as f:
+                f.write("kernel, launches, GFLOP (2*MAC) per frame\n")
+                for tag, d in sorted(summ.items(), key=lambda kv: -kv[1]["flops"]):
+                    f.write(f"{tag}, {d['launches']}, {d['flops'] / 1e9:.1f}\n")
+                f.write(f"\nModel Flops: {bench['flops'] / 1e12:.3f} T per frame\nModel Parameters: {bench['params'] / 1e6:.1f} M\n")
+                f.write(f"\n\n Average fps of {repeat_times} evaluations: {bench['average_fps']}")
+                f.write(f"\n\n The variance of {repeat_times} evaluations: {bench['fps_variance']}\n")
+        return bench

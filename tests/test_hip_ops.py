@@ -130,11 +130,18 @@ def test_conv_cout1_and_dw(P):
     close(P.conv2d_cout1(xf, w.to(DEV), None, 3, res=base.to(DEV), clamp0=True), ref, 1e-5)
     w1, b1 = rnd(4, 1, 32, 1, 1) / 6, rnd(5, 1)
     close(P.conv2d_cout1(xf, w1.to(DEV), b1.to(DEV), 1, act=P.ACT_SIGMOID, scale=80.0), torch.sigmoid(F.conv2d(x, w1, b1)) * 80, 1e-5)
-    for k, s in ((3, 1), (3, 2), (5, 1), (5, 2)):
+    for k, s in ((3, 1), (3, 2), (5, 1), (5, 2), (7, 1), (7, 2)):
         wd, bd = rnd(6, 32, 1, k, k) / k, rnd(7, 32)
         refd = F.relu(F.conv2d(x, wd, bd, stride=s, padding=k // 2, groups=32))
         wt = wd.view(32, k * k).t().contiguous().to(DEV)
         close(P.dwconv2d(xf, wt, bd.to(DEV), k, s, True).to_nchw(), refd, 1e-5, f"dw k{k}s{s}")
+    # stride-1 strip kernel (8 pixels per thread): ragged widths (W % 8 != 0, W < 8 -> naive kernel), no ReLU, no bias
+    for k, (h, w_), c in ((7, (9, 31), 192), (7, (5, 8), 48), (5, (6, 13), 64), (3, (4, 7), 32), (7, (12, 15), 1536)):
+        xs = rnd(8, 2, c, h, w_)
+        wd = rnd(9, c, 1, k, k) / k
+        refd = F.conv2d(xs, wd, None, padding=k // 2, groups=c)
+        wt = wd.view(c, k * k).t().contiguous().to(DEV)
+        close(P.dwconv2d(P.Feat.from_nchw(xs.to(DEV)), wt, None, k, 1, False).to_nchw(), refd, 1e-5, f"dw strip k{k} {h}x{w_}x{c}")
 
 
 @pytest.mark.parametrize("c", [32, 98, 256, 384, 1024])

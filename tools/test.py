@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3"])
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--seed", type=int, default=621)
+    ap.add_argument("--benchmark", action="store_true", help="Tester.benchmark (estimator/tester/tester.py:325) instead of run")
+    ap.add_argument("--repeat-times", type=int, default=10)
+    ap.add_argument("--benchmark-iters", nargs=2, type=int, default=[20, 50], metavar=("WARMUP", "TOTAL"))
     args = ap.parse_args()
     if args.test_type != "general":
         raise SystemExit("only --test-type general (folder of images, optional .npy ground truth via dataset gt_dir) is built")
@@ -75,6 +78,14 @@ def main():
     dataset = DATASETS.build(ds_cfg)
     runner = RunnerInfo(rank=rank, world_size=world, save=args.save, gray_scale=args.gray_scale, work_dir=args.work_dir)
     tester = Tester(cfg, runner, dataset, model)
+    if args.benchmark:
+        b = tester.benchmark(cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
+                             patch_split_num=args.patch_split_num, repeat_times=args.repeat_times,
+                             num_warmup=args.benchmark_iters[0], total_iters=args.benchmark_iters[1], seed=args.seed)
+        print(f"Average fps of {args.repeat_times} evaluations: {b['average_fps']}")
+        print(f"The variance of {args.repeat_times} evaluations: {b['fps_variance']}")
+        print(f"Model Flops: {b['flops'] / 1e12:.3f} T  Model Parameters: {b['params'] / 1e6:.1f} M")
+        return
     for r in tester.run(cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
                         patch_split_num=args.patch_split_num, seed=args.seed):
         print(f"[rank {rank}] {r['name']}: depth {r['shape']} mean {r['mean']:.4f}")
