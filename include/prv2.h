@@ -24,9 +24,10 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 2
+#define PRV2_ABI_VERSION 3
 
-enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4 };
+enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
+                PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
 
 /* arithmetic of the matrix kernels */
 enum prv2_prec {
@@ -75,6 +76,10 @@ typedef struct prv2_conv_desc {
   int32_t part;          /* f32 mode: 3x3 halo convs whose width is 32k + (1..8) run as 32-pixel tiles + a remainder strip
                           * (generic kernel): 0 = both (default), 1 = the tiles only, 2 = the strip only (per-kernel timing).
                           * The bf16 modes do tiles and strip in one launch: part must be 0.                             */
+  int32_t same_pad;      /* != 0: TensorFlow "SAME" padding as timm's Conv2dSame (the reference's stem surgery builds one,
+                          * patchrefinerplus.py:152-158): out = ceil(in / stride), total = max((out-1)*stride + k - in, 0),
+                          * low = total / 2, the rest goes to the high side; ``pad`` is ignored.  Not for convt_k.          */
+  int32_t reserved;
 } prv2_conv_desc;
 
 /* host-side helpers: sizes of the packed weight buffers (in bytes) */
@@ -104,6 +109,17 @@ int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w, int32_t c
  * w: device, TAP-MAJOR [k*k][c] with the BN scale already folded (so that a lane's 4 channels are one float4); bias [c]. */
 int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
                   const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy, void* stream);
+/* The same with any enum prv2_act and, when same_pad != 0, TensorFlow "SAME" padding (see prv2_conv_desc.same_pad):
+ * the depthwise convs of timm's tf_efficientnet_* (Conv2dSame; v2_eff_u4k.py:94).  Output ceil(h/stride) x ceil(w/stride). */
+int prv2_dwconv2d_ex(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
+                     const float* bias, int32_t k, int32_t stride, int32_t act, int32_t same_pad, float* y, int32_t ldy,
+                     void* stream);
+
+/* Squeeze-and-excitation pieces of the EfficientNet refiner encoder (timm SqueezeExcite, un-vendored):
+ *   prv2_global_avgpool: out[n][c] = mean over the h*w pixels of image n (x.mean((2, 3)));  out is dense [n][c].
+ *   prv2_channel_scale:  x[n, pix, c] *= s[n][c]  in place (x * gate). */
+int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, float* out, void* stream);
+int prv2_channel_scale(float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, const float* s, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row LayerNorm (+activation).  Rows of ``c`` contiguous floats with strides ldx / ldy.

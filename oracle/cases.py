@@ -210,3 +210,41 @@ def e2e_v2cx_sd(seed: int = 59):
     spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                     f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
     return W.synth_state_dict(spec, seed=seed)
+
+
+# -- LightWeightRefiner with an EfficientNet encoder (reduced width/depth; real cfg: configs/patchrefinerv2_zoedepth/v2_eff_u4k.py:90-101)
+EFFNET_REFINER = dict(arch=W.EFFNET_TINY_TEST, seed=61, in_seed=620, b=2, h=64, w=96)
+
+
+def effnet_refiner_sd(arch=None, seed=None, prefix=""):
+    arch = arch or EFFNET_REFINER["arch"]
+    return W.synth_state_dict(W.effnet_spec(prefix + "refiner_encoder.", arch, in_chans=4),
+                              seed=EFFNET_REFINER["seed"] if seed is None else seed)
+
+
+def effnet_refiner_inputs(c=None):
+    c = c or EFFNET_REFINER
+    crop = rand_image(c["in_seed"], c["b"], c["h"], c["w"])
+    depth = torch.rand(c["b"], 1, c["h"], c["w"], generator=torch.Generator().manual_seed(c["in_seed"] + 1)) * 10
+    return crop, depth
+
+
+# -- end-to-end V2 with the EfficientNet refiner encoder (configs/patchrefinerv2_zoedepth/v2_eff_u4k.py:90-104), reduced dims
+_EF = W.EFFNET_TINY_TEST
+_EF_CHL = [B["cout"] for B in W.effnet_blocks(_EF) if B["tap"]]
+E2E_V2EF = dict(E2E_V2, arch=_EF, modes=["m1", "r4"], fusion=dict(E2E_V2["fusion"], fine_chl=_EF_CHL))
+E2E_V2EF["ref_config"] = {**E2E_V2["ref_config"], "refiner": dict(
+    fine_branch=dict(type="LightWeightRefiner", coarse_condition=True, with_decoder=False, encoder_name="tf_efficientnet_b5_ap",
+                     arch=_EF),
+    fusion_model=dict(type="BiDirectionalFusion", encoder_name="tf_efficientnet_b5_ap", coarse2fine=True,
+                      coarse2fine_type="coarse-gated", **E2E_V2EF["fusion"]))}
+
+
+def e2e_v2ef_sd(seed: int = 67):
+    spec = OrderedDict()
+    spec.update(W.dav2_spec("coarse_branch.", _E2E2_DA2))
+    spec.update(W.effnet_spec("refiner_fine_branch.refiner_encoder.", _EF, in_chans=4))
+    f = E2E_V2EF["fusion"]
+    spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
+                                    f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
+    return W.synth_state_dict(spec, seed=seed)

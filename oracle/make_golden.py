@@ -549,6 +549,73 @@ def g_convnext():
     save("convnext_refiner", **{f"feat{i}": f for i, f in enumerate(feats)})
 
 
+def g_effnet():
+    """LightWeightRefiner (reference class) over HuggingFace transformers' EfficientNet as the stand-in for
+    timm.create_model('tf_efficientnet_b5_ap', features_only=True): pins oracle/effnet.py (MBConv + SE + SiLU + BN eps 1e-3 +
+    'SAME' padding, feature taps) against an independent port of the TensorFlow model."""
+    print("[effnet]")
+    import timm
+    from transformers import EfficientNetConfig, EfficientNetModel
+    from oracle import effnet as o_eff
+    from oracle.cases import EFFNET_REFINER, effnet_refiner_sd, effnet_refiner_inputs
+    arch = EFFNET_REFINER["arch"]
+    sd = effnet_refiner_sd()
+    blocks = W.effnet_blocks(arch)
+    taps = [i + 1 for i, B in enumerate(blocks) if B["tap"]]  # hidden_states[0] = the stem output
+
+    class Enc(torch.nn.Module):
+        default_cfg = dict(mean=arch["mean"], std=arch["std"])
+
+        def __init__(self):
+            super().__init__()
+            cfg = EfficientNetConfig(num_channels=4, width_coefficient=arch["width"], depth_coefficient=arch["depth"],
+                                     depthwise_padding=[], hidden_dim=W._round_filters(1280, arch["width"]))
+            self.hf = EfficientNetModel(cfg)
+
+        def forward(self, x):
+            hs = self.hf(x, output_hidden_states=True).hidden_states
+            return [hs[t] for t in taps]
+
+    timm.create_model = lambda name, pretrained=True, features_only=True: Enc()
+    lwr = refharness.ref_module("estimator.models.blocks.lightweight_refiner")
+    m = lwr.LightWeightRefiner("tf_efficientnet_b5_ap", True).eval()
+
+    def hf_name(k):  # timm -> transformers
+        if k.startswith("conv_stem."):
+            return k.replace("conv_stem.", "embeddings.convolution.")
+        if k.startswith("bn1."):
+            return k.replace("bn1.", "embeddings.batchnorm.")
+        mm = re.match(r"blocks\.(\d)\.(\d+)\.(.*)", k)
+        si, j, rest = int(mm.group(1)), int(mm.group(2)), mm.group(3)
+        idx = [i for i, B in enumerate(blocks) if B["name"] == f"blocks.{si}.{j}."][0]
+        ds = blocks[idx]["kind"] == "ds"
+        table = ([("conv_dw.", "depthwise_conv.depthwise_conv."), ("bn1.", "depthwise_conv.depthwise_norm."),
+                  ("conv_pw.", "projection.project_conv."), ("bn2.", "projection.project_bn.")] if ds else
+                 [("conv_pw.", "expansion.expand_conv."), ("bn1.", "expansion.expand_bn."),
+                  ("conv_dw.", "depthwise_conv.depthwise_conv."), ("bn2.", "depthwise_conv.depthwise_norm."),
+                  ("conv_pwl.", "projection.project_conv."), ("bn3.", "projection.project_bn.")])
+        table += [("se.conv_reduce.", "squeeze_excite.reduce."), ("se.conv_expand.", "squeeze_excite.expand.")]
+        for a, b in table:
+            if rest.startswith(a):
+                return f"encoder.blocks.{idx}.{b}{rest[len(a):]}"
+        raise KeyError(k)
+
+    ep = "refiner_encoder."
+    hf_sd = {hf_name(k[len(ep):]): v for k, v in sd.items() if k.startswith(ep)}
+    res = m.refiner_encoder.hf.load_state_dict(hf_sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:5]
+    assert all(k.startswith("encoder.top_") or k.endswith("num_batches_tracked") for k in res.missing_keys), res.missing_keys[:8]
+    crop, depth = effnet_refiner_inputs()
+    feats, out_depth = m(crop, depth)
+    o_feats, o_out = o_eff.lightweight_refiner_effnet(sd, "", crop, depth, arch)
+    assert len(feats) == len(o_feats) == 6 and float(out_depth.abs().max()) == 0.0 and o_out.shape == out_depth.shape
+    for i, (a, b) in enumerate(zip(feats, o_feats)):
+        d = maxdiff(a, b)
+        print(f"  feat {i}: {tuple(a.shape)} |x|max {float(a.abs().max()):.2f} oracle-vs-ref max|d| {d:.2e}")
+        assert a.shape == b.shape and d < 1e-4 * max(1.0, float(a.abs().max())), d
+    save("effnet_refiner", **{f"feat{i}": f for i, f in enumerate(feats[:5])})  # (feat5 = the 2x bilinear copy of feat4)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2", "zoedepth", "e2e_v2z"]
     for w in which:

@@ -14,7 +14,7 @@ import random
 
 import torch
 
-from . import convnext, dav2, fusion, mnv4
+from . import convnext, dav2, effnet, fusion, mnv4
 from .ops import bilinear_ac, generatemask, nearest, resize_da, resize_zoe, roi_align
 
 
@@ -218,11 +218,12 @@ class OraclePatchRefinerPlus(OracleRefiner):
     """V2: DA2 coarse + LightWeightRefiner(MNv4-S) + BiDirectionalFusion
     (configs/patchrefinerv2_dav2/plus_mobile_u4k_base_coarse_e2e_c2f_pretrain.py)."""
 
-    def __init__(self, sd, coarse_cfg, coarse_fn=None, convnext_arch=None, **kw):
+    def __init__(self, sd, coarse_cfg, coarse_fn=None, convnext_arch=None, effnet_arch=None, **kw):
         super().__init__(sd, **kw)
         self.coarse_cfg = coarse_cfg
         self.coarse_fn = coarse_fn
         self.convnext_arch = convnext_arch  # set: the v2_convx_u4k.py variant (ConvNeXt refiner encoder)
+        self.effnet_arch = effnet_arch      # set: the v2_eff_u4k.py variant (EfficientNet refiner encoder)
 
     def coarse_forward(self, image_lr):
         if self.coarse_fn is not None:
@@ -230,7 +231,10 @@ class OraclePatchRefinerPlus(OracleRefiner):
         return dav2.coarse_features(dav2.dav2_forward(self.sd, "coarse_branch.", image_lr, self.coarse_cfg))
 
     def infer_forward(self, imgs_crop, post):
-        if self.convnext_arch is not None:
+        if self.effnet_arch is not None:
+            r_feats, r_depth = effnet.lightweight_refiner_effnet(self.sd, "refiner_fine_branch.", imgs_crop,
+                                                                 post["coarse_depth_roi"], self.effnet_arch)
+        elif self.convnext_arch is not None:
             r_feats, r_depth = convnext.lightweight_refiner_convnext(self.sd, "refiner_fine_branch.", imgs_crop,
                                                                      post["coarse_depth_roi"], self.convnext_arch)
         else:

@@ -45,6 +45,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case PRV2_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact-erf GELU (mlp.py:31)
     case PRV2_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     case PRV2_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));  // nn.Softplus(beta=1, threshold=20)
+    case PRV2_ACT_SILU: return v / (1.0f + expf(-v));                  // nn.SiLU: x * sigmoid(x)
     default: return v;
   }
 }

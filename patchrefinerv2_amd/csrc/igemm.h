@@ -25,7 +25,8 @@ struct IgemmParams {
   float* y;
   int N, H, W, OH, OW;
   int Cin, Cin_pad, Cout, Ncols;  // Ncols = GEMM columns (= Cout, or k*k*Cout for convT)
-  int KH, KW, stride, pad;
+  int KH, KW, stride, pad;  // pad = low-side padding in y
+  int pad_x;                // low-side padding in x (== pad unless same_pad)
   int ldx, ldy, ld_mul, ld_res, ld_res2;
   long long x_bstride, y_bstride;
   long long M;
@@ -216,6 +217,7 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
     case PRV2_ACT_GELU: f(std::integral_constant<int, PRV2_ACT_GELU>{}); break;
     case PRV2_ACT_SIGMOID: f(std::integral_constant<int, PRV2_ACT_SIGMOID>{}); break;
     case PRV2_ACT_SOFTPLUS: f(std::integral_constant<int, PRV2_ACT_SOFTPLUS>{}); break;
+    case PRV2_ACT_SILU: f(std::integral_constant<int, PRV2_ACT_SILU>{}); break;
     default: f(std::integral_constant<int, PRV2_ACT_NONE>{}); break;
   }
 }

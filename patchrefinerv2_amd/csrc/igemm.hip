@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
       int rem = (int)(m - (long long)n * ohw);
       int oy = rem / rw, ox = rem - oy * rw + p.rx0;
       a_iy0[i] = oy * p.stride - p.pad;
-      a_ix0[i] = ox * p.stride - p.pad;
+      a_ix0[i] = ox * p.stride - p.pad_x;
       a_ptr[i] = p.x + (long long)n * p.x_bstride + ((long long)a_iy0[i] * p.W + a_ix0[i]) * p.ldx + chunk * 4;
     } else {
       a_iy0[i] = -(1 << 28);  // never in range
@@ -366,6 +366,7 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
   PRV2_REQUIRE(d->ldx >= d->cin, "conv2d: ldx %d < cin %d", d->ldx, d->cin);
   PRV2_REQUIRE(d->prec >= PRV2_PREC_F32 && d->prec <= PRV2_PREC_BF16, "conv2d: unknown precision mode %d", d->prec);
+  PRV2_REQUIRE(d->act >= PRV2_ACT_NONE && d->act <= PRV2_ACT_SILU, "conv2d: unknown activation %d", d->act);
   PRV2_REQUIRE(aligned16(w_packed), "conv2d: packed weights must be 16-byte aligned");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -379,13 +380,21 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   if (d->convt_k > 0) {
     PRV2_REQUIRE(d->kh == d->convt_k && d->kw == d->convt_k && d->stride == d->convt_k && d->pad == 0,
                  "conv2d: convt_k needs kernel == stride == k, pad 0");
-    p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
+    PRV2_REQUIRE(!d->same_pad, "conv2d: same_pad is not defined for convt_k");
+    p.KH = p.KW = 1; p.stride = 1; p.pad = p.pad_x = 0;
     p.OH = d->h; p.OW = d->w;
     p.Ncols = d->convt_k * d->convt_k * d->cout;
   } else {
-    p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = p.pad_x = d->pad;
     p.OH = (d->h + 2 * d->pad - d->kh) / d->stride + 1;
     p.OW = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+    if (d->same_pad) {  // timm Conv2dSame / TensorFlow "SAME": the high side gets the odd pixel, handled by the range checks
+      p.OH = (d->h + d->stride - 1) / d->stride;
+      p.OW = (d->w + d->stride - 1) / d->stride;
+      const int ty = (p.OH - 1) * d->stride + d->kh - d->h, tx = (p.OW - 1) * d->stride + d->kw - d->w;
+      p.pad = (ty > 0 ? ty : 0) / 2;
+      p.pad_x = (tx > 0 ? tx : 0) / 2;
+    }
     p.Ncols = d->cout;
   }
   PRV2_REQUIRE(p.OH > 0 && p.OW > 0, "conv2d: empty output");

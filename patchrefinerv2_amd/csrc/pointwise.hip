@@ -220,10 +220,9 @@ __global__ void __launch_bounds__(256) conv_cout1_k3_kernel(const float* __restr
 // depthwise kxk, float4 over channels; weights tap-major [k*k][C]
 __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
                                                      const float* __restrict__ wgt, const float* __restrict__ bias, int k,
-                                                     int stride, int relu, int OH, int OW, float* __restrict__ y,
-                                                     int ldy) {
+                                                     int stride, int act, int pad_y, int pad_x, int OH, int OW,
+                                                     float* __restrict__ y, int ldy) {
   const int cg = C >> 2;
-  const int pad = k / 2;
   int64_t total = (int64_t)N * OH * OW * cg;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(idx % cg) * 4;
@@ -232,10 +231,10 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
     int n = (int)(pix / ((int64_t)OW * OH));
     float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ky = 0; ky < k; ++ky) {
-      int iy = oy * stride + ky - pad;
+      int iy = oy * stride + ky - pad_y;
       if (iy < 0 || iy >= H) continue;
       for (int kx = 0; kx < k; ++kx) {
-        int ix = ox * stride + kx - pad;
+        int ix = ox * stride + kx - pad_x;
         if (ix < 0 || ix >= W) continue;
         float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + iy) * W + ix) * ldx + c);
         float4 ww = *reinterpret_cast<const float4*>(wgt + (int64_t)(ky * k + kx) * C + c);
@@ -245,12 +244,7 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
         acc.w += v.w * ww.w;
       }
     }
-    if (relu) {
-      acc.x = fmaxf(acc.x, 0.f);
-      acc.y = fmaxf(acc.y, 0.f);
-      acc.z = fmaxf(acc.z, 0.f);
-      acc.w = fmaxf(acc.w, 0.f);
-    }
+    acc = make_float4(act_apply(acc.x, act), act_apply(acc.y, act), act_apply(acc.z, act), act_apply(acc.w, act));
     *reinterpret_cast<float4*>(y + pix * ldy + c) = acc;
   }
 }
@@ -262,7 +256,7 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
 template <int K, int PX>
 __global__ void __launch_bounds__(256) dwconv_strip_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
                                                            const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                           int relu, float* __restrict__ y, int ldy) {
+                                                           int act, float* __restrict__ y, int ldy) {
   constexpr int PAD = K / 2;
   const int cg = C >> 2;
   const int strips = (W + PX - 1) / PX;
@@ -307,9 +301,50 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < PX; ++i) {
     if (ox0 + i >= W) break;
-    float4 v = acc[i];
-    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    const float4 v = make_float4(act_apply(acc[i].x, act), act_apply(acc[i].y, act), act_apply(acc[i].z, act), act_apply(acc[i].w, act));
     *reinterpret_cast<float4*>(out + (int64_t)i * ldy) = v;
+  }
+}
+
+// squeeze: out[n][c] = mean over the HW pixels.  grid (cg blocks of 64 lanes x 4 pixel groups, n); float4 over channels.
+__global__ void __launch_bounds__(256) global_avgpool_kernel(const float* __restrict__ x, int64_t HW, int C, int ldx,
+                                                             float* __restrict__ out) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int n = blockIdx.y;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    const float* base = x + (int64_t)n * HW * ldx + c;
+    for (int64_t pix = grp; pix < HW; pix += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(base + pix * ldx);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    float4 t = part[0][lane];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) { t.x += part[g][lane].x; t.y += part[g][lane].y; t.z += part[g][lane].z; t.w += part[g][lane].w; }
+    const float inv = 1.0f / (float)HW;
+    *reinterpret_cast<float4*>(out + (int64_t)n * C + c) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  }
+}
+
+// excite: x[n, pix, c] *= s[n][c]
+__global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ x, int64_t HW, int C, int ldx,
+                                                            const float* __restrict__ s, int64_t total) {
+  const int cg = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cg) * 4;
+    const int64_t pix = idx / cg;
+    const int n = (int)(pix / HW);
+    float4* q = reinterpret_cast<float4*>(x + pix * ldx + c);
+    const float4 g = *reinterpret_cast<const float4*>(s + (int64_t)n * C + c);
+    float4 v = *q;
+    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+    *q = v;
   }
 }
 
@@ -459,30 +494,62 @@ extern "C" int prv2_conv2d_cout1(const float* x, int32_t n, int32_t h, int32_t w
   return 0;
 }
 
-extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
-                             const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy,
-                             void* stream) {
+extern "C" int prv2_dwconv2d_ex(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
+                                const float* bias, int32_t k, int32_t stride, int32_t act, int32_t same_pad, float* y,
+                                int32_t ldy, void* stream) {
   PRV2_REQUIRE(x && wgt && y, "dwconv2d: null pointer");
   PRV2_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= c && ldy >= c &&
                    (k == 3 || k == 5 || k == 7) && (stride == 1 || stride == 2),
                "dwconv2d: bad geometry c=%d k=%d stride=%d", c, k, stride);
+  PRV2_REQUIRE(act >= PRV2_ACT_NONE && act <= PRV2_ACT_SILU, "dwconv2d: unknown activation %d", act);
   PRV2_REQUIRE(aligned16(x) && aligned16(y) && aligned16(wgt), "dwconv2d: pointers must be 16-byte aligned");
   int oh = (h + 2 * (k / 2) - k) / stride + 1, ow = (w + 2 * (k / 2) - k) / stride + 1;
+  int pad_y = k / 2, pad_x = k / 2;
+  if (same_pad) {  // timm Conv2dSame / TensorFlow "SAME" (see prv2_conv_desc.same_pad)
+    oh = (h + stride - 1) / stride;
+    ow = (w + stride - 1) / stride;
+    const int ty = (oh - 1) * stride + k - h, tx = (ow - 1) * stride + k - w;
+    pad_y = (ty > 0 ? ty : 0) / 2;
+    pad_x = (tx > 0 ? tx : 0) / 2;
+  }
   int64_t total = (int64_t)n * oh * ow * (c / 4);
-  if (stride == 1 && w >= 8) {  // strip kernel: 8 output pixels per thread
+  if (stride == 1 && w >= 8) {  // strip kernel: 8 output pixels per thread (stride 1: "SAME" == symmetric k/2)
     constexpr int PX = 8;
     const int64_t threads = (int64_t)n * h * ((w + PX - 1) / PX) * (c / 4);
     PRV2_REQUIRE((threads + 255) / 256 < (1LL << 31), "dwconv2d: too large");
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<3, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, relu, y, ldy);
-    else if (k == 5) hipLaunchKernelGGL((dwconv_strip_kernel<5, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, relu, y, ldy);
-    else hipLaunchKernelGGL((dwconv_strip_kernel<7, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, relu, y, ldy);
+    if (k == 3) hipLaunchKernelGGL((dwconv_strip_kernel<3, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, act, y, ldy);
+    else if (k == 5) hipLaunchKernelGGL((dwconv_strip_kernel<5, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, act, y, ldy);
+    else hipLaunchKernelGGL((dwconv_strip_kernel<7, PX>), grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt, bias, act, y, ldy);
     PRV2_LAUNCH_CHECK("dwconv2d");
     return 0;
   }
   hipLaunchKernelGGL(dwconv_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, ldx, wgt,
-                     bias, k, stride, relu, oh, ow, y, ldy);
+                     bias, k, stride, act, pad_y, pad_x, oh, ow, y, ldy);
   PRV2_LAUNCH_CHECK("dwconv2d");
+  return 0;
+}
+
+extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, const float* wgt,
+                             const float* bias, int32_t k, int32_t stride, int32_t relu, float* y, int32_t ldy,
+                             void* stream) {
+  return prv2_dwconv2d_ex(x, n, h, w, c, ldx, wgt, bias, k, stride, relu ? PRV2_ACT_RELU : PRV2_ACT_NONE, 0, y, ldy, stream);
+}
+
+extern "C" int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, float* out, void* stream) {
+  PRV2_REQUIRE(x && out && n > 0 && hw > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldx >= c, "global_avgpool: bad arguments");
+  PRV2_REQUIRE(aligned16(x) && aligned16(out), "global_avgpool: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(global_avgpool_kernel, dim3((c / 4 + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, x, hw, c, ldx, out);
+  PRV2_LAUNCH_CHECK("global_avgpool");
+  return 0;
+}
+
+extern "C" int prv2_channel_scale(float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, const float* s, void* stream) {
+  PRV2_REQUIRE(x && s && n > 0 && hw > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldx >= c, "channel_scale: bad arguments");
+  PRV2_REQUIRE(aligned16(x) && aligned16(s), "channel_scale: pointers must be 16-byte aligned");
+  const int64_t total = (int64_t)n * hw * (c / 4);
+  hipLaunchKernelGGL(channel_scale_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, hw, c, ldx, s, total);
+  PRV2_LAUNCH_CHECK("channel_scale");
   return 0;
 }
 

@@ -12,11 +12,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprv2_hip.so")
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 4, 5
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(C.Structure):
@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("relu_in", C.c_int32), ("act", C.c_int32), ("convt_k", C.c_int32),
         ("ld_mul", C.c_int32), ("ld_res", C.c_int32), ("ld_res2", C.c_int32),
         ("prec", C.c_int32), ("force_generic", C.c_int32), ("ln_eps", C.c_float), ("part", C.c_int32),
+        ("same_pad", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -43,6 +44,9 @@ SIGNATURES = {
     "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prv2_conv2d_cout1": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _P]),
     "prv2_dwconv2d": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "prv2_dwconv2d_ex": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "prv2_global_avgpool": (_I, [_P, _I, _L, _I, _I, _P, _P]),
+    "prv2_channel_scale": (_I, [_P, _I, _L, _I, _I, _P, _P]),
     "prv2_layernorm": (_I, [_P, _L, _I, _I, _P, _P, _F, _I, _P, _I, _P]),
     "prv2_patchify": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_assemble_tokens": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

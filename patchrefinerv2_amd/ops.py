@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as L
-from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS, PREC_F32  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_SOFTPLUS, PREC_F32  # noqa: F401
 
 
 def _stream():
@@ -161,10 +161,12 @@ class ConvW:
     pad: int = 0
     convt_k: int = 0
     prec: int = PREC_F32
+    same_pad: bool = False  # timm Conv2dSame / TensorFlow "SAME" padding (prv2_conv_desc.same_pad)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: Optional[int] = None,
-              convt_k: int = 0, bn_scale: Optional[torch.Tensor] = None, prec: int = PREC_F32, device=None) -> ConvW:
+              convt_k: int = 0, bn_scale: Optional[torch.Tensor] = None, prec: int = PREC_F32, device=None,
+              same_pad: bool = False) -> ConvW:
     """weight: PyTorch layout [cout, cin, kh, kw] / [cout, cin] (Linear) / [cin, cout, k, k] (ConvTranspose2d)."""
     lib = L.load()
     device = device or weight.device
@@ -183,12 +185,14 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride:
     L.check(lib.prv2_pack_conv_weight(w.data_ptr(), _ptr(sc), packed.data_ptr(), cout, cin, kh, kw, convt_k, prec,
                                       _stream()), "pack_conv_weight")
     b = bias.detach().to(device=device, dtype=torch.float32).contiguous() if bias is not None else None
-    return ConvW(packed, b, cout, cin, kh, kw, convt_k if convt_k else stride, pad, convt_k, prec)
+    return ConvW(packed, b, cout, cin, kh, kw, convt_k if convt_k else stride, pad, convt_k, prec, same_pad)
 
 
 def conv_out_hw(cw: ConvW, h: int, w: int):
     if cw.convt_k:
         return h * cw.convt_k, w * cw.convt_k
+    if cw.same_pad:
+        return -(-h // cw.stride), -(-w // cw.stride)
     return (h + 2 * cw.pad - cw.kh) // cw.stride + 1, (w + 2 * cw.pad - cw.kw) // cw.stride + 1
 
 
@@ -211,14 +215,14 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
                    ldx=x.ld, ldy=out.ld, x_bstride=x_bstride, y_bstride=0, relu_in=int(relu_in), act=act,
                    convt_k=cw.convt_k, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0,
                    ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, force_generic=int(force_generic),
-                   ln_eps=ln_eps, part=0)
+                   ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
     for aux in (mul, res, res2):
         if aux is not None:
             assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
     ncols = cw.cout * (cw.convt_k ** 2 if cw.convt_k else 1)
     taps = 1 if cw.convt_k else cw.kh * cw.kw
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
-    halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and cw.pad == 1 and not cw.convt_k and x.w >= 24 and x.h >= 4
+    halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and (cw.pad == 1 or cw.same_pad) and not cw.convt_k and x.w >= 24 and x.h >= 4
             and not force_generic)  # mirrors conv3x3_halo_supported() in csrc/conv3x3.hip
     # bf16 modes of the halo conv run on the 16x16x32 MFMA kernel (csrc/conv3x3_m16.hip), f32 on csrc/conv3x3.hip
     kname = ("conv3x3_halo_kernel" if cw.prec == PREC_F32 else "conv3x3_halo16_kernel") if halo else "igemm_kernel"
@@ -279,15 +283,40 @@ def conv2d_cout1(x: Feat, weight: torch.Tensor, bias: Optional[torch.Tensor], k:
     return y
 
 
-def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int, relu: bool) -> Feat:
-    oh = (x.h + 2 * (k // 2) - k) // stride + 1
-    ow = (x.w + 2 * (k // 2) - k) // stride + 1
+def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride: int, relu=False, *,
+             act: Optional[int] = None, same_pad: bool = False) -> Feat:
+    """depthwise k x k; ``relu`` (bool) or any ``act``; ``same_pad``: timm Conv2dSame (output ceil(h / stride))"""
+    act = (ACT_RELU if relu else ACT_NONE) if act is None else act
+    if same_pad:
+        oh, ow = -(-x.h // stride), -(-x.w // stride)
+    else:
+        oh = (x.h + 2 * (k // 2) - k) // stride + 1
+        ow = (x.w + 2 * (k // 2) - k) // stride + 1
     out = Feat.alloc(x.n, oh, ow, x.c, x.device)
     PROFILER.launch("dwconv_kernel", 2.0 * x.n * oh * ow * x.c * k * k,
-                    lambda: L.check(L.load().prv2_dwconv2d(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(),
-                                                           _ptr(bias), k, stride, int(relu), out.ptr, out.ld, _stream()),
-                                    "dwconv2d"))
+                    lambda: L.check(L.load().prv2_dwconv2d_ex(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(),
+                                                              _ptr(bias), k, stride, act, int(same_pad), out.ptr, out.ld,
+                                                              _stream()), "dwconv2d"))
     return out
+
+
+def global_avgpool(x: Feat) -> torch.Tensor:
+    """[n, c] mean over the pixels (the squeeze of timm's SqueezeExcite: x.mean((2, 3)))"""
+    assert x.c % 4 == 0
+    out = torch.empty((x.n, x.c), device=x.device, dtype=torch.float32)
+    PROFILER.launch_aux("global_avgpool", 4.0 * x.n * x.h * x.w * x.c,
+                        lambda: L.check(L.load().prv2_global_avgpool(x.ptr, x.n, x.h * x.w, x.c, x.ld, out.data_ptr(), _stream()),
+                                        "global_avgpool"), f"{x.c}ch {x.n}x{x.h}x{x.w}")
+    return out
+
+
+def channel_scale_(x: Feat, s: torch.Tensor) -> Feat:
+    """x *= s[n, c] in place (the excite of SqueezeExcite)"""
+    assert s.shape == (x.n, x.c) and s.is_contiguous() and x.c % 4 == 0
+    PROFILER.launch_aux("channel_scale", 8.0 * x.n * x.h * x.w * x.c,
+                        lambda: L.check(L.load().prv2_channel_scale(x.ptr, x.n, x.h * x.w, x.c, x.ld, s.data_ptr(), _stream()),
+                                        "channel_scale"), f"{x.c}ch {x.n}x{x.h}x{x.w}")
+    return x
 
 
 def layernorm_rows(x: torch.Tensor, rows: int, c: int, ldx: int, weight, bias, eps: float, act: int, y: torch.Tensor,

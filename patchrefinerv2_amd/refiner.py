@@ -26,7 +26,7 @@ from .ops import ACT_NONE, ACT_RELU, Feat
 
 BN_EPS = 1e-5
 SUPPORTED_ENCODERS = {"mobilenetv4_conv_small.e2400_r224_in1k": W.MNV4_SMALL, "mobilenetv4_conv_small": W.MNV4_SMALL,
-                      "convnext_large": W.CONVNEXT_LARGE}
+                      "convnext_large": W.CONVNEXT_LARGE, "tf_efficientnet_b5_ap": W.EFFNET_B5}
 LN_EPS = 1e-6
 
 
@@ -36,8 +36,8 @@ class LightWeightRefiner(StateDictModule):
         super().__init__()
         if encoder_name not in SUPPORTED_ENCODERS:
             raise NotImplementedError(
-                f"refiner encoder '{encoder_name}': mobilenetv4_conv_small and convnext_large are built "
-                "(EfficientNet-B5-AP is a timm model not vendored in the reference; SURVEY.md 8f rank 3)")
+                f"refiner encoder '{encoder_name}': built are {sorted(SUPPORTED_ENCODERS)} (the V2 configs' three timm "
+                "encoders; SURVEY.md 8f rank 3)")
         if with_decoder or not coarse_condition:
             raise NotImplementedError("with_decoder=True / coarse_condition=False are not used by any V2 config")
         self.encoder_name = encoder_name
@@ -48,6 +48,10 @@ class LightWeightRefiner(StateDictModule):
         self.mean, self.std = self.arch["mean"], self.arch["std"]
         self._packed = None
         self.convnext = "convnext" in encoder_name
+        self.effnet = "efficientnet" in encoder_name
+        if self.effnet:
+            self._spec = W.effnet_spec("refiner_encoder.", self.arch, in_chans=4)
+            return
         if self.convnext:
             d0 = self.arch["dims"][0]
             self._spec = W.convnext_spec("refiner_encoder.", self.arch, in_chans=4)
@@ -62,6 +66,8 @@ class LightWeightRefiner(StateDictModule):
             return
         if self.convnext:
             return self._pack_convnext()
+        if self.effnet:
+            return self._pack_effnet()
         P = []
         for Lr in self.layers:
             b = "refiner_encoder." + Lr["bn"] + "."
@@ -86,6 +92,8 @@ class LightWeightRefiner(StateDictModule):
             raise RuntimeError("LightWeightRefiner: weights not loaded")
         if self.convnext:
             return self._forward_convnext(crop)
+        if self.effnet:
+            return self._forward_effnet(crop)
         x = crop
         feats: List[Feat] = []
         skip = None
@@ -150,5 +158,56 @@ class LightWeightRefiner(StateDictModule):
         feats = [up] + feats
         sizes = [(up.h * 2, up.w * 2)] + [(f.h, f.w) for f in feats]
         return [None] + feats, sizes  # the stride-1 bilinear copy of ``up`` is dropped by the fusion model
+
+    # -- EfficientNet -----------------------------------------------------------------------------------------
+    def _fold(self, b):
+        """eval BatchNorm (eps 1e-3) as a per-channel scale folded into the conv + a bias"""
+        sd = self._sd
+        scale = sd[b + "weight"] / torch.sqrt(sd[b + "running_var"] + self.arch["bn_eps"])
+        return scale, sd[b + "bias"] - sd[b + "running_mean"] * scale
+
+    def _pack_effnet(self):
+        sd, dev, e = self._sd, self.device, "refiner_encoder."
+        pk = lambda w, bn, **kw: ops.pack_conv(w, bn[1], bn_scale=bn[0], device=dev, prec=self.prec, **kw)  # noqa: E731
+
+        def dw(w, bn):  # tap-major [k*k][C] with the BN scale folded
+            c, k = w.shape[0], w.shape[-1]
+            return (w.view(c, k * k) * bn[0][:, None]).t().contiguous().to(dev), bn[1].to(dev).contiguous()
+
+        P = dict(stem=pk(sd[e + "conv_stem.weight"], self._fold(e + "bn1."), stride=2, same_pad=True), blocks=[])
+        for B in W.effnet_blocks(self.arch):
+            b = e + B["name"]
+            Q = dict(B)
+            if B["kind"] == "ds":
+                Q["dw"] = dw(sd[b + "conv_dw.weight"], self._fold(b + "bn1."))
+                Q["proj"] = pk(sd[b + "conv_pw.weight"], self._fold(b + "bn2."))
+            else:
+                Q["expand"] = pk(sd[b + "conv_pw.weight"], self._fold(b + "bn1."))
+                Q["dw"] = dw(sd[b + "conv_dw.weight"], self._fold(b + "bn2."))
+                Q["proj"] = pk(sd[b + "conv_pwl.weight"], self._fold(b + "bn3."))
+            Q["se_r"] = ops.pack_conv(sd[b + "se.conv_reduce.weight"], sd[b + "se.conv_reduce.bias"], device=dev, prec=self.prec)
+            Q["se_e"] = ops.pack_conv(sd[b + "se.conv_expand.weight"], sd[b + "se.conv_expand.bias"], device=dev, prec=self.prec)
+            P["blocks"].append(Q)
+        self._packed = P
+
+    def _forward_effnet(self, crop: Feat):
+        """MBConv: [1x1 expand + SiLU] -> dw kxk 'SAME' + SiLU -> SE (global mean -> FC + SiLU -> FC + sigmoid -> scale)
+        -> 1x1 project (+ x): BatchNorms folded, SiLU / residual fused into the conv epilogues, the SE bottleneck runs as
+        two [n, C] row GEMMs."""
+        P = self._packed
+        x = ops.conv2d(crop, P["stem"], act=ops.ACT_SILU)
+        feats: List[Feat] = []
+        for B in P["blocks"]:
+            h = ops.conv2d(x, B["expand"], act=ops.ACT_SILU) if B["kind"] == "ir" else x
+            h = ops.dwconv2d(h, B["dw"][0], B["dw"][1], B["k"], B["s"], act=ops.ACT_SILU, same_pad=True)
+            s = ops.global_avgpool(h)
+            r = ops.conv2d(Feat(s.view(1, h.n, 1, h.c), h.c), B["se_r"], act=ops.ACT_SILU)
+            g = ops.conv2d(r, B["se_e"], act=ops.ACT_SIGMOID)
+            ops.channel_scale_(h, g.buf.view(h.n, h.c))
+            x = ops.conv2d(h, B["proj"], res=x if B["res"] else None)
+            if B["tap"]:
+                feats.append(x)
+        sizes = [(feats[0].h * 2, feats[0].w * 2)] + [(f.h, f.w) for f in feats]
+        return [None] + feats, sizes
 
     __call__ = forward

@@ -396,6 +396,77 @@ def convnext_spec(prefix: str, arch: dict = CONVNEXT_LARGE, in_chans: int = 4) -
             s[b + "mlp.fc2.bias"] = (c,)
     return s
 
+# EfficientNet (timm ``tf_efficientnet_b5_ap``, features_only; v2_eff_u4k.py:94-101): compound-scaled MBConv stages with
+# squeeze-excite, SiLU, BatchNorm eps 1e-3 and TensorFlow "SAME" padding (timm Conv2dSame -- the reference's stem surgery
+# builds one: patchrefinerplus.py:152-158).  Stage 0 = DepthwiseSeparable blocks (dw -> SE -> pw), the rest
+# InvertedResidual (pw expand x6 -> dw -> SE -> pw-linear); residual when stride 1 and cin == cout; the SE bottleneck is
+# 1/4 of the BLOCK INPUT width.  Feature taps = outputs of stages 0, 1, 2, 4, 6 (strides 2..32): b5 = [24, 40, 64, 176, 512]
+# (the config's fine_chl).  timm is not vendored: the arithmetic is pinned against HuggingFace ``transformers``'
+# EfficientNet (oracle/make_golden.py::g_effnet); key names and the AdvProp mean/std (0.5) are recollection.
+_EFF_BASE = [("ds", 3, 1, 1, 16, 1), ("ir", 3, 2, 6, 24, 2), ("ir", 5, 2, 6, 40, 2), ("ir", 3, 2, 6, 80, 3),
+             ("ir", 5, 1, 6, 112, 3), ("ir", 5, 2, 6, 192, 4), ("ir", 3, 1, 6, 320, 1)]
+
+
+def _round_filters(f, width, divisor=8):
+    f = f * width
+    new = max(divisor, int(f + divisor / 2) // divisor * divisor)
+    if new < 0.9 * f:
+        new += divisor
+    return int(new)
+
+
+def effnet_arch(width: float, depth: float, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)) -> dict:
+    import math
+    stages = [(kind, k, s, e, _round_filters(c, width), int(math.ceil(depth * r))) for kind, k, s, e, c, r in _EFF_BASE]
+    return dict(stem=_round_filters(32, width), stages=stages, taps=(0, 1, 2, 4, 6), se_ratio=0.25, bn_eps=1e-3, mean=mean, std=std,
+                width=width, depth=depth)
+
+
+EFFNET_B5 = effnet_arch(1.6, 2.2)
+EFFNET_TINY_TEST = effnet_arch(0.5, 0.4)
+
+
+def effnet_blocks(arch: dict):
+    """flat list of blocks: dict(name, kind, cin, cmid, cout, k, s, cse, res, tap)"""
+    out = []
+    cin = arch["stem"]
+    for si, (kind, k, s, e, c, r) in enumerate(arch["stages"]):
+        for j in range(r):
+            st = s if j == 0 else 1
+            out.append(dict(name=f"blocks.{si}.{j}.", kind=kind, cin=cin, cmid=cin * e, cout=c, k=k, s=st,
+                            cse=max(1, int(cin * arch["se_ratio"])), res=(st == 1 and cin == c),
+                            tap=(j == r - 1 and si in arch["taps"])))
+            cin = c
+    return out
+
+
+def effnet_spec(prefix: str, arch: dict = None, in_chans: int = 4) -> Spec:
+    arch = arch or EFFNET_B5
+    s: Spec = OrderedDict()
+    s[prefix + "conv_stem.weight"] = (arch["stem"], in_chans, 3, 3)
+    _bn_spec(s, prefix + "bn1.", arch["stem"])
+    for B in effnet_blocks(arch):
+        b = prefix + B["name"]
+        if B["kind"] == "ds":
+            s[b + "conv_dw.weight"] = (B["cin"], 1, B["k"], B["k"])
+            _bn_spec(s, b + "bn1.", B["cin"])
+        else:
+            s[b + "conv_pw.weight"] = (B["cmid"], B["cin"], 1, 1)
+            _bn_spec(s, b + "bn1.", B["cmid"])
+            s[b + "conv_dw.weight"] = (B["cmid"], 1, B["k"], B["k"])
+            _bn_spec(s, b + "bn2.", B["cmid"])
+        s[b + "se.conv_reduce.weight"] = (B["cse"], B["cmid"], 1, 1)
+        s[b + "se.conv_reduce.bias"] = (B["cse"],)
+        s[b + "se.conv_expand.weight"] = (B["cmid"], B["cse"], 1, 1)
+        s[b + "se.conv_expand.bias"] = (B["cmid"],)
+        if B["kind"] == "ds":
+            s[b + "conv_pw.weight"] = (B["cout"], B["cmid"], 1, 1)
+            _bn_spec(s, b + "bn2.", B["cout"])
+        else:
+            s[b + "conv_pwl.weight"] = (B["cout"], B["cmid"], 1, 1)
+            _bn_spec(s, b + "bn3.", B["cout"])
+    return s
+
 
 # ----------------------------------------------------------------------------
 # synthetic weights

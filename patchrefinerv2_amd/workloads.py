@@ -55,6 +55,10 @@ BIDIR_ZOE_CONVX = dict(BIDIR_ZOE, fine_chl=[96, 192, 384, 768, 1536])
 WORKLOADS["v2_convx_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 504], mode="r32",
                                           coarse=None, zoe=dict(ZOE_DA_L, img_size=[392, 504]), fusion=BIDIR_ZOE_CONVX, patches=81,
                                           refiner_encoder="convnext_large")
+# configs/patchrefinerv2_zoedepth/v2_eff_u4k.py: EfficientNet-B5-AP refiner encoder (fine_chl :101)
+WORKLOADS["v2_eff_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 518], mode="r32",
+                                        coarse=None, zoe=ZOE_DA_L, fusion=dict(BIDIR_ZOE, fine_chl=[24, 40, 64, 176, 512]),
+                                        patches=81, refiner_encoder="tf_efficientnet_b5_ap")
 DEFAULT_WORKLOAD = "v2_zoeda_4k_r32"
 MNV4_NAME = "mobilenetv4_conv_small.e2400_r224_in1k"
 
@@ -92,7 +96,9 @@ def state_spec(name: str) -> "OrderedDict[str, tuple]":
     else:
         s.update(W.dav2_spec("coarse_branch.", w["coarse"]))
     if w["kind"] == "PatchRefinerPlus":
-        if "convnext" in w.get("refiner_encoder", ""):
+        if "efficientnet" in w.get("refiner_encoder", ""):
+            s.update(W.effnet_spec("refiner_fine_branch.refiner_encoder.", W.EFFNET_B5, in_chans=4))
+        elif "convnext" in w.get("refiner_encoder", ""):
             s.update(W.convnext_spec("refiner_fine_branch.refiner_encoder.", W.CONVNEXT_LARGE, in_chans=4))
             d0 = W.CONVNEXT_LARGE["dims"][0]
             s["refiner_fine_branch.upsample_convx.0.weight"] = (d0, d0 // 2, 2, 2)

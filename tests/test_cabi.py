@@ -18,7 +18,7 @@ def _declared():
 def test_library_exports_header_symbols():
     from patchrefinerv2_amd import lib as L
     names = _declared()
-    assert len(names) >= 25
+    assert len(names) >= 28
     assert set(names) == set(L.SIGNATURES), set(names) ^ set(L.SIGNATURES)
     lib = ctypes.CDLL(L.LIB_PATH)
     for n in names:
@@ -35,7 +35,7 @@ def test_conv_desc_layout_matches_header():
     for decl in re.findall(r"(?:int(?:32|64)_t|float)\s+([^;]+);", body):
         fields += [f.strip() for f in decl.split(",")]
     assert fields == [f[0] for f in L.ConvDesc._fields_]
-    assert ctypes.sizeof(L.ConvDesc) == 104
+    assert ctypes.sizeof(L.ConvDesc) == 112
 
 
 def test_rejects_bad_arguments_without_gpu():

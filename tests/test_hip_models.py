@@ -162,6 +162,44 @@ def test_lightweight_refiner_convnext_large_width(P, prec):
         close(got.to_nchw(), ref, 5e-5, f"convnext-L {tuple(ref.shape)}")
 
 
+def test_lightweight_refiner_effnet_golden(P, golden):
+    """reduced EfficientNet encoder against the reference's LightWeightRefiner (over transformers' EfficientNet)"""
+    from oracle.cases import EFFNET_REFINER, effnet_refiner_inputs, effnet_refiner_sd
+    from patchrefinerv2_amd.refiner import LightWeightRefiner
+    arch = EFFNET_REFINER["arch"]
+    m = LightWeightRefiner("tf_efficientnet_b5_ap", coarse_condition=True, arch=arch)
+    m.load_state_dict(effnet_refiner_sd(), strict=True)
+    img, depth = effnet_refiner_inputs()
+    feats, sizes = m(P.Feat.from_nchw(_convnext_input(arch, img, depth).to(DEV)))
+    g = golden("effnet_refiner")  # feat0 = stride 32 ... feat4 = stride 2
+    assert feats[0] is None and sizes[0] == (img.shape[-2], img.shape[-1])
+    for i, got in enumerate(feats[1:]):
+        ref = torch.as_tensor(g[f"feat{4 - i}"])
+        assert sizes[i + 1] == tuple(ref.shape[-2:])
+        err = float((got.to_nchw().cpu() - ref).abs().max())
+        assert err <= 3e-5 * float(ref.abs().max()), (i, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("prec,hw", [("f32", (96, 160)), ("bf16x3", (96, 160)), ("f32", (70, 98))])
+def test_lightweight_refiner_effnet_b5_width(P, prec, hw):
+    """real B5 widths (48 .. 3072 expanded channels), depth cut to 0.6; the odd size exercises 'SAME' padding with an odd
+    input at the stride-2 layers (35 -> 18 -> 9 -> 5), which only the oracle covers (transformers pads statically)."""
+    from oracle import effnet as o_eff
+    from oracle.cases import effnet_refiner_sd
+    from patchrefinerv2_amd.refiner import LightWeightRefiner
+    arch = W.effnet_arch(1.6, 0.6)
+    sd = effnet_refiner_sd(arch, seed=17)
+    m = LightWeightRefiner("tf_efficientnet_b5_ap", coarse_condition=True, arch=arch, prec=prec)
+    m.load_state_dict(sd, strict=True)
+    img = rand_image(18, 2, *hw)
+    depth = torch.rand(2, 1, *hw, generator=torch.Generator().manual_seed(19)) * 40
+    ref_feats, _ = o_eff.lightweight_refiner_effnet(sd, "", img, depth, arch)
+    feats, _ = m(P.Feat.from_nchw(_convnext_input(arch, img, depth).to(DEV)))
+    for got, ref in zip(feats[1:], ref_feats[::-1][1:]):
+        err = float((got.to_nchw().cpu() - ref).abs().max())
+        assert got.to_nchw().shape == ref.shape and err <= 1e-4 * float(ref.abs().max()), (tuple(ref.shape), err, float(ref.abs().max()))
+
+
 def _build(kind, c, sd, **extra):
     from patchrefinerv2_amd.models import PatchRefiner, PatchRefinerPlus  # noqa: F401
     from patchrefinerv2_amd.registry import build_model
@@ -208,13 +246,15 @@ def test_e2e_v2_vs_reference_golden(P, golden):
         assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)
 
 
-def test_e2e_v2_convnext_refiner_vs_oracle(P):
-    """PatchRefinerPlus with the ConvNeXt refiner encoder (v2_convx_u4k.py) end to end; the encoder itself is pinned by
-    test_lightweight_refiner_convnext_golden, everything around it by the e2e_v2 goldens."""
-    from oracle.cases import E2E_V2CX, e2e_v2cx_sd
-    c, sd = E2E_V2CX, e2e_v2cx_sd()
+@pytest.mark.parametrize("enc", ["convnext", "effnet"])
+def test_e2e_v2_other_refiner_encoders_vs_oracle(P, enc):
+    """PatchRefinerPlus with the ConvNeXt (v2_convx_u4k.py) / EfficientNet (v2_eff_u4k.py) refiner encoder end to end; the
+    encoders themselves are pinned by test_lightweight_refiner_{convnext,effnet}_golden, everything around them by e2e_v2."""
+    from oracle import cases
+    c, sd = (cases.E2E_V2CX, cases.e2e_v2cx_sd()) if enc == "convnext" else (cases.E2E_V2EF, cases.e2e_v2ef_sd())
     m = _build("PatchRefinerPlus", c, sd)
-    ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}), convnext_arch=c["arch"],
+    ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                          **{f"{enc}_arch": c["arch"]},
                                           patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
     hr = rand_image(c["seed"], 1, *c["raw"])
     tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
