@@ -29,6 +29,7 @@
 // PRV2_ABL_NOA / _NOB / _NOBAR compile out the halo stream / the weight DMA / the barrier for timing ablations
 // (tools/ab_conv.sh; results are wrong with any of them, and stale LDS data raises the clock by itself --
 // compare cycles via tools/pmc_conv.sh, not only wall time).
+#include <cstdlib>
 #include <type_traits>
 
 #include "igemm.h"
@@ -42,14 +43,19 @@ constexpr int AROW = 160;                       // bytes per halo pixel in LDS
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 }  // namespace m16
 
-template <int BN>
+template <int BN, bool PERSIST = false>
 constexpr int halo16_smem_floats() {
   constexpr int main_ = (2 * m16::HALO * m16::AROW + 3 * BN * 128) / 4, epi = 256 * (BN + 4) + 2 * 256;
-  return main_ > epi ? main_ : epi;
+  return PERSIST ? main_ + epi : (main_ > epi ? main_ : epi);  // PERSIST: the C tile has LDS of its own
 }
 
-// one workgroup; `bid` of `nwg` = its index among the workgroups of its tile shape
-template <int BN, int PREC, bool TAIL, bool TALL>
+// one workgroup; `bid` of `nwg` = its index among the workgroups of its tile shape.
+// PERSIST (BN = 32 without tail tile: the 64->32 / 128->32 layers at full resolution): the workgroup walks the tiles
+// bid, bid + nwg, ... as ONE continuous slab sequence -- the halo of the next tile's first slab is loaded during the last
+// slab of the current one, the weight DMAs wrap around, and the C tile has its own 38 KB of LDS, so the epilogue of a tile
+// runs while the next tile's operands are in flight.  These tiles are 18-36 steps of 0.2 us: their fixed cost (workgroup
+// turnaround + halo latency + store drain, ~11 us) was 75 % of the tile time.
+template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false>
 __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, int bid, const int nwg) {
   using namespace m16;
   // Tile = 8 rows x 32 pixels, or (TALL) 32 rows x 8 pixels for the remainder strip of images whose width is
@@ -67,22 +73,33 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   constexpr int NBUF = 3;
   static_assert(NBUF == 3 && (2 * A_BYTES + NBUF * B_BYTES) / 4 <= halo16_smem_floats<BN>() &&
                 TH * TW * CLD + 2 * TH * TW <= halo16_smem_floats<BN>(), "LDS budget");  // main loop / C tile + LN statistics
+  static_assert(!PERSIST || (!TAIL && !TALL && BN == 32), "PERSIST: plain 8 x 32 tiles of the BN = 32 kernel");
   char* const As_b = reinterpret_cast<char*>(smem);
   char* const Bs_b = As_b + 2 * A_BYTES;
+  float* const csm = PERSIST ? smem + (2 * A_BYTES + NBUF * B_BYTES) / 4 : smem;  // C tile (+ LN statistics)
 
   // ---- XCD-aware block -> (pixel tile, channel tile) ----------------------------------------
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_n = bid % p.tiles_n;
-  int tm = bid / p.tiles_n;
   const int tiles_x = TALL ? 1 : p.tiles_x, tiles_y = (p.H + TH - 1) / TH;  // (tiles_x excludes the strip columns [rx0, W))
-  const int tx = tm % tiles_x;
-  tm /= tiles_x;
-  const int ty = tm % tiles_y;
-  const int n_img = tm / tiles_y;
-  const int y0 = ty * TH, x0 = TALL ? p.rx0 : tx * TW;
+  const int ntiles = PERSIST ? p.N * tiles_y * tiles_x * p.tiles_n : nwg;   // tiles of this shape in the launch
+  struct Tile {
+    int tile_n, n_img, y0, x0;
+  };
+  auto decode = [&](int t) {
+    int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+    Tile c;
+    c.tile_n = t % p.tiles_n;
+    int tm = t / p.tiles_n;
+    const int tx = tm % tiles_x;
+    tm /= tiles_x;
+    const int ty = tm % tiles_y;
+    c.n_img = tm / tiles_y;
+    c.y0 = ty * TH;
+    c.x0 = TALL ? p.rx0 : tx * TW;
+    return c;
+  };
+  Tile tl = decode(bid);
+  const int tile_n = tl.tile_n;  // (PERSIST: tiles_n == 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -98,25 +115,31 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   // halo pixel is zero padding, or whose 4 channels lie beyond Cin, gets the out-of-range offset 2^31 and the
   // hardware returns zeros -- no select on the loaded data.  (conv3x3_halo16_usable: extent < 2^31 bytes.)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)n_img * p.x_bstride);
-  i32x4 rsrc;
-  rsrc.x = (int)(unsigned)img_base;
-  rsrc.y = (int)(unsigned)((img_base >> 32) & 0xffffu);  // stride 0: raw buffer
-  rsrc.z = (int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + ((p.Cin + 3) & ~3)) * 4);  // bytes up to the last channel read
-  rsrc.w = 0x00020000;
-  rsrc.x = __builtin_amdgcn_readfirstlane(rsrc.x);
-  rsrc.y = __builtin_amdgcn_readfirstlane(rsrc.y);
-  rsrc.z = __builtin_amdgcn_readfirstlane(rsrc.z);
   constexpr unsigned OOB = 0x80000000u;
-  unsigned a_off[A_IT];  // byte offset of (halo pixel prow + 64*it, channel chunk*4), or OOB
+  struct Halo {
+    i32x4 rsrc;
+    unsigned off[A_IT];  // byte offset of (halo pixel prow + 64*it, channel chunk*4), or OOB
+  };
+  auto halo_of = [&](const Tile& c) {
+    Halo hl;
+    const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)c.n_img * p.x_bstride);
+    hl.rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)img_base);
+    hl.rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((img_base >> 32) & 0xffffu));  // stride 0: raw buffer
+    hl.rsrc.z = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + ((p.Cin + 3) & ~3)) * 4));  // bytes up to the last channel read
+    hl.rsrc.w = 0x00020000;
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    const int hp = prow + 64 * it;
-    const int hy = hp / HW_, hx = hp - hy * HW_;
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    a_off[it] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + chunk * 4) * 4) : OOB;
-  }
+    for (int it = 0; it < A_IT; ++it) {
+      const int hp = prow + 64 * it;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = c.y0 - 1 + hy, ix = c.x0 - 1 + hx;
+      const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      hl.off[it] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + chunk * 4) * 4) : OOB;
+    }
+    return hl;
+  };
+  Halo hcur = halo_of(tl);
+  Halo hnxt = hcur;  // PERSIST: the next tile of this workgroup (loaded from during the last slab)
   const long long w_row_stride = 9LL * p.Cin_pad;
   // With a tail tile (igemm.h: has_tail_tile) the last slab -- 2 real channels -- is not walked tap by tap: its
   // 9 taps x 2 channels are ONE extra step (k = 2*tap + c) after the full slabs.
@@ -128,14 +151,14 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   const int relu_floor = p.relu_in ? 0 : (int)0x80000000;  // fused input ReLU as an integer max on the float bits
 
   f32x4 ra[A_IT];
-  auto a_voff = [&](int cc, int it) {  // (2^31 + cc*128 stays out of range: no wrap)
-    return cc * BK + chunk * 4 < cin4 ? a_off[it] + (unsigned)(cc * BK * 4) : OOB;
+  auto a_voff = [&](const Halo& hl, int cc, int it) {  // (2^31 + cc*128 stays out of range: no wrap)
+    return cc * BK + chunk * 4 < cin4 ? hl.off[it] + (unsigned)(cc * BK * 4) : OOB;
   };
   // Inline asm: (a) hipcc has no counted wait once LDS-DMAs are in flight -- it treats vmcnt as unordered and
   // waits vmcnt(0) in front of the first use; the value is handed back by the counted wait (its "+v" operand);
   // (b) the buffer form with hardware range checking.
-  auto load_a_async = [&](int cc, int it) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it]) : "v"(a_voff(cc, it)), "s"(rsrc) : "memory");
+  auto load_a_async = [&](const Halo& hl, int cc, int it) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it]) : "v"(a_voff(hl, cc, it)), "s"(hl.rsrc) : "memory");
   };
   auto store_a = [&](int abuf, int it) {
     const int hp = prow + 64 * it;
@@ -225,7 +248,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
 
   // ---- prologue ------------------------------------------------------------------------------------------
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) load_a_async(0, it);
+  for (int it = 0; it < A_IT; ++it) load_a_async(hcur, 0, it);
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     dma_b(0, 0, i);
@@ -243,13 +266,27 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   for (int a = 0; a < NA; ++a) read_a(a, 0, 0);
   read_b(0, 0, 0);
 
+  int gs = 0;  // slabs walked so far by this workgroup: slab gs sits in halo buffer gs & 1
+  for (int t = bid;;) {
+  const int t_next = t + nwg;
+  const bool has_next = PERSIST && t_next < ntiles;  // block-uniform
+  Tile tl_next = tl;
+  if (has_next) {
+    tl_next = decode(t_next);
+    hnxt = halo_of(tl_next);
+  }
   for (int cc = 0; cc < cchunks; ++cc) {
-    const int ccn = cc + 1 < cslabs ? cc + 1 : cc;  // last slab: re-load clamped data nobody reads (no branches)
+    // the slab staged during this one: the next slab of the tile; behind the last one the first slab of this workgroup's
+    // next tile (PERSIST) -- or, when there is none, clamped data nobody reads (no branches around the loads)
+    const bool wrap = PERSIST && has_next && cc + 1 == cslabs;
+    const int ccn = cc + 1 < cslabs ? cc + 1 : (wrap ? 0 : cc);
+    const Halo& hl = wrap ? hnxt : hcur;
+    const int ab = (gs + cc) & 1;  // halo buffer of this slab
     auto step = [&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
       constexpr int L0 = tap < A_IT ? 1 : 0, Lm1 = (tap >= 1 && tap - 1 < A_IT) ? 1 : 0;
       const int s = cc * 9 + tap;
-      const int s3 = s + 3 < nsteps ? s + 3 : nsteps - 1;
+      const int s3 = s + 3 < nsteps ? s + 3 : (PERSIST ? s + 3 - nsteps : nsteps - 1);  // PERSIST: wraps into the next tile
       constexpr int bb = tap % 3;  // 9 taps per slab: step mod 3 == tap mod 3
 #pragma unroll
       for (int j = 0; j < NJ - 1; ++j) {
@@ -267,7 +304,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           __builtin_amdgcn_sched_barrier(0);
           if (j == 0 && a == 0) {
 #ifndef PRV2_ABL_NOA
-            if constexpr (tap < A_IT) load_a_async(ccn, tap);
+            if constexpr (tap < A_IT) load_a_async(hl, ccn, tap);
 #endif
           }
           if (j == (NJ > 2 ? 1 : 0) && a == NA - 2) {
@@ -276,7 +313,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
               constexpr int newer = 2 * ND + Lm1 + L0;
               asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
-              store_a((cc + 1) & 1, tap - 2);  // other halo buffer: last read in slab cc-1
+              store_a(ab ^ 1, tap - 2);  // other halo buffer: last read in the previous slab
             }
 #endif
           }
@@ -302,8 +339,8 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           mma(a + 1, NJ - 1, (NJ - 1) & 1, pr);
         }
         __builtin_amdgcn_sched_barrier(0);
-        read_a(a, tap == 8 ? (cc + 1) & 1 : cc & 1, (tap + 1) % 9);
-        read_a(a + 1, tap == 8 ? (cc + 1) & 1 : cc & 1, (tap + 1) % 9);
+        read_a(a, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
+        read_a(a + 1, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
 #ifndef PRV2_ABL_NOB
         if (a / 2 < ND) dma_b_async(s3, tap % 3, a / 2);
 #endif  // this step's tile buffer is free since the barrier
@@ -356,86 +393,106 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         for (int a = 0; a < NA; ++a) mma(a, j, j & 1, pr);
     }
   }
+  if constexpr (!PERSIST) {
   // The clamped DMAs of the last two steps are still in flight and hipcc does not know it (they are inline asm, so
   // __syncthreads() alone emits NO vmcnt wait): drain them by hand before the C tile overwrites the buffers.  Without
   // this a late DMA (HBM contention from kernels on other streams) lands on top of the C tile.
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  // (PERSIST: the C tile has LDS of its own, the DMAs in flight belong to the next tile's first steps -- no drain.  Its
+  // previous contents were last read in the store loop of the previous tile, >= 9 barriers ago.)
+  auto epilogue = [&](const Tile& c) {
+    // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
+  #pragma unroll
+    for (int a = 0; a < NA; ++a)
+  #pragma unroll
+      for (int j = 0; j < NJ; ++j)
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = TALL ? ((wm * NA + a) * 2 + ((4 * g + e) >> 3)) * TW + ((4 * g + e) & 7)
+                               : (NI * wm + a / 2) * TW + (a % 2) * 16 + 4 * g + e;
+          csm[row * CLD + wn * (BN / WN) + j * 16 + m16] = acc[a][j][e];
+        }
+    __syncthreads();
+    float* const ln_stats = csm + TH * TW * CLD;
+    if (p.ln_w) {  // block-uniform
+      ln_row_stats(p, csm, CLD, TH * TW, tid, ln_stats);
+      __syncthreads();
+    }
 
-  // ---- epilogue through LDS (see igemm.hip) ------------------------------------------------------
+    constexpr int C4 = BN / 4;
+    constexpr int RPP = 512 / C4;
+    const int col4 = tid % C4;
+    EpiCols ec;
+    if (!epi_cols(p, c.tile_n * BN + col4 * 4, ec)) return;
+    const long long img_m = (long long)c.n_img * p.H * p.W, img_o = (long long)c.n_img * p.y_bstride + ec.co;
+    // The store loop is VALU-bound (16 rows per thread, 2 waves per SIMD): the general epilogue costs ~100 instructions a
+    // row -- every optional stage as a select -- which was 14 k of the 280 k cycles of a 512->256 tile.
+    // Lean paths for the three common shapes: bias + act; bias + LN + act (fusion encoders); bias + act + one residual
+    // (GatedConvUnit.conv).  Everything else (gates, gamma, two residuals, ragged channels) takes the general loop below.
+    const bool simple = ec.vec && !p.gamma && !p.mul && !p.res2 && !(p.ln_w && p.res);  // block-uniform
+    if (simple) {
+      float* const ybase = p.y + img_o;
+      const float* const rbase = p.res ? p.res + img_m * p.ld_res + ec.co : nullptr;
+      auto lean = [&](auto act_c, auto ln_c, auto res_c) {
+        constexpr bool LN = decltype(ln_c)::value, RES = decltype(res_c)::value;
+        for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+          const int py = rr / TW, px = rr - py * TW;
+          const int oy = c.y0 + py, ox = c.x0 + px;
+          if (oy >= p.H || ox >= p.W) continue;
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + col4 * 4]);
+          const int pix = oy * p.W + ox;
+          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (RES) rv = *reinterpret_cast<const f32x4*>(rbase + (unsigned)(pix * p.ld_res));
+          f32x4 ov;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = cv[e] + ec.bias[e];
+            if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[TH * TW + rr] * ec.lnw[e] + ec.lnb[e];
+            t = act_apply(t, decltype(act_c)::value);
+            if constexpr (RES) t += rv[e];
+            ov[e] = e < ec.nvalid ? t : 0.f;  // pad channels behind cout stay zero
+          }
+          float* dst = ybase + (unsigned)(pix * p.ldy);
+          asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+        }
+      };
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      dispatch_act(p.act, [&](auto act_c) {
+        if (p.ln_w) lean(act_c, T_{}, F_{});
+        else if (p.res) lean(act_c, F_{}, T_{});
+        else lean(act_c, F_{}, F_{});
+      });
+      return;
+    }
+    dispatch_act(p.act, [&](auto act_c) {
+      for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+        const int py = rr / TW, px = rr - py * TW;
+        const int oy = c.y0 + py, ox = c.x0 + px;
+        if (oy >= p.H || ox >= p.W) continue;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + col4 * 4]);
+        const int pix = oy * p.W + ox;
+        epi_store<decltype(act_c)::value>(p, ec, cv, img_m + pix, img_o + (long long)pix * p.ldy, ln_stats[rr],
+                                          ln_stats[TH * TW + rr]);
+      }
+    });
+  };
+#ifndef PRV2_ABL_NOEPI
+  epilogue(tl);
+#endif
+  if (!has_next) break;
+  // next tile of this workgroup: its first slab is staged, its first fragments and weight column are in registers
+  t = t_next;
+  tl = tl_next;
+  hcur = hnxt;
+  gs += cchunks;
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = TALL ? ((wm * NA + a) * 2 + ((4 * g + e) >> 3)) * TW + ((4 * g + e) & 7)
-                             : (NI * wm + a / 2) * TW + (a % 2) * 16 + 4 * g + e;
-        smem[row * CLD + wn * (BN / WN) + j * 16 + m16] = acc[a][j][e];
-      }
-  __syncthreads();
-  float* const ln_stats = smem + TH * TW * CLD;
-  if (p.ln_w) {  // block-uniform
-    ln_row_stats(p, smem, CLD, TH * TW, tid, ln_stats);
-    __syncthreads();
-  }
-
-  constexpr int C4 = BN / 4;
-  constexpr int RPP = 512 / C4;
-  const int col4 = tid % C4;
-  EpiCols ec;
-  if (!epi_cols(p, tile_n * BN + col4 * 4, ec)) return;
-  const long long img_m = (long long)n_img * p.H * p.W, img_o = (long long)n_img * p.y_bstride + ec.co;
-  // The store loop is VALU-bound (16 rows per thread, 2 waves per SIMD): the general epilogue costs ~100 instructions a
-  // row -- every optional stage as a select -- which was 14 k of the 280 k cycles of a 512->256 tile.
-  // Lean paths for the three common shapes: bias + act; bias + LN + act (fusion encoders); bias + act + one residual
-  // (GatedConvUnit.conv).  Everything else (gates, gamma, two residuals, ragged channels) takes the general loop below.
-  const bool simple = ec.vec && !p.gamma && !p.mul && !p.res2 && !(p.ln_w && p.res);  // block-uniform
-  if (simple) {
-    float* const ybase = p.y + img_o;
-    const float* const rbase = p.res ? p.res + img_m * p.ld_res + ec.co : nullptr;
-    auto lean = [&](auto act_c, auto ln_c, auto res_c) {
-      constexpr bool LN = decltype(ln_c)::value, RES = decltype(res_c)::value;
-      for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
-        const int py = rr / TW, px = rr - py * TW;
-        const int oy = y0 + py, ox = x0 + px;
-        if (oy >= p.H || ox >= p.W) continue;
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
-        const int pix = oy * p.W + ox;
-        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (RES) rv = *reinterpret_cast<const f32x4*>(rbase + (unsigned)(pix * p.ld_res));
-        f32x4 ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = cv[e] + ec.bias[e];
-          if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[TH * TW + rr] * ec.lnw[e] + ec.lnb[e];
-          t = act_apply(t, decltype(act_c)::value);
-          if constexpr (RES) t += rv[e];
-          ov[e] = e < ec.nvalid ? t : 0.f;  // pad channels behind cout stay zero
-        }
-        float* dst = ybase + (unsigned)(pix * p.ldy);
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
-      }
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    dispatch_act(p.act, [&](auto act_c) {
-      if (p.ln_w) lean(act_c, T_{}, F_{});
-      else if (p.res) lean(act_c, F_{}, T_{});
-      else lean(act_c, F_{}, F_{});
-    });
-    return;
-  }
-  dispatch_act(p.act, [&](auto act_c) {
-    for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
-      const int py = rr / TW, px = rr - py * TW;
-      const int oy = y0 + py, ox = x0 + px;
-      if (oy >= p.H || ox >= p.W) continue;
-      const f32x4 cv = *reinterpret_cast<const f32x4*>(&smem[rr * CLD + col4 * 4]);
-      const int pix = oy * p.W + ox;
-      epi_store<decltype(act_c)::value>(p, ec, cv, img_m + pix, img_o + (long long)pix * p.ldy, ln_stats[rr],
-                                        ln_stats[TH * TW + rr]);
-    }
-  });
+    for (int j = 0; j < NJ; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }  // tiles of this workgroup
+  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in LDS after the workgroup is gone
 }
 
 // One launch = the 32-pixel tile columns [0, tiles_x) as 8 x 32 tiles + (strip_blocks > 0) the remainder strip
@@ -449,11 +506,39 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   else halo16_body<BN, PREC, TAIL, false>(p, smem, blockIdx.x - strip, gridDim.x - strip);
 }
 
+// BN = 32 without tail tile: the 8 x 32 tiles are walked by persistent workgroups (one per CU: 160 KB of LDS), the strip
+// tiles stay ordinary leading workgroups.
+template <int PREC>
+__global__ void __launch_bounds__(512, 2) conv3x3_halo16_persist_kernel(const IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<32, true>()];
+  const int strip = p.strip_blocks;  // block-uniform
+  if ((int)blockIdx.x < strip) halo16_body<32, PREC, false, true>(p, smem, blockIdx.x, strip);
+  else halo16_body<32, PREC, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+}
+
+static int persist_workgroups() {  // one persistent workgroup per CU
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = cus;
+  }
+  return n;
+}
+
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   using namespace m16;
   p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;
   p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) * p.tiles_n : 0;
   const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x * p.tiles_n + p.strip_blocks;
+  static const bool no_persist = getenv("PRV2_HALO_NO_PERSIST") != nullptr;  // A/B switch
+  if (p.Ncols <= 32 && !p.w_tail && !no_persist) {
+    const int tiles = blocks - p.strip_blocks, wgs = tiles < persist_workgroups() ? tiles : persist_workgroups();
+    if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_halo16_persist_kernel<PRV2_PREC_BF16X3>), dim3(wgs + p.strip_blocks), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo16_persist_kernel<PRV2_PREC_BF16>), dim3(wgs + p.strip_blocks), dim3(512), 0, s, p);
+    return;
+  }
 #define PRV2_LAUNCH_HALO16(BN_, PREC_)                                                                                 \
   do {                                                                                                                 \
     if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_kernel<BN_, PREC_, true>), dim3(blocks), dim3(512), 0, s, p);     \

@@ -446,6 +446,11 @@ STRIP_CASES = [
     (3, 19, 72, 34, 40, dict(bias=True, ln=True, act="gelu")),              # rem 8, BN = 64, fused LayerNorm, tail tile
     (2, 33, 130, 66, 32, dict(bias=True, act="sigmoid", mul=True)),         # rem 2, BN = 32, gate
     (1, 64, 100, 256, 256, dict(res=True, res2=True, gamma=True, bias=True)),  # rem 4
+    # cout <= 32 without tail tile: persistent workgroups walk several tiles each (> 256 tiles), next tile's halo prefetched
+    (3, 200, 264, 64, 32, dict(bias=True, act="gelu")),                      # 2 slabs, 675 tiles + strip (rem 8)
+    (2, 264, 352, 32, 32, dict(bias=True, relu_in=True, res=True)),          # 1 slab: halo buffer parity flips per tile
+    (2, 150, 390, 128, 16, dict(bias=True, ln=True, act="gelu")),            # 4 slabs, cout 16, fused LN, rem 6, H % 8 != 0
+    (5, 96, 224, 96, 24, dict(bias=True, act="sigmoid", mul=True)),          # 3 slabs (odd), 420 tiles: uneven tiles per workgroup
 ]
 
 

@@ -13,6 +13,7 @@ SHAPES = [  # (cin, cout, k, h, w)  -- the heavy layers of BiDirectionalFusion, 
     (322, 322, 3, 112, 112), (642, 642, 3, 56, 56), (128, 128, 3, 448, 448), (98, 32, 3, 448, 448), (770, 770, 3, 28, 28),
     (256, 32, 3, 448, 448), (34, 32, 3, 448, 448),
     (1024, 4096, 1, 1025, 1), (4096, 1024, 1, 1025, 1),
+    (64, 32, 3, 448, 448), (128, 32, 3, 448, 448),  # 17, 18: persistent BN = 32 kernel
 ]
 for si, (cin, cout, k, h, w) in enumerate(SHAPES):
     if ONLY is not None and si not in ONLY:
