@@ -334,6 +334,35 @@ class _PatchModel(StateDictModule):
     def get_save_dict(self):
         return self.state_dict()
 
+    # -- PyTorchModelHubMixin's on-disk layout (patchrefinerplus.py:39,60): <dir>/config.json + <dir>/model.safetensors.
+    #    Local directories only: there is no hub access from this build.
+    def save_pretrained(self, save_directory):
+        import json
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(self.config.to_dict(), f, indent=2, sort_keys=True)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.get_save_dict().items()},
+                  os.path.join(save_directory, "model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, **config_overrides):
+        """``Model.from_pretrained(dir)``: config.json -> ``cls(config)``, model.safetensors -> ``load_dict`` (the mixin
+        builds the class with ``config=`` and loads non-strictly, like the reference's own load_dict)."""
+        import json
+        import os
+        from safetensors.torch import load_file
+        d = str(pretrained_model_name_or_path)
+        if not os.path.isdir(d):
+            raise FileNotFoundError(f"from_pretrained: '{d}' is not a local directory (no hub access in this build)")
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = json.load(f)
+        cfg.update(config_overrides)
+        m = cls(cfg)
+        m.load_dict(load_file(os.path.join(d, "model.safetensors")))
+        return m
+
     def _make_da2(self, branch_cfg, max_depth):
         mc = dict(branch_cfg["model_cfg"])
         return DepthAnythingV2(**{**mc, "max_depth": max_depth}, device=self.device, prec=self.prec)

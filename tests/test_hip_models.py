@@ -266,6 +266,20 @@ def test_e2e_v2_other_refiner_encoders_vs_oracle(P, enc):
         assert ar < 1e-5 and mx < 1e-3, (mode, ar, mx)
 
 
+def test_save_and_from_pretrained_roundtrip(P, tmp_path):
+    """PyTorchModelHubMixin's local layout (config.json + model.safetensors): the re-loaded model reproduces the frame"""
+    from patchrefinerv2_amd.models import PatchRefinerPlus
+    c = E2E_V2
+    m = _build("PatchRefinerPlus", c, e2e_v2_sd())
+    a, _ = _run(m, c, "r4")
+    m.save_pretrained(str(tmp_path / "ckp"))
+    m2 = PatchRefinerPlus.from_pretrained(str(tmp_path / "ckp"))
+    b, _ = _run(m2, c, "r4")
+    assert torch.equal(a, b)
+    with pytest.raises(FileNotFoundError):
+        PatchRefinerPlus.from_pretrained("zhyever/not-a-local-dir")
+
+
 def test_batching_independence(P):
     """per-patch results do not depend on the mini-batch size (the licence for large batches)."""
     c = E2E_V1
