@@ -18,21 +18,30 @@
 // LDS-DMA in flight hipcc's own s_waitcnt vmcnt(N) are exact and counted (tools/probes/vmcnt_order.hip: loads
 // of one wave retire in issue order on gfx950, LDS-DMA included).
 //
-// Per 32-channel slab (step s): 8 column phases of 2 x 3 MFMAs; weight column j+1 is read while column j
+// Per 32-channel slab (step s): 8 column phases of 2 x 3 MFMAs; weight column j+2 is read while column j
 // multiplies; phase 0 issues the loads of slab s+2 (4 row loads + 2 weight loads); the rows of slab s+1
-// (loaded a step ago) are split into the second fragment set in phases 3 / 5, its weights are stored to LDS
-// in phase 6; the barrier sits before the last phase, after which column 0 of the next slab is read.
+// (loaded a step ago) are split into the second fragment set in phases 2 / 4, its weights are stored to LDS
+// in phase 5; the barrier sits before phase 6; phases 6 / 7 read columns 0 / 1 of the next slab (two phases ahead).
 // The loop is unrolled x4 so that register-set parity and weight-buffer index are compile-time.
+#include <cstdlib>
 #include <type_traits>
 
 #include "igemm.h"
 
 namespace prv2 {
 
-template <int PREC>
-__global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
+// NW = 4: 128-row tiles, two workgroups per CU (short K: prologue / epilogue of one overlap the loop of the other).
+// NW = 8: 256-row tiles, one workgroup per CU -- the weight tile is fetched once for 256 rows instead of once per 128:
+// per 32-channel step a CU pulls 32 KB of rows + 16 KB of weights instead of 32 + 32 (1.5 GB goes through L2 in 0.16 ms
+// on 768->3072 @ 10 k rows).  Pays only for very long K.  Open: on the MFMA-bound shapes the kernel sits at ~47 % MFMA
+// utilisation (300-340 TF); removing either operand stream in an ablation gives +38 %, deeper prefetch of rows, weights
+// or weight fragments does not -- the per-element hi/lo split (64 VALU per 48 MFMAs, 9x less reuse than in the 3x3
+// kernel) is the suspect, i.e. 256 columns per wave.
+template <int PREC, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const IgemmParams p) {
   static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
-  constexpr int BN = 128, TM = 128, NW = 4, NA = 2, NJ = 8, ND = BN / (8 * NW), NBUF = 4;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int BN = 128, TM = 32 * NW, NA = 2, NJ = 8, ND = BN / (8 * NW), NBUF = 4;
   constexpr int B_BYTES = BN * 128;
   constexpr int CLD = BN + 4;
   constexpr int SMEM_MAIN = NBUF * B_BYTES / 4;
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
   // main loop: 8 rows x 128 B per instruction into registers (same lane -> byte mapping as the DMA), stored to LDS later
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, 0x7ffffff0, 0x00020000);
   const unsigned wdma_off = (unsigned)((((long long)tile_n * BN + dma_row) * w_row_stride + dma_slot * 4) * 4);
-  f32x4 rb[2][ND];  // weight pieces of steps s+1 / s+2 (set = step parity)
+  f32x4 rb[2][ND];  // weight pieces of steps s+1 / s+2 (set = step parity; a third step ahead bought nothing)
   auto load_w = [&](int set, int s) {
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
@@ -139,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
   const int b_key = (m16 >> 1) & 7;
   const char* const b_lane_hi = Bs_b + m16 * 128 + ((g ^ b_key) << 4);
   const char* const b_lane_lo = Bs_b + m16 * 128 + (((4 + g) ^ b_key) << 4);
-  bf16x8 bh[2], bl[2];
+  bf16x8 bh[4], bl[4];  // weight column c of a step sits in slot c & 3 (NJ = 8: the next step's column 0 is slot 0 again)
   auto read_b = [&](int slot, int bbuf, int j) {
     bh[slot] = *reinterpret_cast<const bf16x8*>(b_lane_hi + bbuf * B_BYTES + j * 16 * 128);
     if constexpr (PREC == PRV2_PREC_BF16X3) bl[slot] = *reinterpret_cast<const bf16x8*>(b_lane_lo + bbuf * B_BYTES + j * 16 * 128);
@@ -173,6 +182,7 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
   for (int a = 0; a < NA; ++a) split_run4(0, 0, a);
   __syncthreads();  // full fence: the weight DMAs have landed
   read_b(0, 0, 0);
+  read_b(1, 0, 1);
 
   // step s: multiplies slab s (fragment set s&1, weight buffer s&3)
   auto step = [&](auto par_c, int s) {
@@ -180,48 +190,63 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
     constexpr int set = q & 1;
     const int s2 = s + 2 < cchunks ? s + 2 : last, s3 = s + 3 < cchunks ? s + 3 : last;
 #pragma unroll
-    for (int j = 0; j < NJ - 1; ++j) {
-      read_b((j + 1) & 1, q, j + 1);
+    for (int j = 0; j < NJ; ++j) {
+      // barrier before phase NJ-2: this wave's LDS store of step s+1's weights (phase NJ-3) and its reads are done; no
+      // global-memory condition.  Phases NJ-2 / NJ-1 then read columns 0 / 1 of the NEXT step.
+      if (j == NJ - 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // weight columns are read TWO phases ahead: a phase is only 6 MFMAs (96 cycles), less than the LDS latency under load
+      if (j + 2 < NJ) read_b((j + 2) & 3, q, j + 2);
+      else read_b((j + 2) & 3, (q + 1) & 3, j + 2 - NJ);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pr = 0; pr < NP; ++pr) {
-        mma(set, 0, j, j & 1, pr);
-        mma(set, 1, j, j & 1, pr);
+        mma(set, 0, j, j & 3, pr);
+        mma(set, 1, j, j & 3, pr);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (j == 0) {  // this set's raw registers were consumed during step s-1
+#ifndef PRV2_ABL_NOA
         load_rows((q + 3) & 3, s3);  // that set's raw registers were consumed during step s-1
+#endif
+#ifndef PRV2_ABL_NOB
         load_w(set, s2);
+#endif
       }
       // rows of slab s+1 were loaded in step s-2, the weights of step s+1 in step s-1 (hipcc counts the waits itself)
-      if (j == 3) {
+      if (j == 2) {
         split_run4((q + 1) & 3, set ^ 1, 0);
       }
-      if (j == 5) {
+      if (j == 4) {
         split_run4((q + 1) & 3, set ^ 1, 1);
       }
-      if (j == 6) {  // weights of step s+1 -> buffer (s+1)&3, last read in step s-3
+      if (j == NJ - 3) {  // weights of step s+1 -> buffer (s+1)&3, last read in step s-3
+#ifndef PRV2_ABL_NOB
         store_w(set ^ 1, (q + 1) & 3);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // barrier: this wave's LDS stores (weights of step s+1) and reads are done; no global-memory condition
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    read_b(NJ & 1, (q + 1) & 3, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int pr = 0; pr < NP; ++pr) {
-      mma(set, 0, NJ - 1, (NJ - 1) & 1, pr);
-      mma(set, 1, NJ - 1, (NJ - 1) & 1, pr);
-    }
-    __builtin_amdgcn_sched_barrier(0);
   };
-  for (int cc = 0; cc < cchunks; cc += 4) {
+  // Four unconditional steps per iteration: with branches between the steps hipcc's waitcnt pass merges the pending-load
+  // state of every path and then drains (vmcnt(3) .. vmcnt(0)) in front of each step's address arithmetic, whose
+  // temporaries alias load destinations -- which exposed the full HBM latency on three steps out of four.
+  int cc = 0;
+  for (; cc + 4 <= cchunks; cc += 4) {
     step(std::integral_constant<int, 0>{}, cc);
-    if (cc + 1 < cchunks) step(std::integral_constant<int, 1>{}, cc + 1);
-    if (cc + 2 < cchunks) step(std::integral_constant<int, 2>{}, cc + 2);
-    if (cc + 3 < cchunks) step(std::integral_constant<int, 3>{}, cc + 3);
+    step(std::integral_constant<int, 1>{}, cc + 1);
+    step(std::integral_constant<int, 2>{}, cc + 2);
+    step(std::integral_constant<int, 3>{}, cc + 3);
   }
+  if (cc < cchunks) {  // K % 128 != 0: up to three more slabs
+    step(std::integral_constant<int, 0>{}, cc);
+    if (cc + 1 < cchunks) {
+      step(std::integral_constant<int, 1>{}, cc + 1);
+      if (cc + 2 < cchunks) step(std::integral_constant<int, 2>{}, cc + 2);
+    }
+  }
+#ifdef PRV2_ABL_NOEPI
+  if (acc[0][0][0] != 12345.f) return;
+#endif
   __syncthreads();  // every wave is done with the weight buffers before the C tile overwrites them
 
   // ---- epilogue through LDS: rows become contiguous 512-byte stores, fused bias / LN / act / gate / residuals ----
@@ -291,14 +316,23 @@ __global__ void __launch_bounds__(256, 2) gemm16_kernel(const IgemmParams p) {
 bool gemm16_supported(const IgemmParams& p, int prec) {
   return prec != PRV2_PREC_F32 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 &&
          p.x_bstride == (long long)p.H * p.W * p.ldx && p.y_bstride == (long long)p.OH * p.OW * p.ldy &&
-         128LL * p.ldx * 4 < (1LL << 31) && p.M >= 512 && p.Ncols > 64;
+         256LL * p.ldx * 4 < (1LL << 31) && p.M >= 512 && p.Ncols > 64;
 }
 
 void launch_gemm16(IgemmParams& p, int prec, hipStream_t s) {
   p.tiles_n = (int)cdiv(p.Ncols, 128);
-  const int tiles_m = (int)cdiv(p.M, 128);
-  if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16X3>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+  static const int force_nw = getenv("PRV2_GEMM16_NW") ? atoi(getenv("PRV2_GEMM16_NW")) : 0;  // A/B switch
+  // 256-row tiles when K is long enough to amortise the lone workgroup's prologue / epilogue and the grid still covers the chip
+  const bool big = force_nw ? force_nw == 8 : (p.Cin_pad >= 2048 && cdiv(p.M, 256) * p.tiles_n >= 256);  // measured: +6 % at K = 3072, -2 % at K = 768
+  const int tiles_m = (int)cdiv(p.M, big ? 256 : 128);
+  const dim3 grid(tiles_m * p.tiles_n);
+  if (big) {
+    if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16X3, 8>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16, 8>), grid, dim3(512), 0, s, p);
+  } else {
+    if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16X3, 4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16, 4>), grid, dim3(256), 0, s, p);
+  }
 }
 
 }  // namespace prv2

@@ -14,11 +14,12 @@ SHAPES = [  # (cin, cout, k, h, w)  -- the heavy layers of BiDirectionalFusion, 
     (256, 32, 3, 448, 448), (34, 32, 3, 448, 448),
     (1024, 4096, 1, 1025, 1), (4096, 1024, 1, 1025, 1),
     (64, 32, 3, 448, 448), (128, 32, 3, 448, 448),  # 17, 18: persistent BN = 32 kernel
+    (768, 3072, 1, 24, 31), (3072, 768, 1, 24, 31), (192, 768, 1, 98, 126), (256, 256, 1, 196, 259),  # 19-22: 1x1 GEMMs (b14)
 ]
 for si, (cin, cout, k, h, w) in enumerate(SHAPES):
     if ONLY is not None and si not in ONLY:
         continue
-    b = 1 if w == 1 else B
+    b = 1 if w == 1 else (14 if si >= 19 else B)
     x = ops.Feat.alloc(b, h, w, cin, "cuda")
     x.buf.normal_()
     cw = ops.pack_conv(torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5, None, prec=prec)
