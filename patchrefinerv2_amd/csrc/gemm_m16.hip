@@ -36,7 +36,10 @@ namespace prv2 {
 // on 768->3072 @ 10 k rows).  Pays only for very long K.  Open: on the MFMA-bound shapes the kernel sits at ~47 % MFMA
 // utilisation (300-340 TF); removing either operand stream in an ablation gives +38 %, deeper prefetch of rows, weights
 // or weight fragments does not -- the per-element hi/lo split (64 VALU per 48 MFMAs, 9x less reuse than in the 3x3
-// kernel) is the suspect, i.e. 256 columns per wave.
+// kernel) was the suspect, but dropping a quarter of it (PRV2_ABL_NORELU) moves nothing either.  PMC (tools/pmc_conv.sh 19):
+// MFMA pipe busy 37.6 % at 2.04 GHz (the 3x3 kernel: 76.7 % at 1.80 GHz on the same box), no LDS bank conflicts, waves
+// wait on instruction issue 49 % and on s_waitcnt 25 % of their cycles -- next: TCP / TCC counters (per-CU L2 fetch rate:
+// a CU pulls 64 KB per 32-channel step here, 3x the 3x3 kernel).
 template <int PREC, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const IgemmParams p) {
   static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
@@ -95,10 +98,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       i32x4v vi = __builtin_bit_cast(i32x4v, ra[rset][a][h]);
+#ifndef PRV2_ABL_NORELU
       vi.x = max(vi.x, relu_floor);
       vi.y = max(vi.y, relu_floor);
       vi.z = max(vi.z, relu_floor);
       vi.w = max(vi.w, relu_floor);
+#endif
       const f32x4 v = __builtin_bit_cast(f32x4, vi);
       const bf16x4 hi = __builtin_convertvector(v, bf16x4);
       const u32x2 hp = __builtin_bit_cast(u32x2, hi);

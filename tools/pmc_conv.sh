@@ -18,7 +18,7 @@ tot=collections.defaultdict(lambda: collections.defaultdict(float)); n=collectio
 for f in glob.glob('/tmp/pc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0].replace('void ','')
-        if 'halo' not in k: continue
+        if 'halo' not in k and 'gemm16' not in k: continue
         tot[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
         dur[k].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
 for k in tot:
