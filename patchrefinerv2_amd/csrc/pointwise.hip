@@ -306,30 +306,46 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const float* __restri
   }
 }
 
-// squeeze: out[n][c] = mean over the HW pixels.  grid (cg blocks of 64 lanes x 4 pixel groups, n); float4 over channels.
-__global__ void __launch_bounds__(256) global_avgpool_kernel(const float* __restrict__ x, int64_t HW, int C, int ldx,
-                                                             float* __restrict__ out) {
-  __shared__ float4 part[4][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + lane) * 4;
-  const int n = blockIdx.y;
+// squeeze: out[n][c] = mean over the HW pixels, in two deterministic stages (fixed summation order, no atomics):
+// stage 1: grid (channel-group blocks, pixel chunks, n); a block = CGW channel groups (float4) x 256/CGW pixel lanes sums its
+// chunk into part[n][chunk][c]; stage 2 adds the chunks in index order.  (A first version with one block per image and
+// channel block ran at 20 GB/s on the 24-channel 196 x 259 maps of EfficientNet's first stage: 14 blocks on 256 CUs.)
+__global__ void __launch_bounds__(256) avgpool_partial_kernel(const float* __restrict__ x, int64_t HW, int C, int ldx, int cgw_log2,
+                                                              int chunk_len, float* __restrict__ part) {
+  __shared__ float4 sm[256];
+  const int cgw = 1 << cgw_log2;
+  const int cl = threadIdx.x & (cgw - 1), pl = threadIdx.x >> cgw_log2, npl = 256 >> cgw_log2;
+  const int c = (blockIdx.x * cgw + cl) * 4;
+  const int chunk = blockIdx.y, n = blockIdx.z, chunks = gridDim.y;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
+    const int64_t p0 = (int64_t)chunk * chunk_len, p1 = p0 + chunk_len < HW ? p0 + chunk_len : HW;
     const float* base = x + (int64_t)n * HW * ldx + c;
-    for (int64_t pix = grp; pix < HW; pix += 4) {
+    for (int64_t pix = p0 + pl; pix < p1; pix += npl) {
       const float4 v = *reinterpret_cast<const float4*>(base + pix * ldx);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
-  part[grp][lane] = acc;
+  sm[threadIdx.x] = acc;
   __syncthreads();
-  if (grp == 0 && c < C) {
-    float4 t = part[0][lane];
-#pragma unroll
-    for (int g = 1; g < 4; ++g) { t.x += part[g][lane].x; t.y += part[g][lane].y; t.z += part[g][lane].z; t.w += part[g][lane].w; }
-    const float inv = 1.0f / (float)HW;
-    *reinterpret_cast<float4*>(out + (int64_t)n * C + c) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  if (pl == 0 && c < C) {
+    float4 t = sm[cl];
+    for (int g = 1; g < npl; ++g) {
+      const float4 u = sm[(g << cgw_log2) + cl];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + ((int64_t)n * chunks + chunk) * C + c) = t;
   }
+}
+
+__global__ void __launch_bounds__(256) avgpool_final_kernel(const float* __restrict__ part, int N, int C, int chunks, float inv,
+                                                            float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * C) return;
+  const int n = idx / C, c = idx - n * C;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += part[((int64_t)n * chunks + k) * C + c];
+  out[idx] = s * inv;
 }
 
 // excite: x[n, pix, c] *= s[n][c]
@@ -536,10 +552,29 @@ extern "C" int prv2_dwconv2d(const float* x, int32_t n, int32_t h, int32_t w, in
   return prv2_dwconv2d_ex(x, n, h, w, c, ldx, wgt, bias, k, stride, relu ? PRV2_ACT_RELU : PRV2_ACT_NONE, 0, y, ldy, stream);
 }
 
-extern "C" int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, float* out, void* stream) {
-  PRV2_REQUIRE(x && out && n > 0 && hw > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldx >= c, "global_avgpool: bad arguments");
-  PRV2_REQUIRE(aligned16(x) && aligned16(out), "global_avgpool: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(global_avgpool_kernel, dim3((c / 4 + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, x, hw, c, ldx, out);
+static int avgpool_chunks(int64_t hw) {
+  int64_t ch = (hw + 511) / 512;
+  return (int)(ch < 1 ? 1 : (ch > 128 ? 128 : ch));
+}
+
+extern "C" int64_t prv2_global_avgpool_workspace_floats(int32_t n, int64_t hw, int32_t c) {
+  return (int64_t)n * avgpool_chunks(hw) * c;
+}
+
+extern "C" int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, float* out, float* workspace,
+                                   void* stream) {
+  PRV2_REQUIRE(x && out && workspace && n > 0 && hw > 0 && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldx >= c,
+               "global_avgpool: bad arguments");
+  PRV2_REQUIRE(aligned16(x) && aligned16(workspace), "global_avgpool: pointers must be 16-byte aligned");
+  const int cg = c / 4, chunks = avgpool_chunks(hw);
+  int cgw_log2 = 0;
+  while ((1 << cgw_log2) < cg && cgw_log2 < 6) ++cgw_log2;
+  const int chunk_len = (int)((hw + chunks - 1) / chunks);
+  hipLaunchKernelGGL(avgpool_partial_kernel, dim3((cg + (1 << cgw_log2) - 1) >> cgw_log2, chunks, n), dim3(256), 0, (hipStream_t)stream, x,
+                     hw, c, ldx, cgw_log2, chunk_len, workspace);
+  PRV2_LAUNCH_CHECK("global_avgpool");
+  hipLaunchKernelGGL(avgpool_final_kernel, dim3((n * c + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, n, c, chunks,
+                     1.0f / (float)hw, out);
   PRV2_LAUNCH_CHECK("global_avgpool");
   return 0;
 }

@@ -304,8 +304,10 @@ def global_avgpool(x: Feat) -> torch.Tensor:
     """[n, c] mean over the pixels (the squeeze of timm's SqueezeExcite: x.mean((2, 3)))"""
     assert x.c % 4 == 0
     out = torch.empty((x.n, x.c), device=x.device, dtype=torch.float32)
+    ws = torch.empty(L.load().prv2_global_avgpool_workspace_floats(x.n, x.h * x.w, x.c), device=x.device, dtype=torch.float32)
     PROFILER.launch_aux("global_avgpool", 4.0 * x.n * x.h * x.w * x.c,
-                        lambda: L.check(L.load().prv2_global_avgpool(x.ptr, x.n, x.h * x.w, x.c, x.ld, out.data_ptr(), _stream()),
+                        lambda: L.check(L.load().prv2_global_avgpool(x.ptr, x.n, x.h * x.w, x.c, x.ld, out.data_ptr(), ws.data_ptr(),
+                                                                      _stream()),
                                         "global_avgpool"), f"{x.c}ch {x.n}x{x.h}x{x.w}")
     return out
 

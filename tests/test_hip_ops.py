@@ -144,6 +144,21 @@ def test_conv_cout1_and_dw(P):
         close(P.dwconv2d(P.Feat.from_nchw(xs.to(DEV)), wt, None, k, 1, False).to_nchw(), refd, 1e-5, f"dw strip k{k} {h}x{w_}x{c}")
 
 
+@pytest.mark.parametrize("n,h,w,c", [(3, 196, 259, 24), (2, 7, 5, 3072), (14, 49, 65, 384), (1, 1, 1, 8), (2, 98, 130, 240), (1, 33, 600, 12)])
+def test_squeeze_excite_pieces(P, n, h, w, c):
+    """global mean per (image, channel): fixed-order two-stage reduction (bit-reproducible), and the in-place channel gate"""
+    x = rnd(21, n, c, h, w) + 0.5
+    xf = P.Feat.from_nchw(x.to(DEV))
+    m1 = P.global_avgpool(xf)
+    m2 = P.global_avgpool(xf)
+    assert torch.equal(m1, m2)
+    ref = x.double().mean((2, 3)).float()
+    assert float((m1.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    g = torch.rand(n, c, generator=torch.Generator().manual_seed(22))
+    P.channel_scale_(xf, g.to(DEV).contiguous())
+    assert torch.equal(xf.to_nchw().cpu(), x * g.view(n, c, 1, 1))
+
+
 @pytest.mark.parametrize("c", [32, 98, 256, 384, 1024])
 def test_layernorm(P, c):
     x = rnd(1, 3, c, 7, 5) * 3 + 1
