@@ -348,6 +348,34 @@ __global__ void __launch_bounds__(256) avgpool_final_kernel(const float* __restr
   out[idx] = s * inv;
 }
 
+// squeeze-excite bottleneck in one launch: g[n][:] = sigmoid(W2 silu(W1 m[n][:] + b1) + b2), one workgroup per image, fp32.
+// (As two [n, C] row GEMMs on the generic MFMA kernel these were 2 x 28 us launches for ~1 MFLOP.)
+__global__ void __launch_bounds__(256) se_gate_kernel(const float* __restrict__ mean, int C, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, int CSE, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ g) {
+  extern __shared__ float sh[];  // [C] means | [CSE] bottleneck
+  float* const m = sh;
+  float* const r = sh + C;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) m[c] = mean[(int64_t)n * C + c];
+  __syncthreads();
+  for (int j = wave; j < CSE; j += 4) {  // one wave per bottleneck channel: lanes stride over C, fixed-order tree reduction
+    const float* wr = w1 + (int64_t)j * C;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += wr[c] * m[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) r[j] = act_apply(acc + (b1 ? b1[j] : 0.f), PRV2_ACT_SILU);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const float* wr = w2 + (int64_t)c * CSE;
+    float acc = b2 ? b2[c] : 0.f;
+    for (int j = 0; j < CSE; ++j) acc += wr[j] * r[j];
+    g[(int64_t)n * C + c] = act_apply(acc, PRV2_ACT_SIGMOID);
+  }
+}
+
 // excite: x[n, pix, c] *= s[n][c]
 __global__ void __launch_bounds__(256) channel_scale_kernel(float* __restrict__ x, int64_t HW, int C, int ldx,
                                                             const float* __restrict__ s, int64_t total) {
@@ -576,6 +604,16 @@ extern "C" int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_
   hipLaunchKernelGGL(avgpool_final_kernel, dim3((n * c + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, n, c, chunks,
                      1.0f / (float)hw, out);
   PRV2_LAUNCH_CHECK("global_avgpool");
+  return 0;
+}
+
+extern "C" int prv2_se_gate(const float* mean, int32_t n, int32_t c, const float* w1, const float* b1, int32_t cse, const float* w2,
+                            const float* b2, float* g, void* stream) {
+  PRV2_REQUIRE(mean && w1 && w2 && g && n > 0 && c > 0 && cse > 0, "se_gate: bad arguments");
+  const size_t shmem = (size_t)(c + cse) * sizeof(float);
+  PRV2_REQUIRE(shmem <= 64 * 1024, "se_gate: c + cse = %d floats do not fit the 64 KB of dynamic LDS", c + cse);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), shmem, (hipStream_t)stream, mean, c, w1, b1, cse, w2, b2, g);
+  PRV2_LAUNCH_CHECK("se_gate");
   return 0;
 }
 

@@ -185,25 +185,23 @@ class LightWeightRefiner(StateDictModule):
                 Q["expand"] = pk(sd[b + "conv_pw.weight"], self._fold(b + "bn1."))
                 Q["dw"] = dw(sd[b + "conv_dw.weight"], self._fold(b + "bn2."))
                 Q["proj"] = pk(sd[b + "conv_pwl.weight"], self._fold(b + "bn3."))
-            Q["se_r"] = ops.pack_conv(sd[b + "se.conv_reduce.weight"], sd[b + "se.conv_reduce.bias"], device=dev, prec=self.prec)
-            Q["se_e"] = ops.pack_conv(sd[b + "se.conv_expand.weight"], sd[b + "se.conv_expand.bias"], device=dev, prec=self.prec)
+            v = lambda k, shape=None: (sd[b + k].view(shape) if shape else sd[b + k]).to(dev).contiguous()  # noqa: E731
+            Q["se"] = (v("se.conv_reduce.weight", (B["cse"], B["cmid"])), v("se.conv_reduce.bias"),
+                       v("se.conv_expand.weight", (B["cmid"], B["cse"])), v("se.conv_expand.bias"))
             P["blocks"].append(Q)
         self._packed = P
 
     def _forward_effnet(self, crop: Feat):
         """MBConv: [1x1 expand + SiLU] -> dw kxk 'SAME' + SiLU -> SE (global mean -> FC + SiLU -> FC + sigmoid -> scale)
-        -> 1x1 project (+ x): BatchNorms folded, SiLU / residual fused into the conv epilogues, the SE bottleneck runs as
-        two [n, C] row GEMMs."""
+        -> 1x1 project (+ x): BatchNorms folded, SiLU / residual fused into the conv epilogues, the SE bottleneck is one
+        fp32 launch (prv2_se_gate)."""
         P = self._packed
         x = ops.conv2d(crop, P["stem"], act=ops.ACT_SILU)
         feats: List[Feat] = []
         for B in P["blocks"]:
             h = ops.conv2d(x, B["expand"], act=ops.ACT_SILU) if B["kind"] == "ir" else x
             h = ops.dwconv2d(h, B["dw"][0], B["dw"][1], B["k"], B["s"], act=ops.ACT_SILU, same_pad=True)
-            s = ops.global_avgpool(h)
-            r = ops.conv2d(Feat(s.view(1, h.n, 1, h.c), h.c), B["se_r"], act=ops.ACT_SILU)
-            g = ops.conv2d(r, B["se_e"], act=ops.ACT_SIGMOID)
-            ops.channel_scale_(h, g.buf.view(h.n, h.c))
+            ops.channel_scale_(h, ops.se_gate(ops.global_avgpool(h), *B["se"]))
             x = ops.conv2d(h, B["proj"], res=x if B["res"] else None)
             if B["tap"]:
                 feats.append(x)
