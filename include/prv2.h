@@ -119,13 +119,14 @@ int prv2_dwconv2d_ex(const float* x, int32_t n, int32_t h, int32_t w, int32_t c,
  *   prv2_global_avgpool: out[n][c] = mean over the h*w pixels of image n (x.mean((2, 3)));  out is dense [n][c];
  *                        workspace: prv2_global_avgpool_workspace_floats(n, hw, c) floats (partial sums of the two-stage,
  *                        fixed-order -- run-to-run deterministic -- reduction).
- *   prv2_se_gate:        g[n][:] = sigmoid(W2 silu(W1 mean[n][:] + b1) + b2), the conv_reduce / conv_expand bottleneck (fp32;
- *                        w1 [cse][c], w2 [c][cse] in PyTorch layout, biases optional); one launch.
+ *   prv2_se_gate:        g[n][:] = sigmoid(W2 silu(W1 mean[n][:] + b1) + b2), the conv_reduce / conv_expand bottleneck in fp32;
+ *                        w1 [cse][c] (PyTorch layout), w2t [cse][c] = conv_expand's weight TRANSPOSED, biases optional,
+ *                        workspace n*cse floats.
  *   prv2_channel_scale:  x[n, pix, c] *= s[n][c]  in place (x * gate). */
 int64_t prv2_global_avgpool_workspace_floats(int32_t n, int64_t hw, int32_t c);
 int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, float* out, float* workspace, void* stream);
-int prv2_se_gate(const float* mean, int32_t n, int32_t c, const float* w1, const float* b1, int32_t cse, const float* w2,
-                 const float* b2, float* g, void* stream);
+int prv2_se_gate(const float* mean, int32_t n, int32_t c, const float* w1, const float* b1, int32_t cse, const float* w2t,
+                 const float* b2, float* g, float* workspace, void* stream);
 int prv2_channel_scale(float* x, int32_t n, int64_t hw, int32_t c, int32_t ldx, const float* s, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -348,32 +348,30 @@ __global__ void __launch_bounds__(256) avgpool_final_kernel(const float* __restr
   out[idx] = s * inv;
 }
 
-// squeeze-excite bottleneck in one launch: g[n][:] = sigmoid(W2 silu(W1 m[n][:] + b1) + b2), one workgroup per image, fp32.
-// (As two [n, C] row GEMMs on the generic MFMA kernel these were 2 x 28 us launches for ~1 MFLOP.)
-__global__ void __launch_bounds__(256) se_gate_kernel(const float* __restrict__ mean, int C, const float* __restrict__ w1,
-                                                      const float* __restrict__ b1, int CSE, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, float* __restrict__ g) {
-  extern __shared__ float sh[];  // [C] means | [CSE] bottleneck
-  float* const m = sh;
-  float* const r = sh + C;
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += 256) m[c] = mean[(int64_t)n * C + c];
-  __syncthreads();
-  for (int j = wave; j < CSE; j += 4) {  // one wave per bottleneck channel: lanes stride over C, fixed-order tree reduction
-    const float* wr = w1 + (int64_t)j * C;
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc += wr[c] * m[c];
+// squeeze-excite bottleneck g[n][:] = sigmoid(W2 silu(W1 m[n][:] + b1) + b2) in fp32, two small launches that cover the chip:
+// reduce: one 64-lane block per (bottleneck channel, image) -- a dot product over C; expand: one thread per (channel, image),
+// W2 passed transposed ([cse][C]) so that the loop over the bottleneck reads coalesced rows.
+// (As two [n, C] row GEMMs on the generic MFMA kernel these were 2 x 28 us for ~1 MFLOP; as ONE workgroup per image 230 us.)
+__global__ void __launch_bounds__(64) se_reduce_kernel(const float* __restrict__ mean, int C, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, int CSE, float* __restrict__ r) {
+  const int j = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const float* wr = w1 + (int64_t)j * C;
+  const float* m = mean + (int64_t)n * C;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) acc += wr[c] * m[c];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) r[j] = act_apply(acc + (b1 ? b1[j] : 0.f), PRV2_ACT_SILU);
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const float* wr = w2 + (int64_t)c * CSE;
-    float acc = b2 ? b2[c] : 0.f;
-    for (int j = 0; j < CSE; ++j) acc += wr[j] * r[j];
-    g[(int64_t)n * C + c] = act_apply(acc, PRV2_ACT_SIGMOID);
-  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);  // fixed-order tree
+  if (lane == 0) r[(int64_t)n * CSE + j] = act_apply(acc + (b1 ? b1[j] : 0.f), PRV2_ACT_SILU);
+}
+
+__global__ void __launch_bounds__(256) se_expand_kernel(const float* __restrict__ r, int C, int CSE, const float* __restrict__ w2t,
+                                                        const float* __restrict__ b2, float* __restrict__ g) {
+  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  const float* rn = r + (int64_t)n * CSE;
+  float acc = b2 ? b2[c] : 0.f;
+  for (int j = 0; j < CSE; ++j) acc += w2t[(int64_t)j * C + c] * rn[j];
+  g[(int64_t)n * C + c] = act_apply(acc, PRV2_ACT_SIGMOID);
 }
 
 // excite: x[n, pix, c] *= s[n][c]
@@ -607,12 +605,12 @@ extern "C" int prv2_global_avgpool(const float* x, int32_t n, int64_t hw, int32_
   return 0;
 }
 
-extern "C" int prv2_se_gate(const float* mean, int32_t n, int32_t c, const float* w1, const float* b1, int32_t cse, const float* w2,
-                            const float* b2, float* g, void* stream) {
-  PRV2_REQUIRE(mean && w1 && w2 && g && n > 0 && c > 0 && cse > 0, "se_gate: bad arguments");
-  const size_t shmem = (size_t)(c + cse) * sizeof(float);
-  PRV2_REQUIRE(shmem <= 64 * 1024, "se_gate: c + cse = %d floats do not fit the 64 KB of dynamic LDS", c + cse);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(n), dim3(256), shmem, (hipStream_t)stream, mean, c, w1, b1, cse, w2, b2, g);
+extern "C" int prv2_se_gate(const float* mean, int32_t n, int32_t c, const float* w1, const float* b1, int32_t cse, const float* w2t,
+                            const float* b2, float* g, float* workspace, void* stream) {
+  PRV2_REQUIRE(mean && w1 && w2t && g && workspace && n > 0 && c > 0 && cse > 0, "se_gate: bad arguments");
+  hipLaunchKernelGGL(se_reduce_kernel, dim3(cse, n), dim3(64), 0, (hipStream_t)stream, mean, c, w1, b1, cse, workspace);
+  PRV2_LAUNCH_CHECK("se_gate");
+  hipLaunchKernelGGL(se_expand_kernel, dim3((c + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, workspace, c, cse, w2t, b2, g);
   PRV2_LAUNCH_CHECK("se_gate");
   return 0;
 }

@@ -47,7 +47,7 @@ SIGNATURES = {
     "prv2_dwconv2d_ex": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_global_avgpool_workspace_floats": (_L, [_I, _L, _I]),
     "prv2_global_avgpool": (_I, [_P, _I, _L, _I, _I, _P, _P, _P]),
-    "prv2_se_gate": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "prv2_se_gate": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
     "prv2_channel_scale": (_I, [_P, _I, _L, _I, _I, _P, _P]),
     "prv2_layernorm": (_I, [_P, _L, _I, _I, _P, _P, _F, _I, _P, _I, _P]),
     "prv2_patchify": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -312,15 +312,18 @@ def global_avgpool(x: Feat) -> torch.Tensor:
     return out
 
 
-def se_gate(mean: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2) -> torch.Tensor:
-    """sigmoid(W2 silu(W1 mean + b1) + b2) per image: timm SqueezeExcite's conv_reduce -> act -> conv_expand -> gate"""
+def se_gate(mean: torch.Tensor, w1: torch.Tensor, b1, w2t: torch.Tensor, b2) -> torch.Tensor:
+    """sigmoid(W2 silu(W1 mean + b1) + b2) per image: timm SqueezeExcite's conv_reduce -> act -> conv_expand -> gate.
+    w1 [cse, c]; w2t [cse, c] = conv_expand's weight transposed."""
     n, c = mean.shape
     cse = w1.shape[0]
-    assert w1.shape == (cse, c) and w2.shape == (c, cse) and w1.is_contiguous() and w2.is_contiguous()
+    assert w1.shape == (cse, c) and w2t.shape == (cse, c) and w1.is_contiguous() and w2t.is_contiguous()
     g = torch.empty((n, c), device=mean.device, dtype=torch.float32)
+    ws = torch.empty((n, cse), device=mean.device, dtype=torch.float32)
     PROFILER.launch_aux("se_gate", 4.0 * (n * c + 2 * c * cse),
-                        lambda: L.check(L.load().prv2_se_gate(mean.data_ptr(), n, c, w1.data_ptr(), _ptr(b1), cse, w2.data_ptr(),
-                                                               _ptr(b2), g.data_ptr(), _stream()), "se_gate"), f"{c}->{cse}->{c} x{n}")
+                        lambda: L.check(L.load().prv2_se_gate(mean.data_ptr(), n, c, w1.data_ptr(), _ptr(b1), cse, w2t.data_ptr(),
+                                                               _ptr(b2), g.data_ptr(), ws.data_ptr(), _stream()), "se_gate"),
+                        f"{c}->{cse}->{c} x{n}")
     return g
 
 

@@ -185,9 +185,9 @@ class LightWeightRefiner(StateDictModule):
                 Q["expand"] = pk(sd[b + "conv_pw.weight"], self._fold(b + "bn1."))
                 Q["dw"] = dw(sd[b + "conv_dw.weight"], self._fold(b + "bn2."))
                 Q["proj"] = pk(sd[b + "conv_pwl.weight"], self._fold(b + "bn3."))
-            v = lambda k, shape=None: (sd[b + k].view(shape) if shape else sd[b + k]).to(dev).contiguous()  # noqa: E731
-            Q["se"] = (v("se.conv_reduce.weight", (B["cse"], B["cmid"])), v("se.conv_reduce.bias"),
-                       v("se.conv_expand.weight", (B["cmid"], B["cse"])), v("se.conv_expand.bias"))
+            v = lambda t: t.to(dev).contiguous()  # noqa: E731
+            Q["se"] = (v(sd[b + "se.conv_reduce.weight"].view(B["cse"], B["cmid"])), v(sd[b + "se.conv_reduce.bias"]),
+                       v(sd[b + "se.conv_expand.weight"].view(B["cmid"], B["cse"]).t()), v(sd[b + "se.conv_expand.bias"]))
             P["blocks"].append(Q)
         self._packed = P
 

@@ -159,7 +159,7 @@ def test_squeeze_excite_pieces(P, n, h, w, c):
     assert torch.equal(xf.to_nchw().cpu(), x * g.view(n, c, 1, 1))
     cse = max(1, c // 24)
     w1, b1, w2, b2 = rnd(23, cse, c) / np.sqrt(c), rnd(24, cse), rnd(25, c, cse) / np.sqrt(cse), rnd(26, c)
-    gate = P.se_gate(m1, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV)).cpu()
+    gate = P.se_gate(m1, w1.to(DEV), b1.to(DEV), w2.t().contiguous().to(DEV), b2.to(DEV)).cpu()
     ref_g = torch.sigmoid(F.linear(F.silu(F.linear(ref.double(), w1.double(), b1.double())), w2.double(), b2.double())).float()
     assert float((gate - ref_g).abs().max()) <= 2e-6
 
