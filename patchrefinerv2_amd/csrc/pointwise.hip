@@ -555,7 +555,8 @@ extern "C" int prv2_dwconv2d_ex(const float* x, int32_t n, int32_t h, int32_t w,
     pad_x = (tx > 0 ? tx : 0) / 2;
   }
   int64_t total = (int64_t)n * oh * ow * (c / 4);
-  if (stride == 1 && w >= 8) {  // strip kernel: 8 output pixels per thread (stride 1: "SAME" == symmetric k/2)
+  if (stride == 1 && w >= 8 && (((w + 7) / 8) * 8 - w) * 8 <= w) {  // strip kernel: 8 output pixels per thread, when the last
+    // strip of a row wastes <= 1/8 of the work (stride 1: "SAME" == symmetric k/2)
     constexpr int PX = 8;
     const int64_t threads = (int64_t)n * h * ((w + PX - 1) / PX) * (c / 4);
     PRV2_REQUIRE((threads + 255) / 256 < (1LL << 31), "dwconv2d: too large");
