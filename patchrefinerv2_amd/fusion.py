@@ -20,7 +20,7 @@ import torch
 from . import ops
 from . import weights as W
 from .dav2 import StateDictModule
-from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, Feat
+from .ops import ACT_GELU, ACT_RELU, ACT_SIGMOID, Feat
 
 
 def as_feat1(t: torch.Tensor) -> Feat:

@@ -18,7 +18,7 @@ What differs from the reference on purpose (results identical, SURVEY.md Q10/Q11
 from __future__ import annotations
 
 import random
-from typing import List, Optional, Sequence
+from typing import List
 
 import numpy as np
 import torch

@@ -21,7 +21,7 @@ from __future__ import annotations
 import hashlib
 import re
 from collections import OrderedDict
-from typing import Dict, List, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 import torch

@@ -16,7 +16,7 @@ import torch
 from . import ops
 from . import weights as W
 from .dav2 import DepthAnythingV2, StateDictModule
-from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SOFTPLUS, Feat
+from .ops import ACT_GELU, ACT_RELU, ACT_SOFTPLUS, Feat
 
 
 class ZoeDepth(StateDictModule):
