@@ -40,11 +40,15 @@ namespace prv2 {
 // MFMA pipe busy 37.6 % at 2.04 GHz (the 3x3 kernel: 76.7 % at 1.80 GHz on the same box), no LDS bank conflicts, waves
 // wait on instruction issue 49 % and on s_waitcnt 25 % of their cycles -- next: TCP / TCC counters (per-CU L2 fetch rate:
 // a CU pulls 64 KB per 32-channel step here, 3x the 3x3 kernel).
-template <int PREC, int NW>
+// BN = 64 (with NW = 4): half-width column tiles for grids that do not cover the chip -- a workgroup's time is its serial K
+// loop, so twice the workgroups at half the MFMAs per step is what shortens e.g. the ViT-L 4096 -> 1024 projection at
+// 1037 tokens (72 -> 144 workgroups on 256 CUs).
+template <int PREC, int NW, int BN = 128>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const IgemmParams p) {
   static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  constexpr int BN = 128, TM = 32 * NW, NA = 2, NJ = 8, ND = BN / (8 * NW), NBUF = 4;
+  static_assert((NW == 4 && (BN == 128 || BN == 64)) || (NW == 8 && BN == 128), "4 or 8 waves; 64 columns only with 4 waves");
+  constexpr int TM = 32 * NW, NA = 2, NJ = BN / 16, ND = BN / (8 * NW), NBUF = 4;
+  constexpr int J_SPLIT0 = NJ == 8 ? 2 : 0, J_SPLIT1 = NJ == 8 ? 4 : 1;  // phases that split the next slab's two pixel runs
   constexpr int B_BYTES = BN * 128;
   constexpr int CLD = BN + 4;
   constexpr int SMEM_MAIN = NBUF * B_BYTES / 4;
@@ -218,10 +222,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const 
 #endif
       }
       // rows of slab s+1 were loaded in step s-2, the weights of step s+1 in step s-1 (hipcc counts the waits itself)
-      if (j == 2) {
+      if (j == J_SPLIT0) {
         split_run4((q + 1) & 3, set ^ 1, 0);
       }
-      if (j == 4) {
+      if (j == J_SPLIT1) {
         split_run4((q + 1) & 3, set ^ 1, 1);
       }
       if (j == NJ - 3) {  // weights of step s+1 -> buffer (s+1)&3, last read in step s-3
@@ -325,13 +329,21 @@ bool gemm16_supported(const IgemmParams& p, int prec) {
 }
 
 void launch_gemm16(IgemmParams& p, int prec, hipStream_t s) {
-  p.tiles_n = (int)cdiv(p.Ncols, 128);
-  static const int force_nw = getenv("PRV2_GEMM16_NW") ? atoi(getenv("PRV2_GEMM16_NW")) : 0;  // A/B switch
+  static const int force_nw = getenv("PRV2_GEMM16_NW") ? atoi(getenv("PRV2_GEMM16_NW")) : 0;      // A/B switches
+  static const int force_bn = getenv("PRV2_GEMM16_BN") ? atoi(getenv("PRV2_GEMM16_BN")) : 0;
+  const long long tiles128 = cdiv(p.M, 128) * cdiv(p.Ncols, 128);
+  // 64-column tiles when 128 x 128 tiles leave more than a third of the CUs without a workgroup
+  // (not with a fused LayerNorm: its row statistics need all <= 128 channels of a pixel in one workgroup tile)
+  const bool narrow = !p.ln_w && (force_bn ? force_bn == 64 : tiles128 <= 160);
   // 256-row tiles when K is long enough to amortise the lone workgroup's prologue / epilogue and the grid still covers the chip
-  const bool big = force_nw ? force_nw == 8 : (p.Cin_pad >= 2048 && cdiv(p.M, 256) * p.tiles_n >= 256);  // measured: +6 % at K = 3072, -2 % at K = 768
+  const bool big = !narrow && (force_nw ? force_nw == 8 : (p.Cin_pad >= 2048 && cdiv(p.M, 256) * cdiv(p.Ncols, 128) >= 256));  // +6 % at K = 3072, -2 % at 768
+  p.tiles_n = (int)cdiv(p.Ncols, narrow ? 64 : 128);
   const int tiles_m = (int)cdiv(p.M, big ? 256 : 128);
   const dim3 grid(tiles_m * p.tiles_n);
-  if (big) {
+  if (narrow) {
+    if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16X3, 4, 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16, 4, 64>), grid, dim3(256), 0, s, p);
+  } else if (big) {
     if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16X3, 8>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16, 8>), grid, dim3(512), 0, s, p);
   } else {

@@ -15,6 +15,7 @@ SHAPES = [  # (cin, cout, k, h, w)  -- the heavy layers of BiDirectionalFusion, 
     (1024, 4096, 1, 1025, 1), (4096, 1024, 1, 1025, 1),
     (64, 32, 3, 448, 448), (128, 32, 3, 448, 448),  # 17, 18: persistent BN = 32 kernel
     (768, 3072, 1, 24, 31), (3072, 768, 1, 24, 31), (192, 768, 1, 98, 126), (256, 256, 1, 196, 259),  # 19-22: 1x1 GEMMs (b14)
+    (1024, 1024, 1, 1037, 1), (1024, 3072, 1, 1037, 1), (4096, 1024, 1, 1037, 1), (384, 1536, 1, 4100, 1),  # 23-26: ViT at few tokens
 ]
 for si, (cin, cout, k, h, w) in enumerate(SHAPES):
     if ONLY is not None and si not in ONLY:
