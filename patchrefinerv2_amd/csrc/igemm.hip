@@ -468,13 +468,16 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   }
 #define PRV2_LAUNCH_IGEMM(BN_, PREC_) \
   hipLaunchKernelGGL((igemm_kernel<BN_, PREC_>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p)
-  if (p.Ncols > 64) {
+  // 64-column tiles also for wider layers whose 128-column grid would leave half the CUs idle (the 13 x 17 level of the
+  // fusion pyramid: 25 row tiles) -- a workgroup's time is its serial K loop; not with a fused LayerNorm (needs the whole row)
+  const bool narrow = p.Ncols > 64 && !p.ln_w && (long long)p.tiles_m * cdiv(p.Ncols, 128) <= 128;
+  if (p.Ncols > 64 && !narrow) {
     p.tiles_n = (int)cdiv(p.Ncols, 128);
     if (d->prec == PRV2_PREC_F32) PRV2_LAUNCH_IGEMM(128, PRV2_PREC_F32);
     else if (d->prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_IGEMM(128, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_IGEMM(128, PRV2_PREC_BF16);
   } else {
-    p.tiles_n = 1;
+    p.tiles_n = (int)cdiv(p.Ncols, 64);
     if (d->prec == PRV2_PREC_F32) PRV2_LAUNCH_IGEMM(64, PRV2_PREC_F32);
     else if (d->prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_IGEMM(64, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_IGEMM(64, PRV2_PREC_BF16);
