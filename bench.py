@@ -12,8 +12,10 @@ when the timed region starts.  Synthetic frames (torch.rand, seeded) and synthet
 
 Multi-GPU (one process per GPU): ``--shard frames`` (default) = the reference's own data
 parallelism, frame f -> rank f mod N, no data-path collective, weak scaling;
-``--shard patches`` = tiles of ONE frame sharded over the ranks + one RCCL all-gather of the
-per-tile predictions (strong scaling).
+``--shard patches`` = tiles of ONE frame sharded over the ranks + one RCCL gather of the per-tile
+predictions to rank 0, which blends (strong scaling; ``--gather all`` = all-gather, every rank blends).
+In ``--shard frames`` mode the per-rank depth maps are gathered to rank 0 over xGMI at the end of every step
+(SURVEY.md 8e cfg 5; ``--gather all`` keeps them on their ranks like the reference's data parallelism).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` (dominant kernel,
 HIP-event timed on its launch stream) and ``cpu_baseline`` (the oracle restatement on host cores,
@@ -45,6 +47,10 @@ def parse():
     ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="matrix-kernel arithmetic (DESIGN.md 3): bf16x3 = split-bf16, AbsRel ~5e-6; f32 = exact fp32 MFMA")
     ap.add_argument("--shard", default="frames", choices=["frames", "patches"])
+    ap.add_argument("--gather", default="rank0", choices=["rank0", "all"],
+                    help="--shard patches: gather the tile predictions to rank 0 (it alone blends and returns the map) or "
+                         "all-gather (every rank blends); --shard frames: rank0 = final RCCL gather of the per-rank maps to "
+                         "rank 0 (SURVEY.md 8e cfg 5), all = every rank keeps its own map (the reference's data parallelism)")
     ap.add_argument("--max-batch", type=int, default=14, help="patches per launch batch (results are batch independent)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,11 +157,39 @@ def main():
 
     frames = [frame(i) for i in range(min(n_frames, 2))]  # resident inputs (2 alternating frames)
 
-    def step(i):
+    gather_dst = 0 if (shard is not None and args.gather == "rank0") else None
+    frame_gather = world > 1 and shard is None and args.gather == "rank0"
+    if frame_gather:
+        import torch.distributed as dist
+        maps = [torch.empty((1, 1, *w["raw"]), device=dev) for _ in range(world)] if rank == 0 else None
+        host_maps = torch.empty((world, 1, 1, *w["raw"]), pin_memory=True) if rank == 0 else None
+    coll = dict(bytes=0, ms=0.0, n=0)
+
+    def step(i, solo=False, timed=False):
+        """one frame; ``solo``: this rank alone, no collective (the instrumented frames that only rank 0 runs)"""
         hr, lr = frames[i % len(frames)]
         random.seed(621)
+        sh = None if solo else shard
+        fg = frame_gather and not solo
         depth, _ = model(mode="infer", cai_mode=w["mode"], process_num=4, tile_cfg=tile_cfg, image_lr=lr, image_hr=hr,
-                         shard=shard)
+                         shard=sh, gather_dst=gather_dst if sh is not None else None, return_device=fg)
+        if fg:
+            # cfg-5 "full xGMI gather": the N per-rank maps (33 MB each at 4K) to rank 0, which hands them to the host
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.gather(depth, maps, dst=0)
+            e1.record()
+            if rank == 0:
+                for r in range(world):
+                    host_maps[r].copy_(maps[r], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                depth = host_maps[0]
+                if timed:
+                    coll["bytes"] += depth.numel() * 4 * (world - 1)
+                    coll["ms"] += e0.elapsed_time(e1)
+                    coll["n"] += 1
+            else:
+                torch.cuda.current_stream().synchronize()
         return depth
 
     def barrier():
@@ -168,7 +202,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(args.warmup + i)
+        out = step(args.warmup + i, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -185,17 +219,31 @@ def main():
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
                     coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else "DA-ZoeDepth/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
-                    max_batch=args.max_batch, streams=args.streams, out_shape=list(out.shape)))
+                    max_batch=args.max_batch, streams=args.streams, out_shape=list(out.shape) if out is not None else None))
+
+    if world > 1:
+        nt = w["patches"]
+        if shard is not None:
+            per = (nt + world - 1) // world
+            result["multi_gpu"] = dict(mode="patches", gather=args.gather, tiles_per_rank=[len(range(r, nt, world)) for r in range(world)],
+                                       collective=("gather->rank0" if gather_dst is not None else "all_gather"),
+                                       collective_bytes_per_frame=per * w["pps"][0] * w["pps"][1] * 4 * (world - 1))
+        else:
+            result["multi_gpu"] = dict(mode="frames", gather=args.gather, tiles_per_rank=[nt] * world,
+                                       collective=("gather->rank0 of the per-rank depth maps" if frame_gather else "none"),
+                                       collective_bytes_per_step=(coll["bytes"] // max(coll["n"], 1) if frame_gather else 0),
+                                       collective_ms_per_step=(coll["ms"] / max(coll["n"], 1) if frame_gather else 0.0))
 
     if rank == 0 and not args.no_roofline:
         # extra, instrumented frames: HIP events on the launch stream around every matrix-kernel launch
+        # rank 0 alone runs these frames: UNSHARDED (a sharded forward would wait in a collective nobody else joins)
         model.n_streams = 1  # per-launch durations must not include kernels of other streams
-        step(0)  # settle into the single-stream regime (allocator, clocks) before timing launches
+        step(0, solo=True)  # settle into the single-stream regime (allocator, clocks) before timing launches
         torch.cuda.synchronize()
         runs = []
         for i in range(3):  # three instrumented frames; per kernel the median total (the chip's clock wanders by 10-20 %)
             ops.PROFILER.start(timed=True)
-            step(i)
+            step(i, solo=True)
             torch.cuda.synchronize()
             ops.PROFILER.stop()
             runs.append(ops.PROFILER.summary())
@@ -219,7 +267,7 @@ def main():
     if rank == 0 and args.layer_report:
         model.n_streams = 1
         ops.PROFILER.start(timed=True, by_shape=True)
-        step(0)
+        step(0, solo=True)
         torch.cuda.synchronize()
         ops.PROFILER.stop()
         rows = sorted(ops.PROFILER.summary().items(), key=lambda kv: -kv[1]["ms"])
@@ -234,6 +282,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        torch.distributed.barrier()  # the other ranks wait here while rank 0 runs its instrumented frames
         torch.distributed.destroy_process_group()
 
 

@@ -2,36 +2,124 @@
 
 LightWeightRefiner.forward   estimator/models/blocks/lightweight_refiner.py:285-322
 4-channel stem surgery       estimator/models/patchrefinerplus.py:159-165
-The encoder itself is timm's ``mobilenetv4_conv_small`` (features_only) -- timm is NOT in
-the reference tree nor installed: PARITY UNPINNED, restated from the public MobileNetV4
-definition (see patchrefinerv2_amd/weights.py::MNV4_SMALL).  BatchNorm in eval mode.
+
+The encoder itself is timm's ``mobilenetv4_conv_small`` (``features_only=True``) -- timm is NOT in the reference tree
+nor installed here: PARITY UNPINNED against timm itself.  What this file does pin: it is a SECOND, independent
+transcription of the architecture -- written from timm's block-definition strings (``_gen_mobilenet_v4``,
+arch_def['conv_small']) with its own decoder, its own ``make_divisible`` and its own key-name builder -- and shares
+nothing with the product's table (patchrefinerv2_amd/weights.py::MNV4_SMALL / mnv4_layers).  A transcription error on
+either side (block order, expansion width, stride placement, residual rule, tap position, key name) shows up as a
+mismatch in tests/test_oracle_golden.py::test_mnv4_two_transcriptions_agree and in every product-vs-oracle parity test.
+What the reference itself confirms: ``conv_stem`` is a 3x3 stride-2 pad-1 conv with 32 outputs
+(patchrefinerplus.py:159-165) and the five feature maps have [32, 32, 64, 96, 960] channels at strides 2..32
+(configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py:101 ``fine_chl``).
+
+timm semantics restated (timm/models/_efficientnet_builder.py, _efficientnet_blocks.py):
+  'cn_r{n}_k{k}_s{s}_e1_c{c}'      ConvBnAct: conv kxk (pad k//2) -> bn1 -> ReLU                      keys conv, bn1
+  'uir_r{n}_a{a}_k{k}_s{s}_e{e}_c{c}'  UniversalInvertedResidual:
+        dw_start (a x a depthwise, no act; present iff a > 0; carries the stride only when there is no dw_mid)
+        pw_exp   (1x1 to make_divisible(cin * e), ReLU)
+        dw_mid   (k x k depthwise, ReLU; present iff k > 0; carries the stride)
+        pw_proj  (1x1 to c, no act);  + input when stride == 1 and cin == c           keys <sub>.conv, <sub>.bn
+  only the first of the r repeats keeps the stride.  Feature taps of FeatureListNet (out_indices 0..4): the stem
+  activation (stride 2) and the outputs of stages 0, 1, 2, 4.  BatchNorm eps 1e-5, eval mode.
 """
 from __future__ import annotations
 
+import re
+
 import torch
 import torch.nn.functional as F
-
-from patchrefinerv2_amd.weights import MNV4_SMALL, mnv4_layers
 
 from .ops import bilinear_ac
 
 BN_EPS = 1e-5
 
+# timm arch_def for mobilenetv4_conv_small, stem_size=32
+CONV_SMALL = [
+    ["cn_r1_k3_s2_e1_c32", "cn_r1_k1_s1_e1_c32"],
+    ["cn_r1_k3_s2_e1_c96", "cn_r1_k1_s1_e1_c64"],
+    ["uir_r1_a5_k5_s2_e3_c96", "uir_r4_a0_k3_s1_e2_c96", "uir_r1_a3_k0_s1_e4_c96"],
+    ["uir_r1_a3_k3_s2_e6_c128", "uir_r1_a5_k5_s1_e4_c128", "uir_r1_a0_k5_s1_e4_c128", "uir_r1_a0_k5_s1_e3_c128",
+     "uir_r2_a0_k3_s1_e4_c128"],
+    ["cn_r1_k1_s1_e1_c960"],
+]
+STEM = 32
+TAP_STAGES = (0, 1, 2, 4)
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
 
-def mnv4_features(sd, p, x, arch=MNV4_SMALL):
-    layers, taps = mnv4_layers(arch, in_chans=x.shape[1])
-    feats = []
-    skip = None
-    for i, L in enumerate(layers):
-        if L.get("res_begin"):
+
+def _round_channels(v: float, divisor: int = 8) -> int:
+    """timm.layers.make_divisible(v, 8, round_limit=0.9)"""
+    new = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    return new + divisor if new < 0.9 * v else new
+
+
+def decode(arch=CONV_SMALL, stem=STEM, in_chans=4):
+    """-> (ops, taps): ops = ordered dicts(conv key, bn key, cin, cout, k, stride, groups, relu, skip_from, add_skip),
+    taps = op indices whose output is a feature map."""
+    ops = [dict(conv="conv_stem", bn="bn1", cin=in_chans, cout=stem, k=3, stride=2, groups=1, relu=True)]
+    taps = [0]
+    cin = stem
+    for si, stage in enumerate(arch):
+        bi = 0
+        for spec in stage:
+            f = dict(re.match(r"([a-z]+)(\d*\.?\d*)$", t).groups() for t in spec.split("_")[1:])
+            kind = spec.split("_")[0]
+            for rep in range(int(f["r"])):
+                stride = int(f["s"]) if rep == 0 else 1
+                cout = int(f["c"])
+                name = f"blocks.{si}.{bi}."
+                if kind == "cn":
+                    ops.append(dict(conv=name + "conv", bn=name + "bn1", cin=cin, cout=cout, k=int(f["k"]), stride=stride,
+                                    groups=1, relu=True))
+                else:
+                    a, k, mid = int(f["a"]), int(f["k"]), _round_channels(cin * float(f["e"]))
+                    first = len(ops)
+                    if a:
+                        ops.append(dict(conv=name + "dw_start.conv", bn=name + "dw_start.bn", cin=cin, cout=cin, k=a,
+                                        stride=stride if not k else 1, groups=cin, relu=False))
+                    ops.append(dict(conv=name + "pw_exp.conv", bn=name + "pw_exp.bn", cin=cin, cout=mid, k=1, stride=1,
+                                    groups=1, relu=True))
+                    if k:
+                        ops.append(dict(conv=name + "dw_mid.conv", bn=name + "dw_mid.bn", cin=mid, cout=mid, k=k,
+                                        stride=stride, groups=mid, relu=True))
+                    ops.append(dict(conv=name + "pw_proj.conv", bn=name + "pw_proj.bn", cin=mid, cout=cout, k=1, stride=1,
+                                    groups=1, relu=False))
+                    if stride == 1 and cin == cout:
+                        ops[first]["skip_begin"] = True
+                        ops[-1]["skip_end"] = True
+                cin = cout
+                bi += 1
+        if si in TAP_STAGES:
+            taps.append(len(ops) - 1)
+    return ops, taps
+
+
+def state_shapes(prefix="", in_chans=4):
+    """the encoder's parameter / buffer names and shapes as this transcription has them"""
+    out = {}
+    for o in decode(in_chans=in_chans)[0]:
+        out[prefix + o["conv"] + ".weight"] = (o["cout"], o["cin"] // o["groups"], o["k"], o["k"])
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            out[f"{prefix}{o['bn']}.{leaf}"] = (o["cout"],)
+    return out
+
+
+def mnv4_features(sd, p, x):
+    ops, taps = decode(in_chans=x.shape[1])
+    feats, skip = [], None
+    for i, o in enumerate(ops):
+        if o.get("skip_begin"):
             skip = x
-        x = F.conv2d(x, sd[p + L["conv"] + ".weight"], None, stride=L["s"], padding=L["k"] // 2, groups=L["g"])
-        b = p + L["bn"] + "."
-        x = F.batch_norm(x, sd[b + "running_mean"], sd[b + "running_var"], sd[b + "weight"], sd[b + "bias"],
-                         False, 0.0, BN_EPS)
-        if L["act"]:
+        x = F.conv2d(x, sd[p + o["conv"] + ".weight"], None, stride=o["stride"], padding=o["k"] // 2, groups=o["groups"])
+        b = p + o["bn"] + "."
+        x = F.batch_norm(x, sd[b + "running_mean"], sd[b + "running_var"], sd[b + "weight"], sd[b + "bias"], False, 0.0,
+                         BN_EPS)
+        if o["relu"]:
             x = F.relu(x)
-        if L.get("res_end"):
+        if o.get("skip_end"):
             x = x + skip
             skip = None
         if i in taps:
@@ -39,13 +127,13 @@ def mnv4_features(sd, p, x, arch=MNV4_SMALL):
     return feats
 
 
-def lightweight_refiner(sd, p, crop_image, coarse_depth, arch=MNV4_SMALL):
-    """Returns (feats high -> low ... wait: reference returns ``refiner_features[::-1]`` =
-    low -> high resolution with the 2x-upsampled copy of map 0 LAST) and out_depth = 0."""
-    mean = torch.tensor(arch["mean"], dtype=crop_image.dtype).view(-1, 1, 1)
-    std = torch.tensor(arch["std"], dtype=crop_image.dtype).view(-1, 1, 1)
+def lightweight_refiner(sd, p, crop_image, coarse_depth):
+    """Returns the reference's ``refiner_features[::-1]`` (low -> high resolution, the 2x-upsampled copy of map 0
+    LAST) and out_depth = 0 (lightweight_refiner.py:285-322)."""
+    mean = torch.tensor(MEAN, dtype=crop_image.dtype).view(-1, 1, 1)
+    std = torch.tensor(STD, dtype=crop_image.dtype).view(-1, 1, 1)
     x = (crop_image - mean) / std
-    feats = mnv4_features(sd, p + "refiner_encoder.", torch.cat([x, coarse_depth], dim=1), arch)
+    feats = mnv4_features(sd, p + "refiner_encoder.", torch.cat([x, coarse_depth], dim=1))
     hi = feats[0]
     up = bilinear_ac(hi, (hi.shape[-2] * 2, hi.shape[-1] * 2))  # scale_factor=2 (lightweight_refiner.py:316)
     feats = [up] + feats

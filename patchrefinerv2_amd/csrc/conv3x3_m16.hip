@@ -516,15 +516,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_persist_kernel(const Ig
   else halo16_body<32, PREC, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
 }
 
-static int persist_workgroups() {  // one persistent workgroup per CU
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    n = cus;
+static int persist_workgroups() {  // one persistent workgroup per CU of the CURRENT device (cached per device ordinal)
+  static int n[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (n[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    n[dev] = cus;
   }
-  return n;
+  return n[dev];
 }
 
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {

@@ -62,7 +62,11 @@ class StateDictModule:
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]} ({len(missing)}), unexpected {unexpected[:5]} "
                                f"({len(unexpected)})")
-        self._assign(sd)
+        if torch.cuda.is_available() and self.device.type == "cuda":
+            with torch.cuda.device(self.device):  # weight packing kernels run on the model's device
+                self._assign(sd)
+        else:
+            self._assign(sd)
         return dict(missing_keys=missing, unexpected_keys=unexpected)
 
     def _assign(self, sd, prefix: str = ""):

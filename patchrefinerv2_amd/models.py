@@ -146,6 +146,7 @@ class _PatchModel(StateDictModule):
 
     crop_channels = 3
     crop_mean, crop_std = IMAGENET_MEAN, IMAGENET_STD
+    STRICT_DA_ZOE = False
 
     # -- BaselinePretrain.prepare_tile_cfg (baseline_pretrain.py:96-124) ---------------------------
     def prepare_tile_cfg(self, image_raw_shape, patch_split_num):
@@ -231,16 +232,27 @@ class _PatchModel(StateDictModule):
     @torch.no_grad()
     def forward(self, mode=None, image_lr=None, image_hr=None, crops_image_hr=None, depth_gt=None, crop_depths=None,
                 bboxs=None, tile_cfg=None, cai_mode="m1", process_num=4, select_patch=-1, shard=None,
-                return_device=False, **kwargs):
+                return_device=False, gather_dst=None, **kwargs):
+        """``shard=(rank, world)``: this process computes tiles rank, rank+world, ... and the predictions are exchanged
+        (RCCL): all-gather when ``gather_dst`` is None (every rank blends and returns the map), gather to rank
+        ``gather_dst`` otherwise (only that rank blends; the others return ``depth=None``)."""
         if mode != "infer":
             raise NotImplementedError("only mode='infer' is built (training is out of scope, SURVEY.md 2 #12-13)")
         if select_patch != -1:
             raise NotImplementedError("select_patch (feature visualisation hook) is not on the inference path")
+        if not (image_lr.is_cuda and image_hr.is_cuda):
+            raise RuntimeError("image_lr / image_hr must be on the GPU (tester.py:43-49 moves them); no CPU path")
+        # every kernel is enqueued on the current device's stream: make the inputs' device current for the whole frame
+        with torch.cuda.device(image_hr.device):
+            return self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device,
+                               gather_dst)
+
+    __call__ = forward
+
+    def _infer(self, image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device, gather_dst):
         tile_cfg = self.tile_cfg if tile_cfg is None else self.prepare_tile_cfg(tile_cfg["image_raw_shape"],
                                                                               tile_cfg["patch_split_num"])
         assert image_hr.shape[0] == 1
-        if not (image_lr.is_cuda and image_hr.is_cuda):
-            raise RuntimeError("image_lr / image_hr must be on the GPU (tester.py:43-49 moves them); no CPU path")
         dev = image_hr.device
         ph, pw = self.patch_process_shape
         rh, rw = tile_cfg["patch_raw_shape"]
@@ -249,6 +261,10 @@ class _PatchModel(StateDictModule):
         coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
         coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
         passes = self.plan_tiles(tile_cfg, cai_mode, process_num)
+        if shard is not None and shard[1] > 1:
+            # every rank consumed ``random`` identically above; the plan that counts is rank 0's (a rank seeded
+            # differently would otherwise blend the others' predictions at its own coordinates)
+            passes = self._sync_plan(passes)
         flat = [t for p in passes for t in p["raw"]]
         self.last_plan = passes
 
@@ -281,7 +297,9 @@ class _PatchModel(StateDictModule):
             for st in streams:
                 main.wait_stream(st)
         if shard is not None and shard[1] > 1:
-            preds = self._gather_predictions(preds, len(flat), shard)
+            preds = self._gather_predictions(preds, len(flat), shard, gather_dst)
+            if preds is None:  # gather-to-one: this rank's part of the frame is done
+                return None, dict(rgb=image_lr, depth_pred=None, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
         preds = preds.view(len(flat), ph, pw)
 
         # ---- overlap blend, in the reference's order ----------------------------------------------
@@ -314,20 +332,40 @@ class _PatchModel(StateDictModule):
             depth = host
         return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
 
-    __call__ = forward
-
-    def _gather_predictions(self, preds, n_total, shard):
-        """The path's only exchange step: all-gather (RCCL over xGMI) of the per-rank prediction stacks.
-        Rank r holds tiles r, r+world, ...; the gathered [world, per] stack read column-major is tile order."""
-        import torch.distributed as dist
+    def _gather_predictions(self, preds, n_total, shard, dst=None):
+        """The path's only exchange step (RCCL over xGMI): the per-rank prediction stacks, padded to a common length.
+        Rank r holds tiles r, r+world, ...; the gathered [world, per] stack read column-major is tile order.
+        Returns None on the ranks that do not receive (gather to ``dst``)."""
         rank, world = shard
         per = (n_total + world - 1) // world
         mine = torch.zeros((per,) + tuple(preds.shape[1:]), device=preds.device)
         mine[:preds.shape[0]] = preds
-        allp = torch.empty((world * per,) + tuple(mine.shape[1:]), device=preds.device)
-        dist.all_gather_into_tensor(allp, mine)
+        allp = self._exchange(mine, shard, dst)
+        if allp is None:
+            return None
         allp = allp.view((world, per) + tuple(mine.shape[1:]))
         return allp.transpose(0, 1).reshape((per * world,) + tuple(preds.shape[1:]))[:n_total].contiguous()
+
+    def _exchange(self, mine, shard, dst):
+        """all-gather (dst None) or gather-to-dst of equally sized stacks -> [world * per, ...] (rank-major) or None."""
+        import torch.distributed as dist
+        rank, world = shard
+        self.last_exchange_bytes = mine.numel() * 4 * (world - 1)  # bytes this frame moves into one receiving rank
+        if dst is None:
+            allp = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), device=mine.device)
+            dist.all_gather_into_tensor(allp, mine)
+            return allp
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, parts, dst=dst)
+        return torch.cat(parts, dim=0) if rank == dst else None
+
+    def _sync_plan(self, passes):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return passes  # single-process emulation of the sharded path (tests)
+        box = [passes]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
     def _streams(self, dev, n):
         cache = self.__dict__.setdefault("_stream_cache", {})
@@ -373,7 +411,37 @@ class _PatchModel(StateDictModule):
 
     def _make_da2(self, branch_cfg, max_depth):
         mc = dict(branch_cfg["model_cfg"])
-        return DepthAnythingV2(**{**mc, "max_depth": max_depth}, device=self.device, prec=self.prec)
+        m = DepthAnythingV2(**{**mc, "max_depth": max_depth}, device=self.device, prec=self.prec)
+        # load_state_dict(torch.load(branch['pretrained'])) -- a bare state dict, strict (patchrefiner.py:94,118)
+        self._load_ckpt(m, branch_cfg.get("pretrained"), None, True, "DepthAnythingV2 weights")
+        return m
+
+    @staticmethod
+    def _load_ckpt(module, path, key, strict, what, keep=None):
+        """The constructor-time checkpoint loads of the reference (patchrefiner.py:82-148, patchrefinerplus.py:104-206):
+        ``torch.load(path, map_location='cpu')[key]`` into ``module``.  A path that does not exist is skipped with a
+        warning (the reference would die in torch.load): the weights then have to arrive through load_state_dict /
+        load_dict, and a forward without them raises 'weights not loaded'."""
+        if path is None:
+            return None
+        import os
+        import warnings
+        if not os.path.exists(str(path)):
+            warnings.warn(f"{what}: checkpoint '{path}' does not exist -- skipped; load the weights with load_dict()")
+            return None
+        sd = torch.load(str(path), map_location="cpu")
+        if key is not None:
+            sd = sd[key]
+        if keep is not None:
+            sd = {k: v for k, v in sd.items() if keep(k)}
+        for k in list(sd):
+            # the reference loads a 3-channel timm stem first and then widens it to 4 input channels with a zero
+            # plane (stem surgery, patchrefinerplus.py:144-200): same result, done on the checkpoint
+            if k.endswith(("refiner_encoder.conv_stem.weight", "refiner_encoder.stem_0.weight")) and sd[k].shape[1] == 3:
+                w = torch.zeros((sd[k].shape[0], 4) + tuple(sd[k].shape[2:]), dtype=sd[k].dtype)
+                w[:, :3] = sd[k]
+                sd[k] = w
+        return module.load_state_dict(sd, strict=strict)
 
     def _common_init(self, config):
         config = _cfg(config)
@@ -388,9 +456,11 @@ class _PatchModel(StateDictModule):
         self.strategy_refiner_target = config.strategy_refiner_target
         self.fusion_feat_level = config.fusion_feat_level
         ctype = config.coarse_branch["type"]
+        pcm = config.get("pretrain_coarse_model", None)
         if ctype == "DA2":
             self.coarse_branch = self._make_da2(config.coarse_branch, config.max_depth)
             self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
+            self._load_ckpt(self.coarse_branch, pcm, "model_state_dict", True, "pretrain_coarse_model")
         elif ctype in ("DA-ZoeDepth", "ZoeDepth"):
             # ZoeDepth.build(**coarse_branch) (patchrefinerplus.py:102-116); only the vendored DepthAnything cores
             # exist here -- W.zoedepth_cfg raises for the torch.hub MiDaS DPT-BEiT-L core of type='ZoeDepth'
@@ -398,6 +468,9 @@ class _PatchModel(StateDictModule):
             zc = {k: v for k, v in config.coarse_branch.to_dict().items() if k != "type"}
             self.coarse_branch = ZoeDepth(device=self.device, prec=self.prec, **zc)
             self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
+            # strict only for DA-ZoeDepth under PatchRefinerPlus (patchrefinerplus.py:108,116; patchrefiner.py:82,89)
+            self._load_ckpt(self.coarse_branch, pcm, "model_state_dict", ctype == "DA-ZoeDepth" and self.STRICT_DA_ZOE,
+                            "pretrain_coarse_model")
         else:
             raise NotImplementedError(f"coarse_branch type {ctype!r}")
         if self.strategy_refiner_target != "offset_coarse":
@@ -424,10 +497,16 @@ class PatchRefiner(_PatchModel):
         if fb["type"] != "DA2":
             raise NotImplementedError("refiner fine_branch type must be 'DA2' (ZoeDepth core un-vendored)")
         self.refiner_fine_branch = self._make_da2(fb, config.max_depth)
+        self._load_ckpt(self.refiner_fine_branch, config.get("pretrain_fine_model", None), "model_state_dict", True,
+                        "pretrain_fine_model")
         self.refiner_fusion_model = build_model({**config.refiner.fusion_model.to_dict(), "device": self.device,
                                                  "prec": self.prec})
         self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
                               refiner_fusion_model=self.refiner_fusion_model)
+        # config.pretrained: the refiner part only unless load_whole (patchrefiner.py:125-143)
+        whole = bool(config.get("load_whole", False))
+        self._load_ckpt(self, config.get("pretrained", None), "model_state_dict", False, "pretrained",
+                        keep=None if whole else (lambda k: "coarse_branch" not in k))
 
     def _pack(self):
         pass
@@ -452,6 +531,7 @@ class PatchRefinerPlus(_PatchModel):
     """V2 (estimator/models/patchrefinerplus.py:60)."""
 
     crop_channels = 4
+    STRICT_DA_ZOE = True
 
     def __init__(self, config):
         super().__init__()
@@ -465,6 +545,9 @@ class PatchRefinerPlus(_PatchModel):
         self.crop_mean, self.crop_std = self.refiner_fine_branch.mean, self.refiner_fine_branch.std
         self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
                               refiner_fusion_model=self.refiner_fusion_model)
+        # patchrefinerplus.py:132-135 (before the stem surgery: a 3-channel conv_stem checkpoint) and :202-205
+        self._load_ckpt(self, config.get("pretrained", None), "model_state_dict", False, "pretrained")
+        self._load_ckpt(self, config.get("whole_pretrained", None), "model_state_dict", False, "whole_pretrained")
 
     def _pack(self):
         pass

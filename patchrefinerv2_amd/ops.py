@@ -84,6 +84,11 @@ def _require_dev(*ts):
     for t in ts:
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise ValueError("prv2 ops need float32 tensors on the GPU (no CPU fallback exists)")
+        if t is not None and t.device.index != torch.cuda.current_device():
+            # kernels are enqueued on the CURRENT device's stream: a tensor of another device would be touched from the
+            # wrong queue (the frame drivers enter torch.cuda.device(model.device) themselves)
+            raise RuntimeError(f"prv2 op on a {t.device} tensor while the current device is cuda:{torch.cuda.current_device()}: "
+                               "wrap the call in torch.cuda.device(tensor.device)")
 
 
 def roundup(a: int, b: int) -> int:

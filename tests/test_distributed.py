@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: the patch-sharded mode's only exchange step (all-gather of the
-per-rank prediction stacks + reorder to tile order) reproduces the single-process ordering."""
+"""CPU, world_size 2 over gloo: the patch-sharded mode's exchange step (all-gather or gather-to-rank-0 of the
+per-rank prediction stacks + reorder to tile order) reproduces the single-process ordering, and the tile plan
+is rank 0's on every rank.  (The sharded FORWARD itself is emulated on one GPU in tests/test_hip_models.py.)"""
 import os
 
 import pytest
@@ -25,8 +26,21 @@ def _worker(rank, world, port, n_tiles, out):
     try:
         full = torch.arange(n_tiles * 24, dtype=torch.float32).view(n_tiles, 1, 4, 6)
         mine = full[rank::world].contiguous()  # tile i -> rank i mod world
-        got = _Host()._gather_predictions(mine, n_tiles, (rank, world))
+        h = _Host()
+        got = h._gather_predictions(mine, n_tiles, (rank, world))              # all-gather: every rank gets the frame
         ok = torch.equal(got, full)
+        got0 = h._gather_predictions(mine, n_tiles, (rank, world), dst=0)      # gather-to-rank-0: only rank 0 does
+        ok = ok and ((torch.equal(got0, full)) if rank == 0 else got0 is None)
+        # the tile plan that counts is rank 0's: a rank whose ``random`` state differs is overruled
+        import random
+        random.seed(621 + rank)
+        h.patch_process_shape = (448, 448)
+        plan = h._sync_plan(h.plan_tiles(h.prepare_tile_cfg([2160, 3840], [4, 4]), "r8", 4))
+        import zlib
+        sig = torch.tensor([zlib.crc32(str(plan).encode())])
+        both = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(both, sig)
+        ok = ok and all(int(b) == int(both[0]) for b in both)
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if rank == 0:
