@@ -248,3 +248,21 @@ def e2e_v2ef_sd(seed: int = 67):
     spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                     f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
     return W.synth_state_dict(spec, seed=seed)
+
+
+# -- BaselinePretrain (estimator/models/baseline_pretrain.py:44-93,377-464): the bare backbone, target 'coarse' (one forward
+#    on image_lr: BASELINE config[0]'s plumbing check) and target 'fine' (the backbone on every tile; N * process_num random
+#    tiles for r<N>, blend mask border 0.1).  Backbone = the reference's 'DA-ZoeDepth' (ZoeDepth.build over DepthAnything ViT-S).
+BASELINE = dict(raw=[216, 384], split=[2, 2], pps=[56, 84], seed=5, sd_seed=71, zcfg={**ZOE_DA["zcfg"], "img_size": [56, 84]},
+                fine_modes=["m1", "m2", "r2"], max_depth=80.0)
+
+
+def baseline_kwargs(target: str) -> dict:
+    c = BASELINE
+    branch = dict(type="DA-ZoeDepth", **c["zcfg"])
+    return dict(coarse_branch=branch, fine_branch=branch, sigloss=dict(type="SILogLoss"), min_depth=1e-3, max_depth=c["max_depth"],
+                image_raw_shape=c["raw"], patch_process_shape=c["pps"], patch_split_num=c["split"], target=target)
+
+
+def baseline_sd(prefix: str = ""):
+    return W.synth_state_dict(W.zoedepth_spec(prefix, BASELINE["zcfg"]), seed=BASELINE["sd_seed"])

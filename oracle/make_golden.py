@@ -616,8 +616,46 @@ def g_effnet():
     save("effnet_refiner", **{f"feat{i}": f for i, f in enumerate(feats[:5])})  # (feat5 = the 2x bilinear copy of feat4)
 
 
+def g_baseline():
+    """The reference's own BaselinePretrain class (estimator/models/baseline_pretrain.py), both targets, with the vendored
+    'DA-ZoeDepth' backbone: pins OracleBaselinePretrain (tile plan with N * process_num random tiles, border-0.1 mask)."""
+    print("[baseline]")
+    from oracle.cases import BASELINE, baseline_kwargs, baseline_sd
+    c = BASELINE
+    bp = refharness.ref_module("estimator.models.baseline_pretrain")
+    sd = baseline_sd()
+    z = W.zoedepth_cfg(c["zcfg"])
+    branch_fn = lambda x: o_zoe.zoedepth_forward(sd, "", x, z)["metric_depth"]  # noqa: E731
+    tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+    image_hr = rand_image(c["seed"], 1, *c["raw"])
+    res = {}
+    for target in ("coarse", "fine"):
+        kw = baseline_kwargs(target)
+        for b in ("coarse_branch", "fine_branch"):
+            kw[b] = refharness.AttrDict(kw[b])
+        m = bp.BaselinePretrain(**kw).eval()
+        r = m.load_dict(dict(sd))
+        assert not r.missing_keys and not r.unexpected_keys, (r.missing_keys[:4], r.unexpected_keys[:4])
+        assert sorted(m.get_save_dict()) == sorted(sd)
+        ora = o_tiling.OracleBaselinePretrain(branch_fn, target=target, patch_process_shape=c["pps"], image_raw_shape=c["raw"],
+                                              patch_split_num=c["split"])
+        image_lr = m.resizer(image_hr)
+        assert maxdiff(image_lr, ora.resizer(image_hr)) == 0.0
+        for mode in (["m1"] if target == "coarse" else c["fine_modes"]):
+            with torch.no_grad():
+                random.seed(621)
+                ref, log = m(mode="infer", image_lr=image_lr, image_hr=image_hr, depth_gt=None, tile_cfg=tc, cai_mode=mode, process_num=4)
+                random.seed(621)
+                out, olog = ora(mode="infer", image_lr=image_lr, image_hr=image_hr, tile_cfg=tc, cai_mode=mode, process_num=4)
+            d = maxdiff(ref, out)
+            print(f"  {target} {mode}: out {tuple(ref.shape)} range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {d:.2e}; log keys {sorted(log)}")
+            assert d < 1e-4 and sorted(log) == sorted(olog), (d, sorted(log), sorted(olog))
+            res[f"{target}_{mode}"] = ref
+    save("baseline", **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2", "zoedepth", "e2e_v2z"]
+    which = sys.argv[1:] or ["dav2", "vit_block", "fusion_unet", "bidir", "tiling", "e2e_v1", "e2e_v2", "zoedepth", "e2e_v2z", "baseline"]
     for w in which:
         globals()["g_" + w]()
     print("done")

@@ -78,6 +78,12 @@ def coarse_postprocess_test(coarse_prediction, coarse_features, bboxs_feat, ph):
 class OracleRefiner:
     """Shared driver; subclasses provide coarse_forward / infer_forward."""
 
+    border = 0.15        # generatemask(border=0.15): patchrefinerplus.py:485,514; patchrefiner.py:358,386
+    needs_coarse = True
+
+    def random_calls(self, cai_mode, process_num):
+        return int(cai_mode[1:]) // process_num   # patchrefinerplus.py:517-520
+
     def __init__(self, sd, patch_process_shape, image_raw_shape, patch_split_num, resizer="da"):
         self.sd = sd
         self.patch_process_shape = tuple(patch_process_shape)
@@ -105,10 +111,13 @@ class OracleRefiner:
         h_starts = [random.randint(0, H - height - 1) for _ in range(process_num)]
         w_starts = [random.randint(0, W - width - 1)]
         crops, bboxs = self._crops(image_hr, h_starts, w_starts, height, width)
-        bf = bboxs_to_feat(bboxs, (H, W), self.patch_process_shape)
-        post = coarse_postprocess_test(tile_temp["coarse_prediction"], tile_temp["coarse_features"], bf,
-                                       self.patch_process_shape[0])
-        pred = self.infer_forward(crops, post)
+        if tile_temp is None:  # BaselinePretrain(target='fine'): the bare backbone (baseline_pretrain.py:204-206)
+            pred = self.infer_forward(crops, None)
+        else:
+            bf = bboxs_to_feat(bboxs, (H, W), self.patch_process_shape)
+            post = coarse_postprocess_test(tile_temp["coarse_prediction"], tile_temp["coarse_features"], bf,
+                                           self.patch_process_shape[0])
+            pred = self.infer_forward(crops, post)
         pred = nearest(pred, (height, width))
         if self.trace is not None:
             self.trace.setdefault("tiles", []).extend(("r", hs, w_starts[0]) for hs in h_starts)
@@ -134,13 +143,14 @@ class OracleRefiner:
         hp_starts = [ph * h + offset_process[0] for h in range((RH - offset_process[0]) // ph)]
         wp_starts = [pw * w + offset_process[1] for w in range((RW - offset_process[1]) // pw)]
         crops, bboxs = self._crops(image_hr, h_starts, w_starts, height, width)
-        bf = bboxs_to_feat(bboxs, (H, W), self.patch_process_shape)
-        post = coarse_postprocess_test(tile_temp["coarse_prediction"], tile_temp["coarse_features"], bf, ph)
+        if tile_temp is not None:
+            bf = bboxs_to_feat(bboxs, (H, W), self.patch_process_shape)
+            post = coarse_postprocess_test(tile_temp["coarse_prediction"], tile_temp["coarse_features"], bf, ph)
         preds = []
         for idx, batch in enumerate(torch.split(crops, process_num, dim=0)):
             sl = slice(idx * process_num, (idx + 1) * process_num)
-            sub = dict(coarse_depth_roi=post["coarse_depth_roi"][sl],
-                       coarse_feats_roi=[f[sl] for f in post["coarse_feats_roi"]])
+            sub = None if tile_temp is None else dict(coarse_depth_roi=post["coarse_depth_roi"][sl],
+                                                      coarse_feats_roi=[f[sl] for f in post["coarse_feats_roi"]])
             preds.append(self.infer_forward(batch, sub))
         preds = torch.cat(preds, dim=0)
         if self.trace is not None:
@@ -176,11 +186,14 @@ class OracleRefiner:
             tile_cfg = prepare_tile_cfg(self.patch_process_shape, tile_cfg["image_raw_shape"],
                                         tile_cfg["patch_split_num"])
         assert image_hr.shape[0] == 1
-        feats, coarse_pred = self.coarse_forward(image_lr)
-        tile_temp = dict(coarse_prediction=coarse_pred, coarse_features=feats)
+        if self.needs_coarse:
+            feats, coarse_pred = self.coarse_forward(image_lr)
+            tile_temp = dict(coarse_prediction=coarse_pred, coarse_features=feats)
+        else:
+            tile_temp = coarse_pred = None
         ph, pw = self.patch_process_shape
         rh, rw = tile_cfg["patch_raw_shape"]
-        blur = torch.tensor(generatemask((ph, pw), border=0.15))
+        blur = torch.tensor(generatemask((ph, pw), border=self.border))
         kw = dict(image_hr=image_hr[0], tile_temp=tile_temp, tile_cfg=tile_cfg, process_num=process_num)
         avg = self.regular_tile([0, 0], [0, 0], init_flag=True, blur_mask=blur, avg=None, **kw)
         if cai_mode == "m2" or cai_mode[0] == "r":
@@ -189,9 +202,9 @@ class OracleRefiner:
             avg = self.regular_tile([rh // 2, rw // 2], [ph // 2, pw // 2], init_flag=False, blur_mask=blur,
                                     avg=avg, **kw)
         if cai_mode[0] == "r":
-            blur = torch.tensor(generatemask((rh, rw), border=0.15) + 1e-3)
+            blur = torch.tensor(generatemask((rh, rw), border=self.border) + 1e-3)
             avg.resize(tile_cfg["image_raw_shape"])
-            for _ in range(int(cai_mode[1:]) // process_num):
+            for _ in range(self.random_calls(cai_mode, process_num)):
                 avg = self.random_tile(blur_mask=blur, avg=avg, **kw)
         depth = avg.get_avg_map()[None, None]
         return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=None, coarse_prediction=coarse_pred)
@@ -243,3 +256,31 @@ class OraclePatchRefinerPlus(OracleRefiner):
         return fusion.bidirectional_fusion(self.sd, "refiner_fusion_model.", post["coarse_feats_roi"][::-1],
                                            r_feats[::-1], post["coarse_depth_roi"], r_depth,
                                            update_base=post["coarse_depth_roi"])
+
+
+class OracleBaselinePretrain(OracleRefiner):
+    """BaselinePretrain (estimator/models/baseline_pretrain.py:44-93, 377-464).  ``branch_fn(x)`` = the backbone on a
+    [B,3,h,w] image in [0,1] -> metric depth [B,1,h,w].  target='coarse': ``branch_fn(image_lr)`` (:409-411);
+    target='fine': tiling with the bare backbone per tile, mask border 0.1 (generatemask's default, :420,447), and N
+    random_tile calls for r<N> (:449-452)."""
+
+    border = 0.1
+    needs_coarse = False
+
+    def __init__(self, branch_fn, target="coarse", **kw):
+        super().__init__(None, **kw)
+        self.branch_fn, self.target = branch_fn, target
+
+    def random_calls(self, cai_mode, process_num):
+        return int(cai_mode[1:])
+
+    def infer_forward(self, imgs_crop, post):
+        return self.branch_fn(imgs_crop)
+
+    @torch.no_grad()
+    def __call__(self, mode="infer", image_lr=None, image_hr=None, **kw):
+        if self.target == "coarse":
+            d = self.branch_fn(image_lr)
+            return d, dict(rgb=image_lr, depth_pred=d, depth_gt=None)
+        depth, _ = super().__call__(mode="infer", image_lr=image_lr, image_hr=image_hr, **kw)
+        return depth, {}

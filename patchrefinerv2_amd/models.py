@@ -147,6 +147,12 @@ class _PatchModel(StateDictModule):
     crop_channels = 3
     crop_mean, crop_std = IMAGENET_MEAN, IMAGENET_STD
     STRICT_DA_ZOE = False
+    blend_border = 0.15      # generatemask(..., border=0.15) (patchrefinerplus.py:485); BaselinePretrain: the default 0.1
+    needs_coarse = True      # coarse forward + ROI pyramid per tile (False: BaselinePretrain(target='fine'))
+
+    def random_calls(self, cai_mode: str, process_num: int) -> int:
+        """random_tile calls of an r<N> mode: N // process_num (patchrefinerplus.py:517-520, patchrefiner.py:388-391)"""
+        return int(cai_mode[1:]) // process_num
 
     # -- BaselinePretrain.prepare_tile_cfg (baseline_pretrain.py:96-124) ---------------------------
     def prepare_tile_cfg(self, image_raw_shape, patch_split_num):
@@ -195,7 +201,7 @@ class _PatchModel(StateDictModule):
             raise ValueError(f"unknown cai_mode {cai_mode!r} (expected m1, m2 or r<N>)")
         if cai_mode[0] == "r":
             tiles = []
-            for _ in range(int(cai_mode[1:]) // process_num):
+            for _ in range(self.random_calls(cai_mode, process_num)):
                 # baseline_pretrain.py:160-161: process_num h-starts, then ONE w-start, per call
                 hs = [random.randint(0, H - rh - 1) for _ in range(process_num)]
                 ws = random.randint(0, W - rw - 1)
@@ -221,6 +227,8 @@ class _PatchModel(StateDictModule):
         t = torch.tensor(tiles, dtype=torch.int32).to(dev)
         crops = Feat.alloc(K, ph, pw, self.crop_channels, dev, pad_to=4)
         ops.crop_resize(image_hr_chw, t, rh, rw, ph, pw, self.crop_mean, self.crop_std, crops)
+        if not self.needs_coarse:
+            return crops, None, None
         boxes = torch.from_numpy(self._boxes(tiles, tile_cfg)).to(dev)
         # roi_align(feat, boxes, (h, w), h / ph, aligned=True) per level (patchrefinerplus.py:268-276)
         rois = [ops.roi_align(f, boxes, f.h / ph, f.h, f.w) for f in coarse_feats]
@@ -258,8 +266,11 @@ class _PatchModel(StateDictModule):
         rh, rw = tile_cfg["patch_raw_shape"]
         RH, RW = tile_cfg["patch_reensemble_shape"]
 
-        coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
-        coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
+        if self.needs_coarse:
+            coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
+            coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
+        else:
+            coarse_feats = coarse_prediction = coarse_depth = None
         passes = self.plan_tiles(tile_cfg, cai_mode, process_num)
         if shard is not None and shard[1] > 1:
             # every rank consumed ``random`` identically above; the plan that counts is rank 0's (a rank seeded
@@ -303,7 +314,7 @@ class _PatchModel(StateDictModule):
         preds = preds.view(len(flat), ph, pw)
 
         # ---- overlap blend, in the reference's order ----------------------------------------------
-        mask = blend_mask((ph, pw), 0.15, 0.0, dev)
+        mask = blend_mask((ph, pw), self.blend_border, 0.0, dev)
         ram = DeviceRunningAverageMap(RH, RW, dev)
         # tile lists of all passes in ONE upload (a pageable H2D per pass is a synchronising copy between the blend kernels)
         counts = [len(p["raw"]) for p in passes]
@@ -318,7 +329,7 @@ class _PatchModel(StateDictModule):
             elif p["kind"] == "grid":
                 ram.update(pr, mask, tiles_dev, ph, pw)
             else:
-                mask_r = blend_mask((rh, rw), 0.15, 1e-3, dev)  # generatemask(...) + 1e-3 (patchrefinerplus.py:514)
+                mask_r = blend_mask((rh, rw), self.blend_border, 1e-3, dev)  # generatemask(...) + 1e-3 (patchrefinerplus.py:514)
                 ram.resize(tile_cfg["image_raw_shape"])
                 if k:
                     ram.update(pr, mask_r, tiles_dev, rh, rw)
@@ -484,6 +495,84 @@ class _PatchModel(StateDictModule):
         feats = [t["x_d0"], t["x_blocks_feat_0"], t["x_blocks_feat_1"], t["x_blocks_feat_2"], t["x_blocks_feat_3"],
                  t["midas_final_feat"]]
         return feats, out["metric_depth"]
+
+
+@MODELS.register_module()
+class BaselinePretrain(_PatchModel):
+    """estimator/models/baseline_pretrain.py:44-93 (constructor: keyword arguments, not one ``config``), 377-464.
+    target='coarse': ONE backbone forward on ``image_lr``, no tiling -- returns the DEVICE tensor [1,1,ph,pw] and
+    dict(rgb, depth_pred, depth_gt) (:409-411,464).  target='fine': the tiling driver with the bare backbone on every
+    tile (``infer_forward`` :144-146), blend mask border 0.1 (generatemask's default, :420,447) and -- unlike the two
+    refiners -- N random_tile CALLS for r<N>, i.e. N * process_num random tiles (:449-452); returns (CPU depth, {})."""
+
+    blend_border = 0.1
+    needs_coarse = False
+
+    def __init__(self, coarse_branch=None, fine_branch=None, sigloss=None, min_depth=1e-3, max_depth=80,
+                 image_raw_shape=(2160, 3840), patch_process_shape=(384, 512), patch_split_num=(4, 4), target="coarse",
+                 coarse_branch_zoe=None, device="cuda", prec="f32", max_batch=None, n_streams=1):
+        super().__init__()
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self.patch_process_shape = tuple(patch_process_shape)
+        self.tile_cfg = self.prepare_tile_cfg(image_raw_shape, patch_split_num)
+        self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
+        self.device = torch.device(device)
+        self.max_batch, self.n_streams = max_batch, n_streams
+        self.target = target
+        if target not in ("coarse", "fine"):
+            raise NotImplementedError(f"BaselinePretrain target {target!r}")  # baseline_pretrain.py:406,461
+        bcfg = _cfg(coarse_branch if target == "coarse" else fine_branch)
+        btype = bcfg["type"]
+        if btype == "DA2" and target == "coarse":
+            branch = self._make_da2(bcfg, max_depth)
+        elif btype in ("ZoeDepth", "DA-ZoeDepth"):
+            from .zoedepth import ZoeDepth
+            branch = ZoeDepth(device=self.device, prec=self.prec, **{k: v for k, v in bcfg.to_dict().items() if k != "type"})
+        else:
+            raise NotImplementedError(f"BaselinePretrain(target={target!r}) with branch type {btype!r} "
+                                      "(baseline_pretrain.py:68-90 builds none either)")
+        self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "zoe" if btype == "ZoeDepth" else "da")
+        name = "coarse_branch" if target == "coarse" else "fine_branch"
+        setattr(self, name, branch)
+        self._branch = branch
+        self._children = {name: branch}
+        self.crop_mean, self.crop_std = getattr(branch, "input_mean", IMAGENET_MEAN), getattr(branch, "input_std", IMAGENET_STD)
+
+    def _pack(self):
+        pass
+
+    # baseline_pretrain.py:126-142: checkpoints hold the bare branch
+    def load_dict(self, sd):
+        return self._branch.load_state_dict(sd, strict=False)
+
+    def get_save_dict(self):
+        return self._branch.state_dict()
+
+    def random_calls(self, cai_mode, process_num):
+        return int(cai_mode[1:])  # ``for i in range(patch_num)`` (baseline_pretrain.py:449-452)
+
+    @torch.no_grad()
+    def forward(self, mode=None, image_lr=None, image_hr=None, depth_gt=None, **kw):
+        if mode == "train":
+            raise NotImplementedError("only inference is built (training is out of scope, SURVEY.md 2 #12-13)")
+        if self.target == "coarse":
+            if not image_lr.is_cuda:
+                raise RuntimeError("image_lr must be on the GPU (tester.py:43-49 moves it); no CPU path")
+            with torch.cuda.device(image_lr.device):
+                depth = self.coarse_branch(image_lr)["metric_depth"]
+            return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt)
+        depth, _ = super().forward(mode="infer", image_lr=image_lr, image_hr=image_hr, depth_gt=depth_gt, **kw)
+        return depth, {}
+
+    __call__ = forward
+
+    def infer_forward(self, crops: Feat, rois, depth_roi, out=None):
+        """baseline_pretrain.py:144-146: ``self.fine_branch(imgs_crop)['metric_depth']``"""
+        d = self.fine_branch.forward_nhwc(crops)["metric_depth"]
+        if out is not None:
+            out.copy_(d)
+            return out
+        return d
 
 
 @MODELS.register_module()

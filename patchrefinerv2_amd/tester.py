@@ -155,6 +155,7 @@ class Tester:
             tile_cfg = dict(image_raw_shape=list(image_raw_shape), patch_split_num=list(patch_split_num))
             result, log = self.model(mode="infer", cai_mode=cai_mode, process_num=process_num, tile_cfg=tile_cfg,
                                      image_lr=lr, image_hr=hr)
+            result = result.cpu()  # BaselinePretrain(target='coarse') hands back the device tensor (baseline_pretrain.py:464)
             if self.runner_info.save:
                 os.makedirs(self.runner_info.work_dir, exist_ok=True)
                 base = os.path.join(self.runner_info.work_dir, item["img_file_basename"])
@@ -167,8 +168,9 @@ class Tester:
                     cmap = "magma_r" if getattr(self.dataloader, "dataset_name", "") == "cityscapes" else "Spectral"
                     color = colorize(result, cmap=cmap, vminp=0, vmaxp=100)
                 write_png8(base + ".png", np.ascontiguousarray(color[:, :, :3]))
-                coarse = F.interpolate(log["coarse_prediction"].cpu(), tuple(image_raw_shape), mode="bilinear")
-                write_png8(base + "_coarse.png", np.ascontiguousarray(colorize(coarse, cmap="Spectral", vminp=0, vmaxp=100)[:, :, :3]))
+                if log.get("coarse_prediction") is not None:  # absent for BaselinePretrain
+                    coarse = F.interpolate(log["coarse_prediction"].cpu(), tuple(image_raw_shape), mode="bilinear")
+                    write_png8(base + "_coarse.png", np.ascontiguousarray(colorize(coarse, cmap="Spectral", vminp=0, vmaxp=100)[:, :, :3]))
             entry = dict(name=item["img_file_basename"], shape=tuple(result.shape), mean=float(result.mean()))
             if item.get("depth_gt") is not None:
                 entry["metrics"] = self.dataloader.get_metrics(item["depth_gt"], result, disp_gt_edges=item.get("boundary"))

@@ -57,8 +57,17 @@ class ZoeDepth(StateDictModule):
             raise RuntimeError("ZoeDepth: weights not loaded")
         z = self.zcfg
         emb_dim = z["bin_embedding_dim"]
-        B, _, H, Wd = x.shape
-        xn = self.core.normalize_nchw(x)
+        return self.forward_nhwc(self.core.normalize_nchw(x))
+
+    def forward_nhwc(self, xn: Feat) -> dict:
+        """xn: normalised NHWC input [B, H, W, >=3] (what PrepForMidas hands to the core)"""
+        P = self._packed
+        if P is None:
+            raise RuntimeError("ZoeDepth: weights not loaded")
+        z = self.zcfg
+        emb_dim = z["bin_embedding_dim"]
+        B, H, Wd = xn.n, xn.h, xn.w
+        x = xn
         # the conditional-log-binomial input [out_conv(32) | rel_depth(1) | b_embedding(emb)] as one buffer:
         # the DPT head writes its 32-channel out_conv feature straight into channels 0..31
         last = Feat.alloc(B, H, Wd, 32 + 1 + emb_dim, x.device)

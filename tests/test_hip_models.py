@@ -339,6 +339,51 @@ def test_zoedepth_da_core(P, golden):
         ZoeDepth.build(midas_model_type="DPT_BEiT_L_384")
 
 
+def test_baseline_pretrain_vs_reference_golden(P, golden):
+    """BaselinePretrain (registered type, keyword constructor) against the reference's own class: target 'coarse' returns
+    the device tensor of one backbone forward, target 'fine' tiles with the bare backbone (N * process_num random tiles)"""
+    from oracle.cases import BASELINE, baseline_kwargs, baseline_sd
+    from patchrefinerv2_amd import models  # noqa: F401
+    from patchrefinerv2_amd.registry import build_model
+    c, g = BASELINE, golden("baseline")
+    hr = rand_image(c["seed"], 1, *c["raw"]).to(DEV)
+    tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+    for target, modes in (("coarse", ["m1"]), ("fine", c["fine_modes"])):
+        m = build_model(dict(type="BaselinePretrain", **baseline_kwargs(target)))
+        res = m.load_dict(baseline_sd())
+        assert not res["missing_keys"] and not res["unexpected_keys"]
+        for mode in modes:
+            random.seed(621)
+            depth, log = m(mode="infer", image_lr=m.resizer(hr), image_hr=hr, depth_gt=None, tile_cfg=tc, cai_mode=mode, process_num=4)
+            assert depth.is_cuda == (target == "coarse") and sorted(log) == (["depth_gt", "depth_pred", "rgb"] if target == "coarse" else [])
+            ar, mx = absrel(depth, g[f"{target}_{mode}"])
+            assert tuple(depth.shape) == tuple(g[f"{target}_{mode}"].shape) and ar < 1e-5 and mx < 1e-3, (target, mode, ar, mx)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_baseline_config0_540x960_coarse_full_size(P, prec):
+    """BASELINE config[0] at its real size: a 540 x 960 frame, BaselinePretrain(target='coarse') with the full ViT-L
+    'DA-ZoeDepth' backbone (the pinned sibling of the un-vendored BEiT-L), image_lr 392 x 518 (1037 tokens,
+    24 blocks) -- the product in both arithmetic modes against the fp32 oracle on the same synthetic weights."""
+    from patchrefinerv2_amd import models  # noqa: F401
+    from patchrefinerv2_amd.registry import build_model
+    from patchrefinerv2_amd.workloads import ZOE_DA_L
+    branch = dict(type="DA-ZoeDepth", **ZOE_DA_L)
+    m = build_model(dict(type="BaselinePretrain", coarse_branch=branch, fine_branch=branch, sigloss=dict(type="SILogLoss"),
+                         min_depth=1e-3, max_depth=80, image_raw_shape=[540, 960], patch_process_shape=[392, 518],
+                         patch_split_num=[1, 1], target="coarse", prec=prec))
+    sd = W.synth_state_dict(W.zoedepth_spec("", ZOE_DA_L), seed=0)
+    m.load_dict(sd)
+    hr = rand_image(11, 1, 540, 960)
+    lr = m.resizer(hr.to(DEV))
+    assert tuple(lr.shape) == (1, 3, 392, 518)
+    depth, log = m(mode="infer", image_lr=lr, image_hr=hr.to(DEV), depth_gt=None)
+    ref = o_zoe.zoedepth_forward(sd, "", lr.cpu(), W.zoedepth_cfg(ZOE_DA_L))["metric_depth"]
+    ar, mx = absrel(depth, ref)
+    print(f"config[0] coarse-only 392x518 ViT-L {prec}: AbsRel {ar:.3e} max|d| {mx:.3e} (depth range {float(ref.min()):.2f}..{float(ref.max()):.2f})")
+    assert tuple(depth.shape) == (1, 1, 392, 518) and ar < (1e-5 if prec == "f32" else ABSREL_TOL), (ar, mx)
+
+
 def test_e2e_v2_zoedepth_coarse_vs_reference_golden(P, golden):
     c, g = E2E_V2Z, golden("e2e_v2z")
     from patchrefinerv2_amd.registry import build_model
