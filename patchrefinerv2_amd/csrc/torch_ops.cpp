@@ -1,0 +1,308 @@
+// PyTorch-ROCm custom ops over the C ABI (include/prv2.h):  torch.ops.prv2.*
+//
+// The reference is pure PyTorch: what its hot path dispatches are torch ops.  This file registers the
+// replacements under TORCH_LIBRARY(prv2, ...) so that they take / return at::Tensor, run on the CURRENT HIP stream of
+// the tensor's device, allocate outputs through torch's caching allocator (or fill a caller's ``out`` view), raise
+// through TORCH_CHECK (-> Python RuntimeError) and keep no state.  Activations are NHWC fp32; a tensor may be a channel
+// slice of a wider buffer (stride(-1) == 1, stride(-2) == ld), which is how a torch.cat is written in place.
+// Host-only translation unit: all device code lives behind the C ABI in libprv2_hip.so.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <vector>
+
+#include "../../include/prv2.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+
+struct Launch {  // device guard + the stream torch considers current on that device
+  c10::hip::HIPGuard guard;
+  void* stream;
+  explicit Launch(const Tensor& t) : guard(t.device()), stream((void*)c10::hip::getCurrentHIPStream(t.device().index()).stream()) {}
+};
+
+void ok(int code, const char* what) { TORCH_CHECK(code == 0, "prv2::", what, " failed (code ", code, "): ", prv2_last_error()); }
+
+void dev_f32(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), "prv2: ", name, " must be a GPU tensor (there is no CPU path)");
+  TORCH_CHECK(t.scalar_type() == at::kFloat, "prv2: ", name, " must be float32");
+}
+
+// NHWC view [n, h, w, c] with unit channel stride, pixel stride ld and dense rows / images on top of it
+int64_t nhwc_ld(const Tensor& t, const char* name) {
+  dev_f32(t, name);
+  TORCH_CHECK(t.dim() == 4, "prv2: ", name, " must be NHWC [n, h, w, c]");
+  const int64_t ld = t.stride(2);
+  TORCH_CHECK(t.stride(3) == 1 && ld >= t.size(3) && t.stride(1) == t.size(2) * ld && (t.size(0) == 1 || t.stride(0) == t.size(1) * t.size(2) * ld),
+              "prv2: ", name, " must be an NHWC tensor or a channel slice of one (strides ", t.strides(), ")");
+  return ld;
+}
+
+const float* opt_ptr(const optional<Tensor>& t, const char* name, int64_t numel = -1) {
+  if (!t.has_value()) return nullptr;
+  dev_f32(*t, name);
+  TORCH_CHECK(t->is_contiguous(), "prv2: ", name, " must be contiguous");
+  TORCH_CHECK(numel < 0 || t->numel() == numel, "prv2: ", name, " has ", t->numel(), " elements, expected ", numel);
+  return t->data_ptr<float>();
+}
+
+Tensor alloc_nhwc(const Tensor& like, int64_t n, int64_t h, int64_t w, int64_t c) {
+  const int64_t ld = (c + 3) / 4 * 4;  // pad channels must be finite: zero the whole buffer when there are any
+  Tensor buf = ld == c ? at::empty({n, h, w, ld}, like.options()) : at::zeros({n, h, w, ld}, like.options());
+  return ld == c ? buf : buf.narrow(3, 0, c);
+}
+
+Tensor out_or_alloc(const optional<Tensor>& out, const Tensor& like, int64_t n, int64_t h, int64_t w, int64_t c, const char* what) {
+  if (!out.has_value()) return alloc_nhwc(like, n, h, w, c);
+  TORCH_CHECK(out->dim() == 4 && out->size(0) == n && out->size(1) == h && out->size(2) == w && out->size(3) == c, "prv2::", what,
+              ": out has shape ", out->sizes(), ", expected [", n, ", ", h, ", ", w, ", ", c, "]");
+  return *out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+Tensor pack_conv_weight(const Tensor& w, const optional<Tensor>& bn_scale, int64_t convt_k, int64_t prec) {
+  dev_f32(w, "weight");
+  TORCH_CHECK(w.dim() == 4 || w.dim() == 2, "prv2::pack_conv_weight: weight must be [cout, cin, kh, kw] or [cout, cin]");
+  Tensor wc = w.contiguous();
+  const int64_t kh = w.dim() == 4 ? w.size(2) : 1, kw = w.dim() == 4 ? w.size(3) : 1;
+  const int64_t cout = convt_k ? w.size(1) : w.size(0), cin = convt_k ? w.size(0) : w.size(1);
+  const int64_t bytes = prv2_packed_weight_bytes((int)cout, (int)cin, (int)kh, (int)kw, (int)convt_k, (int)prec);
+  TORCH_CHECK(bytes > 0, "prv2::pack_conv_weight: ", prv2_last_error());
+  Tensor packed = at::empty({bytes / 4}, w.options());
+  Launch L(w);
+  ok(prv2_pack_conv_weight(wc.data_ptr<float>(), opt_ptr(bn_scale, "bn_scale", cout), packed.data_ptr(), (int)cout, (int)cin, (int)kh, (int)kw,
+                           (int)convt_k, (int)prec, L.stream), "pack_conv_weight");
+  return packed;
+}
+
+// nn.Conv2d / nn.Linear (kh = kw = 1 over an [1, M, 1, K] view) / nn.ConvTranspose2d(k == stride) with the fused epilogue of
+// include/prv2.h::prv2_conv2d
+Tensor conv2d(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+              int64_t pad, int64_t act, bool relu_in, const optional<Tensor>& ln_weight, const optional<Tensor>& ln_bias,
+              const optional<Tensor>& gamma, const optional<Tensor>& mul, const optional<Tensor>& res, const optional<Tensor>& res2,
+              int64_t convt_k, int64_t prec, double ln_eps, bool same_pad, const optional<Tensor>& out) {
+  const int64_t ldx = nhwc_ld(x, "x");
+  dev_f32(w_packed, "w_packed");
+  const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
+  int64_t oh, ow;
+  if (convt_k) { oh = h * convt_k; ow = w * convt_k; }
+  else if (same_pad) { oh = (h + stride - 1) / stride; ow = (w + stride - 1) / stride; }
+  else { oh = (h + 2 * pad - kh) / stride + 1; ow = (w + 2 * pad - kw) / stride + 1; }
+  TORCH_CHECK(oh > 0 && ow > 0, "prv2::conv2d: empty output");
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_packed_weight_bytes((int)cout, (int)cin, (int)kh, (int)kw, (int)convt_k, (int)prec),
+              "prv2::conv2d: w_packed does not match (cout, cin, kh, kw, convt_k, prec) = (", cout, ", ", cin, ", ", kh, ", ", kw, ", ", convt_k, ", ", prec, ")");
+  TORCH_CHECK(ln_weight.has_value() == ln_bias.has_value(), "prv2::conv2d: ln_weight and ln_bias go together");
+  Tensor y = out_or_alloc(out, x, n, oh, ow, cout, "conv2d");
+  prv2_conv_desc d = {};
+  d.n = (int)n; d.h = (int)h; d.w = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.kh = (int)kh; d.kw = (int)kw;
+  d.stride = (int)(convt_k ? convt_k : stride); d.pad = (int)pad; d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out");
+  d.relu_in = relu_in; d.act = (int)act; d.convt_k = (int)convt_k; d.prec = (int)prec; d.ln_eps = (float)ln_eps; d.same_pad = same_pad;
+  auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
+    if (!t.has_value()) return nullptr;
+    ld = (int32_t)nhwc_ld(*t, name);
+    TORCH_CHECK(t->sizes() == y.sizes(), "prv2::conv2d: ", name, " must have the output's shape");
+    return t->data_ptr<float>();
+  };
+  const float* pm = aux(mul, "mul", d.ld_mul);
+  const float* pr = aux(res, "res", d.ld_res);
+  const float* pr2 = aux(res2, "res2", d.ld_res2);
+  Launch L(x);
+  ok(prv2_conv2d(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), opt_ptr(ln_weight, "ln_weight", cout),
+                 opt_ptr(ln_bias, "ln_bias", cout), opt_ptr(gamma, "gamma", cout), pm, pr, pr2, y.data_ptr<float>(), L.stream), "conv2d");
+  return y;
+}
+
+// nn.LayerNorm over the last dimension of [rows, c] (tokens) or of an NHWC map (the reference's channels-first LayerNorm)
+Tensor layernorm(const Tensor& x, const Tensor& weight, const Tensor& bias, double eps, int64_t act) {
+  dev_f32(x, "x");
+  TORCH_CHECK(x.dim() >= 2 && x.stride(-1) == 1, "prv2::layernorm: x must have unit stride along the normalised dimension");
+  const int64_t c = x.size(-1);
+  Tensor xr = x.dim() == 2 ? x : (x.is_contiguous() ? x.view({-1, c}) : x.contiguous().view({-1, c}));
+  TORCH_CHECK(xr.size(0) == 1 || xr.stride(0) >= c, "prv2::layernorm: unsupported strides");
+  Tensor y = at::empty({xr.size(0), c}, x.options());
+  Launch L(x);
+  ok(prv2_layernorm(xr.data_ptr<float>(), xr.size(0), (int)c, (int)(xr.size(0) == 1 ? c : xr.stride(0)), opt_ptr(weight, "weight", c),
+                    opt_ptr(bias, "bias", c), (float)eps, (int)act, y.data_ptr<float>(), (int)c, L.stream), "layernorm");
+  return y.view(x.sizes());
+}
+
+// softmax((q * scale) k^T) v, head_dim 64; qkv rows [3][heads][64] as nn.Linear(dim, 3 * dim) leaves them (attention.py:49-62)
+Tensor attention_fwd(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, int64_t prec) {
+  dev_f32(qkv, "qkv");
+  TORCH_CHECK(qkv.is_contiguous() && qkv.numel() == b * ntok * 3 * heads * 64, "prv2::attention_fwd: qkv must be contiguous [b * ntok, 3 * heads * 64]");
+  Tensor out = at::empty({b * ntok, heads * 64}, qkv.options());
+  const int64_t wsb = prv2_attention_workspace_bytes((int)b, (int)ntok, (int)heads, (int)prec);
+  Tensor ws = at::empty({wsb > 0 ? wsb : 1}, qkv.options().dtype(at::kByte));
+  Launch L(qkv);
+  ok(prv2_attention(qkv.data_ptr<float>(), (int)b, (int)ntok, (int)heads, 64, out.data_ptr<float>(), (int)prec, wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream),
+     "attention_fwd");
+  return out;
+}
+
+// crop + bilinear(align_corners=True) resize of k tiles of a CHW image -> NHWC [k, oh, ow, 3] (+ (v - mean) / std)
+Tensor crop_resize_bilinear(const Tensor& img_chw, const Tensor& tiles, int64_t ch, int64_t cw, int64_t oh, int64_t ow,
+                            optional<at::ArrayRef<double>> mean, optional<at::ArrayRef<double>> std_, const optional<Tensor>& out) {
+  dev_f32(img_chw, "img_chw");
+  TORCH_CHECK(img_chw.dim() == 3 && img_chw.size(0) == 3 && img_chw.is_contiguous(), "prv2::crop_resize_bilinear: img must be contiguous [3, H, W]");
+  TORCH_CHECK(tiles.is_cuda() && tiles.scalar_type() == at::kInt && tiles.dim() == 2 && tiles.size(1) == 2 && tiles.is_contiguous(),
+              "prv2::crop_resize_bilinear: tiles must be an int32 GPU tensor [k, 2] = (h_start, w_start)");
+  TORCH_CHECK(mean.has_value() == std_.has_value() && (!mean.has_value() || (mean->size() == 3 && std_->size() == 3)), "prv2::crop_resize_bilinear: mean / std are 3 + 3 floats");
+  const int64_t k = tiles.size(0);
+  Tensor y = out_or_alloc(out, img_chw, k, oh, ow, 3, "crop_resize_bilinear");
+  float m[3], s[3];
+  if (mean.has_value()) for (int i = 0; i < 3; ++i) { m[i] = (float)(*mean)[i]; s[i] = (float)(*std_)[i]; }
+  Launch L(img_chw);
+  ok(prv2_crop_resize(img_chw.data_ptr<float>(), (int)img_chw.size(1), (int)img_chw.size(2), tiles.data_ptr<int32_t>(), (int)k, (int)ch, (int)cw, (int)oh,
+                      (int)ow, mean.has_value() ? m : nullptr, mean.has_value() ? s : nullptr, y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream),
+     "crop_resize_bilinear");
+  return y;
+}
+
+// torchvision.ops.roi_align(feat.repeat(K), boxes, feat.shape[-2:], h / ph, aligned=True) for every level of the coarse pyramid
+// (patchrefinerplus.py:263-283) without the K copies.  feats: NHWC [1, h, w, c]; boxes [k, 4] = (x1, y1, x2, y2) in lr pixels.
+std::vector<Tensor> roi_gather_pyramid(at::TensorList feats, const Tensor& boxes, int64_t ph) {
+  dev_f32(boxes, "boxes");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && boxes.is_contiguous(), "prv2::roi_gather_pyramid: boxes must be contiguous [k, 4]");
+  std::vector<Tensor> outs;
+  for (const Tensor& f : feats) {
+    const int64_t ld = nhwc_ld(f, "feat");
+    TORCH_CHECK(f.size(0) == 1, "prv2::roi_gather_pyramid: one coarse pyramid per frame (batch 1, patchrefinerplus.py:477)");
+    Tensor y = alloc_nhwc(f, boxes.size(0), f.size(1), f.size(2), f.size(3));
+    Launch L(f);
+    ok(prv2_roi_align(f.data_ptr<float>(), (int)f.size(1), (int)f.size(2), (int)f.size(3), (int)ld, boxes.data_ptr<float>(), (int)boxes.size(0),
+                      (float)((double)f.size(1) / (double)ph), (int)f.size(1), (int)f.size(2), y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream),
+       "roi_gather_pyramid");
+    outs.push_back(y);
+  }
+  return outs;
+}
+
+// F.interpolate(mode='bilinear', align_corners=True) on NHWC
+Tensor upsample_bilinear_ac(const Tensor& x, int64_t oh, int64_t ow, const optional<Tensor>& out) {
+  const int64_t ld = nhwc_ld(x, "x");
+  Tensor y = out_or_alloc(out, x, x.size(0), oh, ow, x.size(3), "upsample_bilinear_ac");
+  Launch L(x);
+  ok(prv2_upsample_bilinear(x.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)ld, (int)oh, (int)ow, y.data_ptr<float>(),
+                            (int)nhwc_ld(y, "out"), L.stream), "upsample_bilinear_ac");
+  return y;
+}
+
+// RunningAverageMap on the device (estimator/models/utils.py:22-49): init = paste of the first pass, update = weighted
+// running mean in tile order, resize = avg nearest / count bilinear(align_corners)
+void blend_args(const Tensor& avg, const Tensor& cnt, const Tensor& pred, const Tensor& mask, const Tensor& tiles, int64_t th, int64_t tw) {
+  dev_f32(avg, "avg"); dev_f32(cnt, "cnt"); dev_f32(pred, "pred"); dev_f32(mask, "mask");
+  TORCH_CHECK(avg.dim() == 2 && avg.is_contiguous() && cnt.sizes() == avg.sizes() && cnt.is_contiguous(), "prv2::blend: avg / cnt must be contiguous [H, W] maps");
+  TORCH_CHECK(pred.is_contiguous() && pred.dim() >= 3, "prv2::blend: pred must be contiguous [k, (1,) ph, pw]");
+  TORCH_CHECK(tiles.is_cuda() && tiles.scalar_type() == at::kInt && tiles.is_contiguous() && tiles.dim() == 2 && tiles.size(1) == 2 && tiles.size(0) == pred.size(0),
+              "prv2::blend: tiles must be an int32 GPU tensor [k, 2], one row per prediction");
+  TORCH_CHECK(mask.is_contiguous() && mask.dim() == 2 && mask.size(0) == th && mask.size(1) == tw, "prv2::blend: mask must be [th, tw]");
+}
+void blend_init(Tensor avg, Tensor cnt, const Tensor& pred, const Tensor& mask, const Tensor& tiles, int64_t th, int64_t tw) {
+  blend_args(avg, cnt, pred, mask, tiles, th, tw);
+  Launch L(avg);
+  ok(prv2_blend_paste(avg.data_ptr<float>(), cnt.data_ptr<float>(), (int)avg.size(0), (int)avg.size(1), pred.data_ptr<float>(), (int)pred.size(-2), (int)pred.size(-1),
+                      mask.data_ptr<float>(), tiles.data_ptr<int32_t>(), (int)tiles.size(0), (int)th, (int)tw, L.stream), "blend_init");
+}
+void blend_update(Tensor avg, Tensor cnt, const Tensor& pred, const Tensor& mask, const Tensor& tiles, int64_t th, int64_t tw) {
+  blend_args(avg, cnt, pred, mask, tiles, th, tw);
+  Launch L(avg);
+  ok(prv2_blend_update(avg.data_ptr<float>(), cnt.data_ptr<float>(), (int)avg.size(0), (int)avg.size(1), pred.data_ptr<float>(), (int)pred.size(-2), (int)pred.size(-1),
+                       mask.data_ptr<float>(), tiles.data_ptr<int32_t>(), (int)tiles.size(0), (int)th, (int)tw, L.stream), "blend_update");
+}
+std::tuple<Tensor, Tensor> blend_resize(const Tensor& avg, const Tensor& cnt, int64_t oh, int64_t ow) {
+  dev_f32(avg, "avg"); dev_f32(cnt, "cnt");
+  TORCH_CHECK(avg.dim() == 2 && avg.is_contiguous() && cnt.sizes() == avg.sizes() && cnt.is_contiguous(), "prv2::blend_resize: avg / cnt must be contiguous [H, W] maps");
+  Tensor a = at::empty({oh, ow}, avg.options()), c = at::empty({oh, ow}, avg.options());
+  Launch L(avg);
+  ok(prv2_blend_resize(avg.data_ptr<float>(), cnt.data_ptr<float>(), (int)avg.size(0), (int)avg.size(1), a.data_ptr<float>(), c.data_ptr<float>(), (int)oh, (int)ow, L.stream),
+     "blend_resize");
+  return {a, c};
+}
+
+// ZoeDepth metric-bins head, elementwise parts (attractor.py:45-57,186-206; dist_layers.py:29-69,100-116; zoedepth_v1.py:219)
+Tensor zoe_attractor(const Tensor& attr, const Tensor& bins, double alpha) {
+  const int64_t lda = nhwc_ld(attr, "attr"), ldb = nhwc_ld(bins, "bins");
+  TORCH_CHECK(attr.size(0) == bins.size(0) && attr.size(1) == bins.size(1) && attr.size(2) == bins.size(2), "prv2::zoe_attractor: attr / bins maps differ in size");
+  Tensor y = alloc_nhwc(bins, bins.size(0), bins.size(1), bins.size(2), bins.size(3));
+  Launch L(bins);
+  ok(prv2_zoe_attractor(attr.data_ptr<float>(), (int)lda, (int)attr.size(3), bins.data_ptr<float>(), (int)ldb, (int)bins.size(3), (float)alpha,
+                        bins.size(0) * bins.size(1) * bins.size(2), y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream), "zoe_attractor");
+  return y;
+}
+Tensor zoe_bins_head(const Tensor& pt, const Tensor& centers, double min_temp, double max_temp) {
+  const int64_t ldp = nhwc_ld(pt, "pt"), ldc = nhwc_ld(centers, "centers");
+  TORCH_CHECK(pt.size(3) == 4 && pt.size(0) == centers.size(0) && pt.size(1) == centers.size(1) && pt.size(2) == centers.size(2),
+              "prv2::zoe_bins_head: pt must be [n, h, w, 4] over the same pixels as centers");
+  Tensor depth = at::empty({pt.size(0), 1, pt.size(1), pt.size(2)}, pt.options());
+  Launch L(pt);
+  ok(prv2_zoe_logbinom_depth(pt.data_ptr<float>(), (int)ldp, centers.data_ptr<float>(), (int)ldc, (int)centers.size(3), (float)min_temp, (float)max_temp,
+                             pt.size(0) * pt.size(1) * pt.size(2), depth.data_ptr<float>(), L.stream), "zoe_bins_head");
+  return depth;
+}
+
+// layout changes at the boundary (image_lr in, features out)
+Tensor nchw_to_nhwc(const Tensor& x) {
+  dev_f32(x, "x");
+  TORCH_CHECK(x.dim() == 4, "prv2::nchw_to_nhwc: x must be [n, c, h, w]");
+  Tensor xc = x.contiguous();
+  Tensor y = alloc_nhwc(x, x.size(0), x.size(2), x.size(3), x.size(1));
+  Launch L(x);
+  ok(prv2_nchw_to_nhwc(xc.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream), "nchw_to_nhwc");
+  return y;
+}
+Tensor nhwc_to_nchw(const Tensor& x) {
+  const int64_t ld = nhwc_ld(x, "x");
+  Tensor y = at::empty({x.size(0), x.size(3), x.size(1), x.size(2)}, x.options());
+  Launch L(x);
+  ok(prv2_nhwc_to_nchw(x.data_ptr<float>(), (int)x.size(0), (int)x.size(3), (int)x.size(1), (int)x.size(2), (int)ld, y.data_ptr<float>(), L.stream), "nhwc_to_nchw");
+  return y;
+}
+
+int64_t abi_version() { return prv2_abi_version(); }
+
+}  // namespace
+
+TORCH_LIBRARY(prv2, m) {
+  m.def("abi_version() -> int", &abi_version);
+  m.def("pack_conv_weight(Tensor weight, Tensor? bn_scale=None, int convt_k=0, int prec=0) -> Tensor");
+  m.def("conv2d(Tensor x, Tensor w_packed, Tensor? bias, int cout, int kh, int kw, int stride=1, int pad=0, int act=0, bool relu_in=False, "
+        "Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? gamma=None, Tensor? mul=None, Tensor? res=None, Tensor? res2=None, int convt_k=0, "
+        "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None) -> Tensor");
+  m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0) -> Tensor");
+  m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0) -> Tensor");
+  m.def("crop_resize_bilinear(Tensor img_chw, Tensor tiles, int ch, int cw, int oh, int ow, float[]? mean=None, float[]? std=None, "
+        "Tensor(a!)? out=None) -> Tensor");
+  m.def("roi_gather_pyramid(Tensor[] feats, Tensor boxes, int ph) -> Tensor[]");
+  m.def("upsample_bilinear_ac(Tensor x, int oh, int ow, Tensor(a!)? out=None) -> Tensor");
+  m.def("blend_init(Tensor(a!) avg, Tensor(b!) cnt, Tensor pred, Tensor mask, Tensor tiles, int th, int tw) -> ()");
+  m.def("blend_update(Tensor(a!) avg, Tensor(b!) cnt, Tensor pred, Tensor mask, Tensor tiles, int th, int tw) -> ()");
+  m.def("blend_resize(Tensor avg, Tensor cnt, int oh, int ow) -> (Tensor, Tensor)");
+  m.def("zoe_attractor(Tensor attr, Tensor bins, float alpha=300.0) -> Tensor");
+  m.def("zoe_bins_head(Tensor pt, Tensor centers, float min_temp, float max_temp) -> Tensor");
+  m.def("nchw_to_nhwc(Tensor x) -> Tensor");
+  m.def("nhwc_to_nchw(Tensor x) -> Tensor");
+}
+
+// every op takes GPU tensors: registered for the CUDA dispatch key (= HIP on PyTorch-ROCm).  Calling one with CPU tensors
+// fails in the dispatcher ("no kernel for CPU backend"): there is no CPU fallback to fall into.
+TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
+  m.impl("pack_conv_weight", &pack_conv_weight);
+  m.impl("conv2d", &conv2d);
+  m.impl("layernorm", &layernorm);
+  m.impl("attention_fwd", &attention_fwd);
+  m.impl("crop_resize_bilinear", &crop_resize_bilinear);
+  m.impl("roi_gather_pyramid", &roi_gather_pyramid);
+  m.impl("upsample_bilinear_ac", &upsample_bilinear_ac);
+  m.impl("blend_init", &blend_init);
+  m.impl("blend_update", &blend_update);
+  m.impl("blend_resize", &blend_resize);
+  m.impl("zoe_attractor", &zoe_attractor);
+  m.impl("zoe_bins_head", &zoe_bins_head);
+  m.impl("nchw_to_nhwc", &nchw_to_nhwc);
+  m.impl("nhwc_to_nchw", &nhwc_to_nchw);
+}

@@ -1,0 +1,173 @@
+"""torch.ops.prv2.* -- the PyTorch-ROCm custom-op surface (TORCH_LIBRARY(prv2), patchrefinerv2_amd/csrc/torch_ops.cpp).
+CPU: the library loads, every op of the SURVEY.md 8(b) minimum set is registered with its schema, CPU tensors are rejected.
+GPU: each op through torch.ops against the oracle (same tolerances as the C-ABI tests)."""
+import pytest
+import torch
+
+from oracle import ops as o_ops
+from oracle.cases import rand_image, randn
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def T():
+    from patchrefinerv2_amd import torch_ops
+    return torch_ops.load(), torch_ops
+
+
+def test_library_loads_and_registers_every_op(T):
+    ops, mod = T
+    assert ops.abi_version() == mod.ABI_VERSION
+    for name in mod.OPS:
+        assert hasattr(ops, name), name
+        getattr(ops, name).default._schema  # registered with a schema
+    s = str(ops.conv2d.default._schema)
+    for frag in ("Tensor x", "Tensor w_packed", "Tensor? ln_weight", "Tensor? mul", "int prec", "Tensor(a!)? out"):
+        assert frag in s, (frag, s)
+
+
+def test_cpu_tensors_are_rejected(T):
+    ops, _ = T
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.upsample_bilinear_ac(torch.zeros(1, 4, 4, 8), 8, 8)
+
+
+gpu = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def _close(got, ref, tol=2e-5):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+
+
+@gpu
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv2d_fused_epilogue_and_slices(T, prec):
+    """3x3 conv + bias + channels-first LayerNorm + GELU written into a channel slice of a wider buffer (an in-place torch.cat),
+    then a 1x1 gate: out * sigmoid(conv1x1(.)) + residual -- the GatedConvUnit pattern (bi_directional_fusion_model.py:56-82)"""
+    import torch.nn.functional as F
+    ops, mod = T
+    x = randn(1, 2, 34, 20, 40)
+    w, b = randn(2, 64, 34, 3, 3) / 17.0, randn(3, 64) * 0.1
+    lw, lb = 1 + 0.1 * randn(4, 64), 0.1 * randn(5, 64)
+    xd = _nhwc(x)
+    cat = torch.zeros(2, 20, 40, 96, device=DEV)
+    wp = ops.pack_conv_weight(w.to(DEV), None, 0, prec)
+    y = ops.conv2d(xd, wp, b.to(DEV), 64, 3, 3, pad=1, act=mod.ACT_GELU, ln_weight=lw.to(DEV), ln_bias=lb.to(DEV), prec=prec,
+                   out=cat[..., 32:])
+    assert y.data_ptr() == cat[..., 32:].data_ptr()
+    c = F.conv2d(x, w, b, padding=1)
+    u = c.mean(1, keepdim=True)
+    s = (c - u).pow(2).mean(1, keepdim=True)
+    ref = F.gelu(lw.view(1, -1, 1, 1) * ((c - u) / torch.sqrt(s + 1e-6)) + lb.view(1, -1, 1, 1))
+    _close(_nchw(cat[..., 32:]), ref, 3e-5)
+    assert float(cat[..., :32].abs().max()) == 0.0  # the neighbouring slice is untouched
+    w1 = randn(6, 64, 64, 1, 1) / 8.0
+    g = ops.conv2d(y, ops.pack_conv_weight(w1.to(DEV), None, 0, prec), None, 64, 1, 1, act=mod.ACT_SIGMOID, mul=y, res=y, prec=prec)
+    _close(_nchw(g), ref * torch.sigmoid(F.conv2d(ref, w1)) + ref, 5e-5)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(xd, wp, b.to(DEV), 32, 3, 3, pad=1, prec=prec)  # cout does not match the packed weight: TORCH_CHECK
+
+
+@gpu
+def test_conv_transpose_and_linear(T):
+    import torch.nn.functional as F
+    ops, _ = T
+    x = randn(7, 1, 48, 9, 11)
+    w, b = randn(8, 48, 24, 2, 2) / 7.0, randn(9, 24) * 0.1
+    y = ops.conv2d(_nhwc(x), ops.pack_conv_weight(w.to(DEV), None, 2, 0), b.to(DEV), 24, 1, 1, convt_k=2)
+    _close(_nchw(y), F.conv_transpose2d(x, w, b, stride=2))
+    rows, wl = randn(10, 300, 96), randn(11, 160, 96) / 10.0
+    z = ops.conv2d(rows.to(DEV).view(1, 300, 1, 96), ops.pack_conv_weight(wl.to(DEV)), None, 160, 1, 1)
+    _close(z.view(300, 160), rows @ wl.t())
+
+
+@gpu
+def test_layernorm_and_attention(T):
+    import torch.nn.functional as F
+    ops, mod = T
+    x, w, b = randn(12, 77, 384), 1 + 0.1 * randn(13, 384), 0.1 * randn(14, 384)
+    _close(ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, mod.ACT_NONE), F.layer_norm(x, (384,), w, b, 1e-6), 1e-5)
+    B, N, H = 2, 197, 6
+    qkv = randn(15, B * N, 3 * H * 64)
+    q, k, v = qkv.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((q * 64 ** -0.5) @ k.transpose(-2, -1), dim=-1) @ v).transpose(1, 2).reshape(B * N, H * 64)
+    for prec, tol in ((0, 2e-5), (1, 2e-4)):
+        _close(ops.attention_fwd(qkv.to(DEV), B, N, H, prec), ref, tol)
+
+
+@gpu
+def test_crop_resize_roi_pyramid_upsample(T):
+    ops, _ = T
+    img = rand_image(16, 1, 108, 192)[0]
+    tiles = torch.tensor([[0, 0], [27, 48], [54, 96]], dtype=torch.int32)
+    out = ops.crop_resize_bilinear(img.to(DEV), tiles.to(DEV), 54, 96, 56, 84, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    for i, (h, w) in enumerate(tiles.tolist()):
+        ref = (o_ops.resize_da(img[None, :, h:h + 54, w:w + 96], 84, 56, 14) - mean) / std
+        _close(_nchw(out[i:i + 1]), ref, 2e-6)
+    feats = [randn(17 + i, 1, c, h, w) for i, (c, h, w) in enumerate(((32, 56, 84), (256, 28, 42), (256, 4, 6)))]
+    boxes = torch.tensor([[0.0, 0.0, 42.0, 28.0], [21.0, 14.0, 63.0, 42.0]])
+    outs = ops.roi_gather_pyramid([_nhwc(f) for f in feats], boxes.to(DEV), 56)
+    for f, o in zip(feats, outs):
+        bf = torch.cat([torch.arange(2.0).view(2, 1), boxes], dim=1)
+        ref = o_ops.roi_align(f.repeat(2, 1, 1, 1), bf, f.shape[-2:], f.shape[-2] / 56, aligned=True)
+        _close(_nchw(o), ref, 2e-6)
+    x = randn(20, 2, 24, 12, 16)
+    _close(_nchw(ops.upsample_bilinear_ac(_nhwc(x), 24, 32)), o_ops.bilinear_ac(x, (24, 32)), 2e-6)
+
+
+@gpu
+def test_blend_ops_sequence(T):
+    """blend_init / blend_update / blend_resize == RunningAverageMap (estimator/models/utils.py:22-49), bit for bit"""
+    from oracle.tiling import RunningAverageMap
+    ops, _ = T
+    g = torch.Generator().manual_seed(21)
+    ph, pw, H, Wd = 12, 16, 24, 32
+    mask = torch.rand(ph, pw, generator=g)
+    mask[:2] = 0
+    preds = torch.rand(5, ph, pw, generator=g) * 10
+    avg, cnt = torch.zeros(H, Wd, device=DEV), torch.zeros(H, Wd, device=DEV)
+    t0 = torch.tensor([[0, 0], [0, 16], [12, 0], [12, 16]], dtype=torch.int32)
+    ops.blend_init(avg, cnt, preds[:4].to(DEV), mask.to(DEV), t0.to(DEV), ph, pw)
+    pd, ct = torch.zeros(H, Wd), torch.zeros(H, Wd)
+    for i, (h, w) in enumerate(t0.tolist()):
+        pd[h:h + ph, w:w + pw], ct[h:h + ph, w:w + pw] = preds[i], mask
+    ram = RunningAverageMap(pd, ct)
+    ops.blend_update(avg, cnt, preds[4:].to(DEV), mask.to(DEV), torch.tensor([[6, 8]], dtype=torch.int32).to(DEV), ph, pw)
+    pd, ct = torch.zeros(H, Wd), torch.zeros(H, Wd)
+    pd[6:18, 8:24], ct[6:18, 8:24] = preds[4], mask
+    ram.update(pd, ct)
+    assert torch.equal(avg.cpu(), ram.average_map) and torch.equal(cnt.cpu(), ram.count_map)
+    a2, c2 = ops.blend_resize(avg, cnt, 36, 48)
+    ram.resize((36, 48))
+    assert torch.equal(a2.cpu(), ram.average_map)
+    _close(c2, ram.count_map, 2e-6)
+
+
+@gpu
+def test_zoe_head_ops_and_layout(T):
+    ops, _ = T
+    x = randn(22, 2, 20, 6, 8)
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.to(DEV))).cpu(), x)
+    attr, bins = torch.rand(1, 6, 8, 16, generator=torch.Generator().manual_seed(23)) * 5, torch.rand(1, 6, 8, 64, generator=torch.Generator().manual_seed(24)) * 5
+    out = ops.zoe_attractor(attr.to(DEV), bins.to(DEV), 300.0)
+    dx = attr.unsqueeze(-1) - bins.unsqueeze(-2)
+    _close(out, bins + (dx / (1 + 300.0 * dx ** 2)).mean(dim=-2), 1e-5)
+    pt = torch.rand(1, 6, 8, 4, generator=torch.Generator().manual_seed(25)) + 0.1
+    d = ops.zoe_bins_head(pt.to(DEV), bins.to(DEV), 0.0212, 50.0)
+    assert tuple(d.shape) == (1, 1, 6, 8) and bool(torch.isfinite(d).all())
+    assert float(d.min()) >= float(bins.min()) - 1e-4 and float(d.max()) <= float(bins.max()) + 1e-4  # an expectation over the bins
