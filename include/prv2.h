@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 3
+#define PRV2_ABI_VERSION 4
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -38,6 +38,11 @@ enum prv2_prec {
 
 int prv2_abi_version(void);
 const char* prv2_last_error(void);
+/* Name of the device kernel the calling thread's last successful prv2_conv2d dispatched to, as "name<BN,prec>"
+ * (e.g. "conv3x3_halo16_kernel<128,bf16x3>", "gemm16_kernel<64,bf16x3>"): what bench.py's roofline attributes time to.
+ * Which kernel runs a layer depends on the layer's shape PER IMAGE, never on the batch size (so results do not depend on
+ * how tiles are batched).  When a call issues two kernels (f32 mode: 3x3 tiles + remainder strip) it names the last. */
+const char* prv2_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer with fused epilogue.

@@ -10,6 +10,7 @@
 namespace prv2 {
 
 void set_error(const char* fmt, ...);
+void set_kernel(const char* name, int bn, int prec);  // what prv2_last_kernel() reports
 
 #define PRV2_REQUIRE(cond, ...)       \
   do {                                \

@@ -314,6 +314,7 @@ void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t s) {
   const int tiles = p.N * ((p.H + TH - 1) / TH) * p.tiles_x;
 #define PRV2_LAUNCH_HALO(BN_, PREC_) \
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN_, PREC_>), dim3(tiles * p.tiles_n), dim3(512), 0, s, p)
+  set_kernel("conv3x3_halo_kernel", p.Ncols > 64 ? 128 : (p.Ncols > 32 ? 64 : 32), prec);
   if (p.Ncols > 64) {
     p.tiles_n = (int)cdiv(p.Ncols, 128);
     if (prec == PRV2_PREC_F32) PRV2_LAUNCH_HALO(128, PRV2_PREC_F32);

@@ -534,6 +534,7 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) * p.tiles_n : 0;
   const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x * p.tiles_n + p.strip_blocks;
   static const bool no_persist = getenv("PRV2_HALO_NO_PERSIST") != nullptr;  // A/B switch
+  set_kernel("conv3x3_halo16_kernel", p.Ncols > 64 ? 128 : (p.Ncols > 32 ? 64 : 32), prec);
   if (p.Ncols <= 32 && !p.w_tail && !no_persist) {
     const int tiles = blocks - p.strip_blocks, wgs = tiles < persist_workgroups() ? tiles : persist_workgroups();
     if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_halo16_persist_kernel<PRV2_PREC_BF16X3>), dim3(wgs + p.strip_blocks), dim3(512), 0, s, p);

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const 
 bool gemm16_supported(const IgemmParams& p, int prec) {
   return prec != PRV2_PREC_F32 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 &&
          p.x_bstride == (long long)p.H * p.W * p.ldx && p.y_bstride == (long long)p.OH * p.OW * p.ldy &&
-         256LL * p.ldx * 4 < (1LL << 31) && p.M >= 512 && p.Ncols > 64;
+         256LL * p.ldx * 4 < (1LL << 31) && (long long)p.OH * p.OW >= 512 && p.Ncols > 64;  // rows PER IMAGE: never the batch
 }
 
 void launch_gemm16(IgemmParams& p, int prec, hipStream_t s) {
@@ -340,6 +340,7 @@ void launch_gemm16(IgemmParams& p, int prec, hipStream_t s) {
   p.tiles_n = (int)cdiv(p.Ncols, narrow ? 64 : 128);
   const int tiles_m = (int)cdiv(p.M, big ? 256 : 128);
   const dim3 grid(tiles_m * p.tiles_n);
+  set_kernel("gemm16_kernel", narrow ? 64 : (big ? 256 : 128), prec);
   if (narrow) {
     if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16X3, 4, 64>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm16_kernel<PRV2_PREC_BF16, 4, 64>), grid, dim3(256), 0, s, p);

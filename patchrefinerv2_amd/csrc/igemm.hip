@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) conv1x1_small_kernel(const IgemmParams p,
 static bool conv1x1_small_supported(const IgemmParams& p) {
   return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 && p.Cin <= 64 && p.Cout <= 64 &&
          p.Cout >= 8 && !p.ln_w && p.x_bstride == (long long)p.H * p.W * p.ldx &&
-         p.y_bstride == (long long)p.OH * p.OW * p.ldy && p.M >= 4096;
+         p.y_bstride == (long long)p.OH * p.OW * p.ldy && (long long)p.OH * p.OW >= 4096;  // per image: the choice (fp32 VALU vs MFMA) must not depend on the batch
 }
 
 
@@ -458,6 +458,7 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;
     hipLaunchKernelGGL(conv1x1_small_kernel, dim3(flat_grid(p.M * ng, 256)), dim3(256), 0, s, p, (int)d->prec);
+    set_kernel("conv1x1_small_kernel", 64, d->prec);
     PRV2_LAUNCH_CHECK("conv2d(1x1 small)");
     return 0;
   }
@@ -473,11 +474,13 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   const bool narrow = p.Ncols > 64 && !p.ln_w && (long long)p.tiles_m * cdiv(p.Ncols, 128) <= 128;
   if (p.Ncols > 64 && !narrow) {
     p.tiles_n = (int)cdiv(p.Ncols, 128);
+    set_kernel("igemm_kernel", 128, d->prec);
     if (d->prec == PRV2_PREC_F32) PRV2_LAUNCH_IGEMM(128, PRV2_PREC_F32);
     else if (d->prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_IGEMM(128, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_IGEMM(128, PRV2_PREC_BF16);
   } else {
     p.tiles_n = (int)cdiv(p.Ncols, 64);
+    set_kernel("igemm_kernel", 64, d->prec);
     if (d->prec == PRV2_PREC_F32) PRV2_LAUNCH_IGEMM(64, PRV2_PREC_F32);
     else if (d->prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_IGEMM(64, PRV2_PREC_BF16X3);
     else PRV2_LAUNCH_IGEMM(64, PRV2_PREC_BF16);

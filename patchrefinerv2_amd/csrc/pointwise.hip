@@ -15,6 +15,13 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// the kernel the calling thread's last prv2_conv2d dispatched to (prv2_last_kernel): "name<BN,prec>"
+static thread_local char g_kernel[96] = "";
+void set_kernel(const char* name, int bn, int prec) {
+  static const char* const pn[3] = {"f32", "bf16x3", "bf16"};
+  snprintf(g_kernel, sizeof(g_kernel), "%s<%d,%s>", name, bn, prec >= 0 && prec < 3 ? pn[prec] : "?");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -473,6 +480,7 @@ using namespace prv2;
 
 extern "C" int prv2_abi_version(void) { return PRV2_ABI_VERSION; }
 extern "C" const char* prv2_last_error(void) { return prv2::g_err; }
+extern "C" const char* prv2_last_kernel(void) { return prv2::g_kernel; }
 
 extern "C" int prv2_layernorm(const float* x, int64_t rows, int32_t c, int32_t ldx, const float* weight,
                               const float* bias, float eps, int32_t act, float* y, int32_t ldy, void* stream) {

@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(C.Structure):
@@ -39,6 +39,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "prv2_abi_version": (_I, []),
     "prv2_last_error": (C.c_char_p, []),
+    "prv2_last_kernel": (C.c_char_p, []),
     "prv2_packed_weight_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "prv2_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

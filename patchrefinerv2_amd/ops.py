@@ -37,19 +37,22 @@ class Profiler:
         return self.records
 
     def launch(self, tag, flops, fn, shape=None):
+        """``tag``: a string, or a callable evaluated AFTER the launch (the library reports which kernel it dispatched)"""
         if not self.enabled:
             return fn()
-        if self.by_shape and shape is not None:
-            tag = f"{tag} {shape}"
+        e0 = e1 = None
         if self.timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn()
             e1.record()
-            self.records.append((tag, flops, e0, e1))
         else:
             fn()
-            self.records.append((tag, flops, None, None))
+        if callable(tag):
+            tag = tag()
+        if self.by_shape and shape is not None:
+            tag = f"{tag} {shape}"
+        self.records.append((tag, flops, e0, e1))
 
     def launch_aux(self, tag, nbytes, fn, shape):
         """memory-bound kernels: only itemised in the per-layer report (by_shape); bytes go into the tag"""
@@ -228,23 +231,14 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     taps = 1 if cw.convt_k else cw.kh * cw.kw
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
     halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and (cw.pad == 1 or cw.same_pad) and not cw.convt_k and x.w >= 24 and x.h >= 4
-            and not force_generic)  # mirrors conv3x3_halo_supported() in csrc/conv3x3.hip
-    # bf16 modes of the halo conv run on the 16x16x32 MFMA kernel (csrc/conv3x3_m16.hip), f32 on csrc/conv3x3.hip
-    kname = ("conv3x3_halo_kernel" if cw.prec == PREC_F32 else "conv3x3_halo16_kernel") if halo else "igemm_kernel"
-    bn = 128 if ncols > 64 else (32 if (halo and ncols <= 32) else 64)
-    if (cw.kh == 1 and cw.kw == 1 and cw.stride == 1 and cw.pad == 0 and not cw.convt_k and cw.prec != PREC_F32
-            and m_rows >= 512 and ncols > 64 and not x_bstride and not force_generic):
-        kname = "gemm16_kernel"  # mirrors gemm16_supported() in csrc/gemm_m16.hip (dense 1x1 / linear)
-    if (cw.kh == 1 and cw.kw == 1 and cw.stride == 1 and cw.pad == 0 and not cw.convt_k and cw.cin <= 64 and 8 <= cw.cout <= 64
-            and ln is None and m_rows >= 4096 and not x_bstride and not force_generic):
-        kname, bn = "conv1x1_small_kernel", 64  # mirrors conv1x1_small_supported() in csrc/igemm.hip (fp32 VALU)
+            and not force_generic)  # only for the f32-mode strip split below; kernel names come from prv2_last_kernel()
     def call():
         L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
                                      _ptr(ln[1]) if ln is not None else None, _ptr(gamma), _ptr(mul), _ptr(res), _ptr(res2),
                                      out.ptr, _stream()), "conv2d")
 
     shape = f"{cw.cin}->{cw.cout} k{cw.kh}s{cw.stride}{'T' if cw.convt_k else ''} {x.n}x{x.h}x{x.w}"
-    tag = f"{kname}<{bn},{L.PREC_LABEL[cw.prec]}>"
+    tag = lambda: L.load().prv2_last_kernel().decode()  # noqa: E731  (the kernel the library dispatched this call to)
     rem = x.w % 32
     if halo and PROFILER.enabled and 0 < rem <= 8 and x.w >= 64 and cw.prec == PREC_F32:
         # f32 mode: the library runs this conv as 32-pixel tiles + a remainder strip on the generic kernel (csrc/igemm.hip;
@@ -253,8 +247,7 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
         d.part = 1
         PROFILER.launch(tag, full * (x.w - rem) / x.w, call, shape=shape)
         d.part = 2
-        PROFILER.launch(f"igemm_kernel<{128 if ncols > 64 else 64},{L.PREC_LABEL[cw.prec]}>", full * rem / x.w, call,
-                        shape=shape + f" strip{rem}")
+        PROFILER.launch(tag, full * rem / x.w, call, shape=shape + f" strip{rem}")
         return out
     PROFILER.launch(tag, 2.0 * m_rows * ncols * cw.cin * taps, call, shape=shape)
     return out
