@@ -75,8 +75,14 @@ def cpu_baseline(name, sd, frame_seed):
     if w.get("zoe"):
         from oracle import dav2 as o_dav2, zoe as o_zoe
         zc = W.zoedepth_cfg(w["zoe"])
-        m = o_tiling.OraclePatchRefinerPlus(
-            sd_cpu, None, coarse_fn=lambda lr: o_dav2.coarse_features(o_zoe.zoedepth_forward(sd_cpu, "coarse_branch.", lr, zc)), **kw)
+        kw["resizer"] = "zoe" if w.get("zoe_type") == "ZoeDepth" else "da"
+        if w["kind"] == "PatchRefinerPlus":
+            m = o_tiling.OraclePatchRefinerPlus(
+                sd_cpu, None, coarse_fn=lambda lr: o_dav2.coarse_features(o_zoe.zoedepth_forward(sd_cpu, "coarse_branch.", lr, zc)), **kw)
+        else:
+            fz = W.zoedepth_cfg(w["fine_zoe"])
+            m = o_tiling.OraclePatchRefiner(sd_cpu, None, None, coarse_fn=lambda lr: o_zoe.zoedepth_forward(sd_cpu, "coarse_branch.", lr, zc),
+                                            fine_fn=lambda x: o_zoe.zoedepth_forward(sd_cpu, "refiner_fine_branch.", x, fz), **kw)
     elif w["kind"] == "PatchRefinerPlus":
         m = o_tiling.OraclePatchRefinerPlus(sd_cpu, ccfg, **kw)
     else:
@@ -218,7 +224,7 @@ def main():
         vs_baseline=None, dtype=args.prec, data="synthetic",
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
-                    coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else "DA-ZoeDepth/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
+                    coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else w.get("zoe_type", "DA-ZoeDepth") + "/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
                     max_batch=args.max_batch, streams=args.streams, out_shape=list(out.shape) if out is not None else None))
 
     if world > 1:

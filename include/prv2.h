@@ -156,6 +156,12 @@ int prv2_assemble_tokens(const float* emb, const float* cls, const float* pos, i
  * Linear (attention.py:49-62).  hd must be 64.  out rows are [heads][hd]. */
 int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out, int32_t prec,
                    void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with an additive score bias shared by the batch: softmax((q*scale) k^T + bias[head]) v -- the relative position
+ * bias of the MiDaS BEiT blocks (torch.hub MiDaS midas/backbones/beit.py attention_forward; called by
+ * external/zoedepth/models/base_models/midas.py:267).  bias: [heads][ntok][ld_bias] fp32, ld_bias >= roundup(ntok, 64),
+ * a multiple of 4, rows 16-byte aligned (pad keys are never read past ntok's 64-key tile and are masked).  bias == NULL: no bias. */
+int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias,
+                        float* out, int32_t prec, void* workspace, int64_t workspace_bytes, void* stream);
 /* device scratch the split-bf16 attention needs (pre-split q/k rows + transposed v planes); 0 for PRV2_PREC_F32.
  * The workspace must be 256-byte aligned; its contents are dead when the call returns (stream order). */
 int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32_t heads, int32_t prec);

@@ -266,3 +266,33 @@ def baseline_kwargs(target: str) -> dict:
 
 def baseline_sd(prefix: str = ""):
     return W.synth_state_dict(W.zoedepth_spec(prefix, BASELINE["zcfg"]), seed=BASELINE["sd_seed"])
+
+
+# -- ZoeDepth over the MiDaS DPT_BEiT_L_384 core (type='ZoeDepth'), reduced BEiT (dim 128, 4 blocks, 2 heads, 4 x 4 window),
+#    non-square inputs so that the relative-position table is resized (configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py:10-66)
+_BEIT_TINY = dict(dim=128, depth=4, heads=2, taps=[0, 1, 2, 3], window=[4, 4], features=256, out_channels=[32, 64, 128, 128])
+ZOE_BEIT = dict(
+    zcfg={**{k: v for k, v in ZOE_DA["zcfg"].items() if k != "midas_model_type"}, "midas_model_type": "DPT_BEiT_L_384",
+          "img_size": [64, 96], "beit": _BEIT_TINY},
+    seed=83, inputs=dict(rect=(64, 96), square=(64, 64), big=(96, 160)),
+)
+
+# -- end-to-end V2 exactly as configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py wires it: coarse_branch type='ZoeDepth'
+#    (MidasCore, BEiT), ResizeZoe (hard-coded 384 x 512, midas.py:171-174) => patch_process_shape 384 x 512; reduced BEiT
+_ZOE_B = {**ZOE_BEIT["zcfg"], "img_size": [384, 512]}
+E2E_V2B = dict(
+    raw=[540, 960], split=[2, 2], pps=[384, 512], max_depth=80.0, seed=0, modes=["m1", "r4"], zcfg=_ZOE_B,
+    fusion=E2E_V2Z["fusion"],
+)
+E2E_V2B["ref_config"] = {**E2E_V2Z["ref_config"], "image_raw_shape": E2E_V2B["raw"], "patch_process_shape": E2E_V2B["pps"],
+                         "patch_raw_shape": [270, 480], "coarse_branch": dict(type="ZoeDepth", **_ZOE_B)}
+
+
+def e2e_v2b_sd(seed: int = 89):
+    spec = OrderedDict()
+    spec.update(W.zoedepth_spec("coarse_branch.", _ZOE_B))
+    spec.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4))
+    f = E2E_V2B["fusion"]
+    spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
+                                    f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
+    return W.synth_state_dict(spec, seed=seed)

@@ -372,7 +372,7 @@ def g_e2e_v1():
     save("e2e_v1", **res)
 
 
-def _g_e2e_v2(tag, c, sd, zoe=False):
+def _g_e2e_v2(tag, c, sd, zoe=False, post_build=None, unmapped_prefix=None, golden_stride=1):
     print(f"[{tag}]")
     import timm
 
@@ -410,16 +410,22 @@ def _g_e2e_v2(tag, c, sd, zoe=False):
         prp.DepthAnythingV2 = orig
     # load everything by name (the encoder's buffers go through Enc._load_from_state_dict)
     res_load = m.load_state_dict(dict(sd), strict=False)
-    assert not res_load.missing_keys, res_load.missing_keys[:5]
     ep = "refiner_fine_branch.refiner_encoder."
-    assert all(k.startswith(ep) for k in res_load.unexpected_keys)
+    if unmapped_prefix is None:
+        assert not res_load.missing_keys, res_load.missing_keys[:5]
+        assert all(k.startswith(ep) for k in res_load.unexpected_keys)
+    else:  # a sub-module that is a stand-in with other parameter names: filled by post_build
+        assert all(k.startswith(unmapped_prefix) for k in res_load.missing_keys), res_load.missing_keys[:5]
+        assert all(k.startswith(ep) or k.startswith(unmapped_prefix) for k in res_load.unexpected_keys)
+        post_build(m)
     m.refiner_fine_branch.refiner_encoder.sd = {k[len(ep):]: v for k, v in sd.items() if k.startswith(ep)}
     assert tuple(m.refiner_fine_branch.refiner_encoder.conv_stem.weight.shape) == (32, 4, 3, 3)
     if zoe:
         zc = W.zoedepth_cfg(c["zcfg"])
         ora = o_tiling.OraclePatchRefinerPlus(
             sd, None, coarse_fn=lambda lr: o_dav2.coarse_features(o_zoe.zoedepth_forward(sd, "coarse_branch.", lr, zc)),
-            patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+            patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"],
+            resizer="zoe" if c["ref_config"]["coarse_branch"]["type"] == "ZoeDepth" else "da")
     else:
         ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
                                               patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
@@ -436,7 +442,7 @@ def _g_e2e_v2(tag, c, sd, zoe=False):
         d = maxdiff(ref, out)
         print(f"  {mode}: out {tuple(ref.shape)} range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {d:.2e}")
         assert d < 2e-4, d
-        res[mode] = ref
+        res[mode] = ref[..., ::golden_stride, ::golden_stride]  # large frames: a regular sub-grid of the map is committed
     save(tag, **res)
 
 
@@ -614,6 +620,148 @@ def g_effnet():
         print(f"  feat {i}: {tuple(a.shape)} |x|max {float(a.abs().max()):.2f} oracle-vs-ref max|d| {d:.2e}")
         assert a.shape == b.shape and d < 1e-4 * max(1.0, float(a.abs().max())), d
     save("effnet_refiner", **{f"feat{i}": f for i, f in enumerate(feats[:5])})  # (feat5 = the 2x bilinear copy of feat4)
+
+
+class _MidasHF(torch.nn.Module):
+    """What ``torch.hub.load("AyaanShah2204/MiDaS", "DPT_BEiT_L_384")`` returns, as far as the reference touches it
+    (midas.py:260-318): a module whose forward gives the relative depth [B,H,W] and which exposes ``scratch.output_conv``
+    (children()[3] = the ReLU behind the 128->32 conv), ``scratch.refinenet1..4``, ``scratch.layer4_rn`` and ``pretrained``.
+    The arithmetic is HuggingFace transformers' independent port of MiDaS 3.1 DPT-BEiT (DPTForDepthEstimation over BeitBackbone)."""
+
+    def __init__(self, beit):
+        super().__init__()
+        from transformers import BeitConfig, DPTConfig, DPTForDepthEstimation
+        b = beit
+        bc = BeitConfig(image_size=[b["window"][0] * b["patch"], b["window"][1] * b["patch"]], patch_size=b["patch"], hidden_size=b["dim"],
+                        num_hidden_layers=b["depth"], num_attention_heads=b["heads"], intermediate_size=b["dim"] * b["mlp_ratio"],
+                        use_relative_position_bias=True, use_shared_relative_position_bias=False, use_absolute_position_embeddings=False,
+                        layer_scale_init_value=0.1, use_mask_token=False, reshape_hidden_states=False, layer_norm_eps=1e-6,
+                        out_features=[f"stage{t + 1}" for t in b["taps"]], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                        drop_path_rate=0.0)
+        dc = DPTConfig(backbone_config=bc, neck_hidden_sizes=list(b["out_channels"]), fusion_hidden_size=b["features"],
+                       reassemble_factors=[4, 2, 1, 0.5], readout_type="project", use_batch_norm_in_fusion_residual=False, add_projection=False,
+                       head_in_index=-1, hidden_act="gelu", hidden_size=b["dim"], use_bias_in_fusion_residual=True)
+        self.hf = DPTForDepthEstimation(dc)
+        self.pretrained = self.hf.backbone
+        self.scratch = torch.nn.Module()
+        self.scratch.output_conv = self.hf.head.head
+        for r in (1, 2, 3, 4):
+            setattr(self.scratch, f"refinenet{r}", self.hf.neck.fusion_stage.layers[4 - r])
+        self.scratch.layer4_rn = self.hf.neck.convs[3]
+
+    def forward(self, x):
+        return self.hf(pixel_values=x).predicted_depth
+
+    def load_midas(self, sd, prefix, beit):
+        """synthetic weights under the MiDaS / timm names (patchrefinerv2_amd/weights.py::midas_beit_spec) -> transformers' names"""
+        D = beit["dim"]
+        out = {}
+        for k, v in sd.items():
+            if not k.startswith(prefix):
+                continue
+            n = k[len(prefix):]
+            if n.startswith("pretrained.model."):
+                n = n[len("pretrained.model."):]
+                if n == "cls_token":
+                    out["backbone.beit.embeddings.cls_token"] = v
+                elif n.startswith("patch_embed.proj."):
+                    out["backbone.beit.embeddings.patch_embeddings.projection." + n.rsplit(".", 1)[1]] = v
+                else:
+                    _, i, rest = n.split(".", 2)
+                    L = f"backbone.beit.layers.{i}."
+                    m = {"gamma_1": "lambda_1", "gamma_2": "lambda_2", "attn.q_bias": "attention.q_proj.bias", "attn.v_bias": "attention.v_proj.bias",
+                         "attn.relative_position_bias_table": "relative_position_bias.relative_position_bias_table",
+                         "attn.proj.weight": "attention.o_proj.weight", "attn.proj.bias": "attention.o_proj.bias"}
+                    if rest == "attn.qkv.weight":
+                        out[L + "attention.q_proj.weight"], out[L + "attention.k_proj.weight"], out[L + "attention.v_proj.weight"] = v[:D], v[D:2 * D], v[2 * D:]
+                    elif rest in m:
+                        out[L + m[rest]] = v
+                    else:
+                        out[L + rest.replace("norm1.", "layernorm_before.").replace("norm2.", "layernorm_after.")] = v
+            elif n.startswith("pretrained.act_postprocess"):
+                i = int(n[len("pretrained.act_postprocess")]) - 1
+                rest = n.split(".", 2)[2]
+                R = "neck.reassemble_stage."
+                if rest.startswith("0.project.0."):
+                    out[f"{R}readout_projects.{i}.0." + rest.rsplit(".", 1)[1]] = v
+                elif rest.startswith("3."):
+                    out[f"{R}layers.{i}.projection." + rest[2:]] = v
+                else:
+                    out[f"{R}layers.{i}.resize." + rest[2:]] = v
+            elif n.startswith("scratch.layer"):
+                out[f"neck.convs.{int(n[len('scratch.layer')]) - 1}.weight"] = v
+            elif n.startswith("scratch.refinenet"):
+                r = int(n[len("scratch.refinenet")])
+                rest = n.split(".", 2)[2]
+                rest = rest.replace("out_conv.", "projection.").replace("resConfUnit", "residual_layer").replace(".conv", ".convolution")
+                out[f"neck.fusion_stage.layers.{4 - r}.{rest}"] = v
+            elif n.startswith("scratch.output_conv."):
+                out["head.head." + n[len("scratch.output_conv."):]] = v
+            else:
+                raise KeyError(k)
+        res = self.hf.load_state_dict(out, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys[:5]
+        assert not res.missing_keys, res.missing_keys[:8]
+
+
+def _install_midas_hub(beit_holder):
+    real = torch.hub.load
+    torch.hub.load = lambda repo, name, **kw: _MidasHF(beit_holder["beit"])
+    return real
+
+
+def g_midas_beit():
+    """type='ZoeDepth': the reference's own ZoeDepth + MidasCore classes (hooks, PrepForMidas, metric-bins head) over
+    transformers' DPT-BEiT behind the torch.hub stand-in, synthetic weights mapped by name: oracle/midas_beit.py == that."""
+    print("[midas_beit]")
+    from oracle.cases import ZOE_BEIT
+    c = ZOE_BEIT
+    z = W.zoedepth_cfg(c["zcfg"])
+    beit = z["core"]["beit"]
+    sd = W.synth_state_dict(W.zoedepth_spec("", c["zcfg"]), seed=c["seed"])
+    zmod = refharness.ref_module("external.zoedepth.models.zoedepth.zoedepth_v1")
+    real = _install_midas_hub(dict(beit=beit))
+    try:
+        m = zmod.ZoeDepth.build(**{k: v for k, v in c["zcfg"].items() if k != "beit"}).eval()
+    finally:
+        torch.hub.load = real
+    assert type(m.core).__name__ == "MidasCore" and m.core.output_channels == (256,) * 5
+    m.core.core.load_midas(sd, "core.core.", beit)
+    res_load = m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("core.core.")}, strict=False)
+    assert all(k.startswith("core.core.") for k in res_load.missing_keys) and not res_load.unexpected_keys
+    res = {}
+    for tag, (h, w) in c["inputs"].items():
+        x = rand_image(c["seed"], 2, h, w)
+        ref = m(x, return_final_centers=True)
+        ora = o_zoe.zoedepth_forward(sd, "", x, z)
+        d = maxdiff(ref["metric_depth"], ora["metric_depth"])
+        print(f"  {tag}: depth range [{float(ref['metric_depth'].min()):.3f}, {float(ref['metric_depth'].max()):.3f}] oracle-vs-ref max|d| {d:.2e}")
+        assert d < 1e-4 * float(ref["metric_depth"].max()), d
+        for k in ("x_d0", "x_blocks_feat_0", "x_blocks_feat_1", "x_blocks_feat_2", "x_blocks_feat_3", "midas_final_feat"):
+            dd = maxdiff(ref["temp_features"][k], ora["temp_features"][k])
+            assert dd < 1e-4 * max(1.0, float(ref["temp_features"][k].abs().max())), (k, dd)
+        res[f"{tag}_depth"] = ref["metric_depth"]
+        res[f"{tag}_x_d0"] = ref["temp_features"]["x_d0"]
+        res[f"{tag}_x_blocks_feat_3_mean"] = ref["temp_features"]["x_blocks_feat_3"].mean(dim=1)
+        res[f"{tag}_final_feat_mean"] = ref["temp_features"]["midas_final_feat"].mean(dim=1)
+    save("zoedepth_beit", **res)
+
+
+def g_e2e_v2b():
+    """PatchRefinerPlus as configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py wires it (coarse_branch type='ZoeDepth' -> MidasCore /
+    BEiT, ResizeZoe 384 x 512), reduced BEiT, the reference's own classes end to end."""
+    from oracle.cases import E2E_V2B, e2e_v2b_sd
+    c = E2E_V2B
+    sd = e2e_v2b_sd()
+    beit = W.zoedepth_cfg(c["zcfg"])["core"]["beit"]
+    real = _install_midas_hub(dict(beit=beit))
+    try:
+        cfg = dict(c)
+        cfg["ref_config"] = {**c["ref_config"], "coarse_branch": {k: v for k, v in c["ref_config"]["coarse_branch"].items() if k != "beit"}}
+        _g_e2e_v2("e2e_v2b", cfg, sd, zoe=True, unmapped_prefix="coarse_branch.core.core.",
+                  post_build=lambda m: m.coarse_branch.core.core.load_midas(sd, "coarse_branch.core.core.", beit), golden_stride=3)
+    finally:
+        torch.hub.load = real
 
 
 def g_baseline():

@@ -213,15 +213,21 @@ class OracleRefiner:
 class OraclePatchRefiner(OracleRefiner):
     """V1: DA2 coarse + DA2 per-patch + FusionUnet (configs/patchrefiner_dav2/pr_u4k.py)."""
 
-    def __init__(self, sd, coarse_cfg, fine_cfg, **kw):
+    def __init__(self, sd, coarse_cfg, fine_cfg, coarse_fn=None, fine_fn=None, **kw):
+        """coarse_fn / fine_fn: a backbone other than DA2 (ZoeDepth: configs/patchrefiner_zoedepth/pr_u4k.py), image -> the
+        backbone's output dict (metric_depth + temp_features)"""
         super().__init__(sd, **kw)
         self.coarse_cfg, self.fine_cfg = coarse_cfg, fine_cfg
+        self.coarse_fn, self.fine_fn = coarse_fn, fine_fn
 
     def coarse_forward(self, image_lr):
+        if self.coarse_fn is not None:
+            return dav2.coarse_features(self.coarse_fn(image_lr))
         return dav2.coarse_features(dav2.dav2_forward(self.sd, "coarse_branch.", image_lr, self.coarse_cfg))
 
     def infer_forward(self, imgs_crop, post):
         r_feats, r_depth = dav2.coarse_features(
+            self.fine_fn(imgs_crop) if self.fine_fn is not None else
             dav2.dav2_forward(self.sd, "refiner_fine_branch.", imgs_crop, self.fine_cfg))
         return fusion.fusion_unet(self.sd, "refiner_fusion_model.", post["coarse_feats_roi"][::-1], r_feats[::-1],
                                   post["coarse_depth_roi"], r_depth, update_base=post["coarse_depth_roi"])

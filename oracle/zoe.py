@@ -8,7 +8,7 @@ Projector                   external/zoedepth/models/layers/localbins_layers.py:
 AttractorLayerUnnormed      external/zoedepth/models/layers/attractor.py:139-208 (inv_attractor :45-57; the
                             call passes no alpha/gamma, so the defaults 300 / 2 always apply -- SURVEY Q7)
 ConditionalLogBinomial      external/zoedepth/models/layers/dist_layers.py:72-120 (log_binom :29-33, LogBinomial :36-69)
-The MiDaS DPT-BEiT-L core (torch.hub, un-vendored) is NOT restated.
+The MiDaS DPT-BEiT-L core (torch.hub, un-vendored) is restated in oracle/midas_beit.py.
 """
 from __future__ import annotations
 
@@ -103,7 +103,11 @@ def conditional_log_binomial(sd, p, x, cond, n_classes, min_temp, max_temp, p_ep
 
 def zoedepth_forward(sd, prefix, x, cfg):
     """ZoeDepth.forward (bin_centers_type='softplus', attractor_kind='mean', attractor_type='inv')."""
-    rel, out = da_v1_core(sd, prefix + "core.core.", x, cfg["core"])
+    if "beit" in cfg["core"]:  # type='ZoeDepth': MidasCore over MiDaS DPT_BEiT_L_384 (oracle/midas_beit.py)
+        from .midas_beit import midas_beit_core
+        rel, out = midas_beit_core(sd, prefix + "core.core.", x, cfg["core"])
+    else:
+        rel, out = da_v1_core(sd, prefix + "core.core.", x, cfg["core"])
     outconv, btlnck, blocks = out[0], out[1], out[2:]
     x_d0 = F.conv2d(btlnck, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])
     temp = dict(x_d0=x_d0)

@@ -30,8 +30,11 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
+// HAS_BIAS: scores += bias[head][q][key] before the softmax (BEiT relative position bias; rows of ldb floats)
+template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restrict__ qkv, int B, int N, int heads,
-                                                            float scale, float* __restrict__ out) {
+                                                            float scale, const float* __restrict__ bias, int ldb,
+                                                            float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float smem[(2 * AT_BK + 4 * 32) * AT_LD];
   float* Ks = smem;
   float* Vs = smem + AT_BK * AT_LD;
@@ -104,6 +107,12 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float s0 = kv0 ? s_acc[0][e] : -INFINITY, s1 = kv1 ? s_acc[1][e] : -INFINITY;
+      if (HAS_BIAS) {
+        const int qb = qt * AT_BQ + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const float* br = bias + ((long long)head * N + (qb < N ? qb : 0)) * ldb + k0 + r32;
+        if (kv0) s0 += br[0];
+        if (kv1) s1 += br[32];
+      }
       float mx = half_max(fmaxf(s0, s1));
       float m_new = fmaxf(m_run[e], mx);
       float corr = expf(m_run[e] - m_new);  // exp(-inf) = 0 on the first tile
@@ -154,23 +163,36 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
 
 using namespace prv2;
 
-int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, float* out, void* workspace,
-                            int64_t workspace_bytes, hipStream_t s);
+int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const float* bias, int ld_bias, float* out,
+                            void* workspace, int64_t workspace_bytes, hipStream_t s);
+
+extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias,
+                                   int32_t ld_bias, float* out, int32_t prec, void* workspace, int64_t workspace_bytes,
+                                   void* stream);
 
 extern "C" int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out,
                               int32_t prec, void* workspace, int64_t workspace_bytes, void* stream) {
+  return prv2_attention_bias(qkv, b, ntok, heads, hd, nullptr, 0, out, prec, workspace, workspace_bytes, stream);
+}
+
+extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias,
+                                   int32_t ld_bias, float* out, int32_t prec, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
   PRV2_REQUIRE(qkv && out, "attention: null pointer");
+  PRV2_REQUIRE(!bias || (ld_bias >= prv2::roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+               "attention: bias rows must be 16-byte aligned and padded to a multiple of 64 keys (ld_bias %d, ntok %d)", ld_bias, ntok);
   PRV2_REQUIRE(b > 0 && ntok > 0 && heads > 0 && hd == 64, "attention: head_dim must be 64 (got %d)", hd);
   PRV2_REQUIRE(prec >= PRV2_PREC_F32 && prec <= PRV2_PREC_BF16, "attention: unknown precision mode %d", prec);
   PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attention: qkv must be 16-byte aligned");
   if (prec != PRV2_PREC_F32) {  // bf16 mode also runs the bf16x3 kernel (attention is never the bottleneck there)
-    int rc = launch_attention_bf16x3(qkv, b, ntok, heads, out, workspace, workspace_bytes, (hipStream_t)stream);
+    int rc = launch_attention_bf16x3(qkv, b, ntok, heads, bias, ld_bias, out, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc) return rc;
     PRV2_LAUNCH_CHECK("attention(bf16x3)");
     return 0;
   }
   dim3 grid((unsigned)cdiv(ntok, AT_BQ), (unsigned)heads, (unsigned)b);
-  hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, b, ntok, heads, 0.125f, out);
+  if (bias) hipLaunchKernelGGL(attention_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, b, ntok, heads, 0.125f, bias, ld_bias, out);
+  else hipLaunchKernelGGL(attention_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, b, ntok, heads, 0.125f, bias, ld_bias, out);
   PRV2_LAUNCH_CHECK("attention");
   return 0;
 }
@@ -258,11 +280,13 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
+template <bool HAS_BIAS>
 __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
                                                                   const __bf16* __restrict__ Ks,
                                                                   const __bf16* __restrict__ VtH,
                                                                   const __bf16* __restrict__ VtL, int N, int Npad,
-                                                                  int heads, float* __restrict__ out) {
+                                                                  int heads, const float* __restrict__ bias, int ldb,
+                                                                  float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AB_VP];  // 34304 B; reused for the output strips
   char* const Kt = smem;
   char* const Vt = smem + 64 * AB_KP;
@@ -321,6 +345,17 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kr + 128);
         st[t] = mfma3(kh, kl, qh[ks], ql[ks], st[t]);
       }
+    if (HAS_BIAS) {
+      // + bias[head][this lane's query][key]: register e = 4g + i is key 8g + 4half + i -> one 16-byte load per g
+      const float* br = bias + ((long long)head * N + (q_row < N ? q_row : 0)) * ldb + k0 + 4 * half;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(br + t * 32 + 8 * g);
+          st[t][4 * g] += bv.x; st[t][4 * g + 1] += bv.y; st[t][4 * g + 2] += bv.z; st[t][4 * g + 3] += bv.w;
+        }
+    }
     // online softmax of this lane's query column (keys live in the registers of both lane halves)
     float mx = -INFINITY;
 #pragma unroll
@@ -403,8 +438,8 @@ extern "C" int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32
   return (int64_t)b * heads * (2 * (int64_t)ntok * 128 + 2 * 64 * npad) * 2 + 256;
 }
 
-int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, float* out, void* workspace,
-                            int64_t workspace_bytes, hipStream_t s) {
+int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const float* bias, int ld_bias, float* out,
+                            void* workspace, int64_t workspace_bytes, hipStream_t s) {
   using namespace prv2;
   const int64_t need = prv2_attention_workspace_bytes(b, ntok, heads, PRV2_PREC_BF16X3);
   PRV2_REQUIRE(workspace && workspace_bytes >= need, "attention: workspace too small (%lld < %lld bytes)",
@@ -418,6 +453,7 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, float*
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
   dim3 g2((unsigned)cdiv(ntok, AT_BQ), (unsigned)heads, (unsigned)b);
-  hipLaunchKernelGGL(attention_bf16x3_kernel, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, out);
+  if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<true>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out);
+  else hipLaunchKernelGGL(attention_bf16x3_kernel<false>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out);
   return 0;
 }

@@ -7,8 +7,8 @@
 // slice of a wider buffer (stride(-1) == 1, stride(-2) == ld), which is how a torch.cat is written in place.
 // Host-only translation unit: all device code lives behind the C ABI in libprv2_hip.so.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
 #include <vector>
@@ -20,10 +20,13 @@ namespace {
 using at::Tensor;
 using c10::optional;
 
-struct Launch {  // device guard + the stream torch considers current on that device
-  c10::hip::HIPGuard guard;
+// device guard + the stream torch considers current on that device.  PyTorch-ROCm presents HIP devices under the "cuda"
+// device type ("masquerading"): the guard is the generic one, the stream comes from the masquerading accessor.
+struct Launch {
+  c10::DeviceGuard guard;
   void* stream;
-  explicit Launch(const Tensor& t) : guard(t.device()), stream((void*)c10::hip::getCurrentHIPStream(t.device().index()).stream()) {}
+  explicit Launch(const Tensor& t)
+      : guard(t.device()), stream((void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream()) {}
 };
 
 void ok(int code, const char* what) { TORCH_CHECK(code == 0, "prv2::", what, " failed (code ", code, "): ", prv2_last_error()); }
@@ -132,14 +135,20 @@ Tensor layernorm(const Tensor& x, const Tensor& weight, const Tensor& bias, doub
 }
 
 // softmax((q * scale) k^T) v, head_dim 64; qkv rows [3][heads][64] as nn.Linear(dim, 3 * dim) leaves them (attention.py:49-62)
-Tensor attention_fwd(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, int64_t prec) {
+Tensor attention_fwd(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, int64_t prec, const optional<Tensor>& bias) {
   dev_f32(qkv, "qkv");
+  if (bias.has_value()) {  // additive score bias [heads, ntok, ld >= roundup(ntok, 64)] shared by the batch (BEiT relative position bias)
+    dev_f32(*bias, "bias");
+    TORCH_CHECK(bias->is_contiguous() && bias->dim() == 3 && bias->size(0) == heads && bias->size(1) == ntok && bias->size(2) >= (ntok + 63) / 64 * 64,
+                "prv2::attention_fwd: bias must be contiguous [heads, ntok, ld] with ld >= ntok rounded up to 64");
+  }
   TORCH_CHECK(qkv.is_contiguous() && qkv.numel() == b * ntok * 3 * heads * 64, "prv2::attention_fwd: qkv must be contiguous [b * ntok, 3 * heads * 64]");
   Tensor out = at::empty({b * ntok, heads * 64}, qkv.options());
   const int64_t wsb = prv2_attention_workspace_bytes((int)b, (int)ntok, (int)heads, (int)prec);
   Tensor ws = at::empty({wsb > 0 ? wsb : 1}, qkv.options().dtype(at::kByte));
   Launch L(qkv);
-  ok(prv2_attention(qkv.data_ptr<float>(), (int)b, (int)ntok, (int)heads, 64, out.data_ptr<float>(), (int)prec, wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream),
+  ok(prv2_attention_bias(qkv.data_ptr<float>(), (int)b, (int)ntok, (int)heads, 64, bias.has_value() ? bias->data_ptr<float>() : nullptr,
+                         bias.has_value() ? (int)bias->size(2) : 0, out.data_ptr<float>(), (int)prec, wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream),
      "attention_fwd");
   return out;
 }
@@ -274,7 +283,7 @@ TORCH_LIBRARY(prv2, m) {
         "Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? gamma=None, Tensor? mul=None, Tensor? res=None, Tensor? res2=None, int convt_k=0, "
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None) -> Tensor");
   m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0) -> Tensor");
-  m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0) -> Tensor");
+  m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0, Tensor? bias=None) -> Tensor");
   m.def("crop_resize_bilinear(Tensor img_chw, Tensor tiles, int ch, int cw, int oh, int ow, float[]? mean=None, float[]? std=None, "
         "Tensor(a!)? out=None) -> Tensor");
   m.def("roi_gather_pyramid(Tensor[] feats, Tensor boxes, int ph) -> Tensor[]");

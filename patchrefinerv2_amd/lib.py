@@ -54,6 +54,7 @@ SIGNATURES = {
     "prv2_patchify": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_assemble_tokens": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "prv2_attention": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _L, _P]),
+    "prv2_attention_bias": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _L, _P]),
     "prv2_attention_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "prv2_bicubic_resize": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "prv2_add": (_I, [_P, _I, _P, _I, _L, _I, _P, _I, _P]),

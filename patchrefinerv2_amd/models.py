@@ -473,12 +473,19 @@ class _PatchModel(StateDictModule):
             self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
             self._load_ckpt(self.coarse_branch, pcm, "model_state_dict", True, "pretrain_coarse_model")
         elif ctype in ("DA-ZoeDepth", "ZoeDepth"):
-            # ZoeDepth.build(**coarse_branch) (patchrefinerplus.py:102-116); only the vendored DepthAnything cores
-            # exist here -- W.zoedepth_cfg raises for the torch.hub MiDaS DPT-BEiT-L core of type='ZoeDepth'
+            # ZoeDepth.build(**coarse_branch) (patchrefinerplus.py:102-116): midas_model_type picks the core -- MiDaS
+            # DPT_BEiT_L_384 (the default) or a DepthAnything ViT; the config's ``type`` picks the resizer
             from .zoedepth import ZoeDepth
             zc = {k: v for k, v in config.coarse_branch.to_dict().items() if k != "type"}
             self.coarse_branch = ZoeDepth(device=self.device, prec=self.prec, **zc)
-            self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
+            if ctype == "ZoeDepth":
+                # ResizeZoe.__call__ is hard-coded to 384 x 512 whatever it is constructed with (midas.py:171-174)
+                if tuple(self.patch_process_shape) != (384, 512):
+                    raise ValueError(f"coarse_branch type 'ZoeDepth' resizes every image to 384 x 512 (midas.py:171-174): "
+                                     f"patch_process_shape {list(self.patch_process_shape)} cannot work (the reference fails too)")
+                self.resizer = Resizer(512, 384, "zoe")
+            else:
+                self.resizer = Resizer(self.patch_process_shape[1], self.patch_process_shape[0], "da")
             # strict only for DA-ZoeDepth under PatchRefinerPlus (patchrefinerplus.py:108,116; patchrefiner.py:82,89)
             self._load_ckpt(self.coarse_branch, pcm, "model_state_dict", ctype == "DA-ZoeDepth" and self.STRICT_DA_ZOE,
                             "pretrain_coarse_model")
@@ -583,11 +590,17 @@ class PatchRefiner(_PatchModel):
         super().__init__()
         config = self._common_init(config)
         fb = config.refiner.fine_branch
-        if fb["type"] != "DA2":
-            raise NotImplementedError("refiner fine_branch type must be 'DA2' (ZoeDepth core un-vendored)")
-        self.refiner_fine_branch = self._make_da2(fb, config.max_depth)
-        self._load_ckpt(self.refiner_fine_branch, config.get("pretrain_fine_model", None), "model_state_dict", True,
-                        "pretrain_fine_model")
+        if fb["type"] == "DA2":
+            self.refiner_fine_branch = self._make_da2(fb, config.max_depth)
+        elif fb["type"] in ("ZoeDepth", "DA-ZoeDepth"):  # patchrefiner.py:104-115: ZoeDepth.build(**fine_branch)
+            from .zoedepth import ZoeDepth
+            self.refiner_fine_branch = ZoeDepth(device=self.device, prec=self.prec,
+                                                **{k: v for k, v in fb.to_dict().items() if k != "type"})
+            self.crop_mean, self.crop_std = self.refiner_fine_branch.input_mean, self.refiner_fine_branch.input_std
+        else:
+            raise NotImplementedError(f"refiner fine_branch type {fb['type']!r}")
+        self._load_ckpt(self.refiner_fine_branch, config.get("pretrain_fine_model", None), "model_state_dict",
+                        fb["type"] == "DA2", "pretrain_fine_model")
         self.refiner_fusion_model = build_model({**config.refiner.fusion_model.to_dict(), "device": self.device,
                                                  "prec": self.prec})
         self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
@@ -613,6 +626,43 @@ class PatchRefiner(_PatchModel):
         base = depth_roi.buf.view(depth_roi.n, 1, depth_roi.h, depth_roi.w)
         return self.refiner_fusion_model(c_feat=rois[-n:][::-1], f_feat=r_feats[-n:][::-1], pred1=base,
                                          pred2=fine["metric_depth"], update_base=base, out=out)
+
+
+@MODELS.register_module()
+class PatchRefinerSemi(StateDictModule):
+    """estimator/models/patchrefiner_semi.py:46-210, inference side only: the teacher / pseudo-label / edge-loss machinery
+    is training; at test time ``forward`` hands everything to the student (:208-210) -- note that it
+    forwards ``cai_mode`` but neither ``tile_cfg`` nor ``process_num``, so the student runs with its configured tiling.
+    The teacher is not built (never used for inference)."""
+
+    def __init__(self, model_cfg_student, teacher_pretrain=None, model_cfg_teacher=None, **_training_only):
+        super().__init__()
+        self.student_model = build_model(model_cfg_student)
+        self._children = dict(student_model=self.student_model)
+        self.device, self.prec = self.student_model.device, self.student_model.prec
+
+    def _pack(self):
+        pass
+
+    def __getattr__(self, name):  # resizer, tile_cfg, patch_process_shape, min/max_depth ... are the student's (:163)
+        if name in ("student_model", "_children", "_spec", "_sd"):
+            raise AttributeError(name)
+        return getattr(self.student_model, name)
+
+    def load_dict(self, sd):
+        if "student_model.coarse_branch.core.core.pretrained.model.cls_token" in sd:  # old checkpoints: teacher + student (:113-115)
+            return self.load_state_dict({k: v for k, v in sd.items() if k.startswith("student_model.")}, strict=True)
+        return self.student_model.load_state_dict(sd, strict=False)
+
+    def get_save_dict(self):
+        return self.student_model.get_save_dict()
+
+    def forward(self, mode=None, image_lr=None, image_hr=None, depth_gt=None, cai_mode="m1", **kw):
+        if mode == "train":
+            raise NotImplementedError("only inference is built (training is out of scope, SURVEY.md 2 #12-14)")
+        return self.student_model(mode=mode, image_lr=image_lr, image_hr=image_hr, depth_gt=depth_gt, cai_mode=cai_mode)
+
+    __call__ = forward
 
 
 @MODELS.register_module()

@@ -365,15 +365,20 @@ def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: 
     return tok
 
 
-def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32) -> torch.Tensor:
+def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``bias``: optional [heads, ntok, ld >= roundup(ntok, 64)] additive score bias shared by the batch (BEiT)"""
     out = torch.empty((b * ntok, heads * 64), device=qkv.device, dtype=torch.float32)
     lib = L.load()
     nbytes = lib.prv2_attention_workspace_bytes(b, ntok, heads, prec)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device) if nbytes else None
+    if bias is not None:
+        _require_dev(bias)
+        assert bias.is_contiguous() and bias.shape[0] == heads and bias.shape[1] == ntok
     PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel",
                     4.0 * b * heads * ntok * ntok * 64,
-                    lambda: L.check(lib.prv2_attention(qkv.data_ptr(), b, ntok, heads, 64, out.data_ptr(), prec, _ptr(ws),
-                                                       nbytes, _stream()), "attention"))
+                    lambda: L.check(lib.prv2_attention_bias(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias),
+                                                            bias.shape[2] if bias is not None else 0, out.data_ptr(), prec,
+                                                            _ptr(ws), nbytes, _stream()), "attention"))
     return out
 
 

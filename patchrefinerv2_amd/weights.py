@@ -139,19 +139,104 @@ DA_CORE = {  # DepthAnythingCore.build (external/zoedepth/models/base_models/dep
 }
 
 
+# MiDaS v3.1 DPT_BEiT_L_384 (torch.hub "AyaanShah2204/MiDaS", midas.py:342-347; timm beit_large_patch16_384): the core of
+# type='ZoeDepth'.  ``beit`` overrides give the reduced nets of the parity tests.
+MIDAS_BEIT = {
+    "DPT_BEiT_L_384": dict(dim=1024, depth=24, heads=16, taps=[5, 11, 17, 23], patch=16, window=(24, 24), mlp_ratio=4,
+                           features=256, out_channels=[256, 512, 1024, 1024]),
+}
+
+
+def midas_beit_cfg(model_type: str = "DPT_BEiT_L_384", **over) -> dict:
+    c = dict(MIDAS_BEIT[model_type])
+    c.update(over)
+    c["window"] = tuple(c["window"])
+    return c
+
+
+def midas_beit_spec(prefix: str, b: dict) -> Spec:
+    """MidasCore.core = DPTDepthModel(backbone='beitl16_384') parameter table: pretrained.model.* (timm BEiT),
+    pretrained.act_postprocess{1..4}.* (midas/backbones/utils.py make_backbone_default), scratch.* (midas/blocks.py).
+    Only what the forward reads; a real checkpoint also carries fc_norm / head / relative_position_index (ignored: the
+    reference loads ZoeDepth checkpoints with strict=False, patchrefinerplus.py:108)."""
+    D, L, p, F_, oc = b["dim"], b["depth"], b["patch"], b["features"], list(b["out_channels"])
+    hid = int(D * b["mlp_ratio"])
+    nrd = (2 * b["window"][0] - 1) * (2 * b["window"][1] - 1) + 3
+    s: Spec = OrderedDict()
+    m = prefix + "pretrained.model."
+    s[m + "cls_token"] = (1, 1, D)
+    s[m + "patch_embed.proj.weight"] = (D, 3, p, p)
+    s[m + "patch_embed.proj.bias"] = (D,)
+    for i in range(L):
+        k = f"{m}blocks.{i}."
+        s[k + "gamma_1"] = (D,)
+        s[k + "gamma_2"] = (D,)
+        s[k + "norm1.weight"] = (D,)
+        s[k + "norm1.bias"] = (D,)
+        s[k + "attn.q_bias"] = (D,)
+        s[k + "attn.v_bias"] = (D,)
+        s[k + "attn.relative_position_bias_table"] = (nrd, b["heads"])
+        s[k + "attn.qkv.weight"] = (3 * D, D)
+        s[k + "attn.proj.weight"] = (D, D)
+        s[k + "attn.proj.bias"] = (D,)
+        s[k + "norm2.weight"] = (D,)
+        s[k + "norm2.bias"] = (D,)
+        s[k + "mlp.fc1.weight"] = (hid, D)
+        s[k + "mlp.fc1.bias"] = (hid,)
+        s[k + "mlp.fc2.weight"] = (D, hid)
+        s[k + "mlp.fc2.bias"] = (D,)
+    for i in range(4):
+        a = f"{prefix}pretrained.act_postprocess{i + 1}."
+        s[a + "0.project.0.weight"] = (D, 2 * D)
+        s[a + "0.project.0.bias"] = (D,)
+        s[a + "3.weight"] = (oc[i], D, 1, 1)
+        s[a + "3.bias"] = (oc[i],)
+        if i == 0:
+            s[a + "4.weight"] = (oc[0], oc[0], 4, 4)  # ConvTranspose2d [in, out, k, k]
+            s[a + "4.bias"] = (oc[0],)
+        elif i == 1:
+            s[a + "4.weight"] = (oc[1], oc[1], 2, 2)
+            s[a + "4.bias"] = (oc[1],)
+        elif i == 3:
+            s[a + "4.weight"] = (oc[3], oc[3], 3, 3)
+            s[a + "4.bias"] = (oc[3],)
+    c = prefix + "scratch."
+    for i in range(4):
+        s[f"{c}layer{i + 1}_rn.weight"] = (F_, oc[i], 3, 3)
+    for r in range(1, 5):
+        k = f"{c}refinenet{r}."
+        s[k + "out_conv.weight"] = (F_, F_, 1, 1)
+        s[k + "out_conv.bias"] = (F_,)
+        for u in (1, 2):
+            for cc in (1, 2):
+                s[f"{k}resConfUnit{u}.conv{cc}.weight"] = (F_, F_, 3, 3)
+                s[f"{k}resConfUnit{u}.conv{cc}.bias"] = (F_,)
+    s[c + "output_conv.0.weight"] = (F_ // 2, F_, 3, 3)
+    s[c + "output_conv.0.bias"] = (F_ // 2,)
+    s[c + "output_conv.2.weight"] = (32, F_ // 2, 3, 3)
+    s[c + "output_conv.2.bias"] = (32,)
+    s[c + "output_conv.4.weight"] = (1, 32, 1, 1)
+    s[c + "output_conv.4.bias"] = (1,)
+    return s
+
+
 def zoedepth_cfg(cfg: dict) -> dict:
     """Normalise a reference ZoeDepth config dict (configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py:10-66)
     for the DepthAnything-core flavour (type='DA-ZoeDepth')."""
     mt = cfg.get("midas_model_type", "DPT_BEiT_L_384")  # ZoeDepth.build default (zoedepth_v1.py:297)
-    if mt not in DA_CORE:
+    if mt not in DA_CORE and mt not in MIDAS_BEIT:
         raise NotImplementedError(
-            f"midas_model_type={mt!r}: only the vendored DepthAnything cores (vits/vitb/vitl) are built; the MiDaS "
-            "DPT-BEiT-L core is fetched by torch.hub in the reference (midas.py:342-347) and is not vendored")
+            f"midas_model_type={mt!r}: built are the vendored DepthAnything cores (vits/vitb/vitl) and MiDaS "
+            f"{sorted(MIDAS_BEIT)} (midas.py:377-385 lists others no shipped config uses)")
     if cfg.get("bin_centers_type", "softplus") != "softplus" or cfg.get("attractor_type", "inv") != "inv" or \
             cfg.get("attractor_kind", "mean") != "mean":
         raise NotImplementedError("only bin_centers_type='softplus', attractor_type='inv', attractor_kind='mean' "
                                   "(every shipped config)")
-    core = dav2_cfg({**DA_CORE[mt], "vit": cfg.get("vit", {})})
+    if mt in MIDAS_BEIT:
+        beit = midas_beit_cfg(mt, **cfg.get("beit", {}))
+        core = dict(beit=beit, features=beit["features"], out_channels=beit["out_channels"])
+    else:
+        core = dav2_cfg({**DA_CORE[mt], "vit": cfg.get("vit", {})})
     return dict(core=core, core_type=mt, n_bins=int(cfg.get("n_bins", 64)),
                 bin_embedding_dim=int(cfg.get("bin_embedding_dim", 128)),
                 n_attractors=list(cfg.get("n_attractors", [16, 8, 4, 1])), min_temp=float(cfg.get("min_temp", 5)),
@@ -165,8 +250,11 @@ def zoedepth_spec(prefix: str, cfg: dict) -> Spec:
     F_ = z["core"]["features"]
     nb, emb = z["n_bins"], z["bin_embedding_dim"]
     s: Spec = OrderedDict()
-    s.update(dinov2_spec(prefix + "core.core.pretrained.", z["core"]["vit"]))
-    s.update(dpt_head_spec(prefix + "core.core.depth_head.", z["core"]["vit"]["dim"], F_, z["core"]["out_channels"]))
+    if "beit" in z["core"]:
+        s.update(midas_beit_spec(prefix + "core.core.", z["core"]["beit"]))
+    else:
+        s.update(dinov2_spec(prefix + "core.core.pretrained.", z["core"]["vit"]))
+        s.update(dpt_head_spec(prefix + "core.core.depth_head.", z["core"]["vit"]["dim"], F_, z["core"]["out_channels"]))
 
     def mlp(name, cin, mid, cout):
         s[f"{prefix}{name}._net.0.weight"] = (mid, cin, 1, 1)
@@ -489,7 +577,13 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
         return torch.zeros(shape)
     n = int(np.prod(shape)) if len(shape) else 1
     z = g.standard_normal(n).astype(np.float32).reshape(shape)
-    if leaf == "gamma" and ".stages_" in name:  # ConvNeXt layer scale: 36 residual blocks deep -- keep the trunk O(1)
+    if leaf in ("gamma_1", "gamma_2"):  # BEiT layer scale (init_values 0.1 in timm; O(1) here like DINOv2's LayerScale test values)
+        v = 1.0 + 0.05 * z
+    elif leaf in ("q_bias", "v_bias"):
+        v = 0.02 * z
+    elif leaf == "relative_position_bias_table":
+        v = 0.5 * z  # O(1) logit offsets: the bias must matter next to q.k
+    elif leaf == "gamma" and ".stages_" in name:  # ConvNeXt layer scale: 36 residual blocks deep -- keep the trunk O(1)
         v = 0.15 + 0.02 * z
     elif leaf == "gamma":  # LayerScale
         v = 1.0 + 0.05 * z
@@ -509,7 +603,8 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
     elif len(shape) == 1:  # norm weight
         v = 1.0 + 0.1 * z
     else:
-        if "resize_layers.0." in name or "resize_layers.1." in name or "upsample_convx" in name:
+        if ("resize_layers.0." in name or "resize_layers.1." in name or "upsample_convx" in name
+                or "act_postprocess1.4." in name or "act_postprocess2.4." in name):
             fan_in = shape[0]  # ConvTranspose2d [in, out, k, k], k == stride
         else:
             fan_in = int(np.prod(shape[1:]))
@@ -517,7 +612,7 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> torch.Tens
             gain = 0.5  # offset head: O(1) metres on top of the coarse depth
         elif "seed_bin_regressor._net.2" in name or "conditional_log_binomial.mlp.2" in name:
             gain = 3.0
-        elif "output_conv2.2." in name:
+        elif "output_conv2.2." in name or "scratch.output_conv.4." in name:
             gain = 1.5  # pre-sigmoid logits O(1): the depth head must not saturate
         elif re.search(r"resConfUnit\d\.conv2\.|GateresConfUnit\d\.conv\.", name):
             gain = 0.4  # residual branches: keep the pyramid's scale flat across levels

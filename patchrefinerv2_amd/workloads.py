@@ -59,7 +59,17 @@ WORKLOADS["v2_convx_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 38
 WORKLOADS["v2_eff_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[392, 518], mode="r32",
                                         coarse=None, zoe=ZOE_DA_L, fusion=dict(BIDIR_ZOE, fine_chl=[24, 40, 64, 176, 512]),
                                         patches=81, refiner_encoder="tf_efficientnet_b5_ap")
-DEFAULT_WORKLOAD = "v2_zoeda_4k_r32"
+# BASELINE config[2] AS THE REFERENCE CONFIGURES IT (configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py): coarse_branch type='ZoeDepth'
+# = the metric-bins head over MiDaS DPT_BEiT_L_384 (:10-17), ResizeZoe -> P = 384 x 512, MNv4-S refiner, BiDirectionalFusion zoe cfg
+ZOE_BEIT_L = dict(ZOE_DA_L, midas_model_type="DPT_BEiT_L_384", img_size=[384, 512])
+WORKLOADS["v2_zoe_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[384, 512], mode="r32",
+                                  coarse=None, zoe=ZOE_BEIT_L, zoe_type="ZoeDepth", fusion=BIDIR_ZOE, patches=81)
+# configs/patchrefiner_zoedepth/pr_u4k.py (the README's example command): V1 with ZoeDepth / BEiT-L on every tile
+WORKLOADS["v1_zoe_4k_r32"] = dict(kind="PatchRefiner", raw=[2160, 3840], split=[4, 4], pps=[384, 512], mode="r32",
+                                  coarse=None, zoe=ZOE_BEIT_L, zoe_type="ZoeDepth", fine_zoe=ZOE_BEIT_L,
+                                  fusion=dict(input_chl=[64, 512, 512, 512, 512, 512], temp_chl=[32, 256, 256, 256, 256, 256],
+                                              dec_chl=[256, 256, 256, 256, 32]), patches=81)
+DEFAULT_WORKLOAD = "v2_zoe_4k_r32"
 MNV4_NAME = "mobilenetv4_conv_small.e2400_r224_in1k"
 
 
@@ -70,7 +80,7 @@ def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> d
         image_raw_shape=raw, patch_process_shape=w["pps"], patch_raw_shape=[raw[0] // split[0], raw[1] // split[1]],
         patch_split_num=split, fusion_feat_level=6, min_depth=1e-3, max_depth=80.0, pretrain_coarse_model=None,
         strategy_refiner_target="offset_coarse",
-        coarse_branch=(dict(type="DA-ZoeDepth", **w["zoe"]) if w.get("zoe") else
+        coarse_branch=(dict(type=w.get("zoe_type", "DA-ZoeDepth"), **w["zoe"]) if w.get("zoe") else
                        dict(type="DA2", pretrained=None, model_cfg=w["coarse"])),
         sigloss=dict(type="SILogLoss"), pretrained=None, pre_norm_bbox=True, prec=prec, max_batch=max_batch, n_streams=n_streams)
     if w["kind"] == "PatchRefinerPlus":
@@ -82,9 +92,8 @@ def model_config(name: str, prec: str = "f32", max_batch=None, n_streams=1) -> d
                                                   encoder_name=w.get("refiner_encoder", MNV4_NAME),
                                                   coarse2fine=True, coarse2fine_type="coarse-gated", **w["fusion"])))
     else:
-        cfg.update(pretrain_fine_model=None,
-                   refiner=dict(fine_branch=dict(type="DA2", pretrained=None, model_cfg=w["fine"]),
-                                fusion_model=dict(type="FusionUnet", **w["fusion"])))
+        fine = (dict(type=w["zoe_type"], **w["fine_zoe"]) if w.get("fine_zoe") else dict(type="DA2", pretrained=None, model_cfg=w["fine"]))
+        cfg.update(pretrain_fine_model=None, refiner=dict(fine_branch=fine, fusion_model=dict(type="FusionUnet", **w["fusion"])))
     return dict(type=w["kind"], config=cfg)
 
 
@@ -109,6 +118,9 @@ def state_spec(name: str) -> "OrderedDict[str, tuple]":
         s.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                      f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
     else:
-        s.update(W.dav2_spec("refiner_fine_branch.", w["fine"]))
+        if w.get("fine_zoe"):
+            s.update(W.zoedepth_spec("refiner_fine_branch.", w["fine_zoe"]))
+        else:
+            s.update(W.dav2_spec("refiner_fine_branch.", w["fine"]))
         s.update(W.fusion_unet_spec("refiner_fusion_model.", **w["fusion"]))
     return s

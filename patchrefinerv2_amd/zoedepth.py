@@ -6,8 +6,8 @@ Host-side mirror of ``ZoeDepth`` (external/zoedepth/models/zoedepth/zoedepth_v1.
 ``coarse_branch.type == 'DA-ZoeDepth'`` flavour.  Same state-dict names (``core.core.pretrained.*``,
 ``core.core.depth_head.*``, ``conv2``, ``seed_bin_regressor._net.*`` ...).
 
-The MiDaS DPT-BEiT-L core of ``type='ZoeDepth'`` is fetched with torch.hub in the reference
-(midas.py:342-347) and is not vendored: asking for it raises NotImplementedError.
+``midas_model_type='DPT_BEiT_L_384'`` (the default; ``coarse_branch.type == 'ZoeDepth'``) selects the MiDaS DPT-BEiT-L core
+(patchrefinerv2_amd/midas.py): the head is the same, the inputs are then multiples of 32 and normalised with 0.5 / 0.5.
 """
 from __future__ import annotations
 
@@ -26,8 +26,14 @@ class ZoeDepth(StateDictModule):
         self.device = torch.device(device)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
         core = self.zcfg["core"]
-        self.core = DepthAnythingV2(encoder=core["encoder"], features=core["features"], out_channels=core["out_channels"],
-                                    vit=cfg.get("vit"), device=device, prec=self.prec, variant="v1")
+        if "beit" in core:  # midas_model_type='DPT_BEiT_L_384': MidasCore (midas.py:191) over MiDaS DPT-BEiT-L
+            from .midas import MidasBeitCore
+            self.core = MidasBeitCore(self.zcfg["core_type"], beit=cfg.get("beit"), device=device, prec=self.prec)
+        else:
+            self.core = DepthAnythingV2(encoder=core["encoder"], features=core["features"], out_channels=core["out_channels"],
+                                        vit=cfg.get("vit"), device=device, prec=self.prec, variant="v1")
+        self.input_mean = getattr(self.core, "input_mean", (0.485, 0.456, 0.406))  # PrepForMidas normalisation of the core
+        self.input_std = getattr(self.core, "input_std", (0.229, 0.224, 0.225))
         self._children = {"core.core": self.core}
         full = W.zoedepth_spec("", cfg)
         self._spec = type(full)((k, v) for k, v in full.items() if not k.startswith("core.core."))
@@ -51,7 +57,8 @@ class ZoeDepth(StateDictModule):
         self._packed = P
 
     def forward(self, x: torch.Tensor, return_final_centers=False, **kwargs) -> dict:
-        """x: [B,3,H,W] in [0,1]; H, W multiples of 14 (PrepForMidas with do_resize=False only normalises)."""
+        """x: [B,3,H,W] in [0,1]; H, W multiples of 14 (DepthAnything cores) / 32 (MiDaS BEiT): PrepForMidas with
+        do_resize=False only normalises."""
         P = self._packed
         if P is None:
             raise RuntimeError("ZoeDepth: weights not loaded")

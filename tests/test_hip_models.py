@@ -336,7 +336,78 @@ def test_zoedepth_da_core(P, golden):
         for k, v in ref["temp_features"].items():
             close(out["temp_features"][k].to_nchw(), v, 3e-5, f"{tag} {k}")
     with pytest.raises(NotImplementedError):
-        ZoeDepth.build(midas_model_type="DPT_BEiT_L_384")
+        ZoeDepth.build(midas_model_type="DPT_SwinV2_L_384")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_zoedepth_midas_beit_core(P, golden, prec):
+    """type='ZoeDepth': ZoeDepth over the MiDaS DPT-BEiT core (relative-position-bias attention, project readout, MiDaS DPT
+    decoder hooks) vs the reference's ZoeDepth / MidasCore classes run over transformers' DPT-BEiT (golden) and vs the oracle;
+    non-square inputs resize the 7 x 7 bias table"""
+    from oracle.cases import ZOE_BEIT
+    from patchrefinerv2_amd.zoedepth import ZoeDepth
+    c, g = ZOE_BEIT, golden("zoedepth_beit")
+    sd = W.synth_state_dict(W.zoedepth_spec("", c["zcfg"]), seed=c["seed"])
+    m = ZoeDepth.build(**c["zcfg"], prec=prec)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res["missing_keys"]
+    z = W.zoedepth_cfg(c["zcfg"])
+    tol = 3e-5 if prec == "f32" else 3e-4
+    for tag, (h, w) in c["inputs"].items():
+        x = rand_image(c["seed"], 2, h, w)
+        out = m(x.to(DEV), return_final_centers=True)
+        ref = o_zoe.zoedepth_forward(sd, "", x, z)
+        close(out["metric_depth"], g[f"{tag}_depth"], tol, f"{tag} depth vs golden")
+        for k, v in ref["temp_features"].items():
+            close(out["temp_features"][k].to_nchw(), v, tol, f"{tag} {k}")
+        ar, _ = absrel(out["metric_depth"], ref["metric_depth"])
+        assert ar < (1e-5 if prec == "f32" else ABSREL_TOL), (tag, ar)
+    with pytest.raises(ValueError):
+        m(rand_image(1, 1, 56, 84).to(DEV))  # not multiples of 32
+
+
+def test_e2e_v2_midas_beit_coarse_vs_reference_golden(P, golden):
+    """PatchRefinerPlus wired as configs/patchrefinerv2_zoedepth/v2_mobile_u4k.py: coarse_branch type='ZoeDepth' (MidasCore / BEiT),
+    ResizeZoe to 384 x 512, P = 384 x 512 -- against the reference's own classes end to end (reduced BEiT)"""
+    from oracle.cases import E2E_V2B, e2e_v2b_sd
+    from patchrefinerv2_amd.registry import build_model
+    import patchrefinerv2_amd.models  # noqa: F401
+    c, g = E2E_V2B, golden("e2e_v2b")
+    m = build_model(dict(type="PatchRefinerPlus", config=dict(c["ref_config"])))
+    res = m.load_state_dict(e2e_v2b_sd(), strict=True)
+    assert not res["missing_keys"] and not res["unexpected_keys"]
+    assert m.resizer.kind == "zoe" and m.resizer.out_hw == (384, 512)
+    for mode, shape in zip(c["modes"], ((768, 1024), (540, 960))):
+        depth, _ = _run(m, c, mode)
+        assert tuple(depth.shape[-2:]) == shape
+        ar, mx = absrel(depth[..., ::3, ::3], g[mode])  # the golden holds every third row / column of the map
+        assert ar < 1e-5 and mx < 1e-3, (mode, ar, mx)
+    with pytest.raises(ValueError):
+        build_model(dict(type="PatchRefinerPlus", config={**c["ref_config"], "patch_process_shape": [392, 518]}))
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_baseline_config0_as_configured_beit_l_full_size(P, prec):
+    """BASELINE config[0] exactly as the reference configures it: a 540 x 960 frame, BaselinePretrain(target='coarse'),
+    coarse_branch type='ZoeDepth' = MiDaS DPT_BEiT_L_384 (24 blocks, 1024 wide, 769 tokens at 384 x 512) -- both arithmetic
+    modes against the fp32 oracle on the same synthetic weights"""
+    from patchrefinerv2_amd import models  # noqa: F401
+    from patchrefinerv2_amd.registry import build_model
+    from patchrefinerv2_amd.workloads import ZOE_BEIT_L
+    branch = dict(type="ZoeDepth", **ZOE_BEIT_L)
+    m = build_model(dict(type="BaselinePretrain", coarse_branch=branch, fine_branch=branch, sigloss=dict(type="SILogLoss"),
+                         min_depth=1e-3, max_depth=80, image_raw_shape=[540, 960], patch_process_shape=[384, 512],
+                         patch_split_num=[1, 1], target="coarse", prec=prec))
+    sd = W.synth_state_dict(W.zoedepth_spec("", ZOE_BEIT_L), seed=0)
+    m.load_dict(sd)
+    hr = rand_image(11, 1, 540, 960)
+    lr = m.resizer(hr.to(DEV))
+    assert tuple(lr.shape) == (1, 3, 384, 512)
+    depth, _ = m(mode="infer", image_lr=lr, image_hr=hr.to(DEV), depth_gt=None)
+    ref = o_zoe.zoedepth_forward(sd, "", lr.cpu(), W.zoedepth_cfg(ZOE_BEIT_L))["metric_depth"]
+    ar, mx = absrel(depth, ref)
+    print(f"config[0] as configured (DPT_BEiT_L_384, 384x512) {prec}: AbsRel {ar:.3e} max|d| {mx:.3e} (depth {float(ref.min()):.2f}..{float(ref.max()):.2f})")
+    assert tuple(depth.shape) == (1, 1, 384, 512) and ar < (1e-5 if prec == "f32" else ABSREL_TOL), (ar, mx)
 
 
 def test_baseline_pretrain_vs_reference_golden(P, golden):

@@ -84,9 +84,12 @@ def test_state_dict_contract_and_loud_failures():
     with pytest.raises(NotImplementedError):
         m(mode="train")
     bad = dict(cfg)
-    bad["coarse_branch"] = dict(type="ZoeDepth")
-    with pytest.raises(NotImplementedError):
+    bad["coarse_branch"] = dict(type="ZoeDepth")  # MidasCore / BEiT-L + ResizeZoe: only P = 384 x 512 can work (midas.py:171-174)
+    with pytest.raises(ValueError):
         build_model(dict(type="PatchRefinerPlus", config=bad))
+    bad["coarse_branch"] = dict(type="ZoeDepth", midas_model_type="DPT_SwinV2_L_384")
+    with pytest.raises(NotImplementedError):
+        build_model(dict(type="PatchRefinerPlus", config={**bad, "patch_process_shape": [384, 512]}))
 
 
 def test_png16_and_read_image(tmp_path):
@@ -165,7 +168,7 @@ def test_output_stage_matches_reference():
         M.get_boundaries(gt.squeeze().numpy(), dilation=3)
 
 
-REFERENCE_CONFIG_FLOOR = 10  # raised as components land; see the printed table
+REFERENCE_CONFIG_FLOOR = 67  # raised as components land; see the printed table
 
 
 def test_reference_model_configs_build_through_the_registry():
