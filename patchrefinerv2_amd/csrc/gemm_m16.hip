@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const 
 bool gemm16_supported(const IgemmParams& p, int prec) {
   return prec != PRV2_PREC_F32 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 &&
          p.x_bstride == (long long)p.H * p.W * p.ldx && p.y_bstride == (long long)p.OH * p.OW * p.ldy &&
-         256LL * p.ldx * 4 < (1LL << 31) && (long long)p.OH * p.OW >= 512 && p.Ncols > 64;  // rows PER IMAGE: never the batch
+         256LL * p.ldx * 4 < (1LL << 31) && p.Ncols > 64;  // (no row-count condition: the choice must not depend on the batch)
 }
 
 void launch_gemm16(IgemmParams& p, int prec, hipStream_t s) {

@@ -85,12 +85,21 @@ Tensor pack_conv_weight(const Tensor& w, const optional<Tensor>& bn_scale, int64
 
 // nn.Conv2d / nn.Linear (kh = kw = 1 over an [1, M, 1, K] view) / nn.ConvTranspose2d(k == stride) with the fused epilogue of
 // include/prv2.h::prv2_conv2d
-Tensor conv2d(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
               int64_t pad, int64_t act, bool relu_in, const optional<Tensor>& ln_weight, const optional<Tensor>& ln_bias,
               const optional<Tensor>& gamma, const optional<Tensor>& mul, const optional<Tensor>& res, const optional<Tensor>& res2,
               int64_t convt_k, int64_t prec, double ln_eps, bool same_pad, const optional<Tensor>& out) {
+  Tensor x = x_in;
+  if (x.is_cuda() && x.dim() == 4 && x.scalar_type() == at::kFloat && (x.stride(2) % 4 != 0 || (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15))) {
+    // the kernels read 16-byte groups: a dense tensor whose channel count is not a multiple of 4 (34, 66, 98 ... channels) is
+    // copied once into a buffer with zeroed pad channels (the host mirror allocates its concat buffers padded from the start)
+    Tensor padded = alloc_nhwc(x, x.size(0), x.size(1), x.size(2), x.size(3));
+    padded.copy_(x);
+    x = padded;
+  }
   const int64_t ldx = nhwc_ld(x, "x");
   dev_f32(w_packed, "w_packed");
+  if (convt_k) TORCH_CHECK(kh == convt_k && kw == convt_k && pad == 0, "prv2::conv2d: convt_k needs kh == kw == convt_k and pad 0");
   const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
   int64_t oh, ow;
   if (convt_k) { oh = h * convt_k; ow = w * convt_k; }

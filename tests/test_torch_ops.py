@@ -88,7 +88,7 @@ def test_conv_transpose_and_linear(T):
     ops, _ = T
     x = randn(7, 1, 48, 9, 11)
     w, b = randn(8, 48, 24, 2, 2) / 7.0, randn(9, 24) * 0.1
-    y = ops.conv2d(_nhwc(x), ops.pack_conv_weight(w.to(DEV), None, 2, 0), b.to(DEV), 24, 1, 1, convt_k=2)
+    y = ops.conv2d(_nhwc(x), ops.pack_conv_weight(w.to(DEV), None, 2, 0), b.to(DEV), 24, 2, 2, convt_k=2)
     _close(_nchw(y), F.conv_transpose2d(x, w, b, stride=2))
     rows, wl = randn(10, 300, 96), randn(11, 160, 96) / 10.0
     z = ops.conv2d(rows.to(DEV).view(1, 300, 1, 96), ops.pack_conv_weight(wl.to(DEV)), None, 160, 1, 1)
