@@ -162,6 +162,27 @@ int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int
  * a multiple of 4, rows 16-byte aligned (pad keys are never read past ntok's 64-key tile and are masked).  bias == NULL: no bias. */
 int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias,
                         float* out, int32_t prec, void* workspace, int64_t workspace_bytes, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Split-swizzled ("ss") operand format and the dense layers that consume it (csrc/gemm_ss.hip) -- the ViT blocks'
+ * Linear layers (attention.py:44,46; mlp.py:30,32) at large token counts, PRV2_PREC_BF16X3 only.
+ * A row of C channels (C % 32 == 0) occupies 4*C bytes like fp32: per 32 channels one 128-byte group of eight 16-byte
+ * slots, logical slot s = 0..3: bf16 hi of channels 8s..8s+7, s = 4..7: bf16 lo of channels 8(s-4)..; stored at
+ * slot s ^ ((row >> 1) & 7) (the image prv2_pack_conv_weight gives the weights).  Producers write it directly:
+ *   prv2_split_ss      fp32 rows -> ss rows
+ *   prv2_layernorm_ss  prv2_layernorm with an ss output (no activation)
+ *   prv2_attention_ss  prv2_attention_bias (bf16x3) with an ss output
+ *   prv2_gemm_ss       y = epilogue(A_ss W^T): t = act(acc + bias[n]); t *= gamma[n]; t += res[m, n]; fp32 rows (y) or ss rows
+ *                      (y_ss; then no gamma / res).  w_packed: prv2_pack_conv_weight(.., kh = kw = 1, PRV2_PREC_BF16X3).
+ * prv2_gemm_ss is bit-identical to prv2_conv2d's 1x1 path on the same values (same split, products, order, epilogue).
+ * ------------------------------------------------------------------------------------------ */
+int prv2_split_ss(const float* x, int64_t rows, int32_t c, int32_t ldx, void* y_ss, void* stream);
+int prv2_layernorm_ss(const float* x, int64_t rows, int32_t c, int32_t ldx, const float* weight, const float* bias, float eps,
+                      void* y_ss, void* stream);
+int prv2_attention_ss(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias,
+                      void* out_ss, void* workspace, int64_t workspace_bytes, void* stream);
+int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias, const float* gamma,
+                 const float* res, int32_t ld_res, int32_t act, float* y, int32_t ldy, void* y_ss, void* stream);
+
 /* device scratch the split-bf16 attention needs (pre-split q/k rows + transposed v planes); 0 for PRV2_PREC_F32.
  * The workspace must be 256-byte aligned; its contents are dead when the call returns (stream order). */
 int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32_t heads, int32_t prec);

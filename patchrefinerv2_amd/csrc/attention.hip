@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) attention_f32_kernel(const float* __restr
 
 using namespace prv2;
 
-int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const float* bias, int ld_bias, float* out,
+int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const float* bias, int ld_bias, float* out, void* out_ss,
                             void* workspace, int64_t workspace_bytes, hipStream_t s);
 
 extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias,
@@ -173,6 +173,19 @@ extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, in
 extern "C" int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, float* out,
                               int32_t prec, void* workspace, int64_t workspace_bytes, void* stream) {
   return prv2_attention_bias(qkv, b, ntok, heads, hd, nullptr, 0, out, prec, workspace, workspace_bytes, stream);
+}
+
+extern "C" int prv2_attention_ss(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias,
+                                 void* out_ss, void* workspace, int64_t workspace_bytes, void* stream) {
+  PRV2_REQUIRE(qkv && out_ss, "attention_ss: null pointer");
+  PRV2_REQUIRE(b > 0 && ntok > 0 && heads > 0 && hd == 64, "attention: head_dim must be 64 (got %d)", hd);
+  PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_ss) & 15) == 0, "attention_ss: 16-byte alignment");
+  PRV2_REQUIRE(!bias || (ld_bias >= prv2::roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+               "attention: bias rows must be 16-byte aligned and padded to a multiple of 64 keys (ld_bias %d, ntok %d)", ld_bias, ntok);
+  int rc = launch_attention_bf16x3(qkv, b, ntok, heads, bias, ld_bias, nullptr, out_ss, workspace, workspace_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  PRV2_LAUNCH_CHECK("attention_ss");
+  return 0;
 }
 
 extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias,
@@ -185,7 +198,7 @@ extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, in
   PRV2_REQUIRE(prec >= PRV2_PREC_F32 && prec <= PRV2_PREC_BF16, "attention: unknown precision mode %d", prec);
   PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attention: qkv must be 16-byte aligned");
   if (prec != PRV2_PREC_F32) {  // bf16 mode also runs the bf16x3 kernel (attention is never the bottleneck there)
-    int rc = launch_attention_bf16x3(qkv, b, ntok, heads, bias, ld_bias, out, workspace, workspace_bytes, (hipStream_t)stream);
+    int rc = launch_attention_bf16x3(qkv, b, ntok, heads, bias, ld_bias, out, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc) return rc;
     PRV2_LAUNCH_CHECK("attention(bf16x3)");
     return 0;
@@ -286,7 +299,7 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
                                                                   const __bf16* __restrict__ VtH,
                                                                   const __bf16* __restrict__ VtL, int N, int Npad,
                                                                   int heads, const float* __restrict__ bias, int ldb,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AB_VP];  // 34304 B; reused for the output strips
   char* const Kt = smem;
   char* const Vt = smem + 64 * AB_KP;
@@ -419,6 +432,27 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   const int D = heads * 64;
+  if (out_ss) {
+    // the output feeds exactly one consumer, the proj Linear: written in its operand format (gemm_ss.hip: per 32 channels
+    // [4 x 16 B bf16 hi | 4 x 16 B bf16 lo], slot c at c ^ ((row >> 1) & 7)); this head's 64 channels = two such groups
+    for (int i = lane; i < 32 * 8; i += 64) {  // 32 rows x 8 groups of 8 channels
+      const int qr = i >> 3, kg = i & 7;
+      const int q = qt * AT_BQ + wave * 32 + qr;
+      if (q < N) {
+        const float* sp = strip + qr * 66 + kg * 8;
+        const f32x4 v0 = {sp[0], sp[1], sp[2], sp[3]}, v1 = {sp[4], sp[5], sp[6], sp[7]};
+        bf16x4 h0, l0, h1, l1;
+        split4(v0, h0, l0);
+        split4(v1, h1, l1);
+        const long long row = (long long)b * N + q;
+        char* const rowp = out_ss + row * ((long long)D * 4) + (head * 2 + (kg >> 2)) * 128;
+        const int chunk = kg & 3, k2 = (int)((row >> 1) & 7);
+        *reinterpret_cast<bf16x8*>(rowp + ((chunk ^ k2) << 4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8*>(rowp + (((4 + chunk) ^ k2) << 4)) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+    return;
+  }
   for (int i = lane; i < 32 * 16; i += 64) {  // 32 rows x 16 float4
     const int qr = i >> 4, c4 = (i & 15) * 4;
     const int q = qt * AT_BQ + wave * 32 + qr;
@@ -438,7 +472,7 @@ extern "C" int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32
   return (int64_t)b * heads * (2 * (int64_t)ntok * 128 + 2 * 64 * npad) * 2 + 256;
 }
 
-int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const float* bias, int ld_bias, float* out,
+int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const float* bias, int ld_bias, float* out, void* out_ss,
                             void* workspace, int64_t workspace_bytes, hipStream_t s) {
   using namespace prv2;
   const int64_t need = prv2_attention_workspace_bytes(b, ntok, heads, PRV2_PREC_BF16X3);
@@ -453,7 +487,8 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
   dim3 g2((unsigned)cdiv(ntok, AT_BQ), (unsigned)heads, (unsigned)b);
-  if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<true>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out);
-  else hipLaunchKernelGGL(attention_bf16x3_kernel<false>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out);
+  char* oss = reinterpret_cast<char*>(out_ss);
+  if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<true>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_bf16x3_kernel<false>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
   return 0;
 }

@@ -1,0 +1,298 @@
+// Dense linear layer on PRE-SPLIT activations:  Y[M, N] = epilogue(A[M, K] W^T), bf16x3, v_mfma_f32_16x16x32_bf16.
+//
+// The ViT blocks (external/depth_anything_v2/dinov2_layers/attention.py:44,46, mlp.py:30,32; MiDaS BEiT blocks) are chains
+// LayerNorm -> Linear -> attention -> Linear -> LayerNorm -> Linear -> GELU -> Linear in which every Linear input has exactly
+// one consumer.  The producers therefore write their result directly in the operand format of the matrix pipe -- the
+// "split-swizzled" row image the packed weights already use (igemm.hip::pack_weight_kernel): per 32 channels one 128-byte
+// group [4 x 16 B bf16 hi | 4 x 16 B bf16 lo], 16-byte slot c stored at c ^ ((row >> 1) & 7) -- same bytes per element as fp32,
+// no conversion arithmetic left in the GEMM.  Both operands then reach LDS by LDS-DMA (global_load_lds_dwordx4: 8 rows x 128 B
+// per wave instruction, linear copy == conflict-free image) and the main loop is ds_read_b128 + MFMA only:
+//   workgroup = 256 x 256 outputs, 8 waves as 2 (rows) x 4 (columns), wave = 128 x 64 = 8 x 4 accumulators of 16 x 16;
+//   per 32-channel slab: 32 KB of A + 32 KB of B in one of two LDS stages, 96 MFMAs per wave (lo*hi, hi*lo, hi*hi);
+//   slab k+1 is in flight (DMA) while slab k multiplies; one s_waitcnt vmcnt(0) + s_barrier per slab orders
+//   "DMA landed" -> "everyone may read" and "everyone has read" -> "DMA may overwrite".
+// The DMA and its waits are inline asm: while hipcc sees an LDS-DMA in flight it drains vmcnt / lgkmcnt at every LDS
+// access (conv3x3_m16.hip has the full story); what asm issues, asm waits for.
+// Arithmetic is IDENTICAL to gemm16_kernel (same split, same three products in the same order, same MFMA, same epilogue
+// formula): the two kernels give bit-equal results (tests/test_hip_ops.py::test_gemm_ss_bit_equal_to_gemm16), so the host may
+// choose between them by problem size without making results depend on the batch.
+// TM x TN = 256 x 256 (rows >= 4096) or 128 x 128 (4 waves as 2 x 2, wave = 64 x 64; two workgroups per CU).
+#include <cstdlib>
+
+#include "igemm.h"
+
+namespace prv2 {
+
+struct GemmSSParams {
+  const char* a;  // split-swizzled activations: row r, slab k at a + r * lda + k * 128
+  long long lda;  // bytes
+  const char* w;  // packed weights, one tap: row n, slab k at w + n * ldw + k * 128
+  long long ldw;
+  long long M;
+  int N;       // valid GEMM columns
+  int w_rows;  // rows present in w (N rounded up to 128)
+  int kslabs;
+  const float* bias;
+  const float* gamma;
+  const float* res;
+  int ld_res;
+  float* y;  // fp32 output rows (y_ss == nullptr)
+  int ldy;
+  char* y_ss;  // split-swizzled output rows
+  long long ldy_ss;
+  int act;
+  int tiles_n;
+};
+
+template <int WM, int WN, int RI, int RJ, bool OUT_SS>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_kernel(const GemmSSParams p) {
+  constexpr int NW = WM * WN, TM = WM * RI * 16, TN = WN * RJ * 16;
+  constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_DMA = TM / 8 / NW, B_DMA = TN / 8 / NW;  // 1 KB pieces per wave and slab
+  constexpr int STRIP_LD = RJ * 16 + 4, STRIP_BYTES = 16 * STRIP_LD * 4;
+  static_assert(NW * STRIP_BYTES <= 2 * STAGE, "epilogue strips fit in the staging memory");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+  int bid = blockIdx.x;
+  {  // XCD-aware: consecutive tiles (sharing rows / weights) on one XCD's L2 (blocks b, b + 8, ... share an XCD)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n;
+  const long long row0 = (long long)(bid / p.tiles_n) * TM;
+  const int col0 = tile_n * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m16 = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- LDS-DMA sources: piece i of this wave = rows (wave * X_DMA + i) * 8 + (lane >> 3), 16-byte slot lane & 7 -------
+  const int dr = lane >> 3, dsl = lane & 7;
+  const char* a_src[A_DMA];
+  const char* b_src[B_DMA];
+#pragma unroll
+  for (int i = 0; i < A_DMA; ++i) {
+    long long r = row0 + (wave * A_DMA + i) * 8 + dr;
+    r = r < p.M ? r : p.M - 1;  // rows behind M: any valid row (their outputs are never stored)
+    a_src[i] = p.a + r * p.lda + dsl * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_DMA; ++i) {
+    int n = col0 + (wave * B_DMA + i) * 8 + dr;
+    n = n < p.w_rows ? n : p.w_rows - 1;
+    b_src[i] = p.w + (long long)n * p.ldw + dsl * 16;
+  }
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  auto dma = [&](const char* src, unsigned dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(src) : "memory");
+  };
+  auto issue = [&](int stage, int k) {
+    const unsigned sb = smem_base + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) dma(a_src[i] + (long long)k * 128, sb + (wave * A_DMA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) dma(b_src[i] + (long long)k * 128, sb + A_BYTES + (wave * B_DMA + i) * 1024);
+  };
+
+  // ---- fragments: lane (m16, g) reads row m16 of a 16-row block, logical slot g (hi) / 4 + g (lo) ---------------------
+  const int key = (m16 >> 1) & 7;
+  const int a_off_hi = (wm * RI * 16 + m16) * 128 + ((g ^ key) << 4), a_off_lo = (wm * RI * 16 + m16) * 128 + (((4 + g) ^ key) << 4);
+  const int b_off_hi = A_BYTES + (wn * RJ * 16 + m16) * 128 + ((g ^ key) << 4);
+  const int b_off_lo = A_BYTES + (wn * RJ * 16 + m16) * 128 + (((4 + g) ^ key) << 4);
+
+  f32x4 acc[RI][RJ];
+#pragma unroll
+  for (int i = 0; i < RI; ++i)
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const char* const sb = smem + stage * STAGE;
+    bf16x8 bh[RJ], bl[RJ], ah[2], al[2];
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+      bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_off_hi + j * 2048);
+      bl[j] = *reinterpret_cast<const bf16x8*>(sb + b_off_lo + j * 2048);
+    }
+    ah[0] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi);
+    al[0] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo);
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      if (i + 1 < RI) {  // the next row block's fragments travel while this one multiplies
+        ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi + (i + 1) * 2048);
+        al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo + (i + 1) * 2048);
+      }
+      // smallest terms first (as gemm16_kernel): lo*hi, hi*lo, hi*hi; consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  for (int k = 0; k < p.kslabs; ++k) {
+    // my DMAs of slab k have landed; behind the barrier everyone's have, and everyone is done reading the other stage
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (k + 1 < p.kslabs) issue((k + 1) & 1, k + 1);
+    compute(k & 1);
+  }
+  asm volatile("s_barrier" ::: "memory");  // the staging memory becomes the epilogue strips
+
+  // ---- epilogue: one 16-row block at a time through a wave-private LDS strip -> whole 256-byte row segments ----------
+  float* const strip = reinterpret_cast<float*>(smem + wave * STRIP_BYTES);
+  const long long wrow0 = row0 + wm * RI * 16;
+  const int wcol0 = col0 + wn * RJ * 16;
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {  // (unrolled: acc is indexed by compile-time constants only; it never enters the lambda below)
+#pragma unroll
+    for (int j = 0; j < RJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) strip[(4 * g + e) * STRIP_LD + j * 16 + m16] = acc[i][j][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    dispatch_act(p.act, [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      if constexpr (!OUT_SS) {
+        constexpr int LPR = RJ * 4, RPI = 64 / LPR;  // lanes per row (16 bytes each), rows per instruction
+#pragma unroll
+        for (int q = 0; q < 16 / RPI; ++q) {
+          const int rl = q * RPI + lane / LPR, c4 = (lane % LPR) * 4;
+          const long long grow = wrow0 + i * 16 + rl;
+          const int gcol = wcol0 + c4;
+          if (grow < p.M && gcol < p.N) {
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(&strip[rl * STRIP_LD + c4]);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, rv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + gcol);
+            if (p.gamma) gv = *reinterpret_cast<const f32x4*>(p.gamma + gcol);
+            if (p.res) rv = *reinterpret_cast<const f32x4*>(p.res + grow * p.ld_res + gcol);
+            f32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = act_apply(cv[e] + bv[e], ACT);
+              if (p.gamma) t *= gv[e];
+              if (p.res) t += rv[e];
+              ov[e] = t;
+            }
+            float* dst = p.y + grow * p.ldy + gcol;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+          }
+        }
+      } else {
+        constexpr int GPR = RJ * 2, RPI = 64 / GPR;  // 8-column groups per row, rows per pass
+#pragma unroll
+        for (int q = 0; q < 16 / RPI; ++q) {
+          const int rl = q * RPI + lane / GPR, kg = lane % GPR;
+          const long long grow = wrow0 + i * 16 + rl;
+          const int gcol = wcol0 + kg * 8;
+          if (grow < p.M && gcol < p.N) {
+            const float* sp = &strip[rl * STRIP_LD + kg * 8];
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            if (p.bias) {
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gcol), b1 = *reinterpret_cast<const f32x4*>(p.bias + gcol + 4);
+              v0 += b0;
+              v1 += b1;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = act_apply(v0[e], ACT);
+              v1[e] = act_apply(v1[e], ACT);
+            }
+            bf16x4 h0, l0, h1, l1;
+            split_bf16(v0, h0, l0);
+            split_bf16(v1, h1, l1);
+            const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            char* const rowp = p.y_ss + grow * p.ldy_ss + (gcol >> 5) * 128;
+            const int chunk = (gcol & 31) >> 3, k2 = (int)((grow >> 1) & 7);
+            *reinterpret_cast<bf16x8*>(rowp + ((chunk ^ k2) << 4)) = hv;
+            *reinterpret_cast<bf16x8*>(rowp + (((4 + chunk) ^ k2) << 4)) = lv;
+          }
+        }
+      }
+    });
+    __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next row block
+  }
+}
+
+// fp32 rows -> split-swizzled rows (inputs that no kernel of ours produced: tests, the first layer of a chain)
+__global__ void __launch_bounds__(256) split_ss_kernel(const float* __restrict__ x, long long rows, int c, int ldx, char* __restrict__ y,
+                                                       long long ldy) {
+  const int groups = c >> 3;
+  const long long total = rows * groups;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / groups;
+    const int gi = (int)(t - r * groups);
+    const float* src = x + r * ldx + gi * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x4 h0, l0, h1, l1;
+    split_bf16(v0, h0, l0);
+    split_bf16(v1, h1, l1);
+    char* const rowp = y + r * ldy + (gi >> 2) * 128;
+    const int chunk = gi & 3, k2 = (int)((r >> 1) & 7);
+    *reinterpret_cast<bf16x8*>(rowp + ((chunk ^ k2) << 4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8*>(rowp + (((4 + chunk) ^ k2) << 4)) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+}  // namespace prv2
+
+using namespace prv2;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int prv2_split_ss(const float* x, int64_t rows, int32_t c, int32_t ldx, void* y_ss, void* stream) {
+  PRV2_REQUIRE(x && y_ss && rows > 0 && c > 0 && c % 32 == 0 && ldx >= c && ldx % 4 == 0 && al16(x) && al16(y_ss),
+               "split_ss: c must be a multiple of 32, rows 16-byte aligned (rows=%lld c=%d ldx=%d)", (long long)rows, c, ldx);
+  hipLaunchKernelGGL(split_ss_kernel, dim3(flat_grid(rows * (c >> 3), 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, c, ldx,
+                     reinterpret_cast<char*>(y_ss), (long long)c * 4);
+  PRV2_LAUNCH_CHECK("split_ss");
+  return 0;
+}
+
+extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias,
+                            const float* gamma, const float* res, int32_t ld_res, int32_t act, float* y, int32_t ldy, void* y_ss,
+                            void* stream) {
+  PRV2_REQUIRE(a_ss && w_packed && (y || y_ss) && !(y && y_ss), "gemm_ss: null pointer / exactly one of y, y_ss");
+  PRV2_REQUIRE(m > 0 && k > 0 && k % 32 == 0 && n > 0 && n % 8 == 0, "gemm_ss: k must be a multiple of 32, n of 8 (m=%lld k=%d n=%d)",
+               (long long)m, k, n);
+  PRV2_REQUIRE(al16(a_ss) && al16(w_packed) && (!bias || al16(bias)) && (!gamma || al16(gamma)), "gemm_ss: 16-byte alignment");
+  PRV2_REQUIRE(!y || (al16(y) && ldy % 4 == 0 && ldy >= n), "gemm_ss: y rows must be 16-byte aligned (ldy=%d)", ldy);
+  PRV2_REQUIRE(!res || (y && al16(res) && ld_res % 4 == 0 && ld_res >= n), "gemm_ss: res needs an fp32 output and aligned rows");
+  PRV2_REQUIRE(!y_ss || (al16(y_ss) && n % 32 == 0 && !gamma), "gemm_ss: a split output needs n %% 32 == 0 and no gamma");
+  GemmSSParams p = {};
+  p.a = reinterpret_cast<const char*>(a_ss);
+  p.lda = (long long)k * 4;
+  p.w = reinterpret_cast<const char*>(w_packed);
+  p.ldw = (long long)k * 4;
+  p.M = m;
+  p.N = n;
+  p.w_rows = (int)roundup(n, 128);
+  p.kslabs = k / 32;
+  p.bias = bias; p.gamma = gamma; p.res = res; p.ld_res = ld_res;
+  p.y = y; p.ldy = ldy;
+  p.y_ss = reinterpret_cast<char*>(y_ss);
+  p.ldy_ss = (long long)n * 4;
+  p.act = act;
+  hipStream_t s = (hipStream_t)stream;
+  const char* const fe = getenv("PRV2_GEMM_SS_TILE");  // A/B switch (128 / 256), read per call so that one process can time both
+  const int force = fe ? atoi(fe) : 0;
+  const bool big = force ? force == 256 : (cdiv(m, 256) * cdiv(n, 256) >= 160);
+  if (big) {
+    p.tiles_n = (int)cdiv(n, 256);
+    const dim3 grid((unsigned)(cdiv(m, 256) * p.tiles_n));
+    if (y_ss) hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, false>), grid, dim3(512), 0, s, p);
+    set_kernel("gemm_ss_kernel", 256, PRV2_PREC_BF16X3);
+  } else {
+    p.tiles_n = (int)cdiv(n, 128);
+    const dim3 grid((unsigned)(cdiv(m, 128) * p.tiles_n));
+    if (y_ss) hipLaunchKernelGGL((gemm_ss_kernel<2, 2, 4, 4, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_ss_kernel<2, 2, 4, 4, false>), grid, dim3(256), 0, s, p);
+    set_kernel("gemm_ss_kernel", 128, PRV2_PREC_BF16X3);
+  }
+  PRV2_LAUNCH_CHECK("gemm_ss");
+  return 0;
+}

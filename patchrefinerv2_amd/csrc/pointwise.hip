@@ -29,7 +29,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // one wave per row; the row lives in registers between the two passes (C <= 64*4*MAXV)
-template <int MAXV>
+// OUT_SS: the normalised row is written in the split-swizzled operand format of gemm_ss.hip (128 bytes per 32 channels:
+// [4 x 16 B bf16 hi | 4 x 16 B bf16 lo], slot c at c ^ ((row >> 1) & 7)); y / ldy then address bytes (ldy = 4 * C)
+template <int MAXV, bool OUT_SS = false>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, int64_t rows, int C, int ldx,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, int act, float* __restrict__ y, int ldy) {
@@ -69,7 +71,31 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         o.y = act_apply((v[i].y - mean) * rstd * ww.y + bb.y, act);
         o.z = act_apply((v[i].z - mean) * rstd * ww.z + bb.z, act);
         o.w = act_apply((v[i].w - mean) * rstd * ww.w + bb.w, act);
-        py[j] = o;
+        if constexpr (!OUT_SS) py[j] = o;
+        else {
+          // lanes 2m / 2m + 1 hold channels 8m .. 8m + 7: both assemble the eight values, the even lane stores the
+          // bf16 hi slot, the odd lane the lo slot (C % 8 == 0: partners are both inside the row)
+          float4 other;
+          other.x = __shfl_xor(o.x, 1, 64); other.y = __shfl_xor(o.y, 1, 64); other.z = __shfl_xor(o.z, 1, 64); other.w = __shfl_xor(o.w, 1, 64);
+          const bool odd = lane & 1;
+          const float4 lo4 = odd ? other : o, hi4 = odd ? o : other;  // channels 8m..8m+3, 8m+4..8m+7
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          typedef __bf16 b4v __attribute__((ext_vector_type(4)));
+          typedef __bf16 b8v __attribute__((ext_vector_type(8)));
+          const f4v a0 = {lo4.x, lo4.y, lo4.z, lo4.w}, a1 = {hi4.x, hi4.y, hi4.z, hi4.w};
+          const b4v h0 = __builtin_convertvector(a0, b4v), h1 = __builtin_convertvector(a1, b4v);
+          b8v outv;
+          if (!odd) outv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          else {
+            const b4v l0 = __builtin_convertvector(a0 - __builtin_convertvector(h0, f4v), b4v);
+            const b4v l1 = __builtin_convertvector(a1 - __builtin_convertvector(h1, f4v), b4v);
+            outv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+          const int grp = j >> 1;  // 8-channel group of the row
+          char* rowp = reinterpret_cast<char*>(y) + r * (int64_t)ldy + (grp >> 2) * 128;
+          const int slot = ((grp & 3) + (odd ? 4 : 0)) ^ (int)((r >> 1) & 7);
+          *reinterpret_cast<b8v*>(rowp + (slot << 4)) = outv;
+        }
       }
     }
   }
@@ -501,6 +527,24 @@ extern "C" int prv2_layernorm(const float* x, int64_t rows, int32_t c, int32_t l
   else
     hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, act, y, ldy);
   PRV2_LAUNCH_CHECK("layernorm");
+  return 0;
+}
+
+extern "C" int prv2_layernorm_ss(const float* x, int64_t rows, int32_t c, int32_t ldx, const float* weight, const float* bias, float eps,
+                                 void* y_ss, void* stream) {
+  PRV2_REQUIRE(x && y_ss && weight && bias, "layernorm_ss: null pointer");
+  PRV2_REQUIRE(rows > 0 && c > 0 && c % 32 == 0 && c <= 2048 && ldx >= c && ldx % 4 == 0 && aligned16(x) && aligned16(y_ss) &&
+                   aligned16(weight) && aligned16(bias),
+               "layernorm_ss: c must be a multiple of 32 (<= 2048), rows 16-byte aligned (rows=%lld c=%d)", (long long)rows, c);
+  int grid = (int)(cdiv(rows, 4) < 8192 ? cdiv(rows, 4) : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  float* y = reinterpret_cast<float*>(y_ss);
+  const int ldy = c * 4;  // bytes
+  if (c <= 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, 0, y, ldy);
+  else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, 0, y, ldy);
+  else if (c <= 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, 0, y, ldy);
+  else hipLaunchKernelGGL((layernorm_kernel<8, true>), dim3(grid), dim3(256), 0, s, x, rows, c, ldx, weight, bias, eps, 0, y, ldy);
+  PRV2_LAUNCH_CHECK("layernorm_ss");
   return 0;
 }
 

@@ -234,14 +234,26 @@ class DepthAnythingV2(StateDictModule):
         M = B * N
         h = torch.empty_like(x)
         taps = []
+        # large token counts (a batch of tiles): every Linear input is produced directly in the matrix pipe's operand format
+        # (ops.gemm_ss); same values bit for bit as the fp32-operand path below, so results do not depend on the batch
+        use_ss = self.prec == ops.L.PREC_BF16X3 and M >= ops.SS_MIN_ROWS and D % 32 == 0 and not ops.SS_DISABLED
         for i, blk in enumerate(P["blocks"]):
-            ops.layernorm_rows(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, ACT_NONE, h, D)
-            qkv = ops.linear(h, blk["qkv"])
-            a = ops.attention(qkv, B, N, heads, self.prec)
-            ops.linear(a, blk["proj"], out=x, gamma=blk["ls1"], res=x)          # x += ls1 * proj(attn)
-            ops.layernorm_rows(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, ACT_NONE, h, D)
-            f = ops.linear(h, blk["fc1"], act=ACT_GELU)
-            ops.linear(f, blk["fc2"], out=x, gamma=blk["ls2"], res=x)           # x += ls2 * fc2(gelu(fc1))
+            if use_ss:
+                ops.layernorm_ss(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, h)
+                qkv = ops.gemm_ss(h, blk["qkv"])
+                a = ops.attention(qkv, B, N, heads, self.prec, out_ss=True)
+                ops.gemm_ss(a, blk["proj"], out=x, gamma=blk["ls1"], res=x)
+                ops.layernorm_ss(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, h)
+                f = ops.gemm_ss(h, blk["fc1"], act=ACT_GELU, out_ss=True)
+                ops.gemm_ss(f, blk["fc2"], out=x, gamma=blk["ls2"], res=x)
+            else:
+                ops.layernorm_rows(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, ACT_NONE, h, D)
+                qkv = ops.linear(h, blk["qkv"])
+                a = ops.attention(qkv, B, N, heads, self.prec)
+                ops.linear(a, blk["proj"], out=x, gamma=blk["ls1"], res=x)          # x += ls1 * proj(attn)
+                ops.layernorm_rows(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, ACT_NONE, h, D)
+                f = ops.linear(h, blk["fc1"], act=ACT_GELU)
+                ops.linear(f, blk["fc2"], out=x, gamma=blk["ls2"], res=x)           # x += ls2 * fc2(gelu(fc1))
             if i in vit["taps"]:
                 t = torch.empty_like(x)
                 ops.layernorm_rows(x, M, D, D, P["norm_w"], P["norm_b"], 1e-6, ACT_NONE, t, D)

@@ -55,6 +55,10 @@ SIGNATURES = {
     "prv2_assemble_tokens": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "prv2_attention": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _L, _P]),
     "prv2_attention_bias": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _L, _P]),
+    "prv2_split_ss": (_I, [_P, _L, _I, _I, _P, _P]),
+    "prv2_layernorm_ss": (_I, [_P, _L, _I, _I, _P, _P, _F, _P, _P]),
+    "prv2_attention_ss": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _L, _P]),
+    "prv2_gemm_ss": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
     "prv2_attention_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "prv2_bicubic_resize": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "prv2_add": (_I, [_P, _I, _P, _I, _L, _I, _P, _I, _P]),

@@ -175,14 +175,24 @@ class MidasBeitCore(StateDictModule):
         h = torch.empty_like(x)
         biases = self._rel_pos_bias(gh, gw)
         taps = []
+        use_ss = self.prec == ops.L.PREC_BF16X3 and M >= ops.SS_MIN_ROWS and D % 32 == 0 and not ops.SS_DISABLED  # (see dav2.py)
         for i, blk in enumerate(P["blocks"]):
-            ops.layernorm_rows(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, ACT_NONE, h, D)
-            qkv = ops.linear(h, blk["qkv"])
-            a = ops.attention(qkv, B, N, heads, self.prec, bias=biases[i])
-            ops.linear(a, blk["proj"], out=x, gamma=blk["g1"], res=x)            # x += gamma_1 * proj(attn)
-            ops.layernorm_rows(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, ACT_NONE, h, D)
-            f = ops.linear(h, blk["fc1"], act=ACT_GELU)
-            ops.linear(f, blk["fc2"], out=x, gamma=blk["g2"], res=x)             # x += gamma_2 * mlp
+            if use_ss:
+                ops.layernorm_ss(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, h)
+                qkv = ops.gemm_ss(h, blk["qkv"])
+                a = ops.attention(qkv, B, N, heads, self.prec, bias=biases[i], out_ss=True)
+                ops.gemm_ss(a, blk["proj"], out=x, gamma=blk["g1"], res=x)
+                ops.layernorm_ss(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, h)
+                f = ops.gemm_ss(h, blk["fc1"], act=ACT_GELU, out_ss=True)
+                ops.gemm_ss(f, blk["fc2"], out=x, gamma=blk["g2"], res=x)
+            else:
+                ops.layernorm_rows(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, ACT_NONE, h, D)
+                qkv = ops.linear(h, blk["qkv"])
+                a = ops.attention(qkv, B, N, heads, self.prec, bias=biases[i])
+                ops.linear(a, blk["proj"], out=x, gamma=blk["g1"], res=x)            # x += gamma_1 * proj(attn)
+                ops.layernorm_rows(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, ACT_NONE, h, D)
+                f = ops.linear(h, blk["fc1"], act=ACT_GELU)
+                ops.linear(f, blk["fc2"], out=x, gamma=blk["g2"], res=x)             # x += gamma_2 * mlp
             if i in c["taps"]:
                 taps.append(x.clone())  # forward hook on blocks[i]: the raw block output
         layers = []

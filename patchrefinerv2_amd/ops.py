@@ -351,6 +351,42 @@ def layernorm_feat(x: Feat, weight, bias, eps: float = 1e-6, act: int = ACT_NONE
     return out
 
 
+# ---- split-swizzled ("ss") operands of the large ViT linears (csrc/gemm_ss.hip; include/prv2.h "Split-swizzled") --------------
+# An ss tensor is carried as a float32 [rows, C] container (same bytes per element as fp32); only the kernels interpret it.
+SS_DISABLED = False  # A/B and test switch: keep the ViT blocks on the fp32-operand kernels
+SS_MIN_ROWS = 2048  # token rows from which the ViT blocks run on the pre-split path (bit-identical to the fp32-operand path)
+
+
+def split_ss(x2d: torch.Tensor) -> torch.Tensor:
+    M, K = x2d.shape
+    _require_dev(x2d)
+    out = torch.empty((M, K), device=x2d.device, dtype=torch.float32)
+    L.check(L.load().prv2_split_ss(x2d.data_ptr(), M, K, x2d.stride(0), out.data_ptr(), _stream()), "split_ss")
+    return out
+
+
+def layernorm_ss(x: torch.Tensor, rows: int, c: int, ldx: int, weight, bias, eps: float, y_ss: torch.Tensor):
+    L.check(L.load().prv2_layernorm_ss(x.data_ptr(), rows, c, ldx, weight.data_ptr(), bias.data_ptr(), eps, y_ss.data_ptr(),
+                                       _stream()), "layernorm_ss")
+
+
+def gemm_ss(a_ss: torch.Tensor, cw: ConvW, out: Optional[torch.Tensor] = None, *, out_ss: bool = False, act: int = ACT_NONE,
+            gamma: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rows (split-swizzled) [M, K] @ W^T (+ bias, act, gamma, residual) -> fp32 rows, or split-swizzled rows (out_ss)"""
+    M, K = a_ss.shape
+    assert cw.prec == L.PREC_BF16X3 and cw.kh == 1 and cw.kw == 1 and cw.cin == K and K % 32 == 0, (cw.prec, cw.cin, K)
+    if out is None:
+        out = torch.empty((M, cw.cout), device=a_ss.device, dtype=torch.float32)
+    lib = L.load()
+
+    def call():
+        L.check(lib.prv2_gemm_ss(a_ss.data_ptr(), M, K, cw.w.data_ptr(), cw.cout, _ptr(cw.bias), _ptr(gamma), _ptr(res),
+                                 res.stride(0) if res is not None else 0, act, None if out_ss else out.data_ptr(), out.stride(0),
+                                 out.data_ptr() if out_ss else None, _stream()), "gemm_ss")
+    PROFILER.launch(lambda: lib.prv2_last_kernel().decode(), 2.0 * M * K * cw.cout, call, shape=f"{K}->{cw.cout} k1s1 1x{M}x1")
+    return out
+
+
 def patchify(img: Feat, p: int, ldo: int) -> torch.Tensor:
     gh, gw = img.h // p, img.w // p
     rows = torch.empty((img.n * gh * gw, ldo), device=img.device, dtype=torch.float32)
@@ -365,8 +401,10 @@ def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: 
     return tok
 
 
-def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``bias``: optional [heads, ntok, ld >= roundup(ntok, 64)] additive score bias shared by the batch (BEiT)"""
+def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32, bias: Optional[torch.Tensor] = None,
+              out_ss: bool = False) -> torch.Tensor:
+    """``bias``: optional [heads, ntok, ld >= roundup(ntok, 64)] additive score bias shared by the batch (BEiT);
+    ``out_ss``: write the output split-swizzled (the operand format of gemm_ss; bf16x3 only)"""
     out = torch.empty((b * ntok, heads * 64), device=qkv.device, dtype=torch.float32)
     lib = L.load()
     nbytes = lib.prv2_attention_workspace_bytes(b, ntok, heads, prec)
@@ -374,6 +412,13 @@ def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC
     if bias is not None:
         _require_dev(bias)
         assert bias.is_contiguous() and bias.shape[0] == heads and bias.shape[1] == ntok
+    if out_ss:
+        assert prec == L.PREC_BF16X3
+        PROFILER.launch("attention_bf16x3_kernel", 4.0 * b * heads * ntok * ntok * 64,
+                        lambda: L.check(lib.prv2_attention_ss(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias),
+                                                              bias.shape[2] if bias is not None else 0, out.data_ptr(), _ptr(ws),
+                                                              nbytes, _stream()), "attention_ss"))
+        return out
     PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel",
                     4.0 * b * heads * ntok * ntok * 64,
                     lambda: L.check(lib.prv2_attention_bias(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias),

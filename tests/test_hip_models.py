@@ -74,6 +74,39 @@ def test_dav2_vits_block_stack(P):
     close(out["temp_features"]["x_blocks_feat_3"].to_nchw(), ref["temp_features"]["x_blocks_feat_3"], 5e-5)
 
 
+def test_vit_blocks_presplit_path_is_bit_identical(P):
+    """a batch of tiles (>= ops.SS_MIN_ROWS token rows) runs the ViT blocks on the pre-split operand path (LayerNorm / attention /
+    GELU epilogues write the matrix pipe's operand format, gemm_ss_kernel consumes it by LDS-DMA); a single tile runs the
+    fp32-operand kernels: same bits, so per-tile results do not depend on the batch (DINOv2 blocks and BEiT blocks)"""
+    from patchrefinerv2_amd import ops
+    from patchrefinerv2_amd.dav2 import DepthAnythingV2
+    from patchrefinerv2_amd.zoedepth import ZoeDepth
+    mc = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], max_depth=80.0, vit=dict(depth=4, taps=[0, 1, 2, 3]))
+    m = DepthAnythingV2(**mc, prec="bf16x3")
+    m.load_state_dict(W.synth_state_dict(W.dav2_spec("", mc), seed=5))
+    x = rand_image(3, 3, 448, 448).to(DEV)                    # 3 x 1025 = 3075 token rows
+    a = m(x)["metric_depth"]
+    try:
+        ops.SS_DISABLED = True
+        b = m(x)["metric_depth"]
+    finally:
+        ops.SS_DISABLED = False
+    assert torch.equal(a, b)
+    assert torch.equal(a[1:2], m(x[1:2])["metric_depth"])     # one image alone (fp32-operand kernels)
+    from oracle.cases import ZOE_BEIT
+    zc = dict(ZOE_BEIT["zcfg"])
+    z = ZoeDepth.build(**zc, prec="bf16x3")
+    z.load_state_dict(W.synth_state_dict(W.zoedepth_spec("", zc), seed=6), strict=True)
+    xb = rand_image(4, 6, 320, 320).to(DEV)                   # 6 x 401 = 2406 token rows
+    a = z(xb)["metric_depth"]
+    try:
+        ops.SS_DISABLED = True
+        b = z(xb)["metric_depth"]
+    finally:
+        ops.SS_DISABLED = False
+    assert torch.equal(a, b)
+
+
 def test_fusion_unet(P, golden):
     from patchrefinerv2_amd.fusion import FusionUnet
     c = TINY_FUSION_UNET

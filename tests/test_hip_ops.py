@@ -540,3 +540,51 @@ def test_bicubic_input_stage(P, case):
     out = P.bicubic_resize(img.to(DEV), H, W).cpu()
     assert out.shape == (3, H, W)
     assert float((out - ref).abs().max()) <= 2.4e-7, float((out - ref).abs().max())   # <= 2 ulp at 1.0
+
+
+# ---- split-swizzled operand path of the large ViT linears (csrc/gemm_ss.hip) ---------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(100, 64, 128), (1037, 256, 384), (4100, 1024, 1024), (2500, 384, 1152)])
+@pytest.mark.parametrize("tile", ["128", "256"])
+def test_gemm_ss_bit_equal_to_gemm16(P, M, K, N, tile, monkeypatch):
+    """gemm_ss_kernel (pre-split operands, LDS-DMA) == gemm16_kernel (fp32 operands split in the kernel), BIT FOR BIT: same
+    split, same three products in the same order, same epilogue.  That equality is what lets the host pick the kernel by
+    problem size without making results depend on the batch.  Also vs the fp32 reference within the bf16x3 tolerance."""
+    monkeypatch.setenv("PRV2_GEMM_SS_TILE", tile)
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    gam, res = 1 + 0.1 * torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    cw = P.pack_conv(w.to(DEV), b.to(DEV), prec=P.L.PREC_BF16X3)
+    xd, gd, rd = x.to(DEV), gam.to(DEV), res.to(DEV)
+    xs = P.split_ss(xd)
+    for kw in (dict(), dict(act=P.ACT_GELU), dict(gamma=gd, res=rd)):
+        y16 = P.linear(xd, cw, **kw)
+        yss = P.gemm_ss(xs, cw, **kw)
+        assert torch.equal(y16, yss), kw.keys()
+    ref = x @ w.t() + b
+    assert float((yss.cpu() - (ref * gam + res)).abs().max()) < 2e-4 * float(ref.abs().max())
+    # chain with a split-swizzled intermediate (fc1 -> GELU -> fc2): the producer's split == the consumer's in-kernel split
+    w2 = torch.randn(K, N, generator=g) / N ** 0.5
+    cw2 = P.pack_conv(w2.to(DEV), None, prec=P.L.PREC_BF16X3)
+    a = P.linear(P.linear(xd, cw, act=P.ACT_GELU), cw2)
+    bq = P.gemm_ss(P.gemm_ss(xs, cw, act=P.ACT_GELU, out_ss=True), cw2)
+    assert torch.equal(a, bq)
+
+
+def test_layernorm_ss_and_attention_ss_feed_gemm_ss_bit_equal(P):
+    g = torch.Generator().manual_seed(5)
+    M, D = 777, 384
+    x = torch.randn(M, D, generator=g).to(DEV)
+    lw, lb = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    cw = P.pack_conv((torch.randn(3 * D, D, generator=g) / D ** 0.5).to(DEV), (torch.randn(3 * D, generator=g) * 0.1).to(DEV), prec=P.L.PREC_BF16X3)
+    h = torch.empty_like(x)
+    P.layernorm_rows(x, M, D, D, lw, lb, 1e-6, P.ACT_NONE, h, D)
+    hs = torch.empty_like(x)
+    P.layernorm_ss(x, M, D, D, lw, lb, 1e-6, hs)
+    qkv = P.linear(h, cw)
+    assert torch.equal(qkv, P.gemm_ss(hs, cw))
+    B, N, H = 3, 259, 6
+    cwp = P.pack_conv((torch.randn(D, D, generator=g) / D ** 0.5).to(DEV), None, prec=P.L.PREC_BF16X3)
+    a = P.attention(qkv, B, N, H, P.L.PREC_BF16X3)
+    a_ss = P.attention(qkv, B, N, H, P.L.PREC_BF16X3, out_ss=True)
+    assert torch.equal(P.linear(a, cwp), P.gemm_ss(a_ss, cwp))
