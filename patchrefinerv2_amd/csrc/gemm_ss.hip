@@ -279,7 +279,7 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
   hipStream_t s = (hipStream_t)stream;
   const char* const fe = getenv("PRV2_GEMM_SS_TILE");  // A/B switch (128 / 256), read per call so that one process can time both
   const int force = fe ? atoi(fe) : 0;
-  const bool big = force ? force == 256 : (cdiv(m, 256) * cdiv(n, 256) >= 160);
+  const bool big = force ? force == 256 : (cdiv(m, 256) * cdiv(n, 256) >= 200);  // measured: 256 x 256 tiles win from ~ 14 k rows x 1024 columns
   if (big) {
     p.tiles_n = (int)cdiv(n, 256);
     const dim3 grid((unsigned)(cdiv(m, 256) * p.tiles_n));

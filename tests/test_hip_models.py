@@ -85,6 +85,8 @@ def test_vit_blocks_presplit_path_is_bit_identical(P):
     m = DepthAnythingV2(**mc, prec="bf16x3")
     m.load_state_dict(W.synth_state_dict(W.dav2_spec("", mc), seed=5))
     x = rand_image(3, 3, 448, 448).to(DEV)                    # 3 x 1025 = 3075 token rows
+    old_min = ops.SS_MIN_ROWS
+    ops.SS_MIN_ROWS = 2048
     a = m(x)["metric_depth"]
     try:
         ops.SS_DISABLED = True
@@ -104,6 +106,7 @@ def test_vit_blocks_presplit_path_is_bit_identical(P):
         b = z(xb)["metric_depth"]
     finally:
         ops.SS_DISABLED = False
+    ops.SS_MIN_ROWS = old_min
     assert torch.equal(a, b)
 
 

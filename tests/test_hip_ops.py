@@ -564,7 +564,8 @@ def test_gemm_ss_bit_equal_to_gemm16(P, M, K, N, tile, monkeypatch):
     ref = x @ w.t() + b
     assert float((yss.cpu() - (ref * gam + res)).abs().max()) < 2e-4 * float(ref.abs().max())
     # chain with a split-swizzled intermediate (fc1 -> GELU -> fc2): the producer's split == the consumer's in-kernel split
-    w2 = torch.randn(K, N, generator=g) / N ** 0.5
+    K2 = max(K, 128)  # (a 64-column layer would go to the generic kernel on the fp32-operand side)
+    w2 = torch.randn(K2, N, generator=g) / N ** 0.5
     cw2 = P.pack_conv(w2.to(DEV), None, prec=P.L.PREC_BF16X3)
     a = P.linear(P.linear(xd, cw, act=P.ACT_GELU), cw2)
     bq = P.gemm_ss(P.gemm_ss(xs, cw, act=P.ACT_GELU, out_ss=True), cw2)
