@@ -53,6 +53,7 @@ def parse():
                          "rank 0 (SURVEY.md 8e cfg 5), all = every rank keeps its own map (the reference's data parallelism)")
     ap.add_argument("--max-batch", type=int, default=14, help="patches per launch batch (results are batch independent)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over")
+    ap.add_argument("--hip-graph", action="store_true", help="capture the device side of a frame into a hipGraph and replay it per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layer-report", default=None, help="write a per-layer-shape timing table (extra instrumented frame)")
@@ -148,6 +149,7 @@ def main():
     w = WORKLOADS[name]
     mc = model_config(name, prec=args.prec, max_batch=args.max_batch, n_streams=args.streams)
     mc["config"]["device"] = str(dev)
+    mc["config"]["hip_graph"] = bool(args.hip_graph)
     model = build_model(mc)
     sd = W.synth_state_dict(state_spec(name), seed=0)
     model.load_state_dict(sd, strict=True)
@@ -225,7 +227,7 @@ def main():
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
                     coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else w.get("zoe_type", "DA-ZoeDepth") + "/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
-                    max_batch=args.max_batch, streams=args.streams, out_shape=list(out.shape) if out is not None else None))
+                    max_batch=args.max_batch, streams=args.streams, hip_graph=bool(args.hip_graph), out_shape=list(out.shape) if out is not None else None))
 
     if world > 1:
         nt = w["patches"]

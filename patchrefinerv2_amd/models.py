@@ -219,20 +219,19 @@ class _PatchModel(StateDictModule):
         fac = np.array([1 / W * pw, 1 / H * ph, 1 / W * pw, 1 / H * ph], dtype=np.float32)
         return (bb * fac[None]).astype(np.float32)
 
-    def _prepare_batch(self, image_hr_chw, tiles, tile_cfg, coarse_feats: List[Feat], coarse_depth: Feat):
+    def _prepare_batch(self, image_hr_chw, t_dev, boxes_dev, tile_cfg, coarse_feats: List[Feat], coarse_depth: Feat):
+        """t_dev: int32 [k, 2] (h_start, w_start) of the batch's tiles, boxes_dev: fp32 [k, 4] lr-frame ROI boxes, on the device"""
         dev = image_hr_chw.device
         ph, pw = self.patch_process_shape
         rh, rw = tile_cfg["patch_raw_shape"]
-        K = len(tiles)
-        t = torch.tensor(tiles, dtype=torch.int32).to(dev)
+        K = t_dev.shape[0]
         crops = Feat.alloc(K, ph, pw, self.crop_channels, dev, pad_to=4)
-        ops.crop_resize(image_hr_chw, t, rh, rw, ph, pw, self.crop_mean, self.crop_std, crops)
+        ops.crop_resize(image_hr_chw, t_dev, rh, rw, ph, pw, self.crop_mean, self.crop_std, crops)
         if not self.needs_coarse:
             return crops, None, None
-        boxes = torch.from_numpy(self._boxes(tiles, tile_cfg)).to(dev)
         # roi_align(feat, boxes, (h, w), h / ph, aligned=True) per level (patchrefinerplus.py:268-276)
-        rois = [ops.roi_align(f, boxes, f.h / ph, f.h, f.w) for f in coarse_feats]
-        depth_roi = ops.roi_align(coarse_depth, boxes, coarse_depth.h / ph, coarse_depth.h, coarse_depth.w,
+        rois = [ops.roi_align(f, boxes_dev, f.h / ph, f.h, f.w) for f in coarse_feats]
+        depth_roi = ops.roi_align(coarse_depth, boxes_dev, coarse_depth.h / ph, coarse_depth.h, coarse_depth.w,
                                   out=Feat(torch.empty((K, coarse_depth.h, coarse_depth.w, 1), device=dev)))
         return crops, rois, depth_roi
 
@@ -262,15 +261,7 @@ class _PatchModel(StateDictModule):
                                                                               tile_cfg["patch_split_num"])
         assert image_hr.shape[0] == 1
         dev = image_hr.device
-        ph, pw = self.patch_process_shape
-        rh, rw = tile_cfg["patch_raw_shape"]
-        RH, RW = tile_cfg["patch_reensemble_shape"]
-
-        if self.needs_coarse:
-            coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
-            coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
-        else:
-            coarse_feats = coarse_prediction = coarse_depth = None
+        # ---- host: the frame's tile plan (consumes Python's ``random`` in the reference's order) ----------------------
         passes = self.plan_tiles(tile_cfg, cai_mode, process_num)
         if shard is not None and shard[1] > 1:
             # every rank consumed ``random`` identically above; the plan that counts is rank 0's (a rank seeded
@@ -278,15 +269,57 @@ class _PatchModel(StateDictModule):
             passes = self._sync_plan(passes)
         flat = [t for p in passes for t in p["raw"]]
         self.last_plan = passes
-
-        # ---- per-patch networks over the flat tile list (any batching; optional rank sharding) ----
-        image_chw = image_hr[0].contiguous().float()
         idx = list(range(len(flat)))
         if shard is not None:
-            rank, world = shard
-            idx = idx[rank::world]
+            idx = idx[shard[0]::shard[1]]
+        mine = [flat[i] for i in idx]
+        # the plan's coordinates: [my tiles (h, w) | every tile's blend coordinates (h, w)] and my tiles' ROI boxes
+        n_mine, n_all = len(mine), len(flat)
+        tiles_i = torch.tensor(mine + [t for p in passes for t in p["proc"]], dtype=torch.int32).view(-1, 2)
+        boxes_f = torch.from_numpy(self._boxes(mine, tile_cfg)) if self.needs_coarse else torch.zeros((n_mine, 4))
+        plan = dict(kinds=[p["kind"] for p in passes], counts=[len(p["raw"]) for p in passes], n_mine=n_mine, n_all=n_all)
+
+        use_graph = bool(getattr(self, "hip_graph", False)) and shard is None and not ops.PROFILER.enabled
+        if use_graph:
+            depth, coarse_prediction = self._graph_frame(image_lr, image_hr, tiles_i, boxes_f, plan, tile_cfg, process_num, cai_mode)
+        else:
+            tiles_dev = tiles_i.to(dev, non_blocking=True)
+            boxes_dev = boxes_f.to(dev, non_blocking=True)
+            depth, coarse_prediction = self._device_frame(image_lr, image_hr, tiles_dev, boxes_dev, plan, tile_cfg, process_num,
+                                                          shard, gather_dst)
+            if depth is None:  # gather-to-one: this rank's part of the frame is done
+                return None, dict(rgb=image_lr, depth_pred=None, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+        if not return_device:
+            # the reference returns a fresh CPU tensor; through torch's caching pinned-memory allocator the 33 MB D2H runs at
+            # PCIe rate instead of being staged through a pageable buffer (3.4 -> ~1 ms per 4K frame)
+            hostd = torch.empty(depth.shape, dtype=depth.dtype, pin_memory=True)
+            hostd.copy_(depth, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            depth = hostd
+        elif use_graph:
+            depth = depth.clone()  # the graph's own output buffer is rewritten by the next replay
+        return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+
+    def _device_frame(self, image_lr, image_hr, tiles_dev, boxes_dev, plan, tile_cfg, process_num, shard=None, gather_dst=None):
+        """Everything of a frame that runs on the device, given the plan's coordinates in device memory: coarse forward, the
+        per-patch networks over this rank's tiles (batches round-robin over the HIP streams), the exchange (sharded mode), the
+        overlap blend.  No host synchronisation inside (captured into a hipGraph by ``_graph_frame``).
+        tiles_dev: int32 [n_mine + n_all, 2]: this rank's tile origins, then every tile's blend coordinates."""
+        dev = image_hr.device
+        ph, pw = self.patch_process_shape
+        rh, rw = tile_cfg["patch_raw_shape"]
+        RH, RW = tile_cfg["patch_reensemble_shape"]
+        n_mine, n_all = plan["n_mine"], plan["n_all"]
+        if self.needs_coarse:
+            coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
+            coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
+        else:
+            coarse_feats = coarse_prediction = coarse_depth = None
+
+        # ---- per-patch networks over the tile list (any batching; optional rank sharding) ----
+        image_chw = image_hr[0].contiguous().float()
         bs = max(1, int(getattr(self, "max_batch", None) or process_num))
-        preds = torch.empty((len(idx), 1, ph, pw), device=dev)  # this rank's predictions, in tile order
+        preds = torch.empty((n_mine, 1, ph, pw), device=dev)  # this rank's predictions, in tile order
         # Tile batches are independent: they are issued round-robin on ``n_streams`` HIP streams so that the
         # HBM-bound kernels of one batch (gathers, LayerNorm, gate 1x1s) run beside the MFMA-bound convs of another.
         n_streams = max(1, int(getattr(self, "n_streams", None) or 1))
@@ -295,53 +328,77 @@ class _PatchModel(StateDictModule):
         if n_streams > 1:
             ready = torch.cuda.Event()
             ready.record(main)
-        for bi, s in enumerate(range(0, len(idx), bs)):
-            sel = idx[s:s + bs]
+        for bi, s in enumerate(range(0, n_mine, bs)):
+            e = min(s + bs, n_mine)
             st = streams[bi % len(streams)]
             with torch.cuda.stream(st):
                 if n_streams > 1 and bi < len(streams):
                     st.wait_event(ready)
-                crops, rois, depth_roi = self._prepare_batch(image_chw, [flat[i] for i in sel], tile_cfg, coarse_feats,
+                crops, rois, depth_roi = self._prepare_batch(image_chw, tiles_dev[s:e], boxes_dev[s:e], tile_cfg, coarse_feats,
                                                              coarse_depth)
-                self.infer_forward(crops, rois, depth_roi, out=preds[s:s + len(sel)])
+                self.infer_forward(crops, rois, depth_roi, out=preds[s:e])
         if n_streams > 1:
             for st in streams:
                 main.wait_stream(st)
         if shard is not None and shard[1] > 1:
-            preds = self._gather_predictions(preds, len(flat), shard, gather_dst)
-            if preds is None:  # gather-to-one: this rank's part of the frame is done
-                return None, dict(rgb=image_lr, depth_pred=None, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
-        preds = preds.view(len(flat), ph, pw)
+            preds = self._gather_predictions(preds, n_all, shard, gather_dst)
+            if preds is None:
+                return None, coarse_prediction
+        preds = preds.view(n_all, ph, pw)
 
         # ---- overlap blend, in the reference's order ----------------------------------------------
         mask = blend_mask((ph, pw), self.blend_border, 0.0, dev)
         ram = DeviceRunningAverageMap(RH, RW, dev)
-        # tile lists of all passes in ONE upload (a pageable H2D per pass is a synchronising copy between the blend kernels)
-        counts = [len(p["raw"]) for p in passes]
-        all_proc = torch.tensor([t for p in passes for t in p["proc"]], dtype=torch.int32).view(-1, 2).to(dev)
+        all_proc = tiles_dev[n_mine:]
         o = 0
-        for p, k in zip(passes, counts):
+        for kind, k in zip(plan["kinds"], plan["counts"]):
             pr = preds[o:o + k]
-            tiles_dev = all_proc[o:o + k]
+            tdev = all_proc[o:o + k]
             o += k
-            if p["kind"] == "init":
-                ram.paste(pr, mask, tiles_dev, ph, pw)
-            elif p["kind"] == "grid":
-                ram.update(pr, mask, tiles_dev, ph, pw)
+            if kind == "init":
+                ram.paste(pr, mask, tdev, ph, pw)
+            elif kind == "grid":
+                ram.update(pr, mask, tdev, ph, pw)
             else:
                 mask_r = blend_mask((rh, rw), self.blend_border, 1e-3, dev)  # generatemask(...) + 1e-3 (patchrefinerplus.py:514)
                 ram.resize(tile_cfg["image_raw_shape"])
                 if k:
-                    ram.update(pr, mask_r, tiles_dev, rh, rw)
-        depth = ram.avg[None, None]
-        if not return_device:
-            # the reference returns a fresh CPU tensor; through torch's caching pinned-memory allocator the 33 MB D2H runs at
-            # PCIe rate instead of being staged through a pageable buffer (3.4 -> ~1 ms per 4K frame)
-            host = torch.empty(depth.shape, dtype=depth.dtype, pin_memory=True)
-            host.copy_(depth, non_blocking=True)
+                    ram.update(pr, mask_r, tdev, rh, rw)
+        return ram.avg[None, None], coarse_prediction
+
+    def _graph_frame(self, image_lr, image_hr, tiles_i, boxes_f, plan, tile_cfg, process_num, cai_mode):
+        """``hip_graph=True``: the device side of a frame (``_device_frame``: a few thousand launches on up to ``n_streams``
+        streams) is captured once per (mode, geometry, batching) into a hipGraph and replayed per frame; the per-frame inputs
+        -- the two images and the plan's coordinates (random tiles change from frame to frame) -- are copied into the graph's
+        static buffers first.  The first frame of a key runs eagerly (it fills the constant caches: blend masks, position
+        embeddings / relative-position biases), the second is captured.  Results are bit-identical to the eager path."""
+        dev = image_hr.device
+        key = (cai_mode, process_num, tuple(tile_cfg["image_raw_shape"]), tuple(tile_cfg["patch_split_num"]), tuple(image_lr.shape),
+               getattr(self, "max_batch", None), getattr(self, "n_streams", 1), tuple(plan["counts"]), str(dev))
+        cache = self.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None:  # first frame: eager (warm-up of every constant cache)
+            cache[key] = "warm"
+            return self._device_frame(image_lr, image_hr, tiles_i.to(dev, non_blocking=True), boxes_f.to(dev, non_blocking=True), plan,
+                                      tile_cfg, process_num)
+        if ent == "warm":
+            st = dict(lr=torch.empty_like(image_lr), hr=torch.empty_like(image_hr), tiles=torch.empty(tiles_i.shape, dtype=torch.int32, device=dev),
+                      boxes=torch.empty(boxes_f.shape, dtype=torch.float32, device=dev),
+                      h_tiles=torch.empty(tiles_i.shape, dtype=torch.int32).pin_memory(), h_boxes=torch.empty(boxes_f.shape, dtype=torch.float32).pin_memory())
             torch.cuda.current_stream(dev).synchronize()
-            depth = host
-        return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["depth"], st["coarse"] = self._device_frame(st["lr"], st["hr"], st["tiles"], st["boxes"], plan, tile_cfg, process_num)
+            st["graph"] = g
+            cache[key] = ent = st
+        ent["h_tiles"].copy_(tiles_i)
+        ent["h_boxes"].copy_(boxes_f)
+        ent["lr"].copy_(image_lr, non_blocking=True)
+        ent["hr"].copy_(image_hr, non_blocking=True)
+        ent["tiles"].copy_(ent["h_tiles"], non_blocking=True)
+        ent["boxes"].copy_(ent["h_boxes"], non_blocking=True)
+        ent["graph"].replay()
+        return ent["depth"], (ent["coarse"].clone() if ent["coarse"] is not None else None)
 
     def _gather_predictions(self, preds, n_total, shard, dst=None):
         """The path's only exchange step (RCCL over xGMI): the per-rank prediction stacks, padded to a common length.
@@ -464,6 +521,7 @@ class _PatchModel(StateDictModule):
         self.device = torch.device(config.get("device", "cuda"))
         self.max_batch = config.get("max_batch", None)
         self.n_streams = config.get("n_streams", 1)
+        self.hip_graph = bool(config.get("hip_graph", False))  # capture + replay the device side of a frame (_graph_frame)
         self.strategy_refiner_target = config.strategy_refiner_target
         self.fusion_feat_level = config.fusion_feat_level
         ctype = config.coarse_branch["type"]

@@ -330,6 +330,31 @@ def test_batching_independence(P):
         assert torch.equal(a, d)
 
 
+@pytest.mark.parametrize("kind", ["PatchRefiner", "PatchRefinerPlus"])
+def test_hip_graph_replay_is_bit_identical(P, kind):
+    """hip_graph=True: the device side of a frame (coarse forward, tile batches on 3 streams, blend) captured once into a
+    hipGraph and replayed -- the eager first frame, the captured second frame and further replays (other image, other random
+    tiles: the plan's coordinates are graph INPUTS) all equal the eager model bit for bit"""
+    c, sd = (E2E_V1, e2e_v1_sd()) if kind == "PatchRefiner" else (E2E_V2, e2e_v2_sd())
+    mode = "r8" if kind == "PatchRefiner" else "r4"
+    eager = _build(kind, c, sd, max_batch=3, n_streams=3)
+    graph = _build(kind, c, sd, max_batch=3, n_streams=3, hip_graph=True)
+    tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+    for it, (img_seed, rnd_seed) in enumerate(((0, 621), (0, 621), (7, 5), (0, 621), (9, 1234))):
+        hr = rand_image(img_seed, 1, *c["raw"]).to(DEV)
+        outs = []
+        for m in (eager, graph):
+            random.seed(rnd_seed)
+            d, log = m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tc, image_lr=m.resizer(hr), image_hr=hr)
+            outs.append((d, log["coarse_prediction"].clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), it
+    assert any(isinstance(v, dict) for v in graph._graphs.values())  # really captured
+    m1a, _ = _run(eager, c, "m1")
+    m1b, _ = _run(graph, c, "m1")   # another mode: its own graph (first call eager)
+    m1c, _ = _run(graph, c, "m1")
+    assert torch.equal(m1a, m1b) and torch.equal(m1a, m1c)
+
+
 def test_rejects_cpu_inputs_and_bad_shapes(P):
     c = E2E_V1
     m = _build("PatchRefiner", c, e2e_v1_sd())
@@ -624,7 +649,9 @@ def _one_tile(model, ora, hr, tile, tile_cfg):
     feats, cp = model.coarse_forward(lr_d)
     cd = Feat(cp.view(1, cp.shape[-2], cp.shape[-1], 1))
     tc = model.prepare_tile_cfg(tile_cfg["image_raw_shape"], tile_cfg["patch_split_num"])
-    crops, rois, droi = model._prepare_batch(hr_d[0].contiguous(), [tile], tc, feats, cd)
+    t_dev = torch.tensor([tile], dtype=torch.int32, device=DEV)
+    boxes = torch.from_numpy(model._boxes([tile], tc)).to(DEV)
+    crops, rois, droi = model._prepare_batch(hr_d[0].contiguous(), t_dev, boxes, tc, feats, cd)
     pred = model.infer_forward(crops, rois, droi)
     rh, rw = tc["patch_raw_shape"]
     lr = lr_d.cpu()
