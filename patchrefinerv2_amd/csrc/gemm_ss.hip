@@ -41,10 +41,10 @@ struct GemmSSParams {
   char* y_ss;  // split-swizzled output rows
   long long ldy_ss;
   int act;
-  int tiles_n;
+  int tiles_n, tiles_m, blocked;
 };
 
-template <int WM, int WN, int RI, int RJ, bool OUT_SS>
+template <int WM, int WN, int RI, int RJ, bool OUT_SS, int ACT>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_kernel(const GemmSSParams p) {
   constexpr int NW = WM * WN, TM = WM * RI * 16, TN = WN * RJ * 16;
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
@@ -58,8 +58,20 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tile_n = bid % p.tiles_n;
-  const long long row0 = (long long)(bid / p.tiles_n) * TM;
+  // The ~32 tiles an XCD has in flight (one per CU, consecutive ids) step through K together: a slab of A rows / W columns
+  // is fetched into that XCD's L2 once and DMA'd by every tile that shares it.  4 x 8 blocks of tiles share 12 such slabs
+  // per step instead of the 18 of a 2 x 16 run (wide layers) -- p.blocked: tiles_n % 8 == 0; ids behind tiles_m are idle
+  int tile_m, tile_n;
+  if (p.blocked) {
+    const int blk = bid >> 5, within = bid & 31, bpr = p.tiles_n >> 3;
+    tile_m = (blk / bpr) * 4 + (within >> 3);
+    tile_n = (blk % bpr) * 8 + (within & 7);
+    if (tile_m >= p.tiles_m) return;
+  } else {
+    tile_n = bid % p.tiles_n;
+    tile_m = bid / p.tiles_n;
+  }
+  const long long row0 = (long long)tile_m * TM;
   const int col0 = tile_n * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, g = lane >> 4;
@@ -153,8 +165,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_
       for (int e = 0; e < 4; ++e) strip[(4 * g + e) * STRIP_LD + j * 16 + m16] = acc[i][j][e];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    dispatch_act(p.act, [&](auto act_c) {
-      constexpr int ACT = decltype(act_c)::value;
+    {  // (the activation is a template parameter: with a run-time dispatch around this block hipcc spilled a third of the
+       //  accumulators to scratch at the loop exit -- 2.9x the output bytes in WRITE_SIZE / FETCH_SIZE)
       if constexpr (!OUT_SS) {
         constexpr int LPR = RJ * 4, RPI = 64 / LPR;  // lanes per row (16 bytes each), rows per instruction
 #pragma unroll
@@ -212,7 +224,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_
           }
         }
       }
-    });
+    }
     __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next row block
   }
 }
@@ -280,19 +292,34 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
   const char* const fe = getenv("PRV2_GEMM_SS_TILE");  // A/B switch (128 / 256), read per call so that one process can time both
   const int force = fe ? atoi(fe) : 0;
   const bool big = force ? force == 256 : (cdiv(m, 256) * cdiv(n, 256) >= 200);  // measured: 256 x 256 tiles win from ~ 14 k rows x 1024 columns
+  PRV2_REQUIRE(act == PRV2_ACT_NONE || act == PRV2_ACT_GELU, "gemm_ss: activation %d (built: none, GELU -- what the ViT blocks use)", act);
+#define PRV2_GSS(WM_, WN_, RI_, RJ_, NT_)                                                                                         \
+  do {                                                                                                                            \
+    if (y_ss) {                                                                                                                   \
+      if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, true, PRV2_ACT_GELU>), grid, dim3(NT_), 0, s, p);  \
+      else hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, true, PRV2_ACT_NONE>), grid, dim3(NT_), 0, s, p);               \
+    } else {                                                                                                                      \
+      if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, false, PRV2_ACT_GELU>), grid, dim3(NT_), 0, s, p); \
+      else hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, false, PRV2_ACT_NONE>), grid, dim3(NT_), 0, s, p);              \
+    }                                                                                                                             \
+  } while (0)
+  const char* const be = getenv("PRV2_GEMM_SS_BLOCKED");  // A/B switch
   if (big) {
     p.tiles_n = (int)cdiv(n, 256);
-    const dim3 grid((unsigned)(cdiv(m, 256) * p.tiles_n));
-    if (y_ss) hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, true>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, false>), grid, dim3(512), 0, s, p);
+    p.tiles_m = (int)cdiv(m, 256);
+    p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
+    const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
+    PRV2_GSS(2, 4, 8, 4, 512);
     set_kernel("gemm_ss_kernel", 256, PRV2_PREC_BF16X3);
   } else {
     p.tiles_n = (int)cdiv(n, 128);
-    const dim3 grid((unsigned)(cdiv(m, 128) * p.tiles_n));
-    if (y_ss) hipLaunchKernelGGL((gemm_ss_kernel<2, 2, 4, 4, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_ss_kernel<2, 2, 4, 4, false>), grid, dim3(256), 0, s, p);
+    p.tiles_m = (int)cdiv(m, 128);
+    p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
+    const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
+    PRV2_GSS(2, 2, 4, 4, 256);
     set_kernel("gemm_ss_kernel", 128, PRV2_PREC_BF16X3);
   }
+#undef PRV2_GSS
   PRV2_LAUNCH_CHECK("gemm_ss");
   return 0;
 }

@@ -24,7 +24,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
-for M in (769, 1037, 4100, 14350):
+for M in (1037, 4100, 14350):
     for K, N in ((1024, 3072), (1024, 1024), (1024, 4096), (4096, 1024)):
         x = torch.randn(M, K, device="cuda")
         cw = P.pack_conv(torch.randn(N, K, device="cuda") / K ** 0.5, torch.randn(N, device="cuda") * 0.1, prec=pr)
@@ -33,9 +33,12 @@ for M in (769, 1037, 4100, 14350):
         t0 = timeit(lambda: P.linear(x, cw))
         row = f"M={M:6d} K={K:5d} N={N:5d}  gemm16 {t0:7.3f} ms {2.0 * M * K * N / t0 / 1e9:6.1f} TF |"
         for tile in ("128", "256"):
-            os.environ["PRV2_GEMM_SS_TILE"] = tile
-            y1 = P.gemm_ss(xs, cw)
-            t1 = timeit(lambda: P.gemm_ss(xs, cw))
-            row += f" ss{tile} {t1:7.3f} ms {2.0 * M * K * N / t1 / 1e9:6.1f} TF eq={bool(torch.equal(y0, y1))} |"
+            for blocked in ("0", "1"):
+                os.environ["PRV2_GEMM_SS_TILE"] = tile
+                os.environ["PRV2_GEMM_SS_BLOCKED"] = blocked
+                y1 = P.gemm_ss(xs, cw)
+                t1 = timeit(lambda: P.gemm_ss(xs, cw))
+                row += f" ss{tile}{'b' if blocked == '1' else ' '} {t1:7.3f} ms {2.0 * M * K * N / t1 / 1e9:6.1f} TF eq={bool(torch.equal(y0, y1))} |"
         os.environ.pop("PRV2_GEMM_SS_TILE")
+        os.environ.pop("PRV2_GEMM_SS_BLOCKED")
         print(row, flush=True)
