@@ -305,7 +305,16 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
   char* const Vt = smem + 64 * AB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
-  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (ids b, b + 8, ... share one), so consecutive ids
+  // are remapped to one XCD -- the query tiles of a (batch, head) then read its K / V through ONE L2 instead of eight
+  // (PMC before: L2 hit rate 26 %, 5.5x the unique bytes fetched)
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int qtiles = (N + AT_BQ - 1) / AT_BQ;
+  const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const long long bh = (long long)b * heads + head;
 
   // Q fragments (B operand of S^T): lane (q = r32, half) holds Q[q][16ks + 8half + j]
@@ -325,25 +334,35 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ld_row = tid >> 2, ld_q = tid & 3;  // staging: 64 rows x 4 quarters (64 B each) per plane
+  // K / V tile k+1 travels from global memory into registers WHILE tile k is multiplied, and is written to LDS behind the
+  // barrier that retires tile k (load-early / write-late): the load latency used to be exposed once per 64 keys
+  f32x4 kreg[4];
+  uint2 vreg[8];
+  auto fetch = [&](int k0) {
+    // K rows: [hi 128 B | lo 128 B] (256 B contiguous in Ks); V^T rows: 128 B from each plane
+    const int key = k0 + ld_row;
+    const char* ksrc = reinterpret_cast<const char*>(Ks + (bh * N + (key < N ? key : 0)) * 128) + ld_q * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kreg[i] = *reinterpret_cast<const f32x4*>(ksrc + i * 16);
+    const long long vrow = (bh * 64 + ld_row) * Npad + k0;
+    const char* vsrc = reinterpret_cast<const char*>((ld_q < 2 ? VtH : VtL) + vrow) + (ld_q & 1) * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vreg[i] = *reinterpret_cast<const uint2*>(vsrc + i * 8);
+  };
+  fetch(0);
   for (int k0 = 0; k0 < N; k0 += AT_BK) {
     __syncthreads();
     {
-      // K rows: [hi 128 B | lo 128 B] (256 B contiguous in Ks); V^T rows: 128 B from each plane
-      const int key = k0 + ld_row;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const char* ksrc = reinterpret_cast<const char*>(Ks + (bh * N + (key < N ? key : 0)) * 128) + ld_q * 64;
+      const bool kvalid = (k0 + ld_row) < N;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(ksrc + i * 16);
-        *reinterpret_cast<f32x4*>(Kt + ld_row * AB_KP + ld_q * 64 + i * 16) = key < N ? v : z;
-      }
-      const long long vrow = (bh * 64 + ld_row) * Npad + k0;
-      const char* vsrc = reinterpret_cast<const char*>((ld_q < 2 ? VtH : VtL) + vrow) + (ld_q & 1) * 64;
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Kt + ld_row * AB_KP + ld_q * 64 + i * 16) = kvalid ? kreg[i] : z;
 #pragma unroll
       for (int i = 0; i < 8; ++i)  // 8-byte stores: the 264-byte pitch is only 8-byte aligned
-        *reinterpret_cast<uint2*>(Vt + ld_row * AB_VP + ld_q * 64 + i * 8) = *reinterpret_cast<const uint2*>(vsrc + i * 8);
+        *reinterpret_cast<uint2*>(Vt + ld_row * AB_VP + ld_q * 64 + i * 8) = vreg[i];
     }
     __syncthreads();
+    if (k0 + AT_BK < N) fetch(k0 + AT_BK);
 
     // S^T tiles: rows = keys (t*32 + row), cols = this wave's 32 queries
     f32x16 st[2];
@@ -486,7 +505,7 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   __bf16* VtL = VtH + (int64_t)b * heads * 64 * npad;
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
-  dim3 g2((unsigned)cdiv(ntok, AT_BQ), (unsigned)heads, (unsigned)b);
+  dim3 g2((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
   char* oss = reinterpret_cast<char*>(out_ss);
   if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<true>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
   else hipLaunchKernelGGL(attention_bf16x3_kernel<false>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);

@@ -291,7 +291,10 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
   hipStream_t s = (hipStream_t)stream;
   const char* const fe = getenv("PRV2_GEMM_SS_TILE");  // A/B switch (128 / 256), read per call so that one process can time both
   const int force = fe ? atoi(fe) : 0;
-  const bool big = force ? force == 256 : (cdiv(m, 256) * cdiv(n, 256) >= 200);  // measured: 256 x 256 tiles win from ~ 14 k rows x 1024 columns
+  const long long t256 = cdiv(m, 256) * cdiv(n, 256);
+  // 256 x 256 tiles (one workgroup per CU) when they fill whole rounds of the 256 CUs; otherwise 128 x 128 (two per CU).
+  // Measured (tools/probes/gemm_ss_bench.py): 14350 x 1024 -> 1024..4096: 375-425 vs 335-385 TF; 4100 rows: 128-tiles win but on 3072 columns
+  const bool big = force ? force == 256 : (t256 >= 180 && (double)t256 / (double)(cdiv(t256, 256) * 256) >= 0.75);
   PRV2_REQUIRE(act == PRV2_ACT_NONE || act == PRV2_ACT_GELU, "gemm_ss: activation %d (built: none, GELU -- what the ViT blocks use)", act);
 #define PRV2_GSS(WM_, WN_, RI_, RJ_, NT_)                                                                                         \
   do {                                                                                                                            \
@@ -314,7 +317,7 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
   } else {
     p.tiles_n = (int)cdiv(n, 128);
     p.tiles_m = (int)cdiv(m, 128);
-    p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
+    p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 64;  // (hurts small grids: 1037 x 3072: 202 -> 148 TF)
     const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
     PRV2_GSS(2, 2, 4, 4, 256);
     set_kernel("gemm_ss_kernel", 128, PRV2_PREC_BF16X3);

@@ -354,8 +354,9 @@ def layernorm_feat(x: Feat, weight, bias, eps: float = 1e-6, act: int = ACT_NONE
 # ---- split-swizzled ("ss") operands of the large ViT linears (csrc/gemm_ss.hip; include/prv2.h "Split-swizzled") --------------
 # An ss tensor is carried as a float32 [rows, C] container (same bytes per element as fp32); only the kernels interpret it.
 SS_DISABLED = False  # A/B and test switch: keep the ViT blocks on the fp32-operand kernels
-SS_MIN_ROWS = 8192  # token rows from which the ViT blocks run on the pre-split path (bit-identical to the fp32-operand path;
-                    # measured +0..10 % per linear at 14 k rows, nothing below ~ 8 k: tools/probes/gemm_ss_bench.py)
+SS_MIN_ROWS = 512   # token rows from which the ViT blocks run on the pre-split path (bit-identical to the fp32-operand path;
+                    # measured per linear vs gemm16: +25..37 % at 14 k rows, +20 % at 4 k, +30 % / 0 / -8 % (qkv, fc1 / proj / fc2) at
+                    # 1037: profiles/r02_gemm_ss_bench.txt)
 
 
 def split_ss(x2d: torch.Tensor) -> torch.Tensor:
