@@ -91,30 +91,41 @@ def cpu_baseline(name, sd, frame_seed):
     image_hr = torch.rand(1, 3, *w["raw"], generator=torch.Generator().manual_seed(frame_seed))
     image_lr = m.resizer(image_hr)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        feats, pred = m.coarse_forward(image_lr)
-        t_coarse = time.perf_counter() - t0
+        tc = []
+        for _ in range(2):  # the first coarse forward also warms the thread pool
+            t0 = time.perf_counter()
+            feats, pred = m.coarse_forward(image_lr)
+            tc.append(time.perf_counter() - t0)
+        t_coarse = min(tc)
         rh, rw = m.tile_cfg["patch_raw_shape"]
-        t0 = time.perf_counter()
-        nb = 4  # one process_num batch of tiles
-        crops, bboxs = m._crops(image_hr[0], [0, rh // 2, rh, rh + rh // 2], [rw // 2], rh, rw)
-        bf = o_tiling.bboxs_to_feat(bboxs, w["raw"], w["pps"])
-        post = o_tiling.coarse_postprocess_test(pred, feats, bf, w["pps"][0])
-        m.infer_forward(crops, post)
-        t_patch = (time.perf_counter() - t0) / nb
+        nb = 4  # one process_num batch of tiles, timed three times (median)
+        tp = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            crops, bboxs = m._crops(image_hr[0], [0, rh // 2, rh, rh + rh // 2], [(rep + 1) * rw // 2], rh, rw)
+            bf = o_tiling.bboxs_to_feat(bboxs, w["raw"], w["pps"])
+            post = o_tiling.coarse_postprocess_test(pred, feats, bf, w["pps"][0])
+            m.infer_forward(crops, post)
+            tp.append((time.perf_counter() - t0) / nb)
+        t_patch = sorted(tp)[1]
     t_frame = t_coarse + w["patches"] * t_patch
-    return dict(value=1.0 / t_frame, unit="depth maps/s", cores=cores, kind="port",
-                sample=f"1 coarse forward ({t_coarse:.1f} s) + 4 of {w['patches']} tiles through crop/ROI/encoder/fusion "
-                       f"({t_patch:.1f} s per tile), extrapolated to the frame ({t_frame:.0f} s); blend excluded (<1%)")
+    return dict(value=1.0 / t_frame, unit="depth maps/s", cores=cores, kind="port", estimated=True,
+                sample=f"coarse forward x2 (best {t_coarse:.1f} s) + a batch of 4 of the {w['patches']} tiles through crop/ROI/encoder/fusion "
+                       f"x3 (median {t_patch:.1f} s per tile), ESTIMATED frame = coarse + {w['patches']} x tile = {t_frame:.0f} s; "
+                       f"blend excluded (<1%)")
 
 
 def pmc_traffic(kernel_tag, workload, prec):
     """HBM bytes per launch of ``kernel_tag`` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_<prec>_pmc_frame_<workload>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, per-launch averages in KB).
-    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 1/2 of the bytes of wide coalesced reads."""
-    path = os.path.join(ROOT, "profiles", f"r01_{prec}_pmc_frame_{workload}.json")
-    if not os.path.exists(path):
-        return None
+    (profiles/r<NN>_<prec>_pmc_frame_<workload>.json, newest round first: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    per-launch averages in KB; tools/profile_round.sh).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 1/2
+    of the bytes of wide coalesced reads.  Returns (bytes, source file) -- (None, None) when no pass of this workload is
+    committed: the counters cannot be collected inside this process."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{prec}_pmc_frame_{workload}.json")), reverse=True)
+    if not cands:
+        return None, None
+    path = cands[0]
     name, _, targs = kernel_tag.partition("<")
     bn, pr = targs.rstrip(">").split(",")
     # the tag covers every instantiation "prv2::<name><bn, prec[, ...]>" (e.g. the im2col-tail variant): launch-weighted mean
@@ -123,8 +134,9 @@ def pmc_traffic(kernel_tag, workload, prec):
             if k.startswith(prefix + ">") or k.startswith(prefix + ",")]
     n = sum(d["launches"] for d in rows)
     if not n:
-        return None
-    return sum((2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * d["launches"] for d in rows) / n * 1024.0
+        return None, None
+    b = sum((2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * d["launches"] for d in rows) / n * 1024.0
+    return b, os.path.relpath(path, ROOT)
 
 
 def main():
@@ -262,9 +274,10 @@ def main():
         d = summ[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         peak = PEAK[args.prec]
+        traffic, traffic_src = pmc_traffic(dom, name, args.prec)
         result["roofline"] = dict(
             bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
-            traffic=pmc_traffic(dom, name, args.prec),
+            traffic=traffic, traffic_source=traffic_src,
             launches_per_frame=d["launches"], avg_launch_ms=d["ms"] / d["launches"],
             algorithmic_gflop_per_launch=d["flops"] / d["launches"] / 1e9,
             frame_algorithmic_tflop=sum(x["flops"] for x in summ.values()) / 1e12,

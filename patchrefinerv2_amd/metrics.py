@@ -118,3 +118,70 @@ def colorize(value, vmin=None, vmax=None, cmap="turbo_r", invalid_val=-99, inval
     if gamma_corrected:
         img = (np.power(img / 255, 2.2) * 255).astype(np.uint8)
     return img
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# <name>_edge.png of the tester's output stage (estimator/tester/tester.py:99-106): Canny edges of the LOG depth
+# (extract_edges(result, use_canny=True, preprocess='log'), estimator/utils/metric.py:169-207), widened by one pixel
+# (kornia.filters.gaussian_blur2d(edges, (3, 3), ...) > 0 == a 3 x 3 binary dilation).
+# skimage.feature.canny and kornia are not vendored in the reference nor installed here: the detector below restates
+# skimage's published algorithm on scipy.ndimage (what skimage itself is built on) -- PARITY UNPINNED.
+# ------------------------------------------------------------------------------------------------------------------
+def canny(image: np.ndarray, sigma: float = 1.0, low_threshold: float = 0.1, high_threshold: float = 0.2) -> np.ndarray:
+    """skimage.feature.canny(image, sigma) with its defaults (mode='constant', cval=0, thresholds 0.1 / 0.2, no mask):
+    Gaussian smoothing corrected for the zero border ("bleed-over"), Sobel gradients, non-maximum suppression with
+    bilinear interpolation along the gradient in four 45-degree sectors, hysteresis = 8-connected components of the
+    low-threshold maxima that contain a high-threshold pixel."""
+    from scipy import ndimage as ndi
+    image = np.asarray(image, dtype=np.float32)
+    ones = np.ones(image.shape, dtype=np.float32)
+    bleed = ndi.gaussian_filter(ones, sigma, mode="constant", cval=0.0) + np.finfo(np.float32).eps
+    smoothed = ndi.gaussian_filter(image, sigma, mode="constant", cval=0.0) / bleed
+    eroded = np.ones(image.shape, dtype=bool)
+    eroded[:1, :] = eroded[-1:, :] = False
+    eroded[:, :1] = eroded[:, -1:] = False
+    jsobel = ndi.sobel(smoothed, axis=1)
+    isobel = ndi.sobel(smoothed, axis=0)
+    magnitude = np.sqrt(isobel * isobel + jsobel * jsobel)
+    ai, aj = np.abs(isobel), np.abs(jsobel)
+    eroded = eroded & (magnitude >= low_threshold)
+    local_max = np.zeros(image.shape, dtype=bool)
+
+    def sector(pts, a_slice, b_slice, pa, pb, c_slice, d_slice, pc, pd, w_num, w_den):
+        pts = eroded & pts
+        m = magnitude[pts]
+        w = w_num[pts] / w_den[pts]
+        c1, c2 = magnitude[a_slice][pts[pa]], magnitude[b_slice][pts[pb]]
+        plus = c2 * w + c1 * (1 - w) <= m
+        c1, c2 = magnitude[c_slice][pts[pc]], magnitude[d_slice][pts[pd]]
+        minus = c2 * w + c1 * (1 - w) <= m
+        local_max[pts] = plus & minus
+
+    s = np.s_
+    same = ((isobel >= 0) & (jsobel >= 0)) | ((isobel <= 0) & (jsobel <= 0))
+    opp = ((isobel <= 0) & (jsobel >= 0)) | ((isobel >= 0) & (jsobel <= 0))
+    # 0 - 45 degrees: neighbours (i+1, j) / (i+1, j+1) and (i-1, j) / (i-1, j-1)
+    sector(same & (ai >= aj), s[1:, :], s[1:, 1:], s[:-1, :], s[:-1, :-1], s[:-1, :], s[:-1, :-1], s[1:, :], s[1:, 1:], aj, ai)
+    # 45 - 90: (i, j+1) / (i+1, j+1) and (i, j-1) / (i-1, j-1)
+    sector(same & (ai <= aj), s[:, 1:], s[1:, 1:], s[:, :-1], s[:-1, :-1], s[:, :-1], s[:-1, :-1], s[:, 1:], s[1:, 1:], ai, aj)
+    # 90 - 135: (i, j+1) / (i-1, j+1) and (i, j-1) / (i+1, j-1)
+    sector(opp & (ai <= aj), s[:, 1:], s[:-1, 1:], s[:, :-1], s[1:, :-1], s[:, :-1], s[1:, :-1], s[:, 1:], s[:-1, 1:], ai, aj)
+    # 135 - 180: (i-1, j) / (i-1, j+1) and (i+1, j) / (i+1, j-1)
+    sector(opp & (ai >= aj), s[:-1, :], s[:-1, 1:], s[1:, :], s[1:, :-1], s[1:, :], s[1:, :-1], s[:-1, :], s[:-1, 1:], aj, ai)
+    low_mask = local_max & (magnitude >= low_threshold)
+    labels, count = ndi.label(low_mask, np.ones((3, 3), bool))
+    if count == 0:
+        return low_mask
+    high_mask = low_mask & (magnitude >= high_threshold)
+    good = np.zeros((count + 1,), bool)
+    good[np.unique(labels[high_mask])] = True
+    good[0] = False
+    return good[labels]
+
+
+def depth_edges(depth) -> np.ndarray:
+    """the boolean map behind <name>_edge.png: canny(log depth) dilated 3 x 3 (tester.py:99-105)"""
+    from scipy import ndimage as ndi
+    d = torch.as_tensor(depth).detach().cpu().float().squeeze()
+    d = (d > 0) * d.clamp(min=torch.finfo(torch.float32).eps).log()  # to_log, metric.py:157-161
+    return ndi.binary_dilation(canny(d.numpy(), sigma=1.0), structure=np.ones((3, 3), bool))

@@ -168,6 +168,8 @@ class Tester:
                     cmap = "magma_r" if getattr(self.dataloader, "dataset_name", "") == "cityscapes" else "Spectral"
                     color = colorize(result, cmap=cmap, vminp=0, vmaxp=100)
                 write_png8(base + ".png", np.ascontiguousarray(color[:, :, :3]))
+                from .metrics import depth_edges
+                write_png8(base + "_edge.png", depth_edges(result).astype(np.uint8) * 255)  # tester.py:99-106
                 if log.get("coarse_prediction") is not None:  # absent for BaselinePretrain
                     coarse = F.interpolate(log["coarse_prediction"].cpu(), tuple(image_raw_shape), mode="bilinear")
                     write_png8(base + "_coarse.png", np.ascontiguousarray(colorize(coarse, cmap="Spectral", vminp=0, vmaxp=100)[:, :, :3]))

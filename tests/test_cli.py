@@ -33,6 +33,8 @@ def test_cli_writes_depth_pngs_and_metrics(tmp_path):
     for name in ("frame0.png", "frame0_coarse.png"):   # colour maps (Spectral, 0..100 percentile)
         c = np.asarray(Image.open(str(out / name)))
         assert c.dtype == np.uint8 and c.shape == (256, 512, 3) and c.std() > 0
+    e = np.asarray(Image.open(str(out / "frame0_edge.png")))   # Canny of the log depth, dilated (tester.py:99-106)
+    assert e.dtype == np.uint8 and e.shape == (256, 512) and set(np.unique(e)) <= {0, 255}
     assert "abs_rel" in r.stdout and "see" in r.stdout
 
 

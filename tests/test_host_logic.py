@@ -198,3 +198,21 @@ def test_reference_model_configs_build_through_the_registry():
         print(f"  {len(v):3d}  {k}")
     assert len(cfgs) == 99
     assert len(ok) >= REFERENCE_CONFIG_FLOOR, (len(ok), dict(fails))
+
+
+def test_canny_edge_map_of_the_output_stage():
+    """<name>_edge.png (tester.py:99-106): Canny of the log depth + 3 x 3 dilation.  skimage / kornia are absent: the detector
+    is a restatement on scipy.ndimage (parity unpinned); checked on shapes whose edges are known."""
+    import torch
+    from patchrefinerv2_amd.metrics import canny, depth_edges
+    img = np.zeros((64, 96), np.float32)
+    img[:, 40:] = 1.0
+    yy, xx = np.mgrid[:64, :96]
+    img[(yy - 32) ** 2 + (xx - 20) ** 2 < 100] = 2.0
+    e = canny(img)
+    assert e.dtype == bool and e[5:60, 39:41].all() and not e[:, 50:90].any() and not e[:, :5].any()
+    ring = np.hypot(yy - 32, xx - 20)
+    assert e[(ring > 8) & (ring < 12)].sum() > 40 and not e[ring < 7].any()
+    assert not canny(np.full((32, 32), 3.0, np.float32)).any()            # constant image: the zero border is corrected for
+    d = depth_edges(torch.tensor(np.exp(img))[None, None])
+    assert d.shape == (64, 96) and d.sum() > e.sum() and (d | ~e).all()    # dilation contains the thin edges

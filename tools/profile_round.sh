@@ -2,11 +2,15 @@
 # Run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): regenerates the profiles/ evidence of the default
 # bench workload into gpurun_out/profiles/ (copy what should be judged into profiles/ afterwards).
 set -u
-TAG=${1:-r01}; PREC=${2:-bf16x3}
+TAG=${1:-r02}; PREC=${2:-bf16x3}
 R=$(pwd); O=$R/gpurun_out/profiles; mkdir -p $O
 WL=$(python3 -c "from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD as w; print(w)")
 export TMPDIR=/tmp
-python3 bench.py --steps 5 --warmup 2 > $O/${TAG}_${PREC}_bench.json 2> $O/bench.err
+python3 bench.py --steps 5 --warmup 2 > $O/${TAG}_${PREC}_bench_${WL}.json 2> $O/bench.err
+for W2 in v1_zoe_4k_r32 v1_dav2l_4k_r32 v2_zoeda_4k_r32 v2_dav2l_4k_r64 v1_dav2s_1080p_m1; do
+  python3 bench.py --workload $W2 --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_${PREC}_bench_${W2}.json 2>> $O/bench.err
+done
+python3 bench.py --prec f32 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_f32_bench_${WL}.json 2>> $O/bench.err
 python3 bench.py --layer-report $O/${TAG}_${PREC}_layers_${WL}.csv --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/bench.err
 # kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
 cd /tmp
