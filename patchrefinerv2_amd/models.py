@@ -300,6 +300,32 @@ class _PatchModel(StateDictModule):
             depth = depth.clone()  # the graph's own output buffer is rewritten by the next replay
         return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
 
+    @torch.no_grad()
+    def predict_tiles(self, image_lr, image_hr, tiles, tile_cfg=None):
+        """Per-tile predictions [K, 1, ph, pw] (device) for explicit tile origins ``tiles`` = [(h_start, w_start), ...] of
+        patch_raw_shape-sized crops, no blending: what the reference's ``mode='train'`` forward computes for given crops /
+        bboxs (coarse forward + ROI of the crop + refiner; patchrefinerplus.py:405-467) -- the building block of
+        Tester.run_consistency (tester.py:211-321)."""
+        tile_cfg = self.tile_cfg if tile_cfg is None else self.prepare_tile_cfg(tile_cfg["image_raw_shape"], tile_cfg["patch_split_num"])
+        dev = image_hr.device
+        ph, pw = self.patch_process_shape
+        with torch.cuda.device(dev):
+            if self.needs_coarse:
+                feats, cp = self.coarse_forward(image_lr)
+                cd = Feat(cp.view(1, cp.shape[-2], cp.shape[-1], 1))
+            else:
+                feats = cd = None
+            t_dev = torch.tensor(list(tiles), dtype=torch.int32).view(-1, 2).to(dev)
+            boxes = torch.from_numpy(self._boxes(list(tiles), tile_cfg)).to(dev) if self.needs_coarse else None
+            preds = torch.empty((len(tiles), 1, ph, pw), device=dev)
+            bs = max(1, int(getattr(self, "max_batch", None) or 4))
+            image_chw = image_hr[0].contiguous().float()
+            for s0 in range(0, len(tiles), bs):
+                e = min(s0 + bs, len(tiles))
+                crops, rois, droi = self._prepare_batch(image_chw, t_dev[s0:e], boxes[s0:e] if boxes is not None else None, tile_cfg, feats, cd)
+                self.infer_forward(crops, rois, droi, out=preds[s0:e])
+        return preds
+
     def _device_frame(self, image_lr, image_hr, tiles_dev, boxes_dev, plan, tile_cfg, process_num, shard=None, gather_dst=None):
         """Everything of a frame that runs on the device, given the plan's coordinates in device memory: coarse forward, the
         per-patch networks over this rank's tiles (batches round-robin over the HIP streams), the exchange (sharded mode), the

@@ -183,6 +183,54 @@ class Tester:
         return results
 
     @torch.no_grad()
+    def run_consistency(self, image_raw_shape=(2160, 3840), patch_split_num=(4, 4), overlap=270):
+        """Seam-consistency protocol of the reference (estimator/tester/tester.py:211-321 with the U4K / ETH3D consistency
+        crops, eth_dataset.py:86-93): the frame's sh x sw crops of patch_raw_shape are shifted towards the centre so that
+        neighbours overlap by ``overlap`` pixels, each crop is predicted on its own (the reference drives ``mode='train'`` once
+        per crop: coarse forward + that crop's ROI + refiner), resized bilinear(align_corners) to the crop's raw size, and the
+        error is the mean |difference| over the strips two adjacent crops share (left and up neighbours, tester.py:250-293).
+        Returns one dict per frame with ``consistency_error``; ``self.last_eval`` holds the dataset mean."""
+        from . import ops
+        sh, sw = patch_split_num
+        H, W = image_raw_shape
+        rh, rw = H // sh, W // sw
+        half = overlap // 2
+
+        def starts(n, size):  # eth_dataset.py:92-93 generalised: shift crop i by ((n - 1) - 2 i) * overlap / 2 towards the centre
+            return [int(i * size + ((n - 1) - 2 * i) * overlap / 2) for i in range(n)]
+
+        hs, ws = starts(sh, rh), starts(sw, rw)
+        tiles = [(h, w) for h in hs for w in ws]
+        tile_cfg = dict(image_raw_shape=list(image_raw_shape), patch_split_num=list(patch_split_num))
+        results = []
+        rank, world = self.runner_info.rank, getattr(self.runner_info, "world_size", 1)
+        for idx in range(rank, len(self.dataloader), world):
+            item = self.dataloader[idx]
+            hr = item["image_hr"].unsqueeze(0).cuda()
+            preds = self.model.predict_tiles(self.model.resizer(hr), hr, tiles, tile_cfg)
+            up = ops.upsample_bilinear(ops.Feat(preds.view(len(tiles), preds.shape[-2], preds.shape[-1], 1)), rh, rw).buf.view(len(tiles), rh, rw)
+            errs = []
+            for ii in range(sh):
+                for jj in range(sw):
+                    cur = up[ii * sw + jj]
+                    if jj > 0:  # left neighbour: its last ``overlap`` columns == my first ones
+                        errs.append((up[ii * sw + jj - 1][:, -overlap:] - cur[:, :overlap]).abs().flatten())
+                    if ii > 0:  # upper neighbour
+                        errs.append((up[(ii - 1) * sw + jj][-overlap:, :] - cur[:overlap, :]).abs().flatten())
+            ce = float(torch.cat(errs).mean()) if errs else 0.0
+            entry = dict(name=item["img_file_basename"], consistency_error=ce)
+            if self.runner_info.save:  # the stitched centres (tester.py:243-247) as a colour map
+                os.makedirs(self.runner_info.work_dir, exist_ok=True)
+                full = torch.zeros((H, W))
+                for k, (h, w) in enumerate(tiles):
+                    full[h + half:h + rh - half, w + half:w + rw - half] = up[k][half:rh - half, half:rw - half].cpu()
+                from .metrics import colorize
+                write_png8(os.path.join(self.runner_info.work_dir, entry["name"] + ".png"), np.ascontiguousarray(colorize(full[None, None])[:, :, :3]))
+            results.append(entry)
+        self.last_eval = dict(consistency_error=float(np.mean([r["consistency_error"] for r in results]))) if results else {}
+        return results
+
+    @torch.no_grad()
     def benchmark(self, cai_mode="m1", process_num=4, image_raw_shape=(2160, 3840), patch_split_num=(4, 4), repeat_times=10,
                   log_interval=10, num_warmup=20, total_iters=50, seed=None):
         """The reference's own throughput protocol (estimator/tester/tester.py:325-406): ``repeat_times`` passes over the

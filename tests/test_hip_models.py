@@ -355,6 +355,33 @@ def test_hip_graph_replay_is_bit_identical(P, kind):
     assert torch.equal(m1a, m1b) and torch.equal(m1a, m1c)
 
 
+def test_predict_tiles_and_run_consistency(P, tmp_path):
+    """predict_tiles (explicit crop origins, no blend: the reference's mode='train' forward per crop) gives exactly the tiles the
+    m1 frame pastes; Tester.run_consistency (tester.py:211-321) on top of it: shifted overlapping crops, mean |difference| over
+    the shared strips"""
+    import numpy as np
+    from patchrefinerv2_amd.tester import ImageDataset, RunnerInfo, Tester, write_png8
+    c = E2E_V1
+    m = _build("PatchRefiner", c, e2e_v1_sd())
+    hr = rand_image(c["seed"], 1, *c["raw"]).to(DEV)
+    m1, _ = _run(m, c, "m1")
+    rh, rw = c["raw"][0] // 2, c["raw"][1] // 2
+    tiles = [(0, 0), (0, rw), (rh, 0), (rh, rw)]
+    preds = m.predict_tiles(m.resizer(hr), hr, tiles)
+    ph, pw = c["pps"]
+    for k, (i, j) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        assert torch.equal(preds[k, 0].cpu(), m1[0, 0, i * ph:(i + 1) * ph, j * pw:(j + 1) * pw])
+    d = tmp_path / "rgb"
+    d.mkdir()
+    img = (rand_image(3, 1, *c["raw"])[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    write_png8(str(d / "f0.png"), img)
+    ds = ImageDataset(str(d), image_resolution=c["raw"], network_process_size=c["pps"])
+    t = Tester(None, RunnerInfo(save=True, work_dir=str(tmp_path / "out")), ds, m)
+    res = t.run_consistency(image_raw_shape=c["raw"], patch_split_num=c["split"], overlap=rh // 2)
+    assert len(res) == 1 and np.isfinite(res[0]["consistency_error"]) and res[0]["consistency_error"] > 0
+    assert t.last_eval["consistency_error"] == res[0]["consistency_error"] and (tmp_path / "out" / "f0.png").exists()
+
+
 def test_rejects_cpu_inputs_and_bad_shapes(P):
     c = E2E_V1
     m = _build("PatchRefiner", c, e2e_v1_sd())

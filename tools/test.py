@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3"])
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--seed", type=int, default=621)
+    ap.add_argument("--consistency", type=int, default=0, metavar="OVERLAP",
+                    help="Tester.run_consistency (estimator/tester/tester.py:211): seam error over crops overlapping by OVERLAP pixels (reference: 270)")
     ap.add_argument("--benchmark", action="store_true", help="Tester.benchmark (estimator/tester/tester.py:325) instead of run")
     ap.add_argument("--repeat-times", type=int, default=10)
     ap.add_argument("--benchmark-iters", nargs=2, type=int, default=[20, 50], metavar=("WARMUP", "TOTAL"))
@@ -78,6 +80,11 @@ def main():
     dataset = DATASETS.build(ds_cfg)
     runner = RunnerInfo(rank=rank, world_size=world, save=args.save, gray_scale=args.gray_scale, work_dir=args.work_dir)
     tester = Tester(cfg, runner, dataset, model)
+    if args.consistency:
+        for r in tester.run_consistency(image_raw_shape=args.image_raw_shape, patch_split_num=args.patch_split_num, overlap=args.consistency):
+            print(f"[rank {rank}] {r['name']}: consistency_error {r['consistency_error']:.6f}")
+        print(f"[rank {rank}] consistency_error {tester.last_eval.get('consistency_error', float('nan')):.6f}")
+        return
     if args.benchmark:
         b = tester.benchmark(cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
                              patch_split_num=args.patch_split_num, repeat_times=args.repeat_times,
