@@ -9,6 +9,8 @@
 // P goes through a per-wave LDS strip to become the A operand of the P*V product.
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact products, fp32 accumulate) -- same arithmetic class
 // as the reference's fp32 matmuls.
+#include <type_traits>
+
 #include "common.h"
 
 namespace prv2 {
@@ -254,7 +256,9 @@ __global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict_
     f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
     if (tok < N) {
       const float* src = qkv + ((long long)b * N + tok) * D3 + head * 64 + d4;
-      q = *reinterpret_cast<const f32x4*>(src) * 0.125f;
+      // pre-scaled by hd^-0.5 * log2(e): the kernel's softmax runs in the base-2 domain (one v_exp_f32 per score instead of
+      // expf's ten instructions; the loop was VALU-issue bound: 786 VALU per 48 MFMAs)
+      q = *reinterpret_cast<const f32x4*>(src) * (0.125f * 1.4426950408889634f);
       k = *reinterpret_cast<const f32x4*>(src + heads * 64);
       v = *reinterpret_cast<const f32x4*>(src + 2 * heads * 64);
       bf16x4 hi, lo;
@@ -350,7 +354,8 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
     for (int i = 0; i < 8; ++i) vreg[i] = *reinterpret_cast<const uint2*>(vsrc + i * 8);
   };
   fetch(0);
-  for (int k0 = 0; k0 < N; k0 += AT_BK) {
+  auto tile = [&](int k0, auto mask_c) {
+    constexpr bool MASK = decltype(mask_c)::value;  // keys behind N exist only in the last tile
     __syncthreads();
     {
       const bool kvalid = (k0 + ld_row) < N;
@@ -384,29 +389,34 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(br + t * 32 + 8 * g);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(br + t * 32 + 8 * g) * 1.4426950408889634f;  // (base-2 domain)
           st[t][4 * g] += bv.x; st[t][4 * g + 1] += bv.y; st[t][4 * g + 2] += bv.z; st[t][4 * g + 3] += bv.w;
         }
     }
-    // online softmax of this lane's query column (keys live in the registers of both lane halves)
+    // online softmax of this lane's query column (keys live in the registers of both lane halves); scores are base-2 logits
+    if constexpr (MASK) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = k0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          st[t][e] = key < N ? st[t][e] : -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = k0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        st[t][e] = key < N ? st[t][e] : -INFINITY;
-        mx = fmaxf(mx, st[t][e]);
-      }
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float corr = expf(m_run - m_new);
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
     float rs = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        st[t][e] = expf(st[t][e] - m_new);  // exp(-inf) = 0 for masked keys
+        st[t][e] = __builtin_amdgcn_exp2f(st[t][e] - m_new);  // exp2(-inf) = 0 for masked keys
         rs += st[t][e];
       }
     rs += __shfl_xor(rs, 32, 64);
@@ -438,7 +448,10 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
           o_acc[dt] = mfma3(vh, vl, ph, pl, o_acc[dt]);
         }
       }
-  }
+  };
+  int k0 = 0;
+  for (; k0 + AT_BK <= N; k0 += AT_BK) tile(k0, std::false_type{});
+  if (k0 < N) tile(k0, std::true_type{});
 
   // O^T accumulators: col = query (lane), row = d.  Transpose through a per-wave LDS strip [32 q][64 d + pad]
   __syncthreads();
