@@ -208,7 +208,9 @@ class Tester:
             item = self.dataloader[idx]
             hr = item["image_hr"].unsqueeze(0).cuda()
             preds = self.model.predict_tiles(self.model.resizer(hr), hr, tiles, tile_cfg)
-            up = ops.upsample_bilinear(ops.Feat(preds.view(len(tiles), preds.shape[-2], preds.shape[-1], 1)), rh, rw).buf.view(len(tiles), rh, rw)
+            up = torch.empty((len(tiles), rh, rw, 1), device=preds.device)  # dense 1-channel NHWC == [K, rh, rw]
+            ops.upsample_bilinear(ops.Feat(preds.view(len(tiles), preds.shape[-2], preds.shape[-1], 1)), rh, rw, out=ops.Feat(up))
+            up = up.view(len(tiles), rh, rw)
             errs = []
             for ii in range(sh):
                 for jj in range(sw):
