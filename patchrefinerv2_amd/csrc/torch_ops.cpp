@@ -130,8 +130,18 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
 }
 
 // nn.LayerNorm over the last dimension of [rows, c] (tokens) or of an NHWC map (the reference's channels-first LayerNorm)
-Tensor layernorm(const Tensor& x, const Tensor& weight, const Tensor& bias, double eps, int64_t act) {
+Tensor layernorm(const Tensor& x, const Tensor& weight, const Tensor& bias, double eps, int64_t act, const optional<Tensor>& out) {
   dev_f32(x, "x");
+  if (out.has_value()) {  // rows [M, c] with a row stride (in place: out may be x itself)
+    TORCH_CHECK(x.dim() == 2 && out->dim() == 2 && out->sizes() == x.sizes() && x.stride(1) == 1 && out->stride(1) == 1,
+                "prv2::layernorm: with out=, x and out are [rows, c] tensors with unit column stride");
+    dev_f32(*out, "out");
+    const int64_t rows = x.size(0), c = x.size(1);
+    Launch L(x);
+    ok(prv2_layernorm(x.data_ptr<float>(), rows, (int)c, (int)(rows == 1 ? c : x.stride(0)), opt_ptr(weight, "weight", c), opt_ptr(bias, "bias", c),
+                      (float)eps, (int)act, out->data_ptr<float>(), (int)(rows == 1 ? c : out->stride(0)), L.stream), "layernorm");
+    return *out;
+  }
   TORCH_CHECK(x.dim() >= 2 && x.stride(-1) == 1, "prv2::layernorm: x must have unit stride along the normalised dimension");
   const int64_t c = x.size(-1);
   Tensor xr = x.dim() == 2 ? x : (x.is_contiguous() ? x.view({-1, c}) : x.contiguous().view({-1, c}));
@@ -198,6 +208,19 @@ std::vector<Tensor> roi_gather_pyramid(at::TensorList feats, const Tensor& boxes
     outs.push_back(y);
   }
   return outs;
+}
+
+// one level of the above with explicit scale / output size: torchvision.ops.roi_align(feat.repeat(K), boxes, (oh, ow), scale, aligned=True)
+Tensor roi_align(const Tensor& feat, const Tensor& boxes, double spatial_scale, int64_t oh, int64_t ow, const optional<Tensor>& out) {
+  dev_f32(boxes, "boxes");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && boxes.is_contiguous(), "prv2::roi_align: boxes must be contiguous [k, 4]");
+  const int64_t ld = nhwc_ld(feat, "feat");
+  TORCH_CHECK(feat.size(0) == 1, "prv2::roi_align: one feature map (batch 1)");
+  Tensor y = out_or_alloc(out, feat, boxes.size(0), oh, ow, feat.size(3), "roi_align");
+  Launch L(feat);
+  ok(prv2_roi_align(feat.data_ptr<float>(), (int)feat.size(1), (int)feat.size(2), (int)feat.size(3), (int)ld, boxes.data_ptr<float>(), (int)boxes.size(0),
+                    (float)spatial_scale, (int)oh, (int)ow, y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream), "roi_align");
+  return y;
 }
 
 // F.interpolate(mode='bilinear', align_corners=True) on NHWC
@@ -291,7 +314,8 @@ TORCH_LIBRARY(prv2, m) {
   m.def("conv2d(Tensor x, Tensor w_packed, Tensor? bias, int cout, int kh, int kw, int stride=1, int pad=0, int act=0, bool relu_in=False, "
         "Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? gamma=None, Tensor? mul=None, Tensor? res=None, Tensor? res2=None, int convt_k=0, "
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None) -> Tensor");
-  m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0) -> Tensor");
+  m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0, Tensor(a!)? out=None) -> Tensor");
+  m.def("roi_align(Tensor feat, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None) -> Tensor");
   m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0, Tensor? bias=None) -> Tensor");
   m.def("crop_resize_bilinear(Tensor img_chw, Tensor tiles, int ch, int cw, int oh, int ow, float[]? mean=None, float[]? std=None, "
         "Tensor(a!)? out=None) -> Tensor");
@@ -315,6 +339,7 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("attention_fwd", &attention_fwd);
   m.impl("crop_resize_bilinear", &crop_resize_bilinear);
   m.impl("roi_gather_pyramid", &roi_gather_pyramid);
+  m.impl("roi_align", &roi_align);
   m.impl("upsample_bilinear_ac", &upsample_bilinear_ac);
   m.impl("blend_init", &blend_init);
   m.impl("blend_update", &blend_update);

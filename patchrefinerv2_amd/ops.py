@@ -19,6 +19,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# How the host mirror reaches the kernels: "ctypes" = straight through the C ABI (lib.py), "torch" = through the PyTorch
+# custom ops torch.ops.prv2.* (csrc/torch_ops.cpp) for every operator that surface covers (conv2d / linear, layernorm,
+# attention, crop+resize, ROI gather, upsample, blend, ZoeDepth head ops); the rest stays on ctypes.  Same kernels, same
+# results bit for bit (tests/test_hip_models.py::test_models_through_torch_custom_ops).
+DISPATCH = "ctypes"
+
+
+def _tops():
+    from . import torch_ops
+    return torch_ops.load()
+
+
 class Profiler:
     """Optional per-launch accounting for bench.py: algorithmic FLOPs (2*MAC) and, when ``timed``,
     HIP events recorded on the launch stream around each matrix-kernel launch."""
@@ -136,6 +148,10 @@ class Feat:
     def slice(self, c0: int, c: int) -> "Feat":
         return Feat(self.buf, c, self.c0 + c0)
 
+    def view(self) -> torch.Tensor:
+        """this activation as a (strided) torch tensor [n, h, w, c]: what the torch.ops.prv2 operators take"""
+        return self.buf[..., self.c0:self.c0 + self.c]
+
     def batch(self, b0: int, b1: int) -> "Feat":
         return Feat(self.buf[b0:b1], self.c, self.c0)
 
@@ -232,7 +248,15 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
     halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and (cw.pad == 1 or cw.same_pad) and not cw.convt_k and x.w >= 24 and x.h >= 4
             and not force_generic)  # only for the f32-mode strip split below; kernel names come from prv2_last_kernel()
+    via_torch = DISPATCH == "torch" and type(x) is Feat and not x_bstride and not force_generic
+
     def call():
+        if via_torch and d.part == 0:
+            v = lambda f: None if f is None else f.view()  # noqa: E731
+            _tops().conv2d(x.view(), cw.w, cw.bias, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, act, relu_in,
+                           ln[0] if ln is not None else None, ln[1] if ln is not None else None, gamma, v(mul), v(res), v(res2),
+                           cw.convt_k, cw.prec, ln_eps, cw.same_pad, out.view())
+            return
         L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
                                      _ptr(ln[1]) if ln is not None else None, _ptr(gamma), _ptr(mul), _ptr(res), _ptr(res2),
                                      out.ptr, _stream()), "conv2d")
@@ -336,6 +360,9 @@ def channel_scale_(x: Feat, s: torch.Tensor) -> Feat:
 
 def layernorm_rows(x: torch.Tensor, rows: int, c: int, ldx: int, weight, bias, eps: float, act: int, y: torch.Tensor,
                    ldy: int, x_off: int = 0, y_off: int = 0):
+    if DISPATCH == "torch" and not x_off and not y_off:
+        _tops().layernorm(torch.as_strided(x, (rows, c), (ldx, 1)), weight, bias, eps, act, torch.as_strided(y, (rows, c), (ldy, 1)))
+        return
     L.check(L.load().prv2_layernorm(x.data_ptr() + 4 * x_off, rows, c, ldx, weight.data_ptr(), bias.data_ptr(), eps,
                                     act, y.data_ptr() + 4 * y_off, ldy, _stream()), "layernorm")
 
@@ -344,6 +371,14 @@ def layernorm_feat(x: Feat, weight, bias, eps: float = 1e-6, act: int = ACT_NONE
     """channels-first LayerNorm of the reference == row LayerNorm in NHWC (convs.py:21-29)."""
     if out is None:
         out = x
+    if DISPATCH == "torch":
+        rows = x.n * x.h * x.w
+        PROFILER.launch_aux("layernorm", 8.0 * rows * x.c,
+                            lambda: _tops().layernorm(x.view().reshape(rows, x.c) if x.ld == x.c else torch.as_strided(x.buf, (rows, x.c), (x.ld, 1), x.buf.storage_offset() + x.c0),
+                                                      weight, bias, eps, act,
+                                                      torch.as_strided(out.buf, (rows, out.c), (out.ld, 1), out.buf.storage_offset() + out.c0)),
+                            f"{x.c}ch {x.n}x{x.h}x{x.w}")
+        return out
     PROFILER.launch_aux("layernorm", 8.0 * x.n * x.h * x.w * x.c,
                         lambda: L.check(L.load().prv2_layernorm(x.ptr, x.n * x.h * x.w, x.c, x.ld, weight.data_ptr(),
                                                                  bias.data_ptr(), eps, act, out.ptr, out.ld, _stream()),
@@ -414,6 +449,11 @@ def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC
     if bias is not None:
         _require_dev(bias)
         assert bias.is_contiguous() and bias.shape[0] == heads and bias.shape[1] == ntok
+    if DISPATCH == "torch" and not out_ss:
+        res = []
+        PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel", 4.0 * b * heads * ntok * ntok * 64,
+                        lambda: res.append(_tops().attention_fwd(qkv, b, ntok, heads, prec, bias)))
+        return res[0]
     if out_ss:
         assert prec == L.PREC_BF16X3
         PROFILER.launch("attention_bf16x3_kernel", 4.0 * b * heads * ntok * ntok * 64,
@@ -435,6 +475,10 @@ def crop_resize(img_chw: torch.Tensor, tiles: torch.Tensor, ch: int, cw: int, oh
     _require_dev(img_chw)
     assert tiles.dtype == torch.int32 and tiles.is_cuda and img_chw.is_contiguous()
     k = tiles.shape[0]
+    if DISPATCH == "torch":
+        _tops().crop_resize_bilinear(img_chw, tiles.contiguous(), ch, cw, oh, ow, list(mean) if mean is not None else None,
+                                     list(std) if std is not None else None, out.slice(0, 3).view())
+        return
     m = (C.c_float * 3)(*mean) if mean is not None else None
     s = (C.c_float * 3)(*std) if std is not None else None
     L.check(L.load().prv2_crop_resize(img_chw.data_ptr(), img_chw.shape[1], img_chw.shape[2], tiles.data_ptr(), k, ch,
@@ -459,6 +503,11 @@ def roi_align(feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow
     k = boxes.shape[0]
     if out is None:
         out = Feat.alloc(k, oh, ow, feat.c, feat.device)
+    if DISPATCH == "torch":
+        PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
+                            lambda: _tops().roi_align(feat.view(), boxes.contiguous(), float(spatial_scale), oh, ow, out.view()),
+                            f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}")
+        return out
     PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
                         lambda: L.check(L.load().prv2_roi_align(feat.ptr, feat.h, feat.w, feat.c, feat.ld, boxes.data_ptr(), k,
                                                                  spatial_scale, oh, ow, out.ptr, out.ld, _stream()), "roi_align"),
@@ -470,6 +519,10 @@ def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> 
     if out is None:
         out = Feat.alloc(x.n, oh, ow, x.c, x.device)
     assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, x.c)
+    if DISPATCH == "torch":
+        PROFILER.launch_aux("upsample_bilinear", 4.0 * x.n * x.c * (x.h * x.w + oh * ow),
+                            lambda: _tops().upsample_bilinear_ac(x.view(), oh, ow, out.view()), f"{x.c}ch {x.n}x{x.h}x{x.w}->{oh}x{ow}")
+        return out
     PROFILER.launch_aux("upsample_bilinear", 4.0 * x.n * x.c * (x.h * x.w + oh * ow),
                         lambda: L.check(L.load().prv2_upsample_bilinear(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, out.ptr,
                                                                          out.ld, _stream()), "upsample_bilinear"),
@@ -478,18 +531,24 @@ def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> 
 
 
 def blend_paste(avg, cnt, pred, mask, tiles, th, tw):
+    if DISPATCH == "torch":
+        return _tops().blend_init(avg, cnt, pred.contiguous(), mask, tiles.contiguous(), th, tw)
     L.check(L.load().prv2_blend_paste(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], pred.data_ptr(),
                                       pred.shape[-2], pred.shape[-1], mask.data_ptr(), tiles.data_ptr(), tiles.shape[0],
                                       th, tw, _stream()), "blend_paste")
 
 
 def blend_update(avg, cnt, pred, mask, tiles, th, tw):
+    if DISPATCH == "torch":
+        return _tops().blend_update(avg, cnt, pred.contiguous(), mask, tiles.contiguous(), th, tw)
     L.check(L.load().prv2_blend_update(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], pred.data_ptr(),
                                        pred.shape[-2], pred.shape[-1], mask.data_ptr(), tiles.data_ptr(), tiles.shape[0],
                                        th, tw, _stream()), "blend_update")
 
 
 def blend_resize(avg, cnt, oh, ow):
+    if DISPATCH == "torch":
+        return _tops().blend_resize(avg, cnt, oh, ow)
     a = torch.empty((oh, ow), device=avg.device, dtype=torch.float32)
     c = torch.empty((oh, ow), device=avg.device, dtype=torch.float32)
     L.check(L.load().prv2_blend_resize(avg.data_ptr(), cnt.data_ptr(), avg.shape[0], avg.shape[1], a.data_ptr(),
@@ -507,6 +566,8 @@ def add(a: Feat, b: Feat, out: Optional[Feat] = None) -> Feat:
 
 def zoe_attractor(attr: Feat, bins: Feat, alpha: float = 300.0) -> Feat:
     assert (attr.n, attr.h, attr.w) == (bins.n, bins.h, bins.w)
+    if DISPATCH == "torch" and bins.c % 4 == 0:
+        return Feat(_tops().zoe_attractor(attr.view(), bins.view(), alpha))
     out = Feat.alloc(bins.n, bins.h, bins.w, bins.c, bins.device)
     L.check(L.load().prv2_zoe_attractor(attr.ptr, attr.ld, attr.c, bins.ptr, bins.ld, bins.c, alpha,
                                         bins.n * bins.h * bins.w, out.ptr, out.ld, _stream()), "zoe_attractor")
@@ -515,6 +576,8 @@ def zoe_attractor(attr: Feat, bins: Feat, alpha: float = 300.0) -> Feat:
 
 def zoe_logbinom_depth(pt: Feat, centers: Feat, min_temp: float, max_temp: float) -> torch.Tensor:
     assert pt.c == 4 and (pt.n, pt.h, pt.w) == (centers.n, centers.h, centers.w)
+    if DISPATCH == "torch":
+        return _tops().zoe_bins_head(pt.view(), centers.view(), min_temp, max_temp)
     depth = torch.empty((pt.n, 1, pt.h, pt.w), device=pt.device, dtype=torch.float32)
     L.check(L.load().prv2_zoe_logbinom_depth(pt.ptr, pt.ld, centers.ptr, centers.ld, centers.c, min_temp, max_temp,
                                              pt.n * pt.h * pt.w, depth.data_ptr(), _stream()), "zoe_logbinom_depth")
