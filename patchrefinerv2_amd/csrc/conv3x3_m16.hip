@@ -103,7 +103,13 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  // Wave -> (pixel rows wm, channel half wn).  A workgroup's waves go to the SIMDs in cyclic order, so waves w and w + 4 share a
+  // SIMD: with wn = wave >> 2 every SIMD hosts one wave of EACH channel half -- when the upper half of a tile is (partly)
+  // padding (Cout = 98, 194, 322, 642, 770 ...) and its all-pad 16-column blocks are skipped (jv below), the saved MFMA
+  // cycles are the SIMD's, not an idle half of the chip's.  (p.wave_map = 0: the old wave & 1 mapping, for A/B.)
+  const int wm = WN == 2 ? (p.wave_map ? wave & 3 : wave >> 1) : wave, wn = WN == 2 ? (p.wave_map ? wave >> 2 : wave & 1) : 0;
+  // 16-column blocks of this wave that hold at least one real output channel (block-uniform per wave)
+  const int jv = p.wave_map ? __builtin_amdgcn_readfirstlane(min(NJ, max(0, (p.Ncols - tile_n * BN - wn * (BN / WN) + 15) >> 4))) : NJ;
   const int m16 = lane & 15, g = lane >> 4;
   // loader role: float4 `chunk` of halo pixels prow + 64*i.  A 16-lane ds_write_b64 group covers two pixels: with
   // 160-byte rows neighbours p, p+1 share 8 of the 32 store banks, p and p+2 none -> swap bits 0/1 of the pixel index
@@ -296,10 +302,12 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         // refilled last (end of the previous step) are needed last
 #pragma unroll
         for (int a = 0; a < NA; a += 2) {
+          if (j < jv) {
 #pragma unroll
           for (int pr = 0; pr < NP; ++pr) {
             mma(a, j, j & 1, pr);
             mma(a + 1, j, j & 1, pr);
+          }
           }
           __builtin_amdgcn_sched_barrier(0);
           if (j == 0 && a == 0) {
@@ -333,10 +341,12 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
       // last column, two pixel runs at a time; as a pair retires its registers take the NEXT tap's runs
 #pragma unroll
       for (int a = 0; a < NA; a += 2) {
+        if (NJ - 1 < jv) {
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
           mma(a, NJ - 1, (NJ - 1) & 1, pr);
           mma(a + 1, NJ - 1, (NJ - 1) & 1, pr);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         read_a(a, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
@@ -387,10 +397,12 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if (j + 1 < NJ) read_b((j + 1) & 1, 0, j + 1);
+      if (j < jv) {
 #pragma unroll
       for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
         for (int a = 0; a < NA; ++a) mma(a, j, j & 1, pr);
+      }
     }
   }
   if constexpr (!PERSIST) {
@@ -530,6 +542,8 @@ static int persist_workgroups() {  // one persistent workgroup per CU of the CUR
 
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   using namespace m16;
+  static const int wave_map = getenv("PRV2_HALO_WAVE_MAP") ? atoi(getenv("PRV2_HALO_WAVE_MAP")) : 1;  // A/B switch
+  p.wave_map = wave_map;
   p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;
   p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) * p.tiles_n : 0;
   const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x * p.tiles_n + p.strip_blocks;

@@ -35,6 +35,7 @@ struct IgemmParams {
   int tiles_x;         // halo kernels: 32-pixel tile columns to process (the rest is the remainder strip)
   int strip_blocks;    // conv3x3_m16: leading workgroups of the grid that take the strip (32 x 8 tiles)
   int rx0, rw;         // remainder strip = output columns [rx0, rx0 + rw): tall halo tiles, or the generic kernel's window (rw = 0: none)
+  int wave_map;        // conv3x3_m16: 1 = waves w, w + 4 (one SIMD) take the two channel halves and skip all-pad column blocks
   const void* w_tail;  // im2col tile of the last (Cin % 32 == 2) channels for the 16x16x32 halo kernel, or null
 };
 
