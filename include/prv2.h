@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 4
+#define PRV2_ABI_VERSION 5
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -235,6 +235,13 @@ int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c, int32_t l
 /* F.interpolate(mode='bilinear', align_corners=True) on NHWC (every decoder upsample; Appendix C row 1) */
 int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t oh,
                            int32_t ow, float* y, int32_t ldy, void* stream);
+
+/* The two depth maps every fusion level appends to its features ([feat | pred1 | pred2], fusion_model.py:91-118,
+ * bi_directional_fusion_model.py:424-436): p1, p2 dense [n, h, w], resized bilinear(align_corners=True) to oh x ow and written
+ * as y[pixel][0..3] = (p1, p2, 0, 0) -- y points at the first of the buffer's last four channels (the two maps and the two
+ * pad channels), 16-byte aligned, pixel stride ldy.  Same arithmetic per map as prv2_upsample_bilinear. */
+int prv2_depth_pair_fill(const float* p1, const float* p2, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow, float* y,
+                         int32_t ldy, void* stream);
 
 /* NCHW <-> NHWC layout changes at the boundary (image_lr in, coarse_prediction out) */
 int prv2_nchw_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, float* y, int32_t ldy, void* stream);

@@ -251,6 +251,33 @@ __global__ void __launch_bounds__(256) upsample_bilinear_rows_kernel(const float
   }
 }
 
+// Two dense 1-channel maps (the two depth predictions every fusion level appends to its features: fusion_model.py:91-118,
+// bi_directional_fusion_model.py:424-436) resized bilinear(align_corners=True) and written as channels c, c + 1 of an NHWC
+// buffer whose last four channels are [pred1 | pred2 | pad | pad]: ONE 16-byte store per pixel instead of two scattered
+// 4-byte stores per pixel plus the pad-zeroing pass.  Arithmetic identical to upsample_bilinear_kernel<1> per map.
+__global__ void __launch_bounds__(256) depth_pair_fill_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int H, int W,
+                                                              int oh, int ow, float sy, float sx, float* __restrict__ y, int ldy) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ox >= ow) return;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  const AxisTap ty = ac_tap(oy, sy, H), tx = ac_tap(ox, sx, W);
+  auto interp = [&](const float* p) {
+    p += (int64_t)n * H * W;
+    const float v00 = p[(int64_t)ty.i0 * W + tx.i0], v01 = p[(int64_t)ty.i0 * W + tx.i1];
+    const float v10 = p[(int64_t)ty.i1 * W + tx.i0], v11 = p[(int64_t)ty.i1 * W + tx.i1];
+    float top = 0.f, bot = 0.f, r = 0.f;
+    vfma(top, tx.w0, v00);
+    vfma(top, tx.w1, v01);
+    vfma(bot, tx.w0, v10);
+    vfma(bot, tx.w1, v11);
+    vfma(r, ty.w0, top);
+    vfma(r, ty.w1, bot);
+    return r;
+  };
+  const float4 o = make_float4(interp(p1), interp(p2), 0.f, 0.f);
+  *reinterpret_cast<float4*>(y + (((int64_t)n * oh + oy) * ow + ox) * ldy) = o;
+}
+
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W,
                                                            float* __restrict__ y, int ldy) {
   int64_t total = (int64_t)N * H * W * C;
@@ -351,6 +378,17 @@ extern "C" int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int3
     hipLaunchKernelGGL(upsample_bilinear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, n,
                        h, w, c, ldx, oh, ow, ac_scale(h, oh), ac_scale(w, ow), y, ldy);
   PRV2_LAUNCH_CHECK("upsample_bilinear");
+  return 0;
+}
+
+extern "C" int prv2_depth_pair_fill(const float* p1, const float* p2, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow, float* y,
+                                    int32_t ldy, void* stream) {
+  PRV2_REQUIRE(p1 && p2 && y && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "depth_pair_fill: bad arguments");
+  PRV2_REQUIRE(ldy % 4 == 0 && aligned16(y), "depth_pair_fill: the four destination channels must be 16-byte aligned (ldy %d)", ldy);
+  PRV2_REQUIRE(oh <= 65535 && n <= 65535, "depth_pair_fill: grid too large");
+  hipLaunchKernelGGL(depth_pair_fill_kernel, dim3((unsigned)cdiv(ow, 256), oh, n), dim3(256), 0, (hipStream_t)stream, p1, p2, h, w, oh, ow,
+                     ac_scale(h, oh), ac_scale(w, ow), y, ldy);
+  PRV2_LAUNCH_CHECK("depth_pair_fill");
   return 0;
 }
 

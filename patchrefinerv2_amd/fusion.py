@@ -29,9 +29,34 @@ def as_feat1(t: torch.Tensor) -> Feat:
     return Feat(t.contiguous().view(B, H, Wd, 1))
 
 
-def place(src: Feat, dst: Feat):
-    """bilinear(align_corners) resize of ``src`` into ``dst`` (an exact copy when sizes match)."""
+def place(src, dst: Feat):
+    """bilinear(align_corners) resize of ``src`` into ``dst`` (an exact copy when sizes match).  A coarse-pyramid ROI that has
+    not been materialised (ops.RoiSource) is gathered straight into ``dst`` when the sizes match."""
+    if isinstance(src, ops.RoiSource):
+        if (src.h, src.w) == (dst.h, dst.w):
+            return src.write(dst)
+        src = src.materialize()
     ops.upsample_bilinear(src, dst.h, dst.w, out=dst)
+
+
+def _fused_tail(c0: int) -> bool:
+    """can [.. c0 channels | pred1 | pred2 | pad | pad] be closed by ops.depth_pair_fill?"""
+    return c0 % 4 == 0 and ops.DIRECT_PLACEMENT and ops.DISPATCH != "torch"
+
+
+def alloc_with_pred_tail(B, h, w, c0, dev) -> Feat:
+    """concat buffer [c0 feature channels | pred1 | pred2]; when the tail is 16-byte aligned ``place_preds`` writes the two
+    pad channels too, so nothing has to be zeroed beforehand"""
+    return Feat.alloc_raw(B, h, w, c0 + 2, dev) if _fused_tail(c0) else Feat.alloc(B, h, w, c0 + 2, dev)
+
+
+def place_preds(pred1: Feat, pred2: Feat, buf: Feat, c0: int):
+    """the [pred1 | pred2] tail of a buffer from ``alloc_with_pred_tail`` (the two depth maps resized to the level)"""
+    assert buf.c0 == 0 and buf.c == c0 + 2 and pred1.ld == 1 and pred2.ld == 1
+    if _fused_tail(c0):
+        return ops.depth_pair_fill(pred1, pred2, buf, c0)
+    place(pred1, buf.slice(c0, 1))
+    place(pred2, buf.slice(c0 + 1, 1))
 
 
 class _EncDec(StateDictModule):
@@ -73,7 +98,7 @@ class _EncDec(StateDictModule):
         dec_bufs = []
         for j, (c1, c2, dc) in enumerate(self.dec_in):
             h, w = sizes[L_ - 2 - j]
-            dec_bufs.append(Feat.alloc(B, h, w, c1 + c2 + 2, dev))
+            dec_bufs.append(alloc_with_pred_tail(B, h, w, c1 + c2, dev))
         temps = [None] * L_
         for l in range(L_):
             h, w = sizes[l]
@@ -81,10 +106,9 @@ class _EncDec(StateDictModule):
             cat1 = cat1_bufs[l] if cat1_bufs is not None else Feat.alloc(B, h, w, self.in_chl[l], dev)
             pairs[l](cat1)
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
-            cat2 = Feat.alloc(B, h, w, tc + 2, dev)
+            cat2 = alloc_with_pred_tail(B, h, w, tc, dev)
             ops.conv2d(cat1, conv, cat2.slice(0, tc), act=ACT_GELU, ln=(lnw, lnb))  # conv -> LN -> GELU (convs.py:67-72)
-            place(pred1, cat2.slice(tc, 1))
-            place(pred2, cat2.slice(tc + 1, 1))
+            place_preds(pred1, pred2, cat2, tc)
             conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
             j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
             if 0 <= j < nd:
@@ -98,8 +122,7 @@ class _EncDec(StateDictModule):
         for j, (c1, c2, dc) in enumerate(self.dec_in):
             buf = dec_bufs[j]
             place(feat, buf.slice(0, c1))
-            place(pred1, buf.slice(c1 + c2, 1))
-            place(pred2, buf.slice(c1 + c2 + 1, 1))
+            place_preds(pred1, pred2, buf, c1 + c2)
             c0w, c2w = P[f"{self.DEC}.{j}"]
             t = ops.conv2d(buf, c0w, act=ACT_GELU)
             feat = ops.conv2d(t, c2w, act=ACT_GELU)

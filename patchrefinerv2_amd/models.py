@@ -230,7 +230,8 @@ class _PatchModel(StateDictModule):
         if not self.needs_coarse:
             return crops, None, None
         # roi_align(feat, boxes, (h, w), h / ph, aligned=True) per level (patchrefinerplus.py:268-276)
-        rois = [ops.roi_align(f, boxes_dev, f.h / ph, f.h, f.w) for f in coarse_feats]
+        # (not materialised: each level is gathered straight into the concat buffers that consume it -- ops.RoiSource)
+        rois = [ops.RoiSource(f, boxes_dev, f.h / ph, f.h, f.w) for f in coarse_feats]
         depth_roi = ops.roi_align(coarse_depth, boxes_dev, coarse_depth.h / ph, coarse_depth.h, coarse_depth.w,
                                   out=Feat(torch.empty((K, coarse_depth.h, coarse_depth.w, 1), device=dev)))
         return crops, rois, depth_roi

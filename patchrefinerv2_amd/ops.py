@@ -9,6 +9,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
+import os
+
 import torch
 
 from . import lib as L
@@ -123,6 +125,11 @@ class Feat:
         self.c = buf.shape[3] - c0 if c is None else c
         self.c0 = c0
         assert 0 <= c0 and c0 + self.c <= buf.shape[3]
+
+    @staticmethod
+    def alloc_raw(n, h, w, c, device, pad_to: int = 4) -> "Feat":
+        """like ``alloc`` but the pad channels are left to the caller (a producer that writes them: ops.depth_pair_fill)"""
+        return Feat(torch.empty((n, h, w, roundup(c, pad_to)), device=device, dtype=torch.float32), c)
 
     @staticmethod
     def alloc(n, h, w, c, device, pad_to: int = 4) -> "Feat":
@@ -528,6 +535,45 @@ def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> 
                                                                          out.ld, _stream()), "upsample_bilinear"),
                         f"{x.c}ch {x.n}x{x.h}x{x.w}->{oh}x{ow}")
     return out
+
+
+DIRECT_PLACEMENT = os.environ.get("PRV2_DIRECT_PLACEMENT", "1") != "0"  # A/B and test switch: ROI levels / depth pairs written by their producers
+
+
+class RoiSource:
+    """A level of the coarse pyramid as seen by one batch of tiles: ``roi_align(feat.repeat(K), boxes, (h, w), scale)`` that has
+    not been materialised.  Its consumers are concat buffers (the [coarse | fine] inputs of the fusion convs): ``write(dst)``
+    gathers straight into a destination slice -- reading the small, L2-resident coarse map again is cheaper than writing the
+    K-tile ROI once and copying it into each consumer (1 + 2 x (read + write) of K x c x h x w floats -> 2 writes)."""
+
+    def __init__(self, feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow: int):
+        self.feat, self.boxes, self.scale = feat, boxes, spatial_scale
+        self.n, self.h, self.w, self.c = boxes.shape[0], oh, ow, feat.c
+        self._mat: Optional[Feat] = None
+
+    @property
+    def device(self):
+        return self.feat.device
+
+    def write(self, dst: Feat):
+        assert (dst.n, dst.h, dst.w, dst.c) == (self.n, self.h, self.w, self.c)
+        if not DIRECT_PLACEMENT:
+            return upsample_bilinear(self.materialize(), dst.h, dst.w, out=dst)
+        roi_align(self.feat, self.boxes, self.scale, self.h, self.w, out=dst)
+
+    def materialize(self) -> Feat:
+        if self._mat is None:
+            self._mat = roi_align(self.feat, self.boxes, self.scale, self.h, self.w)
+        return self._mat
+
+
+def depth_pair_fill(p1: Feat, p2: Feat, buf: Feat, c0: int):
+    """channels c0, c0 + 1 of ``buf`` <- (p1, p2) resized to the buffer's size, channels c0 + 2, c0 + 3 (the pad) <- 0"""
+    assert p1.c == 1 and p2.c == 1 and p1.ld == 1 and p2.ld == 1 and (p1.n, p1.h, p1.w) == (p2.n, p2.h, p2.w) == (buf.n, p1.h, p1.w)
+    assert buf.ld == buf.c0 + c0 + 4 and (buf.c0 + c0) % 4 == 0, (buf.ld, buf.c0, c0)
+    PROFILER.launch_aux("depth_pair_fill", 16.0 * buf.n * buf.h * buf.w,
+                        lambda: L.check(L.load().prv2_depth_pair_fill(p1.ptr, p2.ptr, p1.n, p1.h, p1.w, buf.h, buf.w, buf.ptr + 4 * c0, buf.ld,
+                                                                      _stream()), "depth_pair_fill"), f"{buf.n}x{p1.h}x{p1.w}->{buf.h}x{buf.w}")
 
 
 def blend_paste(avg, cnt, pred, mask, tiles, th, tw):

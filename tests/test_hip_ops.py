@@ -265,6 +265,40 @@ def test_upsample(P, case):
     close(got.to_nchw(), o_ops.bilinear_ac(x, (oh, ow)), 2e-6)
 
 
+@pytest.mark.parametrize("case", [(3, 56, 84, 56, 84, 64), (2, 56, 84, 28, 42, 32), (2, 24, 32, 48, 61, 8), (1, 12, 16, 3, 5, 0)])
+def test_depth_pair_fill_is_the_two_placements(P, case):
+    """[feat | pred1 | pred2 | 0 | 0]: the fused tail writer == two 1-channel bilinear placements + zeroed pads, bit for bit,
+    and == the oracle's bilinear(align_corners=True) (fusion_model.py:91-118)"""
+    n, h, w, oh, ow, c0 = case
+    p1, p2 = rnd(3, n, 1, h, w), rnd(4, n, 1, h, w)
+    f1, f2 = (P.Feat(t.to(DEV).view(n, h, w, 1).contiguous()) for t in (p1, p2))
+    ref = P.Feat(torch.zeros((n, oh, ow, c0 + 4), device=DEV), c0 + 2)
+    P.upsample_bilinear(f1, oh, ow, out=ref.slice(c0, 1))
+    P.upsample_bilinear(f2, oh, ow, out=ref.slice(c0 + 1, 1))
+    got = P.Feat.alloc_raw(n, oh, ow, c0 + 2, DEV)
+    got.buf.fill_(float("nan"))
+    if c0:
+        got.buf[..., :c0] = 0
+    P.depth_pair_fill(f1, f2, got, c0)
+    assert torch.equal(got.buf, ref.buf)
+    close(got.buf[..., c0].cpu(), o_ops.bilinear_ac(p1, (oh, ow))[:, 0], 1e-5, "pair fill vs oracle")
+    with pytest.raises(RuntimeError, match="16-byte"):
+        P.L.check(P.L.load().prv2_depth_pair_fill(f1.ptr, f2.ptr, n, h, w, oh, ow, got.ptr + 4, got.ld, 0), "x")
+
+
+def test_roi_source_writes_what_roi_align_materialises(P):
+    """the un-materialised pyramid level gathers the same numbers into a slice of a concat buffer (patchrefinerplus.py:263-283)"""
+    feat = P.Feat.from_nchw(rnd(1, 1, 32, 24, 32).to(DEV))
+    bboxs = torch.tensor([[0, 0, 192, 108], [192, 108, 384, 216], [96, 54, 288, 162]])
+    boxes = o_tiling.bboxs_to_feat(bboxs, (216, 384), (56, 84))[:, 1:].contiguous().to(DEV)
+    ref = P.roi_align(feat, boxes, 24 / 56, 24, 32)
+    src = P.RoiSource(feat, boxes, 24 / 56, 24, 32)
+    cat = P.Feat.alloc(3, 24, 32, 32 + 40, DEV)
+    src.write(cat.slice(40, 32))
+    assert torch.equal(cat.buf[..., 40:72], ref.buf) and float(cat.buf[..., :40].abs().max()) == 0
+    assert torch.equal(src.materialize().buf, ref.buf) and (src.n, src.h, src.w, src.c) == (3, 24, 32, 32)
+
+
 def test_blend_sequence(P):
     g = torch.Generator().manual_seed(4)
     ph, pw, MH, MW = 24, 32, 48, 64
