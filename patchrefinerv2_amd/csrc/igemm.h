@@ -291,6 +291,8 @@ bool conv3x3_halo_supported(const IgemmParams& p);
 void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t stream);
 bool conv3x3_halo16_usable(const IgemmParams& p, int prec);
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t stream);  // tiles [0, tiles_x) + strip [rx0, rx0 + rw)
+// conv3x3_gate.hip: 3x3 convs with 256 output channels (8 x 16 pixel tiles x all channels; fused LayerNorm / gate tail)
+bool conv3x3_c256_eligible(const prv2_conv_desc* d, const float* x, const float* res, const float* y);
 // gemm_m16.hip: dense 1x1 / linear layers in the bf16 modes
 bool gemm16_supported(const IgemmParams& p, int prec);
 void launch_gemm16(IgemmParams& p, int prec, hipStream_t stream);

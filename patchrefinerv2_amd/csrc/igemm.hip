@@ -368,11 +368,15 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   PRV2_REQUIRE(d->prec >= PRV2_PREC_F32 && d->prec <= PRV2_PREC_BF16, "conv2d: unknown precision mode %d", d->prec);
   PRV2_REQUIRE(d->act >= PRV2_ACT_NONE && d->act <= PRV2_ACT_SILU, "conv2d: unknown activation %d", d->act);
   PRV2_REQUIRE(aligned16(w_packed), "conv2d: packed weights must be 16-byte aligned");
+  PRV2_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "conv2d: ln_weight and ln_bias go together");
+  // 3x3 convs with 256 output channels (a layer property: the choice never depends on the batch): the workgroup holds the whole
+  // channel row, so the LayerNorm is fused for this width too
+  if (!d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
+    return prv2_conv3x3_ln_gate(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, nullptr, res, y, stream);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps;
-  PRV2_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "conv2d: ln_weight and ln_bias go together");
   PRV2_REQUIRE(!ln_weight || (d->cout <= 128 && d->convt_k == 0), "conv2d: fused LayerNorm needs cout <= 128 (got %d)", d->cout);
   p.N = d->n; p.H = d->h; p.W = d->w;
   p.Cin = d->cin; p.Cin_pad = (int)roundup(d->cin, BK); p.Cout = d->cout;

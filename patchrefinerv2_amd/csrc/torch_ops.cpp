@@ -129,6 +129,49 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
   return y;
 }
 
+// include/prv2.h::prv2_pack_gate_weight / prv2_conv3x3_ln_gate: the GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80)
+Tensor pack_gate_weight(const Tensor& w) {
+  dev_f32(w, "weight");
+  TORCH_CHECK(w.numel() == 256 * 256 && w.size(0) == 256, "prv2::pack_gate_weight: the fused gate is a 256 -> 256 1x1 conv");
+  Tensor wc = w.contiguous();
+  Tensor packed = at::empty({prv2_gate_weight_bytes() / 4}, w.options());
+  Launch L(w);
+  ok(prv2_pack_gate_weight(wc.data_ptr<float>(), packed.data_ptr(), 256, 256, L.stream), "pack_gate_weight");
+  return packed;
+}
+
+Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, const Tensor& ln_weight, const Tensor& ln_bias,
+                       const optional<Tensor>& gate_w_packed, const optional<Tensor>& gate_bias, const optional<Tensor>& mul,
+                       const optional<Tensor>& res, int64_t act, bool relu_in, int64_t prec, double ln_eps, const optional<Tensor>& out) {
+  const int64_t ldx = nhwc_ld(x, "x");
+  dev_f32(w_packed, "w_packed");
+  const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = 256;
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_packed_weight_bytes((int)cout, (int)cin, 3, 3, 0, (int)prec), "prv2::conv3x3_ln_gate: w_packed does not match a 3x3 ",
+              cin, " -> 256 conv in mode ", prec);
+  Tensor y = out_or_alloc(out, x, n, h, w, cout, "conv3x3_ln_gate");
+  prv2_conv_desc d = {};
+  d.n = (int)n; d.h = (int)h; d.w = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.kh = 3; d.kw = 3; d.stride = 1; d.pad = 1;
+  d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out"); d.relu_in = relu_in; d.act = (int)act; d.prec = (int)prec; d.ln_eps = (float)ln_eps;
+  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256, cin % 32 == 0, width % 16 == 0, bf16 modes)");
+  auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
+    if (!t.has_value()) return nullptr;
+    ld = (int32_t)nhwc_ld(*t, name);
+    TORCH_CHECK(t->sizes() == y.sizes(), "prv2::conv3x3_ln_gate: ", name, " must have the output's shape");
+    return t->data_ptr<float>();
+  };
+  const float* pm = aux(mul, "mul", d.ld_mul);
+  const float* pr = aux(res, "res", d.ld_res);
+  if (gate_w_packed.has_value()) {
+    dev_f32(*gate_w_packed, "gate_w_packed");
+    TORCH_CHECK(gate_w_packed->numel() * 4 == prv2_gate_weight_bytes(), "prv2::conv3x3_ln_gate: gate_w_packed is not a pack_gate_weight image");
+  }
+  Launch L(x);
+  ok(prv2_conv3x3_ln_gate(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), opt_ptr(ln_weight, "ln_weight", cout),
+                          opt_ptr(ln_bias, "ln_bias", cout), gate_w_packed.has_value() ? gate_w_packed->data_ptr() : nullptr,
+                          opt_ptr(gate_bias, "gate_bias", cout), pm, pr, y.data_ptr<float>(), L.stream), "conv3x3_ln_gate");
+  return y;
+}
+
 // nn.LayerNorm over the last dimension of [rows, c] (tokens) or of an NHWC map (the reference's channels-first LayerNorm)
 Tensor layernorm(const Tensor& x, const Tensor& weight, const Tensor& bias, double eps, int64_t act, const optional<Tensor>& out) {
   dev_f32(x, "x");
@@ -314,6 +357,9 @@ TORCH_LIBRARY(prv2, m) {
   m.def("conv2d(Tensor x, Tensor w_packed, Tensor? bias, int cout, int kh, int kw, int stride=1, int pad=0, int act=0, bool relu_in=False, "
         "Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? gamma=None, Tensor? mul=None, Tensor? res=None, Tensor? res2=None, int convt_k=0, "
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None) -> Tensor");
+  m.def("pack_gate_weight(Tensor weight) -> Tensor");
+  m.def("conv3x3_ln_gate(Tensor x, Tensor w_packed, Tensor? bias, Tensor ln_weight, Tensor ln_bias, Tensor? gate_w_packed=None, Tensor? gate_bias=None, "
+        "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
   m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0, Tensor(a!)? out=None) -> Tensor");
   m.def("roi_align(Tensor feat, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None) -> Tensor");
   m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0, Tensor? bias=None) -> Tensor");
@@ -335,6 +381,8 @@ TORCH_LIBRARY(prv2, m) {
 TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("pack_conv_weight", &pack_conv_weight);
   m.impl("conv2d", &conv2d);
+  m.impl("pack_gate_weight", &pack_gate_weight);
+  m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
   m.impl("layernorm", &layernorm);
   m.impl("attention_fwd", &attention_fwd);
   m.impl("crop_resize_bilinear", &crop_resize_bilinear);

@@ -194,9 +194,13 @@ class BiDirectionalFusion(_EncDec):
         P["rn"] = [self._conv(f"{s}layer{i + 1}_rn") for i in range(5)]
 
         def unit(b):
-            return dict(conv=self._conv(b + "conv"), f0=self._conv(b + "fusion_conv.0"),
-                        lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
-                        f3=self._conv(b + "fusion_conv.3"))
+            u = dict(conv=self._conv(b + "conv"), f0=self._conv(b + "fusion_conv.0"),
+                     lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
+                     f3=self._conv(b + "fusion_conv.3"))
+            w3 = self._sd[b + "fusion_conv.3.weight"]
+            if self.prec != ops.PREC_F32 and tuple(w3.shape[:2]) == (256, 256):  # fused tail kernel (ops.conv3x3_ln_gate)
+                u["f3g"] = ops.pack_gate(w3.to(self.device))
+            return u
 
         def block(b):
             return dict(out_conv=self._conv(b + "out_conv"), u1=unit(b + "GateresConfUnit1."),
@@ -216,6 +220,8 @@ class BiDirectionalFusion(_EncDec):
         """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
         half already holds the coarse feature; the lower half receives ``out``."""
         out = ops.conv2d(x, u["conv"], cat.slice(0, F_), relu_in=True, res=x)            # conv(relu(x)) + x
+        if "f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]):                  # the whole fusion_conv + gate in one kernel
+            return ops.conv3x3_ln_gate(cat, u["f0"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res)
         fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
         return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])
 

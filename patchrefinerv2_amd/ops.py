@@ -227,13 +227,21 @@ def conv_out_hw(cw: ConvW, h: int, w: int):
     return (h + 2 * cw.pad - cw.kh) // cw.stride + 1, (w + 2 * cw.pad - cw.kw) // cw.stride + 1
 
 
+def _c256(x: Feat, cw: ConvW) -> bool:
+    """does the library run this conv on its 256-channel 3x3 kernel (which fuses the LayerNorm at that width)?"""
+    if x.c != cw.cin or x.ld % 4 or os.environ.get("PRV2_NO_C256"):
+        return False
+    return bool(L.load().prv2_conv3x3_ln_gate_supported(C.byref(_gate_desc(x, cw, roundup(cw.cout, 4), False, ACT_NONE, None, None, 1e-6))))
+
+
 def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = False, act: int = ACT_NONE,
            gamma: Optional[torch.Tensor] = None, mul: Optional[Feat] = None, res: Optional[Feat] = None,
            res2: Optional[Feat] = None, x_bstride: int = 0, force_generic: bool = False, ln=None,
            ln_eps: float = 1e-6) -> Feat:
     """y = epilogue(conv(x)); see include/prv2.h::prv2_conv2d.  ``ln`` = (weight, bias) of a channels-first
     LayerNorm applied between the bias and the activation (fused when cout <= 128, else a separate row-LN pass)."""
-    if ln is not None and cw.cout > 128:
+    if ln is not None and cw.cout > 128 and not (gamma is None and mul is None and res2 is None and not force_generic and not x_bstride
+                                                 and _c256(x, cw)):
         y = conv2d(x, cw, out, relu_in=relu_in, x_bstride=x_bstride, force_generic=force_generic)
         assert gamma is None and mul is None and res is None and res2 is None
         return layernorm_feat(y, ln[0], ln[1], ln_eps, act)
@@ -281,6 +289,59 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
         PROFILER.launch(tag, full * rem / x.w, call, shape=shape + f" strip{rem}")
         return out
     PROFILER.launch(tag, 2.0 * m_rows * ncols * cw.cin * taps, call, shape=shape)
+    return out
+
+
+GATE_FUSION = os.environ.get("PRV2_GATE_FUSION", "1") != "0"  # A/B and test switch: GatedConvUnit tail as one kernel
+
+
+def pack_gate(weight: torch.Tensor) -> torch.Tensor:
+    """fragment-major image of a 256 -> 256 1x1 conv's weights for ``conv3x3_ln_gate`` (prv2_pack_gate_weight)"""
+    w = weight.detach().to(torch.float32).reshape(weight.shape[0], -1).contiguous()
+    assert w.shape == (256, 256) and w.is_cuda
+    if DISPATCH == "torch":
+        return _tops().pack_gate_weight(w)
+    dst = torch.empty(L.load().prv2_gate_weight_bytes() // 4, device=w.device, dtype=torch.float32)
+    _require_dev(w)
+    L.check(L.load().prv2_pack_gate_weight(w.data_ptr(), dst.data_ptr(), 256, 256, _stream()), "pack_gate_weight")
+    return dst
+
+
+def _gate_desc(x: Feat, cw: ConvW, out_ld: int, relu_in, act, mul, res, ln_eps):
+    return L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad,
+                      ldx=x.ld, ldy=out_ld, x_bstride=0, y_bstride=0, relu_in=int(relu_in), act=act, convt_k=cw.convt_k,
+                      ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0, ld_res2=0, prec=cw.prec,
+                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+
+
+def conv3x3_ln_gate_supported(x: Feat, cw: ConvW) -> bool:
+    """shape contract of the fused kernel (layer shape per image only: the choice never depends on the batch)"""
+    return GATE_FUSION and _c256(x, cw)
+
+
+def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate_bias: Optional[torch.Tensor], out: Optional[Feat] = None,
+                    *, act: int = ACT_RELU, mul: Optional[Feat] = None, res: Optional[Feat] = None, relu_in: bool = False,
+                    ln_eps: float = 1e-6) -> Feat:
+    """y = mul * sigmoid(conv1x1(act(LN(conv3x3(x) + b))) + gate_bias) (+ res) in one kernel (include/prv2.h::prv2_conv3x3_ln_gate);
+    ``gate_w`` None: y = act(LN(conv3x3(x) + b))."""
+    if out is None:
+        out = Feat.alloc(x.n, x.h, x.w, cw.cout, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and x.c == cw.cin
+    for aux in (mul, res):
+        assert aux is None or (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
+    d = _gate_desc(x, cw, out.ld, relu_in, act, mul, res, ln_eps)
+    flops = 2.0 * x.n * x.h * x.w * cw.cout * (cw.cin * 9 + (cw.cout if gate_w is not None else 0))
+    if DISPATCH == "torch" and type(x) is Feat:
+        v = lambda f: None if f is None else f.view()  # noqa: E731
+        PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
+                        lambda: _tops().conv3x3_ln_gate(x.view(), cw.w, cw.bias, ln[0], ln[1], gate_w, gate_bias, v(mul), v(res), act, relu_in, cw.prec,
+                                                        ln_eps, out.view()))
+        return out
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
+                    lambda: L.check(L.load().prv2_conv3x3_ln_gate(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]), _ptr(ln[1]),
+                                                                  _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), out.ptr, _stream()),
+                                    "conv3x3_ln_gate"),
+                    shape=f"{cw.cin}->{cw.cout}{'->' + str(cw.cout) + ' gate' if gate_w is not None else ''} k3s1 {x.n}x{x.h}x{x.w}")
     return out
 
 

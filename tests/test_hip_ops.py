@@ -84,6 +84,83 @@ def test_conv2d(P, case):
     close(y.to_nchw(), ref, 2e-5, f"conv {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 20, 32, 64, True, True), (1, 8, 16, 512, True, False), (3, 13, 48, 96, False, False), (1, 24, 16, 32, True, True)])
+@pytest.mark.parametrize("prec", ["bf16x3", "f32ref"])
+def test_conv3x3_ln_gate_fused_tail(P, case, prec):
+    """GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80) as one kernel: vs plain torch fp32, and vs the unfused
+    kernel sequence conv2d -> LayerNorm -> conv2d(1x1, sigmoid, mul, res) in the same arithmetic mode"""
+    n, h, w, cin, gate, with_res = case
+    x = rnd(1, n, cin, h, w)
+    w0, b0 = rnd(2, 256, cin, 3, 3) / np.sqrt(9 * cin), rnd(3, 256) * 0.1
+    lnw, lnb = 1 + 0.2 * rnd(4, 256), 0.1 * rnd(5, 256)
+    w3, b3 = rnd(6, 256, 256, 1, 1) / 16, rnd(7, 256) * 0.1
+    mul, res = rnd(8, n, 256, h, w), rnd(9, n, 256, h, w)
+    y = F.conv2d(x, w0, b0, padding=1)
+    u = y.mean(1, keepdim=True)
+    sd = (y - u).pow(2).mean(1, keepdim=True)
+    fused = F.relu((y - u) / torch.sqrt(sd + 1e-6) * lnw.view(1, -1, 1, 1) + lnb.view(1, -1, 1, 1))
+    ref = mul * torch.sigmoid(F.conv2d(fused, w3, b3)) + (res if with_res else 0) if gate else fused
+    PR = P.L.PREC_NAMES["bf16x3"]
+    f = lambda t: P.Feat.from_nchw(t.to(DEV))  # noqa: E731
+    cw0, cw3 = P.pack_conv(w0.to(DEV), b0.to(DEV), pad=1, prec=PR), P.pack_conv(w3.to(DEV), b3.to(DEV), prec=PR)
+    xf, ln = f(x), (lnw.to(DEV), lnb.to(DEV))
+    assert P.conv3x3_ln_gate_supported(xf, cw0)
+    got = P.conv3x3_ln_gate(xf, cw0, ln, P.pack_gate(w3.to(DEV)) if gate else None, b3.to(DEV) if gate else None, act=P.ACT_RELU,
+                            mul=f(mul) if gate else None, res=f(res) if gate and with_res else None)
+    assert P.L.load().prv2_last_kernel().decode().startswith("conv3x3_c256_gate_kernel<256" if gate else "conv3x3_c256_kernel<256")
+    if prec == "f32ref":
+        close(got.to_nchw(), ref, 2e-5, f"fused tail {case}")
+        return
+    t = P.conv2d(xf, cw0, act=P.ACT_RELU, ln=ln)
+    if gate:
+        t = P.conv2d(t, cw3, act=P.ACT_SIGMOID, mul=f(mul), res=f(res) if with_res else None)
+    close(got.to_nchw(), t.to_nchw().cpu(), 2e-6, f"fused vs unfused {case}")
+
+
+@pytest.mark.parametrize("case", [(2, 20, 32, 64, dict(bias=True, relu_in=True, res=True)), (1, 9, 48, 96, dict(act="gelu")),
+                                  (3, 8, 16, 512, dict(bias=True, ln=True, act="gelu")), (1, 24, 64, 32, dict(bias=True, ln=True, res=True))])
+def test_conv2d_256_channels_take_the_wide_tile_kernel(P, case):
+    """prv2_conv2d sends 3x3 convs with 256 output channels (width % 16 == 0, Cin % 32 == 0, bf16 modes) to the 8 x 16 x 256 kernel
+    of conv3x3_gate.hip -- also with a fused LayerNorm, which the 128-column kernel cannot do at this width"""
+    n, h, w, cin, o = case
+    PR = P.L.PREC_NAMES["bf16x3"]
+    x = rnd(1, n, cin, h, w)
+    wt, bias = rnd(2, 256, cin, 3, 3) / np.sqrt(9 * cin), (rnd(3, 256) * 0.1 if o.get("bias") else None)
+    lnw, lnb = 1 + 0.2 * rnd(4, 256), 0.1 * rnd(5, 256)
+    res = rnd(6, n, 256, h, w) if o.get("res") else None
+    ref = F.conv2d(F.relu(x) if o.get("relu_in") else x, wt, bias, padding=1)
+    if o.get("ln"):
+        u = ref.mean(1, keepdim=True)
+        ref = (ref - u) / torch.sqrt((ref - u).pow(2).mean(1, keepdim=True) + 1e-6) * lnw.view(1, -1, 1, 1) + lnb.view(1, -1, 1, 1)
+    if o.get("act") == "gelu":
+        ref = F.gelu(ref)
+    if res is not None:
+        ref = ref + res
+    cw = P.pack_conv(wt.to(DEV), bias.to(DEV) if bias is not None else None, pad=1, prec=PR)
+    f = lambda t: P.Feat.from_nchw(t.to(DEV)) if t is not None else None  # noqa: E731
+    kw = dict(relu_in=bool(o.get("relu_in")), act=P.ACT_GELU if o.get("act") else P.ACT_NONE, res=f(res))
+    y = P.conv2d(f(x), cw, ln=(lnw.to(DEV), lnb.to(DEV)) if o.get("ln") else None, **kw)
+    assert P.L.load().prv2_last_kernel().decode() == "conv3x3_c256_kernel<256,bf16x3>"
+    close(y.to_nchw(), ref, 2e-5, f"c256 {case}")
+    if not o.get("ln"):
+        g = P.conv2d(f(x), cw, force_generic=True, **kw)
+        close(y.to_nchw(), g.to_nchw().cpu(), 2e-6, "c256 vs generic")
+
+
+def test_conv3x3_ln_gate_rejects_what_it_does_not_cover(P):
+    PR = P.L.PREC_NAMES["bf16x3"]
+    cw = P.pack_conv(rnd(1, 256, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
+    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 24).to(DEV)), cw)      # width % 16
+    cw128 = P.pack_conv(rnd(1, 128, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
+    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cw128)   # cout != 256
+    cwf = P.pack_conv(rnd(1, 256, 64, 3, 3).to(DEV), None, pad=1)
+    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cwf)     # f32 mode
+    x = P.Feat.from_nchw(rnd(2, 1, 64, 8, 24).to(DEV))
+    ln = (torch.ones(256, device=DEV), torch.zeros(256, device=DEV))
+    with pytest.raises(RuntimeError, match="width"):
+        P.conv3x3_ln_gate(x, cw, ln, None, None)
+
+
 def test_conv_into_concat_slice(P):
     """producer writes into a channel slice of a wider buffer == torch.cat"""
     x = rnd(1, 1, 32, 10, 12)
@@ -293,7 +370,7 @@ def test_roi_source_writes_what_roi_align_materialises(P):
     boxes = o_tiling.bboxs_to_feat(bboxs, (216, 384), (56, 84))[:, 1:].contiguous().to(DEV)
     ref = P.roi_align(feat, boxes, 24 / 56, 24, 32)
     src = P.RoiSource(feat, boxes, 24 / 56, 24, 32)
-    cat = P.Feat.alloc(3, 24, 32, 32 + 40, DEV)
+    cat = P.Feat(torch.zeros(3, 24, 32, 32 + 40, device=DEV))
     src.write(cat.slice(40, 32))
     assert torch.equal(cat.buf[..., 40:72], ref.buf) and float(cat.buf[..., :40].abs().max()) == 0
     assert torch.equal(src.materialize().buf, ref.buf) and (src.n, src.h, src.w, src.c) == (3, 24, 32, 32)

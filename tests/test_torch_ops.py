@@ -83,6 +83,33 @@ def test_conv2d_fused_epilogue_and_slices(T, prec):
 
 
 @gpu
+def test_conv3x3_ln_gate_op(T):
+    """GatedConvUnit tail as ONE op (bi_directional_fusion_model.py:44-51,70-80): out * sigmoid(conv1x1(relu(LN(conv3x3(cat))))) + xs[0],
+    written into a channel slice; == the three-op sequence of the test above at 256 channels"""
+    import torch.nn.functional as F
+    ops, mod = T
+    x = randn(1, 2, 64, 12, 32)
+    w, b = randn(2, 256, 64, 3, 3) / 24.0, randn(3, 256) * 0.1
+    lw, lb = 1 + 0.1 * randn(4, 256), 0.1 * randn(5, 256)
+    w1, b1 = randn(6, 256, 256, 1, 1) / 16.0, randn(7, 256) * 0.1
+    mul, res = randn(8, 2, 256, 12, 32), randn(9, 2, 256, 12, 32)
+    c = F.conv2d(x, w, b, padding=1)
+    u = c.mean(1, keepdim=True)
+    sd = (c - u).pow(2).mean(1, keepdim=True)
+    fused = F.relu(lw.view(1, -1, 1, 1) * ((c - u) / torch.sqrt(sd + 1e-6)) + lb.view(1, -1, 1, 1))
+    ref = mul * torch.sigmoid(F.conv2d(fused, w1, b1)) + res
+    buf = torch.zeros(2, 12, 32, 256 + 32, device=DEV)
+    wp, gp = ops.pack_conv_weight(w.to(DEV), None, 0, mod.PREC_BF16X3), ops.pack_gate_weight(w1.to(DEV))
+    y = ops.conv3x3_ln_gate(_nhwc(x), wp, b.to(DEV), lw.to(DEV), lb.to(DEV), gp, b1.to(DEV), _nhwc(mul), _nhwc(res), act=mod.ACT_RELU,
+                            prec=mod.PREC_BF16X3, out=buf[..., 32:])
+    assert y.data_ptr() == buf[..., 32:].data_ptr() and float(buf[..., :32].abs().max()) == 0.0
+    _close(_nchw(y), ref, 3e-5)
+    _close(_nchw(ops.conv3x3_ln_gate(_nhwc(x), wp, b.to(DEV), lw.to(DEV), lb.to(DEV), act=mod.ACT_RELU, prec=mod.PREC_BF16X3)), fused, 3e-5)
+    with pytest.raises(RuntimeError, match="not covered"):
+        ops.conv3x3_ln_gate(_nhwc(x)[:, :, :24].contiguous(), wp, b.to(DEV), lw.to(DEV), lb.to(DEV))  # width % 16
+
+
+@gpu
 def test_conv_transpose_and_linear(T):
     import torch.nn.functional as F
     ops, _ = T

@@ -1,0 +1,28 @@
+"""see gate_phase_stamps.sh"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+stamps = torch.zeros(100000 * 10, dtype=torch.int64, device="cuda")
+os.environ["PRV2_STAMP_PTR"] = hex(stamps.data_ptr())
+from patchrefinerv2_amd import lib as L
+L.LIB_PATH = os.environ["PRV2_LIB_OVERRIDE"]
+from patchrefinerv2_amd import ops as P
+PR = L.PREC_NAMES["bf16x3"]
+NAMES = ["prologue", "main loop", "C tile -> LDS", "row stats", "normalise + split", "gate GEMM", "gate acc -> LDS", "store loop", "store drain"]
+for n, h, w, cin in ((14, 192, 256, 512), (14, 96, 128, 512), (14, 192, 256, 256)):
+    x = P.Feat(torch.randn(n, h, w, cin, device="cuda"))
+    cw0 = P.pack_conv(torch.randn(256, cin, 3, 3, device="cuda") / (3 * cin ** 0.5), torch.randn(256, device="cuda"), pad=1, prec=PR)
+    w3 = torch.randn(256, 256, 1, 1, device="cuda") / 16
+    gw, gb = P.pack_gate(w3), torch.randn(256, device="cuda")
+    ln = (torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda") * 0.1)
+    mul, res = P.Feat(torch.randn(n, h, w, 256, device="cuda")), P.Feat(torch.randn(n, h, w, 256, device="cuda"))
+    out = P.Feat.alloc(n, h, w, 256, "cuda")
+    for _ in range(3):
+        P.conv3x3_ln_gate(x, cw0, ln, gw, gb, out, act=P.ACT_RELU, mul=mul, res=res)
+    torch.cuda.synchronize()
+    nblk = n * (h // 8) * (w // 16)
+    s = stamps[: nblk * 10].view(nblk, 10).cpu().double()
+    d = (s[:, 1:] - s[:, :-1]) / 1000.0
+    tot = (s[:, 9] - s[:, 0]) / 1000.0
+    print(f"{n}x{h}x{w} {cin}->256->256: {nblk} workgroups, median {tot.median():.1f} kcycles (s_memtime units) per workgroup: " +
+          "  ".join(f"{nm} {d[:, i].median():.2f}" for i, nm in enumerate(NAMES)), flush=True)
