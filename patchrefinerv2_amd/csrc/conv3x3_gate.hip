@@ -52,13 +52,13 @@ struct GateConvParams {
   IgemmParams c;           // the 3x3 conv: x, w, bias, ln_w, ln_b, ln_eps, act; final stage: mul, res, y (+ their strides)
   const void* gate_w;      // fragment-major packed 256 x 256 gate weights, or null: y = act(LN(conv + bias))
   const float* gate_bias;
-  long long* stamps;       // -DPRV2_GATE_STAMPS builds (tools/probes/gate_phase_stamps.sh): 10 s_memtime stamps per workgroup
+  long long* stamps;       // -DPRV2_GATE_STAMPS builds (tools/probes/gate_phase_stamps.sh): 10 s_memtime stamps per wave
 };
 
 #ifdef PRV2_GATE_STAMPS
 #define PRV2_STAMP(i)                                                                                      \
   do {                                                                                                     \
-    if (gp.stamps && threadIdx.x == 0) gp.stamps[(long long)blockIdx.x * 10 + (i)] = __builtin_readcyclecounter(); \
+    if (gp.stamps && (threadIdx.x & 63) == 0) gp.stamps[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 10 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define PRV2_STAMP(i)
@@ -240,21 +240,29 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
             mma(acc[a + 1][j], ah[a + 1], al[a + 1], bh[j & 1], bl[j & 1], pr);
           }
           __builtin_amdgcn_sched_barrier(0);
+#ifndef PRV2_ABL_NOA  // (timing ablations of tools/probes/gate_phase_stamps.sh: results are wrong with any of them)
           if (j == 0 && a == 0) {
             if constexpr (tap < A_IT) load_a_async(ccn, tap);
           }
+#endif
           if (j == 1 && a == NA - 2) {
+#ifndef PRV2_ABL_NOA
             if constexpr (tap >= 2 && tap - 2 < A_IT) {
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
               constexpr int newer = 2 * ND + Lm1 + L0;
               asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
               store_a(ab ^ 1, tap - 2);
             }
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#ifdef PRV2_ABL_NOBAR
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ND + Lm1 + L0) : "memory");
+#else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ND + Lm1 + L0) : "memory");
+#endif
       read_b(NJ & 1, (tap + 1) % 3, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -267,8 +275,10 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
         __builtin_amdgcn_sched_barrier(0);
         read_a(a, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
         read_a(a + 1, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
+#ifndef PRV2_ABL_NOB
         dma_b_async(s3, tap % 3, a);      // this step's tile buffer is free since the barrier
         dma_b_async(s3, tap % 3, a + 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -303,8 +313,27 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     ln_par[tid] = p.ln_w[tid];
     ln_par[BN + tid] = p.ln_b[tid];
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (bare barriers from here on: __syncthreads() also drains vmcnt)
   PRV2_STAMP(3);
+  // Gate weights: wave w multiplies ALL 128 pixels with gate columns 32w .. 32w + 31, so that every weight fragment is fetched
+  // by exactly one wave (256 KB per tile from L2; 64 x 64 wave tiles fetched 512 KB and the GEMM ran at half the MFMA rate).
+  // All 32 fragments of the wave (128 registers, free between the two GEMMs) are requested HERE and land during the row
+  // statistics and the normalisation pass: a weight fetch issued inside the GEMM costs the wave an L2 round trip per slab --
+  // the two waves of a SIMD then ran one after the other, 21 k cycles for 12.3 k of MFMAs (per-wave stamps,
+  // tools/probes/gate_phase_stamps.sh).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NA2 = 8, NJ2 = 2, KS2 = BN / 32;
+  u32x4 wf[GATE ? KS2 : 1][NJ2][2];  // [slab][column][hi / lo]
+  if constexpr (GATE) {
+    const u32x4* const gw = reinterpret_cast<const u32x4*>(gp.gate_w) + (long long)wave * (KS2 * NJ2 * 2 * 64) + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+      for (int j = 0; j < NJ2; ++j) {
+        wf[ks][j][0] = gw[((ks * NJ2 + j) * 2 + 0) * 64];
+        if constexpr (PREC == PRV2_PREC_BF16X3) wf[ks][j][1] = gw[((ks * NJ2 + j) * 2 + 1) * 64];
+      }
+  }
   // row statistics, two passes like convs.py:25-27; threads 4r..4r+3 share pixel r: thread `part` takes the 16-channel
   // groups 64k + 16 part (k = 0..3) -- the 16 lanes (4 rows x 4 parts) of a ds_read_b128 group then hit 16 distinct bank slots
   if (has_ln) {
@@ -332,29 +361,17 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
       ln_stats[r] = mean;
       ln_stats[ROWS + r] = 1.0f / sqrtf(d2 / (float)BN + p.ln_eps);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   PRV2_STAMP(4);
 
   if constexpr (GATE) {
-    // ---- gate GEMM: this wave's 64 pixels x all 256 normalised channels x its 64 gate columns -----------------------
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* const gw = reinterpret_cast<const u32x4*>(gp.gate_w) + (long long)wn * (8 * NJ * 2 * 64) + lane;
-    f32x4 acc2[NA][NJ];
+    // ---- gate GEMM: wave w = all 128 pixels (8 runs) x all 256 normalised channels x gate columns 32w .. 32w + 31 ---------
+    f32x4 acc2[NA2][NJ2];
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+    for (int a = 0; a < NA2; ++a)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc2[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 wf[3][NJ][2];  // [slab % 3][column][hi / lo]: two slabs in flight while one multiplies
-    auto load_w = [&](int ks) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        wf[ks % 3][j][0] = gw[((ks * NJ + j) * 2 + 0) * 64];
-        if constexpr (PREC == PRV2_PREC_BF16X3) wf[ks % 3][j][1] = gw[((ks * NJ + j) * 2 + 1) * 64];
-      }
-    };
-    load_w(0);
-    load_w(1);
+      for (int j = 0; j < NJ2; ++j) acc2[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // normalise + activate + split the C tile IN PLACE, once: the 32 bytes of 8 fp32 channels become [8 bf16 hi | 8 bf16 lo] --
     // exactly one A fragment of the gate GEMM.  Thread = pixel (tid & 127) x every 4th 8-channel chunk: the 16 lanes of a
     // ds_read_b128 group are 16 consecutive rows (row pitch 65 x 16 B: 16 distinct bank slots), for this pass and for the
@@ -384,33 +401,12 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
         *reinterpret_cast<bf16x8*>(q + 4) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (bare: the weight fragments stay in flight)
     PRV2_STAMP(5);
-#pragma unroll
-    for (int ks = 0; ks < BN / 32; ++ks) {
-      if (ks + 2 < BN / 32) load_w(ks + 2);
-      bf16x8 xh[NA], xl[NA];
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const float* q = csm + ((4 * wm + a) * TW + m16) * CLD + ks * 32 + 8 * g;
-        xh[a] = *reinterpret_cast<const bf16x8*>(q);
-        xl[a] = *reinterpret_cast<const bf16x8*>(q + 4);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[ks % 3][j][0]);
-        const bf16x8 wl = __builtin_bit_cast(bf16x8, wf[ks % 3][j][1]);
-#pragma unroll
-        for (int pr = 0; pr < NP; ++pr)
-#pragma unroll
-          for (int a = 0; a < NA; ++a) mma(acc2[a][j], xh[a], xl[a], wh, wl, pr);
-      }
-    }
-    PRV2_STAMP(6);
-    // ---- final stage: y = mul * sigmoid(gate + bias) + res; 64 threads x float4 = one 1 KB pixel row, 16 rows per thread.
-    // ALL mul / res rows of the thread are requested here, before the gate accumulators go through LDS: with one workgroup
-    // per CU nothing else hides this traffic, and a CU only reaches its memory rate with the whole tile (256 KB) in flight
-    // (4 rows in flight: 19 k cycles for the store loop, phase stamps of tools/probes/gate_phase_stamps.sh).
+    // ---- operands of the final stage y = mul * sigmoid(gate + bias) + res: 64 threads x float4 = one 1 KB pixel row, 16 rows per
+    // thread, ALL requested long before their use: with one workgroup per CU nothing else hides this traffic, and a CU only
+    // reaches its memory rate with a whole operand tile (128 KB) in flight (4 rows in flight: 19 k cycles for the store loop;
+    // phase stamps of tools/probes/gate_phase_stamps.sh)
     constexpr int C4 = BN / 4, RPP = 512 / C4, NR = ROWS / RPP;
     const int col4 = tid % C4;
     auto pix_of = [&](int i) {  // (rows below the image: clamped address, never stored)
@@ -428,20 +424,43 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     const bool has_mul = p.mul != nullptr;  // block-uniform
     f32x4 mv[NR], rv[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int pix = pix_of(i);
-      mv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mul_rs, (pix * p.ld_mul + col4 * 4) * 4, 0, 0));
-      rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (pix * p.ld_res + col4 * 4) * 4, 0, 0));
+    for (int ks = 0; ks < KS2; ++ks) {
+      if (ks == KS2 - 3) {  // five slabs of weight registers are free again: the mul rows fly during the rest of the GEMM
+#pragma unroll
+        for (int i = 0; i < NR; ++i) mv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mul_rs, (pix_of(i) * p.ld_mul + col4 * 4) * 4, 0, 0));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // four pixel runs at a time (their fragments: 32 registers)
+        bf16x8 xh[4], xl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float* q = csm + ((4 * h + a) * TW + m16) * CLD + ks * 32 + 8 * g;
+          xh[a] = *reinterpret_cast<const bf16x8*>(q);
+          xl[a] = *reinterpret_cast<const bf16x8*>(q + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) {
+          const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[ks][j][0]);
+          const bf16x8 wl = __builtin_bit_cast(bf16x8, wf[ks][j][1]);
+#pragma unroll
+          for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) mma(acc2[4 * h + a][j], xh[a], xl[a], wh, wl, pr);
+        }
+      }
     }
+    PRV2_STAMP(6);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (pix_of(i) * p.ld_res + col4 * 4) * 4, 0, 0));
     // (bare barriers: __syncthreads() would first drain vmcnt, i.e. wait for the rows just requested)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read its rows of the C tile
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int col = wn * 64 + j * 16 + m16;
+    for (int j = 0; j < NJ2; ++j) {
+      const int col = wave * 32 + j * 16 + m16;
 #pragma unroll
-      for (int a = 0; a < NA; ++a)
+      for (int a = 0; a < NA2; ++a)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) csm[((4 * wm + a) * TW + 4 * g + e) * CLD + col] = acc2[a][j][e];
+        for (int e = 0; e < 4; ++e) csm[(a * TW + 4 * g + e) * CLD + col] = acc2[a][j][e];
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PRV2_STAMP(7);
@@ -527,21 +546,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_kernel(const GateCon
   c256_body<PREC, true>(gp, smem);
 }
 
-// 256 x 256 gate weights (PyTorch [cout][cin][1][1]) -> fragment-major image: [wn 4][slab 8][column 4][hi, lo][lane 64] x 16 B,
-// lane (m = lane & 15, g = lane >> 4) holding bf16 hi (resp. lo) of W[64 wn + 16 j + m][32 ks + 8 g .. + 7]
+// 256 x 256 gate weights (PyTorch [cout][cin][1][1]) -> fragment-major image: [wave 8][slab 8][column 2][hi, lo][lane 64] x 16 B,
+// lane (m = lane & 15, g = lane >> 4) holding bf16 hi (resp. lo) of W[32 wave + 16 j + m][32 ks + 8 g .. + 7]
 __global__ void __launch_bounds__(256) pack_gate_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ dst) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (wn, ks, j, lane) = 8 weights
-  if (idx >= 4 * 8 * 4 * 64) return;
-  const int lane = idx & 63, j = (idx >> 6) & 3, ks = (idx >> 8) & 7, wn = idx >> 11;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (wave, ks, j, lane) = 8 weights
+  if (idx >= 8 * 8 * 2 * 64) return;
+  const int lane = idx & 63, j = (idx >> 6) & 1, ks = (idx >> 7) & 7, wv = idx >> 10;
   const int m = lane & 15, g = lane >> 4;
-  const float* src = w + (long long)(64 * wn + 16 * j + m) * 256 + 32 * ks + 8 * g;
+  const float* src = w + (long long)(32 * wv + 16 * j + m) * 256 + 32 * ks + 8 * g;
   const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
   bf16x4 h0, l0, h1, l1;
   split_bf16(v0, h0, l0);
   split_bf16(v1, h1, l1);
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1), c = __builtin_bit_cast(u32x2, l0), d = __builtin_bit_cast(u32x2, l1);
-  unsigned* o = dst + ((long long)(((wn * 8 + ks) * 4 + j) * 2) * 64 + lane) * 4;
+  unsigned* o = dst + ((long long)(((wv * 8 + ks) * 2 + j) * 2) * 64 + lane) * 4;
   o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
   o += 64 * 4;
   o[0] = c.x; o[1] = c.y; o[2] = d.x; o[3] = d.y;

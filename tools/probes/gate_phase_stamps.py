@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-stamps = torch.zeros(100000 * 10, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(100000 * 80, dtype=torch.int64, device="cuda")
 os.environ["PRV2_STAMP_PTR"] = hex(stamps.data_ptr())
 from patchrefinerv2_amd import lib as L
 L.LIB_PATH = os.environ["PRV2_LIB_OVERRIDE"]
@@ -21,8 +21,12 @@ for n, h, w, cin in ((14, 192, 256, 512), (14, 96, 128, 512), (14, 192, 256, 256
         P.conv3x3_ln_gate(x, cw0, ln, gw, gb, out, act=P.ACT_RELU, mul=mul, res=res)
     torch.cuda.synchronize()
     nblk = n * (h // 8) * (w // 16)
-    s = stamps[: nblk * 10].view(nblk, 10).cpu().double()
+    sw = stamps[: nblk * 80].view(nblk, 8, 10).cpu().double()
+    s = sw[:, 0]  # wave 0
     d = (s[:, 1:] - s[:, :-1]) / 1000.0
     tot = (s[:, 9] - s[:, 0]) / 1000.0
     print(f"{n}x{h}x{w} {cin}->256->256: {nblk} workgroups, median {tot.median():.1f} kcycles (s_memtime units) per workgroup: " +
           "  ".join(f"{nm} {d[:, i].median():.2f}" for i, nm in enumerate(NAMES)), flush=True)
+    rel = (sw - sw[:, :1, :1]) / 1000.0  # every wave's stamps relative to wave 0's kernel start
+    for i in (4, 5, 6, 7, 8):
+        print(f"    stamp {i} ({NAMES[i - 1]} done) per wave, median kcycles since start: " + " ".join(f"{rel[:, wv, i].median():.1f}" for wv in range(8)), flush=True)
