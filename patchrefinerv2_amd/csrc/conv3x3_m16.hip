@@ -43,9 +43,9 @@ constexpr int AROW = 160;                       // bytes per halo pixel in LDS
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 }  // namespace m16
 
-template <int BN, bool PERSIST = false>
+template <int BN, bool PERSIST = false, bool SINGLE = false>
 constexpr int halo16_smem_floats() {
-  constexpr int main_ = (2 * m16::HALO * m16::AROW + 3 * BN * 128) / 4, epi = 256 * (BN + 4) + 2 * 256;
+  constexpr int main_ = ((SINGLE ? 1 : 2) * m16::HALO * m16::AROW + 3 * BN * 128) / 4, epi = 256 * (BN + 4) + 2 * 256;
   return PERSIST ? main_ + epi : (main_ > epi ? main_ : epi);  // PERSIST: the C tile has LDS of its own
 }
 
@@ -55,7 +55,12 @@ constexpr int halo16_smem_floats() {
 // slab of the current one, the weight DMAs wrap around, and the C tile has its own 38 KB of LDS, so the epilogue of a tile
 // runs while the next tile's operands are in flight.  These tiles are 18-36 steps of 0.2 us: their fixed cost (workgroup
 // turnaround + halo latency + store drain, ~11 us) was 75 % of the tile time.
-template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false>
+// SINGLE (BN = 32): ONE halo buffer -- the next slab waits in registers (loaded during taps 0-5 as before) and is converted and
+// stored behind the barrier of tap 8, when nobody reads the current slab any more; one extra barrier per slab.  66 KB of LDS and
+// ~110 registers: TWO workgroups per CU.  The narrow layers run 18-36 steps of 384 MFMA cycles per tile against ~1.4 k cycles
+// per step (barrier, DMA issue, fragment latency, and the in-order vmcnt that queues a tile's stores in front of the next
+// halo): a second resident workgroup fills those gaps.
+template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false, bool SINGLE = false>
 __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, int bid, const int nwg) {
   using namespace m16;
   // Tile = 8 rows x 32 pixels, or (TALL) 32 rows x 8 pixels for the remainder strip of images whose width is
@@ -71,11 +76,13 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   constexpr int B_BYTES = BN * 128;
   constexpr int CLD = BN + 4;
   constexpr int NBUF = 3;
-  static_assert(NBUF == 3 && (2 * A_BYTES + NBUF * B_BYTES) / 4 <= halo16_smem_floats<BN>() &&
-                TH * TW * CLD + 2 * TH * TW <= halo16_smem_floats<BN>(), "LDS budget");  // main loop / C tile + LN statistics
+  constexpr int NHB = SINGLE ? 1 : 2;  // halo buffers
+  static_assert(NBUF == 3 && (NHB * A_BYTES + NBUF * B_BYTES) / 4 <= halo16_smem_floats<BN, PERSIST, SINGLE>() &&
+                TH * TW * CLD + 2 * TH * TW <= halo16_smem_floats<BN, PERSIST, SINGLE>(), "LDS budget");  // main loop / C tile + LN statistics
   static_assert(!PERSIST || (!TAIL && !TALL && BN == 32), "PERSIST: plain 8 x 32 tiles of the BN = 32 kernel");
+  static_assert(!SINGLE || (!PERSIST && BN == 32), "SINGLE: the BN = 32 kernel, two workgroups per CU");
   char* const As_b = reinterpret_cast<char*>(smem);
-  char* const Bs_b = As_b + 2 * A_BYTES;
+  char* const Bs_b = As_b + NHB * A_BYTES;
   float* const csm = PERSIST ? smem + (2 * A_BYTES + NBUF * B_BYTES) / 4 : smem;  // C tile (+ LN statistics)
 
   // ---- XCD-aware block -> (pixel tile, channel tile) ----------------------------------------
@@ -287,7 +294,8 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
     const bool wrap = PERSIST && has_next && cc + 1 == cslabs;
     const int ccn = cc + 1 < cslabs ? cc + 1 : (wrap ? 0 : cc);
     const Halo& hl = wrap ? hnxt : hcur;
-    const int ab = (gs + cc) & 1;  // halo buffer of this slab
+    const int ab = SINGLE ? 0 : (gs + cc) & 1;  // halo buffer of this slab
+    const int ab_next = SINGLE ? 0 : ab ^ 1;
     auto step = [&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
       constexpr int L0 = tap < A_IT ? 1 : 0, Lm1 = (tap >= 1 && tap - 1 < A_IT) ? 1 : 0;
@@ -317,7 +325,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           }
           if (j == (NJ > 2 ? 1 : 0) && a == NA - 2) {
 #ifndef PRV2_ABL_NOA
-            if constexpr (tap >= 2 && tap - 2 < A_IT) {
+            if constexpr (!SINGLE && tap >= 2 && tap - 2 < A_IT) {
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
               constexpr int newer = 2 * ND + Lm1 + L0;
               asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
@@ -349,12 +357,30 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         }
         }
         __builtin_amdgcn_sched_barrier(0);
-        read_a(a, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
-        read_a(a + 1, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
+        if constexpr (SINGLE && tap == 8) {
+          // behind this tap's barrier nobody reads the slab any more: the next one (in registers since taps 0-5) takes its place
+          static_assert(NA == 2, "one pass");
+          if (cc + 1 < cslabs) {  // block-uniform
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+              // VMEM instructions issued since the last halo load (tap A_IT - 1): the DMAs of taps A_IT - 1 .. 7
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[it]) : "n"((8 - (A_IT - 1)) * ND) : "memory");
+              store_a(0, it);
+            }
+          }
+        } else {
+          read_a(a, tap == 8 ? ab_next : ab, (tap + 1) % 9);
+          read_a(a + 1, tap == 8 ? ab_next : ab, (tap + 1) % 9);
+        }
 #ifndef PRV2_ABL_NOB
         if (a / 2 < ND) dma_b_async(s3, tap % 3, a / 2);
 #endif  // this step's tile buffer is free since the barrier
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (SINGLE && tap == 8) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the new slab is in place
+#pragma unroll
+        for (int a = 0; a < NA; ++a) read_a(a, 0, 0);
       }
       if constexpr ((NJ & 1) != 0) {  // (not instantiated: NJ is 2 or 4, so next step's column 0 sits in slot 0)
         bh[0] = bh[1];
@@ -376,7 +402,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
     // 4g..4g+3 (channels 0,1 of the slab = the first 4 bytes of the pixel's hi / lo plane).  The weight tile sits
     // in buffer 0 (step index 9*cchunks), column 0 already in slot 0; the fragments refilled by the last
     // regular step are replaced.
-    const int abuf = cchunks & 1;
+    const int abuf = SINGLE ? 0 : cchunks & 1;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
@@ -528,6 +554,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_persist_kernel(const Ig
   else halo16_body<32, PREC, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
 }
 
+// BN = 32, single halo buffer: two workgroups per CU (66 KB of LDS, <= 128 registers)
+template <int PREC, bool TAIL>
+__global__ void __launch_bounds__(512, 4) conv3x3_halo16_n32_kernel(const IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<32, false, true>()];
+  const int strip = p.strip_blocks;  // block-uniform
+  if ((int)blockIdx.x < strip) halo16_body<32, PREC, TAIL, true, false, true>(p, smem, blockIdx.x, strip);
+  else halo16_body<32, PREC, TAIL, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+}
+
 static int persist_workgroups() {  // one persistent workgroup per CU of the CURRENT device (cached per device ordinal)
   static int n[64] = {0};
   int dev = 0;
@@ -547,8 +582,20 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;
   p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) * p.tiles_n : 0;
   const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x * p.tiles_n + p.strip_blocks;
-  static const bool no_persist = getenv("PRV2_HALO_NO_PERSIST") != nullptr;  // A/B switch
+  static const bool no_persist = getenv("PRV2_HALO_NO_PERSIST") != nullptr;  // A/B switches
+  static const int n32_mode = getenv("PRV2_HALO_N32") ? atoi(getenv("PRV2_HALO_N32")) : 1;  // 1: two single-halo workgroups per CU; 0: round-1 paths
   set_kernel("conv3x3_halo16_kernel", p.Ncols > 64 ? 128 : (p.Ncols > 32 ? 64 : 32), prec);
+  if (p.Ncols <= 32 && n32_mode == 1) {
+    const dim3 grid(blocks);
+    if (prec == PRV2_PREC_BF16X3) {
+      if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16X3, true>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16X3, false>), grid, dim3(512), 0, s, p);
+    } else {
+      if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16, true>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16, false>), grid, dim3(512), 0, s, p);
+    }
+    return;
+  }
   if (p.Ncols <= 32 && !p.w_tail && !no_persist) {
     const int tiles = blocks - p.strip_blocks, wgs = tiles < persist_workgroups() ? tiles : persist_workgroups();
     if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_halo16_persist_kernel<PRV2_PREC_BF16X3>), dim3(wgs + p.strip_blocks), dim3(512), 0, s, p);
