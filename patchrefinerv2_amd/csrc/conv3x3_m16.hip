@@ -80,7 +80,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   static_assert(NBUF == 3 && (NHB * A_BYTES + NBUF * B_BYTES) / 4 <= halo16_smem_floats<BN, PERSIST, SINGLE>() &&
                 TH * TW * CLD + 2 * TH * TW <= halo16_smem_floats<BN, PERSIST, SINGLE>(), "LDS budget");  // main loop / C tile + LN statistics
   static_assert(!PERSIST || (!TAIL && !TALL && BN == 32), "PERSIST: plain 8 x 32 tiles of the BN = 32 kernel");
-  static_assert(!SINGLE || (!PERSIST && BN == 32), "SINGLE: the BN = 32 kernel, two workgroups per CU");
+  static_assert(!SINGLE || (!PERSIST && BN <= 64), "SINGLE: the narrow kernels, two workgroups per CU");
   char* const As_b = reinterpret_cast<char*>(smem);
   char* const Bs_b = As_b + NHB * A_BYTES;
   float* const csm = PERSIST ? smem + (2 * A_BYTES + NBUF * B_BYTES) / 4 : smem;  // C tile (+ LN statistics)
@@ -359,8 +359,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SINGLE && tap == 8) {
           // behind this tap's barrier nobody reads the slab any more: the next one (in registers since taps 0-5) takes its place
-          static_assert(NA == 2, "one pass");
-          if (cc + 1 < cslabs) {  // block-uniform
+          if (a == 0 && cc + 1 < cslabs) {  // (first pass only; block-uniform)
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
               // VMEM instructions issued since the last halo load (tap A_IT - 1): the DMAs of taps A_IT - 1 .. 7
@@ -555,12 +554,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_persist_kernel(const Ig
 }
 
 // BN = 32, single halo buffer: two workgroups per CU (66 KB of LDS, <= 128 registers)
-template <int PREC, bool TAIL>
-__global__ void __launch_bounds__(512, 4) conv3x3_halo16_n32_kernel(const IgemmParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<32, false, true>()];
+template <int BN, int PREC, bool TAIL>
+__global__ void __launch_bounds__(512, 4) conv3x3_halo16_narrow_kernel(const IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<BN, false, true>()];
   const int strip = p.strip_blocks;  // block-uniform
-  if ((int)blockIdx.x < strip) halo16_body<32, PREC, TAIL, true, false, true>(p, smem, blockIdx.x, strip);
-  else halo16_body<32, PREC, TAIL, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+  if ((int)blockIdx.x < strip) halo16_body<BN, PREC, TAIL, true, false, true>(p, smem, blockIdx.x, strip);
+  else halo16_body<BN, PREC, TAIL, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
 }
 
 static int persist_workgroups() {  // one persistent workgroup per CU of the CURRENT device (cached per device ordinal)
@@ -585,17 +584,18 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   static const bool no_persist = getenv("PRV2_HALO_NO_PERSIST") != nullptr;  // A/B switches
   static const int n32_mode = getenv("PRV2_HALO_N32") ? atoi(getenv("PRV2_HALO_N32")) : 1;  // 1: two single-halo workgroups per CU; 0: round-1 paths
   set_kernel("conv3x3_halo16_kernel", p.Ncols > 64 ? 128 : (p.Ncols > 32 ? 64 : 32), prec);
+#define PRV2_LAUNCH_NARROW(BN_, PREC_)                                                                                       \
+  do {                                                                                                                       \
+    if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_narrow_kernel<BN_, PREC_, true>), dim3(blocks), dim3(512), 0, s, p);    \
+    else hipLaunchKernelGGL((conv3x3_halo16_narrow_kernel<BN_, PREC_, false>), dim3(blocks), dim3(512), 0, s, p);            \
+  } while (0)
   if (p.Ncols <= 32 && n32_mode == 1) {
-    const dim3 grid(blocks);
-    if (prec == PRV2_PREC_BF16X3) {
-      if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16X3, true>), grid, dim3(512), 0, s, p);
-      else hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16X3, false>), grid, dim3(512), 0, s, p);
-    } else {
-      if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16, true>), grid, dim3(512), 0, s, p);
-      else hipLaunchKernelGGL((conv3x3_halo16_n32_kernel<PRV2_PREC_BF16, false>), grid, dim3(512), 0, s, p);
-    }
+    if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_NARROW(32, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_NARROW(32, PRV2_PREC_BF16);
     return;
   }
+  // (BN = 64 on this scheme needs 142-151 registers: at 128 it spills 33-51 of them and runs 15-20 % slower than one workgroup per CU)
+#undef PRV2_LAUNCH_NARROW
   if (p.Ncols <= 32 && !p.w_tail && !no_persist) {
     const int tiles = blocks - p.strip_blocks, wgs = tiles < persist_workgroups() ? tiles : persist_workgroups();
     if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_halo16_persist_kernel<PRV2_PREC_BF16X3>), dim3(wgs + p.strip_blocks), dim3(512), 0, s, p);
