@@ -53,6 +53,8 @@ def parse():
                          "rank 0 (SURVEY.md 8e cfg 5), all = every rank keeps its own map (the reference's data parallelism)")
     ap.add_argument("--max-batch", type=int, default=14, help="patches per launch batch (results are batch independent)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over")
+    ap.add_argument("--no-prefetch-coarse", dest="prefetch_coarse", action="store_false",
+                    help="do not enqueue the next frame's coarse forward beside the current frame's tile batches")
     ap.add_argument("--hip-graph", action="store_true", help="capture the device side of a frame into a hipGraph and replay it per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -185,14 +187,16 @@ def main():
         host_maps = torch.empty((world, 1, 1, *w["raw"]), pin_memory=True) if rank == 0 else None
     coll = dict(bytes=0, ms=0.0, n=0)
 
-    def step(i, solo=False, timed=False):
+    def step(i, solo=False, timed=False, last=False):
         """one frame; ``solo``: this rank alone, no collective (the instrumented frames that only rank 0 runs)"""
         hr, lr = frames[i % len(frames)]
+        # a frame loop knows its next frame: its coarse forward is enqueued beside this frame's tile batches (models.forward)
+        nxt = None if (solo or last or not args.prefetch_coarse) else frames[(i + 1) % len(frames)][1]
         random.seed(621)
         sh = None if solo else shard
         fg = frame_gather and not solo
         depth, _ = model(mode="infer", cai_mode=w["mode"], process_num=4, tile_cfg=tile_cfg, image_lr=lr, image_hr=hr,
-                         shard=sh, gather_dst=gather_dst if sh is not None else None, return_device=fg)
+                         shard=sh, gather_dst=gather_dst if sh is not None else None, return_device=fg, next_image_lr=nxt)
         if fg:
             # cfg-5 "full xGMI gather": the N per-rank maps (33 MB each at 4K) to rank 0, which hands them to the host
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -218,11 +222,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        step(i, last=i == args.warmup - 1)  # (no prefetch across t0: the timed region does exactly K coarse forwards)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(args.warmup + i, timed=True)
+        out = step(args.warmup + i, timed=True, last=i == args.steps - 1)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -239,7 +243,7 @@ def main():
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
                     coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else w.get("zoe_type", "DA-ZoeDepth") + "/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
-                    max_batch=args.max_batch, streams=args.streams, hip_graph=bool(args.hip_graph), out_shape=list(out.shape) if out is not None else None))
+                    max_batch=args.max_batch, streams=args.streams, hip_graph=bool(args.hip_graph), prefetch_next_coarse=bool(args.prefetch_coarse), out_shape=list(out.shape) if out is not None else None))
 
     if world > 1:
         nt = w["patches"]

@@ -240,10 +240,14 @@ class _PatchModel(StateDictModule):
     @torch.no_grad()
     def forward(self, mode=None, image_lr=None, image_hr=None, crops_image_hr=None, depth_gt=None, crop_depths=None,
                 bboxs=None, tile_cfg=None, cai_mode="m1", process_num=4, select_patch=-1, shard=None,
-                return_device=False, gather_dst=None, **kwargs):
+                return_device=False, gather_dst=None, next_image_lr=None, **kwargs):
         """``shard=(rank, world)``: this process computes tiles rank, rank+world, ... and the predictions are exchanged
         (RCCL): all-gather when ``gather_dst`` is None (every rank blends and returns the map), gather to rank
-        ``gather_dst`` otherwise (only that rank blends; the others return ``depth=None``)."""
+        ``gather_dst`` otherwise (only that rank blends; the others return ``depth=None``).
+        ``next_image_lr``: the low-resolution image of the frame the caller will submit NEXT (a video / dataset loop knows
+        it): its coarse forward -- one image through the backbone, ~10 ms of kernels that cover a fraction of the chip -- is
+        enqueued on a stream of its own beside this frame's tile batches and picked up by the next call (same tensor object);
+        results are bit-identical with and without."""
         if mode != "infer":
             raise NotImplementedError("only mode='infer' is built (training is out of scope, SURVEY.md 2 #12-13)")
         if select_patch != -1:
@@ -252,8 +256,12 @@ class _PatchModel(StateDictModule):
             raise RuntimeError("image_lr / image_hr must be on the GPU (tester.py:43-49 moves them); no CPU path")
         # every kernel is enqueued on the current device's stream: make the inputs' device current for the whole frame
         with torch.cuda.device(image_hr.device):
-            return self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device,
-                               gather_dst)
+            self._next_lr = next_image_lr
+            try:
+                return self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device,
+                                   gather_dst)
+            finally:
+                self._next_lr = None
 
     __call__ = forward
 
@@ -338,7 +346,7 @@ class _PatchModel(StateDictModule):
         RH, RW = tile_cfg["patch_reensemble_shape"]
         n_mine, n_all = plan["n_mine"], plan["n_all"]
         if self.needs_coarse:
-            coarse_feats, coarse_prediction = self.coarse_forward(image_lr)
+            coarse_feats, coarse_prediction = self._coarse_of(image_lr)
             coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
         else:
             coarse_feats = coarse_prediction = coarse_depth = None
@@ -364,6 +372,7 @@ class _PatchModel(StateDictModule):
                 crops, rois, depth_roi = self._prepare_batch(image_chw, tiles_dev[s:e], boxes_dev[s:e], tile_cfg, coarse_feats,
                                                              coarse_depth)
                 self.infer_forward(crops, rois, depth_roi, out=preds[s:e])
+        self._prefetch_coarse(getattr(self, "_next_lr", None), main)
         if n_streams > 1:
             for st in streams:
                 main.wait_stream(st)
@@ -461,6 +470,37 @@ class _PatchModel(StateDictModule):
         box = [passes]
         dist.broadcast_object_list(box, src=0)
         return box[0]
+
+    # -- coarse forward of the NEXT frame beside this frame's tile batches (forward(next_image_lr=...)) -----------------------
+    @staticmethod
+    def _lr_key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+    def _coarse_of(self, image_lr):
+        """this frame's coarse pyramid: the one prefetched by the previous call if it was made for this very tensor"""
+        pf = self.__dict__.pop("_coarse_prefetched", None)
+        if pf is not None and pf["key"] == self._lr_key(image_lr):
+            torch.cuda.current_stream(image_lr.device).wait_event(pf["done"])
+            for t in pf["tensors"]:  # allocated on the prefetch stream, consumed on this frame's streams from here on
+                t.record_stream(torch.cuda.current_stream(image_lr.device))
+            self._coarse_hold = pf  # (alive until the next frame replaces it: every consumer stream is long done by then)
+            return pf["feats"], pf["pred"]
+        return self.coarse_forward(image_lr)
+
+    def _prefetch_coarse(self, next_lr, main):
+        if next_lr is None or not self.needs_coarse or ops.PROFILER.enabled or torch.cuda.is_current_stream_capturing():
+            return
+        dev = next_lr.device
+        st = self.__dict__.setdefault("_coarse_stream", {}).get(str(dev))
+        if st is None:
+            st = self._coarse_stream[str(dev)] = torch.cuda.Stream(device=dev, priority=0)
+        st.wait_stream(main)  # (the image may have been produced on the caller's stream)
+        with torch.cuda.stream(st):
+            feats, pred = self.coarse_forward(next_lr)
+            done = torch.cuda.Event()
+            done.record(st)
+        tensors = [f.buf for f in feats] + [pred]
+        self._coarse_prefetched = dict(key=self._lr_key(next_lr), feats=feats, pred=pred, done=done, tensors=tensors)
 
     def _streams(self, dev, n):
         cache = self.__dict__.setdefault("_stream_cache", {})

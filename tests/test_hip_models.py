@@ -413,6 +413,32 @@ def test_models_through_torch_custom_ops(P):
     assert torch.equal(a, b)
 
 
+def test_next_frame_coarse_prefetch_is_bit_identical(P):
+    """forward(next_image_lr=...): the next frame's coarse forward runs on a stream of its own beside this frame's tile batches and
+    is picked up by the next call; frames are bit-identical with / without, a mismatching tensor is simply ignored"""
+    c = E2E_V2
+    m = _build("PatchRefinerPlus", c, e2e_v2_sd(), prec="bf16x3", n_streams=2, max_batch=3)
+    frames = []
+    for seed in (0, 1, 2):
+        hr = rand_image(seed, 1, *c["raw"]).cuda()
+        frames.append((hr, m.resizer(hr)))
+    tc = dict(image_raw_shape=list(c["raw"]), patch_split_num=list(c["split"]))
+
+    def run(i, nxt):
+        random.seed(5)
+        d, log = m(mode="infer", cai_mode="r4", process_num=2, tile_cfg=tc, image_lr=frames[i][1], image_hr=frames[i][0], next_image_lr=nxt)
+        return d, log["coarse_prediction"].clone()
+
+    ref = [run(i, None) for i in range(3)]
+    got = [run(0, frames[1][1]), run(1, frames[2][1]), run(2, None)]
+    for (a, ca), (b, cb) in zip(ref, got):
+        assert torch.equal(a, b) and torch.equal(ca, cb)
+    assert "_coarse_prefetched" not in m.__dict__  # consumed
+    run(0, frames[2][1])          # prefetched for frame 2 ...
+    d, cp = run(1, None)          # ... but frame 1 arrives: computed inline
+    assert torch.equal(d, ref[1][0]) and torch.equal(cp, ref[1][1])
+
+
 def test_rejects_cpu_inputs_and_bad_shapes(P):
     c = E2E_V1
     m = _build("PatchRefiner", c, e2e_v1_sd())
