@@ -67,8 +67,10 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   // 32k + (1..8): same pixel count, same halo size, a pixel run of 16 is then 2 rows x 8 pixels.
   constexpr int TH = TALL ? 32 : 8, TW = TALL ? 8 : 32, HW_ = TW + 2;
   static_assert(PREC == PRV2_PREC_BF16X3 || PREC == PRV2_PREC_BF16, "bf16 modes only");
-  constexpr int WN = BN >= 64 ? 2 : 1;
-  constexpr int NI = BN >= 64 ? 2 : 1;             // image rows per wave
+  // (SINGLE with BN = 64: a wave takes ONE image row x all 64 columns -- 2 runs x 4 columns, 16 fewer fragment registers than
+  //  2 rows x 32 columns: the kernel has to fit 128 registers for two workgroups per CU)
+  constexpr int WN = (BN >= 64 && !(SINGLE && BN == 64)) ? 2 : 1;
+  constexpr int NI = (BN >= 64 && !(SINGLE && BN == 64)) ? 2 : 1;  // image rows per wave
   constexpr int NA = 2 * NI;                       // 16-pixel runs per wave
   constexpr int NJ = BN / (16 * WN);               // 16-channel columns per wave
   constexpr int ND = BN >= 64 ? BN / 64 : 1;       // LDS-DMA pieces (8 rows x 128 B) per wave per weight tile
@@ -553,7 +555,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_persist_kernel(const Ig
   else halo16_body<32, PREC, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
 }
 
-// BN = 32, single halo buffer: two workgroups per CU (66 KB of LDS, <= 128 registers)
+// BN = 32 / 64, single halo buffer: two workgroups per CU (66 / 79 KB of LDS, <= 128 registers)
 template <int BN, int PREC, bool TAIL>
 __global__ void __launch_bounds__(512, 4) conv3x3_halo16_narrow_kernel(const IgemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<BN, false, true>()];
@@ -594,7 +596,12 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
     else PRV2_LAUNCH_NARROW(32, PRV2_PREC_BF16);
     return;
   }
-  // (BN = 64 on this scheme needs 142-151 registers: at 128 it spills 33-51 of them and runs 15-20 % slower than one workgroup per CU)
+  static const int n64_mode = getenv("PRV2_HALO_N64") ? atoi(getenv("PRV2_HALO_N64")) : 1;
+  if (p.Ncols > 32 && p.Ncols <= 64 && n64_mode == 1) {
+    if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_NARROW(64, PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_NARROW(64, PRV2_PREC_BF16);
+    return;
+  }
 #undef PRV2_LAUNCH_NARROW
   if (p.Ncols <= 32 && !p.w_tail && !no_persist) {
     const int tiles = blocks - p.strip_blocks, wgs = tiles < persist_workgroups() ? tiles : persist_workgroups();
