@@ -91,6 +91,61 @@ def compute_metrics(gt, pred, interpolate=True, garg_crop=False, eigen_crop=True
     return metrics
 
 
+@torch.no_grad()
+def compute_metrics_device(gt: torch.Tensor, pred: torch.Tensor, interpolate=True, garg_crop=False, eigen_crop=True, dataset="nyu",
+                           min_depth_eval=0.1, max_depth_eval=10, disp_gt_edges=None, additional_mask=None) -> dict:
+    """``compute_metrics`` (estimator/utils/metric.py:87-149) on the tensors' device -- the prediction does not have to leave the
+    GPU to be scored: same clamping, masks, error formulas and soft-edge error; the reductions accumulate in
+    float64 (the numpy version sums float32 pairwise: agreement to ~1e-6 relative, tests/test_host_logic.py)."""
+    dev = pred.device
+    gt = gt.to(dev)
+    if gt.shape[-2:] != pred.shape[-2:] and interpolate:
+        pred = F.interpolate(pred, gt.shape[-2:], mode="bilinear", align_corners=False)
+    p = pred.squeeze().float().clone()
+    p = torch.where(torch.isnan(p), torch.full_like(p, min_depth_eval), p)  # (order as the reference: < min, > max, inf, nan)
+    p = p.clamp(min_depth_eval, max_depth_eval)
+    g = gt.squeeze().float()
+    valid = (g > min_depth_eval) & (g < max_depth_eval)
+    if garg_crop or eigen_crop:
+        h, w = g.shape
+        m = torch.zeros_like(valid)
+        if garg_crop:
+            m[int(0.40810811 * h):int(0.99189189 * h), int(0.03594771 * w):int(0.96405229 * w)] = True
+        elif dataset == "kitti":
+            m[int(0.3324324 * h):int(0.91351351 * h), int(0.0359477 * w):int(0.96405229 * w)] = True
+        else:
+            m[45:471, 41:601] = True
+        valid &= m
+    if additional_mask is not None:
+        valid &= additional_mask.squeeze().to(dev).bool()
+    gv, pv = g[valid].double(), p[valid].double()
+    thresh = torch.maximum(gv / pv, pv / gv)
+    d = gv - pv
+    err = torch.log(pv) - torch.log(gv)
+    out = dict(a1=(thresh < 1.25).double().mean(), a2=(thresh < 1.25 ** 2).double().mean(), a3=(thresh < 1.25 ** 3).double().mean(),
+               abs_rel=(d.abs() / gv).mean(), rmse=(d ** 2).mean().sqrt(), log_10=(torch.log10(gv) - torch.log10(pv)).abs().mean(),
+               rmse_log=(err ** 2).mean().sqrt(), silog=((err ** 2).mean() - err.mean() ** 2).sqrt() * 100, sq_rel=(d ** 2 / gv).mean())
+    if disp_gt_edges is not None:
+        edges = torch.as_tensor(disp_gt_edges).squeeze().to(dev) != 0
+        mask = valid & edges
+        see = torch.zeros((), device=dev, dtype=torch.float64)
+        if bool(mask.any()):
+            best = None
+            for i in (-1, 0, 1):      # soft_edge_error(radius=1): min over the 3 x 3 shifts of gt (zero-filled borders)
+                for j in (-1, 0, 1):
+                    sh = torch.zeros_like(g)
+                    ys, yd = (slice(0, g.shape[0] - j), slice(j, None)) if j >= 0 else (slice(-j, None), slice(0, g.shape[0] + j))
+                    xs, xd = (slice(0, g.shape[1] - i), slice(i, None)) if i >= 0 else (slice(-i, None), slice(0, g.shape[1] + i))
+                    sh[yd, xd] = g[ys, xs]
+                    diff = (sh - p).abs()
+                    best = diff if best is None else torch.minimum(best, diff)
+            see = best[mask].double().mean()
+        out["see"] = see
+    keys = list(out)
+    vals = torch.stack([out[k].double() for k in keys]).cpu().tolist()  # one D2H of ten scalars
+    return dict(zip(keys, vals))
+
+
 def evaluate(per_frame: list) -> dict:
     """mean of every metric over the frames (general_dataset.py evaluate / mmengine-style collect)."""
     keys = per_frame[0].keys()

@@ -147,6 +147,7 @@ class _PatchModel(StateDictModule):
     crop_channels = 3
     crop_mean, crop_std = IMAGENET_MEAN, IMAGENET_STD
     STRICT_DA_ZOE = False
+    supports_return_device = True  # forward(return_device=True): the depth map stays on the GPU (Tester scores it there)
     blend_border = 0.15      # generatemask(..., border=0.15) (patchrefinerplus.py:485); BaselinePretrain: the default 0.1
     needs_coarse = True      # coarse forward + ROI pyramid per tile (False: BaselinePretrain(target='fine'))
 

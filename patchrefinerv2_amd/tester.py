@@ -123,8 +123,11 @@ class ImageDataset:
         return item
 
     def get_metrics(self, depth_gt, result, disp_gt_edges=None, **kw):
-        """general_dataset.py:236-245"""
-        from .metrics import compute_metrics
+        """general_dataset.py:236-245 (a GPU ``result`` is scored where it is: metrics.compute_metrics_device)"""
+        from .metrics import compute_metrics, compute_metrics_device
+        if isinstance(result, torch.Tensor) and result.is_cuda:
+            return compute_metrics_device(depth_gt, result, disp_gt_edges=disp_gt_edges, min_depth_eval=self.min_depth,
+                                          max_depth_eval=self.max_depth, garg_crop=False, eigen_crop=False, dataset=self.dataset_name)
         return compute_metrics(depth_gt, result, disp_gt_edges=disp_gt_edges, min_depth_eval=self.min_depth,
                                max_depth_eval=self.max_depth, garg_crop=False, eigen_crop=False, dataset=self.dataset_name)
 
@@ -153,8 +156,11 @@ class Tester:
             if seed is not None:
                 random.seed(seed)
             tile_cfg = dict(image_raw_shape=list(image_raw_shape), patch_split_num=list(patch_split_num))
+            # with ground truth the frame is scored on the device (metrics.compute_metrics_device): ask for the device map
+            kw = dict(return_device=True) if item.get("depth_gt") is not None and getattr(self.model, "supports_return_device", False) else {}
             result, log = self.model(mode="infer", cai_mode=cai_mode, process_num=process_num, tile_cfg=tile_cfg,
-                                     image_lr=lr, image_hr=hr)
+                                     image_lr=lr, image_hr=hr, **kw)
+            result_dev = result if result.is_cuda else None
             result = result.cpu()  # BaselinePretrain(target='coarse') hands back the device tensor (baseline_pretrain.py:464)
             if self.runner_info.save:
                 os.makedirs(self.runner_info.work_dir, exist_ok=True)
@@ -175,7 +181,8 @@ class Tester:
                     write_png8(base + "_coarse.png", np.ascontiguousarray(colorize(coarse, cmap="Spectral", vminp=0, vmaxp=100)[:, :, :3]))
             entry = dict(name=item["img_file_basename"], shape=tuple(result.shape), mean=float(result.mean()))
             if item.get("depth_gt") is not None:
-                entry["metrics"] = self.dataloader.get_metrics(item["depth_gt"], result, disp_gt_edges=item.get("boundary"))
+                entry["metrics"] = self.dataloader.get_metrics(item["depth_gt"], result if result_dev is None else result_dev,
+                                                               disp_gt_edges=item.get("boundary"))
             results.append(entry)
         if results and "metrics" in results[0]:
             from .metrics import evaluate

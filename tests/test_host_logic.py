@@ -163,6 +163,14 @@ def test_output_stage_matches_reference():
     for tag, m in (("m1", m1), ("m2", m2)):
         for k, v in m.items():
             np.testing.assert_equal(float(v), float(g[f"{tag}_{k}"]), f"{tag} {k}")
+    # the device-side restatement (torch ops; runs on whatever device the tensors live on) agrees with the pinned host version
+    d1 = M.compute_metrics_device(gt, pred.clone(), garg_crop=False, eigen_crop=False, dataset="u4k", min_depth_eval=0.1, max_depth_eval=10,
+                                  disp_gt_edges=edges)
+    d2 = M.compute_metrics_device(gt, pred_lo.clone(), garg_crop=True, eigen_crop=False, dataset="kitti", min_depth_eval=0.1, max_depth_eval=10)
+    for ref, got in ((m1, d1), (m2, d2)):
+        assert set(ref) == set(got)
+        for k in ref:
+            np.testing.assert_allclose(float(got[k]), float(ref[k]), rtol=2e-5, atol=1e-7, err_msg=k)
     np.testing.assert_array_equal(M.soft_edge_error(np.abs(pred.squeeze().numpy()), gt.squeeze().numpy(), radius=2), g["see_r2"])
     with pytest.raises(NotImplementedError):
         M.get_boundaries(gt.squeeze().numpy(), dilation=3)
