@@ -105,7 +105,7 @@ int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, c
  *     y     = mul * sigmoid(conv1x1(fused) + gate_bias) (+ res)
  * gate_w_packed == NULL: y = act(LN(conv3x3(x) + bias)) -- the 256-channel conv with the LayerNorm fused (prv2_conv2d fuses it
  * for cout <= 128 only); mul / res / gate_bias must then be NULL and d->act may be any activation.
- * Shape contract (prv2_conv3x3_ln_gate_supported(d) != 0): 3x3, stride 1, pad 1, cout == 256, cin % 32 == 0, width % 16 == 0,
+ * Shape contract (prv2_conv3x3_ln_gate_supported(d) != 0): 3x3, stride 1, pad 1, cout == 256, cin % 32 == 0, width >= 16,
  * bf16 modes; x / y / mul / res NHWC fp32 with pixel strides ldx / ldy / ld_mul / ld_res (multiples of 4, 16-byte aligned).
  * w_packed: prv2_pack_conv_weight image of the 3x3 weights; gate_w_packed: prv2_pack_gate_weight image (prv2_gate_weight_bytes()
  * bytes) of the 1x1 weights [256][256].  Same arithmetic as the unfused sequence conv2d -> layernorm -> conv2d(1x1, sigmoid, mul,

@@ -73,7 +73,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   float* const csm = smem;
 
   // ---- XCD-aware block -> pixel tile -------------------------------------------------------------------
-  const int tiles_x = p.W / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;  // (ragged right / bottom edges: zero-filled halo, guarded stores)
   const int ntiles = gridDim.x;
   int t = blockIdx.x;
   {
@@ -411,7 +411,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     const int col4 = tid % C4;
     auto pix_of = [&](int i) {  // (rows below the image: clamped address, never stored)
       const int rr = tid / C4 + i * RPP;
-      return min(y0 + rr / TW, p.H - 1) * p.W + x0 + (rr & (TW - 1));
+      return min(y0 + rr / TW, p.H - 1) * p.W + min(x0 + (rr & (TW - 1)), p.W - 1);
     };
     // buffer loads (per-image base, 32-bit offsets; an absent operand is a resource of zero records: the hardware returns zeros,
     // no branches around the loads)
@@ -474,7 +474,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
       f32x4 ov;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ov[e] = (has_mul ? mv[i][e] : 1.0f) * sigmoid_fast(cv[e] + gb[e]) + rv[i][e];
-      if (y0 + rr / TW < p.H) {
+      if (y0 + rr / TW < p.H && x0 + (rr & (TW - 1)) < p.W) {
         float* dst = ybase + (long long)pix_of(i) * p.ldy;
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
       }
@@ -493,7 +493,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   const int col4 = tid % C4;
   auto pix_of = [&](int i) {
     const int rr = tid / C4 + i * RPP;
-    return min(y0 + rr / TW, p.H - 1) * p.W + x0 + (rr & (TW - 1));
+    return min(y0 + rr / TW, p.H - 1) * p.W + min(x0 + (rr & (TW - 1)), p.W - 1);
   };
   const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.res ? p.res + (long long)n_img * p.H * p.W * p.ld_res : p.x), 0, p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + BN) * 4u) : 0,
@@ -520,7 +520,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
         if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[ROWS + rr] * lw[e] + lb[e];
         ov[e] = act_apply(t, decltype(act_c)::value) + rv[i][e];
       }
-      if (y0 + rr / TW < p.H) {
+      if (y0 + rr / TW < p.H && x0 + (rr & (TW - 1)) < p.W) {
         float* dst = ybase + (long long)pix_of(i) * p.ldy;
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
       }
@@ -570,7 +570,7 @@ static inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t
 
 static bool gate_conv_shape_ok(const prv2_conv_desc* d) {
   return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->convt_k == 0 && !d->same_pad && d->cout == g256::BN && d->cin >= 32 &&
-         d->cin % 32 == 0 && d->w % g256::TW == 0 && d->prec != PRV2_PREC_F32 && (long long)d->h * d->w * d->ldx < (1LL << 29);
+         d->cin % 32 == 0 && d->w >= g256::TW && d->prec != PRV2_PREC_F32 && (long long)d->h * d->w * d->ldx < (1LL << 29);
 }
 
 // prv2_conv2d's dispatch: 3x3 convs with 256 output channels whose epilogue is bias, [LayerNorm,] activation, [+ res]
@@ -602,7 +602,7 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
                                     float* y, void* stream) {
   PRV2_REQUIRE(d && x && w_packed && y && (ln_weight != nullptr) == (ln_bias != nullptr), "conv3x3_ln_gate: null pointer");
   PRV2_REQUIRE(ln_weight || !gate_w_packed, "conv3x3_ln_gate: the gate stage sits behind the LayerNorm");
-  PRV2_REQUIRE(gate_conv_shape_ok(d), "conv3x3_ln_gate: 3x3 s1 p1, cout 256, cin %% 32 == 0, width %% 16 == 0, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
+  PRV2_REQUIRE(gate_conv_shape_ok(d), "conv3x3_ln_gate: 3x3 s1 p1, cout 256, cin %% 32 == 0, width >= 16, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
                d->h, d->w, d->cin, d->cout, d->kh, d->stride, d->prec);
   PRV2_REQUIRE(gate_w_packed || (!mul && !gate_bias), "conv3x3_ln_gate: mul / gate_bias belong to the gate stage");
   PRV2_REQUIRE(!gate_w_packed || d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate: ReLU or no activation in front of the gate (act %d)", d->act);
@@ -629,7 +629,7 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
 #ifdef PRV2_GATE_STAMPS
   gp.stamps = getenv("PRV2_STAMP_PTR") ? (long long*)strtoull(getenv("PRV2_STAMP_PTR"), nullptr, 16) : nullptr;
 #endif
-  const int64_t blocks = (int64_t)d->n * cdiv(d->h, g256::TH) * (d->w / g256::TW);
+  const int64_t blocks = (int64_t)d->n * cdiv(d->h, g256::TH) * cdiv(d->w, g256::TW);
   PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate: grid too large");
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = d->prec == PRV2_PREC_BF16X3;

@@ -152,7 +152,7 @@ Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<T
   prv2_conv_desc d = {};
   d.n = (int)n; d.h = (int)h; d.w = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.kh = 3; d.kw = 3; d.stride = 1; d.pad = 1;
   d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out"); d.relu_in = relu_in; d.act = (int)act; d.prec = (int)prec; d.ln_eps = (float)ln_eps;
-  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256, cin % 32 == 0, width % 16 == 0, bf16 modes)");
+  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256, cin % 32 == 0, width >= 16, bf16 modes)");
   auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
     if (!t.has_value()) return nullptr;
     ld = (int32_t)nhwc_ld(*t, name);

@@ -84,7 +84,8 @@ def test_conv2d(P, case):
     close(y.to_nchw(), ref, 2e-5, f"conv {case}")
 
 
-@pytest.mark.parametrize("case", [(2, 20, 32, 64, True, True), (1, 8, 16, 512, True, False), (3, 13, 48, 96, False, False), (1, 24, 16, 32, True, True)])
+@pytest.mark.parametrize("case", [(2, 20, 32, 64, True, True), (1, 8, 16, 512, True, False), (3, 13, 48, 96, False, False), (1, 24, 16, 32, True, True),
+                                  (2, 13, 24, 64, True, True), (1, 9, 37, 32, True, False)])  # (the last two: ragged right edge)
 @pytest.mark.parametrize("prec", ["bf16x3", "f32ref"])
 def test_conv3x3_ln_gate_fused_tail(P, case, prec):
     """GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80) as one kernel: vs plain torch fp32, and vs the unfused
@@ -117,10 +118,10 @@ def test_conv3x3_ln_gate_fused_tail(P, case, prec):
     close(got.to_nchw(), t.to_nchw().cpu(), 2e-6, f"fused vs unfused {case}")
 
 
-@pytest.mark.parametrize("case", [(2, 20, 32, 64, dict(bias=True, relu_in=True, res=True)), (1, 9, 48, 96, dict(act="gelu")),
+@pytest.mark.parametrize("case", [(2, 20, 32, 64, dict(bias=True, relu_in=True, res=True)), (1, 9, 48, 96, dict(act="gelu")), (2, 11, 41, 64, dict(bias=True, res=True)),
                                   (3, 8, 16, 512, dict(bias=True, ln=True, act="gelu")), (1, 24, 64, 32, dict(bias=True, ln=True, res=True))])
 def test_conv2d_256_channels_take_the_wide_tile_kernel(P, case):
-    """prv2_conv2d sends 3x3 convs with 256 output channels (width % 16 == 0, Cin % 32 == 0, bf16 modes) to the 8 x 16 x 256 kernel
+    """prv2_conv2d sends 3x3 convs with 256 output channels (width >= 16, Cin % 32 == 0, bf16 modes) to the 8 x 16 x 256 kernel
     of conv3x3_gate.hip -- also with a fused LayerNorm, which the 128-column kernel cannot do at this width"""
     n, h, w, cin, o = case
     PR = P.L.PREC_NAMES["bf16x3"]
@@ -150,12 +151,12 @@ def test_conv2d_256_channels_take_the_wide_tile_kernel(P, case):
 def test_conv3x3_ln_gate_rejects_what_it_does_not_cover(P):
     PR = P.L.PREC_NAMES["bf16x3"]
     cw = P.pack_conv(rnd(1, 256, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
-    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 24).to(DEV)), cw)      # width % 16
+    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 12).to(DEV)), cw)      # narrower than a tile
     cw128 = P.pack_conv(rnd(1, 128, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
     assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cw128)   # cout != 256
     cwf = P.pack_conv(rnd(1, 256, 64, 3, 3).to(DEV), None, pad=1)
     assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cwf)     # f32 mode
-    x = P.Feat.from_nchw(rnd(2, 1, 64, 8, 24).to(DEV))
+    x = P.Feat.from_nchw(rnd(2, 1, 64, 8, 12).to(DEV))
     ln = (torch.ones(256, device=DEV), torch.zeros(256, device=DEV))
     with pytest.raises(RuntimeError, match="width"):
         P.conv3x3_ln_gate(x, cw, ln, None, None)
