@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 6
+#define PRV2_ABI_VERSION 7
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -105,13 +105,14 @@ int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, c
  *     y     = mul * sigmoid(conv1x1(fused) + gate_bias) (+ res)
  * gate_w_packed == NULL: y = act(LN(conv3x3(x) + bias)) -- the 256-channel conv with the LayerNorm fused (prv2_conv2d fuses it
  * for cout <= 128 only); mul / res / gate_bias must then be NULL and d->act may be any activation.
- * Shape contract (prv2_conv3x3_ln_gate_supported(d) != 0): 3x3, stride 1, pad 1, cout == 256, cin % 32 == 0, width >= 16,
- * bf16 modes; x / y / mul / res NHWC fp32 with pixel strides ldx / ldy / ld_mul / ld_res (multiples of 4, 16-byte aligned).
- * w_packed: prv2_pack_conv_weight image of the 3x3 weights; gate_w_packed: prv2_pack_gate_weight image (prv2_gate_weight_bytes()
- * bytes) of the 1x1 weights [256][256].  Same arithmetic as the unfused sequence conv2d -> layernorm -> conv2d(1x1, sigmoid, mul,
+ * Shape contract (prv2_conv3x3_ln_gate_supported(d) != 0): 3x3, stride 1, pad 1, cin % 32 == 0, bf16 modes; cout == 256 (F of the
+ * refinenets: 8 x 16-pixel x 256-channel tiles, width >= 16), or -- with gate weights -- cout == 128 / 32 (the full-resolution
+ * output_conv2_fusion block of the DepthAnything / ZoeDepth fusion configs: 8 x 32-pixel tiles, width >= 24, height >= 4); x / y / mul / res NHWC fp32 with pixel strides ldx / ldy / ld_mul / ld_res (multiples of 4, 16-byte aligned).
+ * w_packed: prv2_pack_conv_weight image of the 3x3 weights; gate_w_packed: prv2_pack_gate_weight image (prv2_gate_weight_bytes(cout)
+ * bytes) of the 1x1 weights [cout][cout].  Same arithmetic as the unfused sequence conv2d -> layernorm -> conv2d(1x1, sigmoid, mul,
  * res) (split products, accumulation order); the row statistics are reduced in a different (fixed) order. */
 int prv2_conv3x3_ln_gate_supported(const prv2_conv_desc* d);
-int64_t prv2_gate_weight_bytes(void);
+int64_t prv2_gate_weight_bytes(int32_t channels);
 int prv2_pack_gate_weight(const float* w_src, void* w_packed, int32_t cout, int32_t cin, void* stream);
 int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
                          const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul, const float* res,

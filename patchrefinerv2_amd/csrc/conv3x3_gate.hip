@@ -325,13 +325,13 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   constexpr int NA2 = 8, NJ2 = 2, KS2 = BN / 32;
   u32x4 wf[GATE ? KS2 : 1][NJ2][2];  // [slab][column][hi / lo]
   if constexpr (GATE) {
-    const u32x4* const gw = reinterpret_cast<const u32x4*>(gp.gate_w) + (long long)wave * (KS2 * NJ2 * 2 * 64) + lane;
+    const u32x4* const gw = reinterpret_cast<const u32x4*>(gp.gate_w) + lane;
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
       for (int j = 0; j < NJ2; ++j) {
-        wf[ks][j][0] = gw[((ks * NJ2 + j) * 2 + 0) * 64];
-        if constexpr (PREC == PRV2_PREC_BF16X3) wf[ks][j][1] = gw[((ks * NJ2 + j) * 2 + 1) * 64];
+        wf[ks][j][0] = gw[gate_frag_index(BN, wave * NJ2 + j, ks, 0)];
+        if constexpr (PREC == PRV2_PREC_BF16X3) wf[ks][j][1] = gw[gate_frag_index(BN, wave * NJ2 + j, ks, 1)];
       }
   }
   // row statistics, two passes like convs.py:25-27; threads 4r..4r+3 share pixel r: thread `part` takes the 16-channel
@@ -546,24 +546,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_kernel(const GateCon
   c256_body<PREC, true>(gp, smem);
 }
 
-// 256 x 256 gate weights (PyTorch [cout][cin][1][1]) -> fragment-major image: [wave 8][slab 8][column 2][hi, lo][lane 64] x 16 B,
-// lane (m = lane & 15, g = lane >> 4) holding bf16 hi (resp. lo) of W[32 wave + 16 j + m][32 ks + 8 g .. + 7]
-__global__ void __launch_bounds__(256) pack_gate_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ dst) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (wave, ks, j, lane) = 8 weights
-  if (idx >= 8 * 8 * 2 * 64) return;
-  const int lane = idx & 63, j = (idx >> 6) & 1, ks = (idx >> 7) & 7, wv = idx >> 10;
+// C x C gate weights (PyTorch [cout][cin][1][1]; C = 32, 128, 256) -> the fragment-major image of igemm.h::gate_frag_index
+__global__ void __launch_bounds__(256) pack_gate_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one (column block, slab, lane) = 8 weights
+  const int ks_n = c / 32;
+  if (idx >= (c / 16) * ks_n * 64) return;
+  const int lane = idx & 63, ks = (idx >> 6) % ks_n, cb = (idx >> 6) / ks_n;
   const int m = lane & 15, g = lane >> 4;
-  const float* src = w + (long long)(32 * wv + 16 * j + m) * 256 + 32 * ks + 8 * g;
+  const float* src = w + (long long)(16 * cb + m) * c + 32 * ks + 8 * g;
   const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
   bf16x4 h0, l0, h1, l1;
   split_bf16(v0, h0, l0);
   split_bf16(v1, h1, l1);
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1), c = __builtin_bit_cast(u32x2, l0), d = __builtin_bit_cast(u32x2, l1);
-  unsigned* o = dst + ((long long)(((wv * 8 + ks) * 2 + j) * 2) * 64 + lane) * 4;
+  const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1), cc = __builtin_bit_cast(u32x2, l0), d = __builtin_bit_cast(u32x2, l1);
+  unsigned* o = dst + (gate_frag_index(c, cb, ks, 0) + lane) * 4;
   o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
-  o += 64 * 4;
-  o[0] = c.x; o[1] = c.y; o[2] = d.x; o[3] = d.y;
+  o = dst + (gate_frag_index(c, cb, ks, 1) + lane) * 4;
+  o[0] = cc.x; o[1] = cc.y; o[2] = d.x; o[3] = d.y;
 }
 
 static inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -585,14 +585,25 @@ bool conv3x3_c256_eligible(const prv2_conv_desc* d, const float* x, const float*
 
 using namespace prv2;
 
-extern "C" int prv2_conv3x3_ln_gate_supported(const prv2_conv_desc* d) { return d && gate_conv_shape_ok(d) ? 1 : 0; }
+static bool gate_channels_ok(int c) { return c == 32 || c == 128 || c == 256; }
 
-extern "C" int64_t prv2_gate_weight_bytes(void) { return 256LL * 256 * 4; }
+// 32 / 128 channels: the layer runs on the 8 x 32-pixel kernels of conv3x3_m16.hip (their shape contract), gate stage in the epilogue
+static bool gate_narrow_shape_ok(const prv2_conv_desc* d) {
+  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->convt_k == 0 && !d->same_pad && (d->cout == 32 || d->cout == 128) &&
+         d->cin >= 32 && d->cin % 32 == 0 && d->w >= 24 && d->h >= 4 && d->prec != PRV2_PREC_F32 && (long long)d->h * d->w * d->ldx < (1LL << 29) &&
+         (long long)d->h * d->w * d->ldy < (1LL << 29);
+}
+
+extern "C" int prv2_conv3x3_ln_gate_supported(const prv2_conv_desc* d) { return d && (gate_conv_shape_ok(d) || gate_narrow_shape_ok(d)) ? 1 : 0; }
+
+extern "C" int64_t prv2_gate_weight_bytes(int32_t channels) { return gate_channels_ok(channels) ? (int64_t)channels * channels * 4 : 0; }
 
 extern "C" int prv2_pack_gate_weight(const float* w_src, void* w_packed, int32_t cout, int32_t cin, void* stream) {
   PRV2_REQUIRE(w_src && w_packed && aligned16(w_src) && aligned16(w_packed), "pack_gate_weight: null / unaligned pointer");
-  PRV2_REQUIRE(cout == 256 && cin == 256, "pack_gate_weight: the fused gate is 256 -> 256 (got %d -> %d)", cin, cout);
-  hipLaunchKernelGGL(pack_gate_weight_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w_src, reinterpret_cast<unsigned*>(w_packed));
+  PRV2_REQUIRE(cout == cin && gate_channels_ok(cout), "pack_gate_weight: the fused gate is a C -> C 1x1 conv, C = 32, 128 or 256 (got %d -> %d)", cin, cout);
+  const int items = (cout / 16) * (cout / 32) * 64;
+  hipLaunchKernelGGL(pack_gate_weight_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, w_src,
+                     reinterpret_cast<unsigned*>(w_packed), (int)cout);
   PRV2_LAUNCH_CHECK("pack_gate_weight");
   return 0;
 }
@@ -601,6 +612,12 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
                                     const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul, const float* res,
                                     float* y, void* stream) {
   PRV2_REQUIRE(d && x && w_packed && y && (ln_weight != nullptr) == (ln_bias != nullptr), "conv3x3_ln_gate: null pointer");
+  if (gate_w_packed && d->cout != g256::BN) {  // 32 / 128 channels: conv3x3_m16.hip's kernels with the gate stage in their epilogue
+    PRV2_REQUIRE(gate_narrow_shape_ok(d) && ln_weight, "conv3x3_ln_gate: 3x3 s1 p1, cout 32 / 128 / 256, cin %% 32 == 0, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
+                 d->h, d->w, d->cin, d->cout, d->kh, d->stride, d->prec);
+    PRV2_REQUIRE(d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate: ReLU or no activation in front of the gate (act %d)", d->act);
+    return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, mul, res, nullptr, y, stream, gate_w_packed, gate_bias);
+  }
   PRV2_REQUIRE(ln_weight || !gate_w_packed, "conv3x3_ln_gate: the gate stage sits behind the LayerNorm");
   PRV2_REQUIRE(gate_conv_shape_ok(d), "conv3x3_ln_gate: 3x3 s1 p1, cout 256, cin %% 32 == 0, width >= 16, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
                d->h, d->w, d->cin, d->cout, d->kh, d->stride, d->prec);

@@ -60,7 +60,11 @@ constexpr int halo16_smem_floats() {
 // ~110 registers: TWO workgroups per CU.  The narrow layers run 18-36 steps of 384 MFMA cycles per tile against ~1.4 k cycles
 // per step (barrier, DMA issue, fragment latency, and the in-order vmcnt that queues a tile's stores in front of the next
 // halo): a second resident workgroup fills those gaps.
-template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false, bool SINGLE = false>
+// GATE (BN = Cout = 32 or 128, a GatedConvUnit's fusion_conv: bi_directional_fusion_model.py:44-51,70-80): the epilogue goes on
+// with the 1x1 gate on the tile -- normalise + activate + bf16 split of the C tile in place, gate GEMM from LDS with the (small)
+// weight fragments in registers, sigmoid * mul (+ res) in the store loop -- see conv3x3_gate.hip, which does the same at 256
+// channels on tiles of its own.
+template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false, bool SINGLE = false, bool GATE = false>
 __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, int bid, const int nwg) {
   using namespace m16;
   // Tile = 8 rows x 32 pixels, or (TALL) 32 rows x 8 pixels for the remainder strip of images whose width is
@@ -83,6 +87,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
                 TH * TW * CLD + 2 * TH * TW <= halo16_smem_floats<BN, PERSIST, SINGLE>(), "LDS budget");  // main loop / C tile + LN statistics
   static_assert(!PERSIST || (!TAIL && !TALL && BN == 32), "PERSIST: plain 8 x 32 tiles of the BN = 32 kernel");
   static_assert(!SINGLE || (!PERSIST && BN <= 64), "SINGLE: the narrow kernels, two workgroups per CU");
+  static_assert(!GATE || (!PERSIST && !TAIL && (BN == 32 || BN == 128)), "GATE: Cout = BN = 32 or 128");
   char* const As_b = reinterpret_cast<char*>(smem);
   char* const Bs_b = As_b + NHB * A_BYTES;
   float* const csm = PERSIST ? smem + (2 * A_BYTES + NBUF * B_BYTES) / 4 : smem;  // C tile (+ LN statistics)
@@ -454,6 +459,130 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         }
     __syncthreads();
     float* const ln_stats = csm + TH * TW * CLD;
+    if constexpr (GATE) {
+      // ---- gate stage (host: p.ln_w != null, Cout == BN, act none / ReLU, 16-byte rows) ----------------------------------
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int ROWS = TH * TW, KS2 = BN / 32;
+      // wave -> (pixel runs, 16-column blocks) of the gate GEMM: BN = 128: every run x block `wave`; BN = 32: runs 2w, 2w + 1 x both
+      constexpr int G_RUNS = BN == 128 ? 16 : 2, G_COLS = BN == 128 ? 1 : 2;
+      const int run0 = BN == 128 ? 0 : 2 * wave, cb0 = BN == 128 ? wave : 0;
+      // the wave's weight fragments (BN = 128: 32 registers), requested before the statistics pass
+      u32x4 wf[KS2][G_COLS][2];
+      {
+        const u32x4* const gw = reinterpret_cast<const u32x4*>(p.gate_w) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+          for (int j = 0; j < G_COLS; ++j) {
+            wf[ks][j][0] = gw[gate_frag_index(BN, cb0 + j, ks, 0)];
+            if constexpr (PREC == PRV2_PREC_BF16X3) wf[ks][j][1] = gw[gate_frag_index(BN, cb0 + j, ks, 1)];
+          }
+      }
+      ln_row_stats(p, csm, CLD, ROWS, tid, ln_stats);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (bare barriers: __syncthreads() also drains vmcnt)
+      {  // normalise + activate + split in place: the 32 bytes of 8 fp32 channels become [8 bf16 hi | 8 bf16 lo] = one A fragment
+        const int r = tid & (ROWS - 1);
+        const float mean = ln_stats[r], rstd = ln_stats[ROWS + r];
+        const float act_floor = p.act == PRV2_ACT_RELU ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < BN / 16; ++i) {
+          const int c8 = (tid >> 8) + 2 * i;
+          float* q = csm + r * CLD + c8 * 8;
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(q), v1 = *reinterpret_cast<const f32x4*>(q + 4);
+          const float* bp = p.bias ? p.bias + c8 * 8 : nullptr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = fmaxf((v0[e] + (bp ? bp[e] : 0.f) - mean) * rstd * p.ln_w[c8 * 8 + e] + p.ln_b[c8 * 8 + e], act_floor);
+            v1[e] = fmaxf((v1[e] + (bp ? bp[4 + e] : 0.f) - mean) * rstd * p.ln_w[c8 * 8 + 4 + e] + p.ln_b[c8 * 8 + 4 + e], act_floor);
+          }
+          bf16x4 h0, l0, h1, l1;
+          split_bf16(v0, h0, l0);
+          split_bf16(v1, h1, l1);
+          *reinterpret_cast<bf16x8*>(q) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          *reinterpret_cast<bf16x8*>(q + 4) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      f32x4 acc2[G_RUNS][G_COLS];
+#pragma unroll
+      for (int a = 0; a < G_RUNS; ++a)
+#pragma unroll
+        for (int j = 0; j < G_COLS; ++j) acc2[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+        for (int a0 = 0; a0 < G_RUNS; a0 += (G_RUNS < 4 ? G_RUNS : 4)) {  // up to four pixel runs at a time
+          constexpr int NR_ = G_RUNS < 4 ? G_RUNS : 4;
+          bf16x8 xh[NR_], xl[NR_];
+#pragma unroll
+          for (int a = 0; a < NR_; ++a) {
+            const float* q = csm + ((run0 + a0 + a) * 16 + m16) * CLD + ks * 32 + 8 * g;
+            xh[a] = *reinterpret_cast<const bf16x8*>(q);
+            xl[a] = *reinterpret_cast<const bf16x8*>(q + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < G_COLS; ++j) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[ks][j][0]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, wf[ks][j][1]);
+#pragma unroll
+            for (int a = 0; a < NR_; ++a) {  // same product order as the stand-alone GEMM: lo*hi, hi*lo, hi*hi per slab
+              if constexpr (PREC == PRV2_PREC_BF16X3) {
+                acc2[a0 + a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[a], wh, acc2[a0 + a][j], 0, 0, 0);
+                acc2[a0 + a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], wl, acc2[a0 + a][j], 0, 0, 0);
+              }
+              acc2[a0 + a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[a], wh, acc2[a0 + a][j], 0, 0, 0);
+            }
+          }
+        }
+      // final stage: y = mul * sigmoid(gate + gate_bias) + res; all mul / res rows of the thread requested up front
+      constexpr int C4g = BN / 4, RPPg = 512 / C4g, NRg = ROWS / RPPg;
+      const int col4g = tid % C4g;
+      auto pix_of = [&](int i) {  // (pixels outside the image: clamped address, never stored)
+        const int rr = tid / C4g + i * RPPg;
+        const int py = rr / TW, px = rr - py * TW;
+        return min(c.y0 + py, p.H - 1) * p.W + min(c.x0 + px, p.W - 1);
+      };
+      const long long img_mg = (long long)c.n_img * p.H * p.W;
+      const unsigned img_px = (unsigned)(p.H * p.W - 1);
+      const __amdgpu_buffer_rsrc_t mul_rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.mul ? p.mul + img_mg * p.ld_mul : p.x), 0, p.mul ? (int)((img_px * p.ld_mul + BN) * 4u) : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.res ? p.res + img_mg * p.ld_res : p.x), 0, p.res ? (int)((img_px * p.ld_res + BN) * 4u) : 0, 0x00020000);
+      const bool has_mul = p.mul != nullptr;  // block-uniform
+      f32x4 mv[NRg], rv[NRg];
+#pragma unroll
+      for (int i = 0; i < NRg; ++i) {
+        const int pix = pix_of(i);
+        mv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mul_rs, (pix * p.ld_mul + col4g * 4) * 4, 0, 0));
+        rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (pix * p.ld_res + col4g * 4) * 4, 0, 0));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read its rows of the C tile
+#pragma unroll
+      for (int a = 0; a < G_RUNS; ++a)
+#pragma unroll
+        for (int j = 0; j < G_COLS; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) csm[((run0 + a) * 16 + 4 * g + e) * CLD + (cb0 + j) * 16 + m16] = acc2[a][j][e];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      f32x4 gb = {0.f, 0.f, 0.f, 0.f};
+      if (p.gate_bias) gb = *reinterpret_cast<const f32x4*>(p.gate_bias + col4g * 4);
+      float* const ybase = p.y + (long long)c.n_img * p.y_bstride + col4g * 4;
+#pragma unroll
+      for (int i = 0; i < NRg; ++i) {
+        const int rr = tid / C4g + i * RPPg;
+        const int py = rr / TW, px = rr - py * TW;
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + col4g * 4]);
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ov[e] = (has_mul ? mv[i][e] : 1.0f) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((cv[e] + gb[e]) * -1.44269504088896340736f)) + rv[i][e];
+        if (c.y0 + py < p.H && c.x0 + px < p.W) {
+          float* dst = ybase + (long long)pix_of(i) * p.ldy;
+          asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+        }
+      }
+      return;
+    }
     if (p.ln_w) {  // block-uniform
       ln_row_stats(p, csm, CLD, TH * TW, tid, ln_stats);
       __syncthreads();
@@ -562,6 +691,36 @@ __global__ void __launch_bounds__(512, 4) conv3x3_halo16_narrow_kernel(const Ige
   const int strip = p.strip_blocks;  // block-uniform
   if ((int)blockIdx.x < strip) halo16_body<BN, PREC, TAIL, true, false, true>(p, smem, blockIdx.x, strip);
   else halo16_body<BN, PREC, TAIL, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+}
+
+// GatedConvUnit tail at 128 / 32 channels (one workgroup per CU / the two-workgroup narrow scheme)
+template <int BN, int PREC>
+__global__ void __launch_bounds__(512, BN == 32 ? 4 : 2) conv3x3_halo16_gate_kernel(const IgemmParams p) {
+  constexpr bool SGL = BN == 32;
+  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<BN, false, SGL>()];
+  const int strip = p.strip_blocks;  // block-uniform
+  if ((int)blockIdx.x < strip) halo16_body<BN, PREC, false, true, false, SGL, true>(p, smem, blockIdx.x, strip);
+  else halo16_body<BN, PREC, false, false, false, SGL, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+}
+
+bool conv3x3_halo16_gate_usable(const IgemmParams& p, int prec) {
+  return conv3x3_halo16_usable(p, prec) && (p.Cout == 32 || p.Cout == 128) && p.Ncols == p.Cout && p.Cin % 32 == 0 && p.ln_w && p.vec_epi &&
+         !p.gamma && !p.res2 && (p.act == PRV2_ACT_NONE || p.act == PRV2_ACT_RELU) && (long long)p.H * p.W * (p.ld_mul > p.ld_res ? p.ld_mul : p.ld_res) < (1LL << 29);
+}
+
+void launch_conv3x3_halo16_gate(IgemmParams& p, int prec, hipStream_t s) {
+  p.wave_map = 1;
+  p.tiles_n = 1;
+  p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) : 0;
+  const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x + p.strip_blocks;
+  set_kernel("conv3x3_halo16_gate_kernel", p.Cout, prec);
+  if (p.Cout == 128) {
+    if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_halo16_gate_kernel<128, PRV2_PREC_BF16X3>), dim3(blocks), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo16_gate_kernel<128, PRV2_PREC_BF16>), dim3(blocks), dim3(512), 0, s, p);
+  } else {
+    if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((conv3x3_halo16_gate_kernel<32, PRV2_PREC_BF16X3>), dim3(blocks), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo16_gate_kernel<32, PRV2_PREC_BF16>), dim3(blocks), dim3(512), 0, s, p);
+  }
 }
 
 static int persist_workgroups() {  // one persistent workgroup per CU of the CURRENT device (cached per device ordinal)

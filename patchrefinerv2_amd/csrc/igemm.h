@@ -37,7 +37,14 @@ struct IgemmParams {
   int rx0, rw;         // remainder strip = output columns [rx0, rx0 + rw): tall halo tiles, or the generic kernel's window (rw = 0: none)
   int wave_map;        // conv3x3_m16: 1 = waves w, w + 4 (one SIMD) take the two channel halves and skip all-pad column blocks
   const void* w_tail;  // im2col tile of the last (Cin % 32 == 2) channels for the 16x16x32 halo kernel, or null
+  // GatedConvUnit tail (conv3x3_m16.hip GATE / conv3x3_gate.hip): y = mul * sigmoid(W_g act(LN(conv + bias)) + gate_bias) (+ res)
+  const void* gate_w;  // fragment-major Cout x Cout gate weights (prv2_pack_gate_weight), or null
+  const float* gate_bias;
 };
+
+// fragment-major gate weights: [16-column block cb][32-channel slab ks][hi, lo][lane 64] x 16 B, lane (m = lane & 15, g = lane >> 4)
+// holding bf16 hi (resp. lo) of W[16 cb + m][32 ks + 8 g .. + 7]: one coalesced KB per MFMA B fragment
+__host__ __device__ inline long long gate_frag_index(int c, int cb, int ks, int hl) { return (((long long)cb * (c / 32) + ks) * 2 + hl) * 64; }
 
 // 3x3 convs whose Cin is a multiple of 32 plus the two appended depth maps ([feat | pred1 | pred2] concats:
 // Cin = 34, 66, 98, 194, 322, 642, 770) carry one extra 128-byte tile per output row behind the regular packed
@@ -291,6 +298,11 @@ bool conv3x3_halo_supported(const IgemmParams& p);
 void launch_conv3x3_halo(IgemmParams& p, int prec, hipStream_t stream);
 bool conv3x3_halo16_usable(const IgemmParams& p, int prec);
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t stream);  // tiles [0, tiles_x) + strip [rx0, rx0 + rw)
+int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
+                const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
+                const float* gate_bias);  // igemm.hip: prv2_conv2d, with the optional gate stage of the 32 / 128-channel layers
+bool conv3x3_halo16_gate_usable(const IgemmParams& p, int prec);                 // p.gate_w layers: Cout == 32 or 128, Cin % 32 == 0
+void launch_conv3x3_halo16_gate(IgemmParams& p, int prec, hipStream_t stream);
 // conv3x3_gate.hip: 3x3 convs with 256 output channels (8 x 16 pixel tiles x all channels; fused LayerNorm / gate tail)
 bool conv3x3_c256_eligible(const prv2_conv_desc* d, const float* x, const float* res, const float* y);
 // gemm_m16.hip: dense 1x1 / linear layers in the bf16 modes

@@ -358,9 +358,23 @@ extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, 
   return 0;
 }
 
+namespace prv2 {
+int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
+                const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
+                const float* gate_bias);
+}
+
 extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
                            const float* ln_weight, const float* ln_bias, const float* gamma, const float* mul,
                            const float* res, const float* res2, float* y, void* stream) {
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, gamma, mul, res, res2, y, stream, nullptr, nullptr);
+}
+
+// gate_w != null: the GatedConvUnit tail at 32 / 128 channels (prv2_conv3x3_ln_gate routes here; conv3x3_m16.hip GATE): mul / res then
+// belong to the final stage y = mul * sigmoid(W_g act(LN(conv + bias)) + gate_bias) (+ res)
+int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
+                      const float* ln_bias, const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream,
+                      const void* gate_w, const float* gate_bias) {
   PRV2_REQUIRE(d && x && w_packed && y, "conv2d: null pointer");
   PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -371,12 +385,13 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
   PRV2_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "conv2d: ln_weight and ln_bias go together");
   // 3x3 convs with 256 output channels (a layer property: the choice never depends on the batch): the workgroup holds the whole
   // channel row, so the LayerNorm is fused for this width too
-  if (!d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
+  if (!gate_w && !d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
     return prv2_conv3x3_ln_gate(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, nullptr, res, y, stream);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps;
+  p.gate_w = gate_w; p.gate_bias = gate_bias;
   PRV2_REQUIRE(!ln_weight || (d->cout <= 128 && d->convt_k == 0), "conv2d: fused LayerNorm needs cout <= 128 (got %d)", d->cout);
   p.N = d->n; p.H = d->h; p.W = d->w;
   p.Cin = d->cin; p.Cin_pad = (int)roundup(d->cin, BK); p.Cout = d->cout;
@@ -439,6 +454,17 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
     const int rem = p.W % 32;
     const bool strip = rem != 0 && rem <= 8 && p.W >= 64;
     p.tiles_x = strip ? p.W / 32 : (int)cdiv(p.W, 32);
+    if (gate_w) {
+      PRV2_REQUIRE(conv3x3_halo16_gate_usable(p, d->prec) && d->part == 0, "conv3x3_ln_gate: layer not covered by the gate kernel (%d->%d, %dx%d, prec %d)",
+                   d->cin, d->cout, d->h, d->w, d->prec);
+      if (strip) {
+        p.rx0 = p.W - rem;
+        p.rw = rem;
+      }
+      launch_conv3x3_halo16_gate(p, d->prec, s);
+      PRV2_LAUNCH_CHECK("conv3x3_ln_gate(halo16)");
+      return 0;
+    }
     if (strip && conv3x3_halo16_usable(p, d->prec)) {  // bf16 modes: tiles and strip are one launch
       PRV2_REQUIRE(d->part == 0, "conv2d: part=%d is only meaningful when the strip is a launch of its own (f32 mode)", d->part);
       p.rx0 = p.W - rem;
@@ -458,6 +484,9 @@ extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* 
     p.rw = rem;
     p.M = (long long)d->n * p.OH * rem;
     p.tiles_m = (int)cdiv(p.M, BM);
+  } else
+  if (gate_w) {
+    PRV2_REQUIRE(false, "conv3x3_ln_gate: layer not covered by the gate kernel (%d->%d k%d, %dx%d)", d->cin, d->cout, d->kh, d->h, d->w);
   } else
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;

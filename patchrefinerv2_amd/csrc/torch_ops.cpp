@@ -132,11 +132,12 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
 // include/prv2.h::prv2_pack_gate_weight / prv2_conv3x3_ln_gate: the GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80)
 Tensor pack_gate_weight(const Tensor& w) {
   dev_f32(w, "weight");
-  TORCH_CHECK(w.numel() == 256 * 256 && w.size(0) == 256, "prv2::pack_gate_weight: the fused gate is a 256 -> 256 1x1 conv");
+  const int64_t c = w.size(0);
+  TORCH_CHECK(w.numel() == c * c && prv2_gate_weight_bytes((int)c) > 0, "prv2::pack_gate_weight: the fused gate is a C -> C 1x1 conv, C = 32, 128 or 256");
   Tensor wc = w.contiguous();
-  Tensor packed = at::empty({prv2_gate_weight_bytes() / 4}, w.options());
+  Tensor packed = at::empty({prv2_gate_weight_bytes((int)c) / 4}, w.options());
   Launch L(w);
-  ok(prv2_pack_gate_weight(wc.data_ptr<float>(), packed.data_ptr(), 256, 256, L.stream), "pack_gate_weight");
+  ok(prv2_pack_gate_weight(wc.data_ptr<float>(), packed.data_ptr(), (int)c, (int)c, L.stream), "pack_gate_weight");
   return packed;
 }
 
@@ -145,14 +146,14 @@ Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<T
                        const optional<Tensor>& res, int64_t act, bool relu_in, int64_t prec, double ln_eps, const optional<Tensor>& out) {
   const int64_t ldx = nhwc_ld(x, "x");
   dev_f32(w_packed, "w_packed");
-  const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = 256;
+  const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = ln_weight.numel();
   TORCH_CHECK(w_packed.numel() * 4 == prv2_packed_weight_bytes((int)cout, (int)cin, 3, 3, 0, (int)prec), "prv2::conv3x3_ln_gate: w_packed does not match a 3x3 ",
-              cin, " -> 256 conv in mode ", prec);
+              cin, " -> ", cout, " conv in mode ", prec);
   Tensor y = out_or_alloc(out, x, n, h, w, cout, "conv3x3_ln_gate");
   prv2_conv_desc d = {};
   d.n = (int)n; d.h = (int)h; d.w = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.kh = 3; d.kw = 3; d.stride = 1; d.pad = 1;
   d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out"); d.relu_in = relu_in; d.act = (int)act; d.prec = (int)prec; d.ln_eps = (float)ln_eps;
-  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256, cin % 32 == 0, width >= 16, bf16 modes)");
+  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256 / 128 / 32, cin % 32 == 0, bf16 modes)");
   auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
     if (!t.has_value()) return nullptr;
     ld = (int32_t)nhwc_ld(*t, name);
@@ -163,7 +164,7 @@ Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<T
   const float* pr = aux(res, "res", d.ld_res);
   if (gate_w_packed.has_value()) {
     dev_f32(*gate_w_packed, "gate_w_packed");
-    TORCH_CHECK(gate_w_packed->numel() * 4 == prv2_gate_weight_bytes(), "prv2::conv3x3_ln_gate: gate_w_packed is not a pack_gate_weight image");
+    TORCH_CHECK(gate_w_packed->numel() * 4 == prv2_gate_weight_bytes((int)cout), "prv2::conv3x3_ln_gate: gate_w_packed is not a pack_gate_weight image");
   }
   Launch L(x);
   ok(prv2_conv3x3_ln_gate(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), opt_ptr(ln_weight, "ln_weight", cout),

@@ -198,7 +198,7 @@ class BiDirectionalFusion(_EncDec):
                      lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
                      f3=self._conv(b + "fusion_conv.3"))
             w3 = self._sd[b + "fusion_conv.3.weight"]
-            if self.prec != ops.PREC_F32 and tuple(w3.shape[:2]) == (256, 256):  # fused tail kernel (ops.conv3x3_ln_gate)
+            if self.prec != ops.PREC_F32 and w3.shape[0] == w3.shape[1] and w3.shape[0] in ops.GATE_CHANNELS:  # fused tail kernel (ops.conv3x3_ln_gate)
                 u["f3g"] = ops.pack_gate(w3.to(self.device))
             return u
 

@@ -229,7 +229,7 @@ def conv_out_hw(cw: ConvW, h: int, w: int):
 
 def _c256(x: Feat, cw: ConvW) -> bool:
     """does the library run this conv on its 256-channel 3x3 kernel (which fuses the LayerNorm at that width)?"""
-    if x.c != cw.cin or x.ld % 4 or os.environ.get("PRV2_NO_C256"):
+    if x.c != cw.cin or x.ld % 4 or cw.cout != 256 or os.environ.get("PRV2_NO_C256"):
         return False
     return bool(L.load().prv2_conv3x3_ln_gate_supported(C.byref(_gate_desc(x, cw, roundup(cw.cout, 4), False, ACT_NONE, None, None, 1e-6))))
 
@@ -293,17 +293,20 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
 
 
 GATE_FUSION = os.environ.get("PRV2_GATE_FUSION", "1") != "0"  # A/B and test switch: GatedConvUnit tail as one kernel
+# widths F of a GatedConvUnit the library fuses (prv2_conv3x3_ln_gate); PRV2_GATE_CHANNELS=256 restricts them for A/B runs
+GATE_CHANNELS = tuple(int(c) for c in os.environ.get("PRV2_GATE_CHANNELS", "32,128,256").split(","))
 
 
 def pack_gate(weight: torch.Tensor) -> torch.Tensor:
-    """fragment-major image of a 256 -> 256 1x1 conv's weights for ``conv3x3_ln_gate`` (prv2_pack_gate_weight)"""
+    """fragment-major image of a C -> C 1x1 conv's weights (C = 32, 128, 256) for ``conv3x3_ln_gate`` (prv2_pack_gate_weight)"""
     w = weight.detach().to(torch.float32).reshape(weight.shape[0], -1).contiguous()
-    assert w.shape == (256, 256) and w.is_cuda
+    c = w.shape[0]
+    assert w.shape == (c, c) and c in GATE_CHANNELS and w.is_cuda
     if DISPATCH == "torch":
         return _tops().pack_gate_weight(w)
-    dst = torch.empty(L.load().prv2_gate_weight_bytes() // 4, device=w.device, dtype=torch.float32)
+    dst = torch.empty(L.load().prv2_gate_weight_bytes(c) // 4, device=w.device, dtype=torch.float32)
     _require_dev(w)
-    L.check(L.load().prv2_pack_gate_weight(w.data_ptr(), dst.data_ptr(), 256, 256, _stream()), "pack_gate_weight")
+    L.check(L.load().prv2_pack_gate_weight(w.data_ptr(), dst.data_ptr(), c, c, _stream()), "pack_gate_weight")
     return dst
 
 
@@ -316,7 +319,9 @@ def _gate_desc(x: Feat, cw: ConvW, out_ld: int, relu_in, act, mul, res, ln_eps):
 
 def conv3x3_ln_gate_supported(x: Feat, cw: ConvW) -> bool:
     """shape contract of the fused kernel (layer shape per image only: the choice never depends on the batch)"""
-    return GATE_FUSION and _c256(x, cw)
+    if not GATE_FUSION or x.c != cw.cin or x.ld % 4 or cw.cout not in GATE_CHANNELS:
+        return False
+    return bool(L.load().prv2_conv3x3_ln_gate_supported(C.byref(_gate_desc(x, cw, roundup(cw.cout, 4), False, ACT_NONE, None, None, 1e-6))))
 
 
 def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate_bias: Optional[torch.Tensor], out: Optional[Feat] = None,

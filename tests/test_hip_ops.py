@@ -84,18 +84,26 @@ def test_conv2d(P, case):
     close(y.to_nchw(), ref, 2e-5, f"conv {case}")
 
 
-@pytest.mark.parametrize("case", [(2, 20, 32, 64, True, True), (1, 8, 16, 512, True, False), (3, 13, 48, 96, False, False), (1, 24, 16, 32, True, True),
-                                  (2, 13, 24, 64, True, True), (1, 9, 37, 32, True, False)])  # (the last two: ragged right edge)
+GATE_CASES = [  # n, h, w, cin, channels F, gate, residual
+    (2, 20, 32, 64, 256, True, True), (1, 8, 16, 512, 256, True, False), (3, 13, 48, 96, 256, False, False), (1, 24, 16, 32, 256, True, True),
+    (2, 13, 24, 64, 256, True, True), (1, 9, 37, 32, 256, True, False),   # ragged right edge
+    # F = 128 / 32 (the full-resolution output_conv2_fusion block): the 8 x 32-pixel kernels with the gate stage in their epilogue
+    (2, 20, 32, 256, 128, True, True), (1, 11, 70, 64, 128, True, False), (1, 33, 40, 32, 128, True, True),   # (70, 40: 32 k + 6 / 8 -> strip tiles)
+    (2, 20, 32, 64, 32, True, True), (1, 9, 37, 32, 32, True, False), (3, 8, 64, 96, 32, True, True),
+]
+
+
+@pytest.mark.parametrize("case", GATE_CASES)
 @pytest.mark.parametrize("prec", ["bf16x3", "f32ref"])
 def test_conv3x3_ln_gate_fused_tail(P, case, prec):
     """GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80) as one kernel: vs plain torch fp32, and vs the unfused
     kernel sequence conv2d -> LayerNorm -> conv2d(1x1, sigmoid, mul, res) in the same arithmetic mode"""
-    n, h, w, cin, gate, with_res = case
+    n, h, w, cin, C_, gate, with_res = case
     x = rnd(1, n, cin, h, w)
-    w0, b0 = rnd(2, 256, cin, 3, 3) / np.sqrt(9 * cin), rnd(3, 256) * 0.1
-    lnw, lnb = 1 + 0.2 * rnd(4, 256), 0.1 * rnd(5, 256)
-    w3, b3 = rnd(6, 256, 256, 1, 1) / 16, rnd(7, 256) * 0.1
-    mul, res = rnd(8, n, 256, h, w), rnd(9, n, 256, h, w)
+    w0, b0 = rnd(2, C_, cin, 3, 3) / np.sqrt(9 * cin), rnd(3, C_) * 0.1
+    lnw, lnb = 1 + 0.2 * rnd(4, C_), 0.1 * rnd(5, C_)
+    w3, b3 = rnd(6, C_, C_, 1, 1) / np.sqrt(C_), rnd(7, C_) * 0.1
+    mul, res = rnd(8, n, C_, h, w), rnd(9, n, C_, h, w)
     y = F.conv2d(x, w0, b0, padding=1)
     u = y.mean(1, keepdim=True)
     sd = (y - u).pow(2).mean(1, keepdim=True)
@@ -108,7 +116,9 @@ def test_conv3x3_ln_gate_fused_tail(P, case, prec):
     assert P.conv3x3_ln_gate_supported(xf, cw0)
     got = P.conv3x3_ln_gate(xf, cw0, ln, P.pack_gate(w3.to(DEV)) if gate else None, b3.to(DEV) if gate else None, act=P.ACT_RELU,
                             mul=f(mul) if gate else None, res=f(res) if gate and with_res else None)
-    assert P.L.load().prv2_last_kernel().decode().startswith("conv3x3_c256_gate_kernel<256" if gate else "conv3x3_c256_kernel<256")
+    kname = P.L.load().prv2_last_kernel().decode()
+    assert kname.startswith({256: "conv3x3_c256_gate_kernel<256" if gate else "conv3x3_c256_kernel<256", 128: "conv3x3_halo16_gate_kernel<128",
+                             32: "conv3x3_halo16_gate_kernel<32"}[C_]), kname
     if prec == "f32ref":
         close(got.to_nchw(), ref, 2e-5, f"fused tail {case}")
         return
@@ -152,8 +162,10 @@ def test_conv3x3_ln_gate_rejects_what_it_does_not_cover(P):
     PR = P.L.PREC_NAMES["bf16x3"]
     cw = P.pack_conv(rnd(1, 256, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
     assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 12).to(DEV)), cw)      # narrower than a tile
+    cw64 = P.pack_conv(rnd(1, 64, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
+    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cw64)    # cout not 32 / 128 / 256
     cw128 = P.pack_conv(rnd(1, 128, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
-    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cw128)   # cout != 256
+    assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 16).to(DEV)), cw128)   # 128 channels: width >= 24
     cwf = P.pack_conv(rnd(1, 256, 64, 3, 3).to(DEV), None, pad=1)
     assert not P.conv3x3_ln_gate_supported(P.Feat.from_nchw(rnd(2, 1, 64, 8, 32).to(DEV)), cwf)     # f32 mode
     x = P.Feat.from_nchw(rnd(2, 1, 64, 8, 12).to(DEV))
