@@ -16,7 +16,7 @@
 // Arithmetic is IDENTICAL to gemm16_kernel (same split, same three products in the same order, same MFMA, same epilogue
 // formula): the two kernels give bit-equal results (tests/test_hip_ops.py::test_gemm_ss_bit_equal_to_gemm16), so the host may
 // choose between them by problem size without making results depend on the batch.
-// TM x TN = 256 x 256 (rows >= 4096) or 128 x 128 (4 waves as 2 x 2, wave = 64 x 64; two workgroups per CU).
+// TM x TN = 256 x 256 (rows >= 4096), 128 x 128 (4 waves as 2 x 2, wave = 64 x 64; two workgroups per CU) or 64 x 64 (grids of one image).
 #include <cstdlib>
 
 #include "igemm.h"
@@ -44,14 +44,16 @@ struct GemmSSParams {
   int tiles_n, tiles_m, blocked;
 };
 
-template <int WM, int WN, int RI, int RJ, bool OUT_SS, int ACT>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_kernel(const GemmSSParams p) {
+// NS = LDS stages.  2: slab k + 1 in flight while slab k multiplies (what the LDS allows for 256 x 256 tiles and for two 128 x 128
+// workgroups per CU).  4 (clamped issue, counted waits): the 64 x 64 tiles of grids with at most one workgroup per CU.
+template <int WM, int WN, int RI, int RJ, bool OUT_SS, int ACT, int NS = 2>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2) gemm_ss_kernel(const GemmSSParams p) {
   constexpr int NW = WM * WN, TM = WM * RI * 16, TN = WN * RJ * 16;
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_DMA = TM / 8 / NW, B_DMA = TN / 8 / NW;  // 1 KB pieces per wave and slab
   constexpr int STRIP_LD = RJ * 16 + 4, STRIP_BYTES = 16 * STRIP_LD * 4;
-  static_assert(NW * STRIP_BYTES <= 2 * STAGE, "epilogue strips fit in the staging memory");
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  static_assert(NW * STRIP_BYTES <= NS * STAGE && NS * STAGE <= 160 * 1024, "epilogue strips fit in the staging memory");
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
   int bid = blockIdx.x;
   {  // XCD-aware: consecutive tiles (sharing rows / weights) on one XCD's L2 (blocks b, b + 8, ... share an XCD)
@@ -144,14 +146,29 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 1 : 2) gemm_ss_
     }
   };
 
-  issue(0, 0);
-  for (int k = 0; k < p.kslabs; ++k) {
-    // my DMAs of slab k have landed; behind the barrier everyone's have, and everyone is done reading the other stage
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (k + 1 < p.kslabs) issue((k + 1) & 1, k + 1);
-    compute(k & 1);
+  if constexpr (NS == 2) {
+    issue(0, 0);
+    for (int k = 0; k < p.kslabs; ++k) {
+      // my DMAs of slab k have landed; behind the barrier everyone's have, and everyone is done reading the other stage
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (k + 1 < p.kslabs) issue((k + 1) & 1, k + 1);
+      compute(k & 1);
+    }
+    asm volatile("s_barrier" ::: "memory");  // the staging memory becomes the epilogue strips
+  } else {
+    // NS - 1 slabs in flight; behind the last slab the issue is clamped (re-fetches of the last slab into stages nobody reads any
+    // more), so that "slab k has landed" is the same counted wait in every iteration
+    const int last = p.kslabs - 1;
+#pragma unroll
+    for (int k0 = 0; k0 < NS - 1; ++k0) issue(k0, k0 < last ? k0 : last);
+    for (int k = 0; k < p.kslabs; ++k) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (A_DMA + B_DMA)) : "memory");
+      const int kn = k + NS - 1;
+      issue(kn % NS, kn < last ? kn : last);  // the stage of slab k - 1: everyone is behind this iteration's barrier, i.e. done with it
+      compute(k % NS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // nothing may land on the epilogue strips
   }
-  asm volatile("s_barrier" ::: "memory");  // the staging memory becomes the epilogue strips
 
   // ---- epilogue: one 16-row block at a time through a wave-private LDS strip -> whole 256-byte row segments ----------
   float* const strip = reinterpret_cast<float*>(smem + wave * STRIP_BYTES);
@@ -296,15 +313,15 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
   // Measured (tools/probes/gemm_ss_bench.py): 14350 x 1024 -> 1024..4096: 375-425 vs 335-385 TF; 4100 rows: 128-tiles win but on 3072 columns
   const bool big = force ? force == 256 : (t256 >= 180 && (double)t256 / (double)(cdiv(t256, 256) * 256) >= 0.75);
   PRV2_REQUIRE(act == PRV2_ACT_NONE || act == PRV2_ACT_GELU, "gemm_ss: activation %d (built: none, GELU -- what the ViT blocks use)", act);
-#define PRV2_GSS(WM_, WN_, RI_, RJ_, NT_)                                                                                         \
-  do {                                                                                                                            \
-    if (y_ss) {                                                                                                                   \
-      if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, true, PRV2_ACT_GELU>), grid, dim3(NT_), 0, s, p);  \
-      else hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, true, PRV2_ACT_NONE>), grid, dim3(NT_), 0, s, p);               \
-    } else {                                                                                                                      \
-      if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, false, PRV2_ACT_GELU>), grid, dim3(NT_), 0, s, p); \
-      else hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, false, PRV2_ACT_NONE>), grid, dim3(NT_), 0, s, p);              \
-    }                                                                                                                             \
+#define PRV2_GSS(WM_, WN_, RI_, RJ_, NT_, NS_)                                                                                         \
+  do {                                                                                                                                 \
+    if (y_ss) {                                                                                                                        \
+      if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, true, PRV2_ACT_GELU, NS_>), grid, dim3(NT_), 0, s, p);  \
+      else hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, true, PRV2_ACT_NONE, NS_>), grid, dim3(NT_), 0, s, p);               \
+    } else {                                                                                                                           \
+      if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, false, PRV2_ACT_GELU, NS_>), grid, dim3(NT_), 0, s, p); \
+      else hipLaunchKernelGGL((gemm_ss_kernel<WM_, WN_, RI_, RJ_, false, PRV2_ACT_NONE, NS_>), grid, dim3(NT_), 0, s, p);              \
+    }                                                                                                                                  \
   } while (0)
   const char* const be = getenv("PRV2_GEMM_SS_BLOCKED");  // A/B switch
   if (big) {
@@ -312,15 +329,36 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
     p.tiles_m = (int)cdiv(m, 256);
     p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
     const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
-    PRV2_GSS(2, 4, 8, 4, 512);
+    PRV2_GSS(2, 4, 8, 4, 512, 2);
     set_kernel("gemm_ss_kernel", 256, PRV2_PREC_BF16X3);
   } else {
     p.tiles_n = (int)cdiv(n, 128);
     p.tiles_m = (int)cdiv(m, 128);
     p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 64;  // (hurts small grids: 1037 x 3072: 202 -> 148 TF)
     const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
-    PRV2_GSS(2, 2, 4, 4, 256);
-    set_kernel("gemm_ss_kernel", 128, PRV2_PREC_BF16X3);
+    // Grids that leave most of the chip idle (one image: 769 / 1037 token rows -> 56-224 tiles of 128 x 128) take 64 x 64 tiles: four
+    // times the workgroups; a workgroup's time is its serial K loop (a slab of a 128-tile is 768 MFMA cycles in ~1.25 k: compute,
+    // not latency -- four LDS stages instead of two made it 13 % SLOWER, tools/probes/gemm_ss_small_bench.py), so only more of
+    // them in parallel helps: 4096 -> 1024 at 769 rows 87 -> 61 us.  Same arithmetic per output element: bit-identical.
+    const char* const se = getenv("PRV2_GEMM_SS_SMALL");  // A/B switch
+    const bool small = (se ? atoi(se) != 0 : true) && !force && (long long)p.tiles_m * p.tiles_n < 256;
+    if (small) {
+      p.tiles_n = (int)cdiv(n, 64);
+      p.tiles_m = (int)cdiv(m, 64);
+      p.blocked = 0;
+      const dim3 grid64((unsigned)(p.tiles_m * p.tiles_n));
+      // <= 256 of them (one per CU): four LDS stages -- three slabs in flight hide the L2 round trip that a 192-MFMA-cycle slab
+      // cannot (4096 -> 1024: 61 -> 41 us); more than 256: two stages, so that several workgroups share a CU (four stages: -20 %)
+      const char* const de = getenv("PRV2_GEMM_SS_DEEP");  // A/B switch: 2 / 4 forces the stage count
+      const dim3 grid = grid64;
+      const bool deep = de ? atoi(de) == 4 : (long long)p.tiles_m * p.tiles_n <= 256;
+      if (deep) PRV2_GSS(2, 2, 2, 2, 256, 4);
+      else PRV2_GSS(2, 2, 2, 2, 256, 2);
+      set_kernel("gemm_ss_kernel", 64, PRV2_PREC_BF16X3);
+    } else {
+      PRV2_GSS(2, 2, 4, 4, 256, 2);
+      set_kernel("gemm_ss_kernel", 128, PRV2_PREC_BF16X3);
+    }
   }
 #undef PRV2_GSS
   PRV2_LAUNCH_CHECK("gemm_ss");
