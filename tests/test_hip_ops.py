@@ -668,12 +668,13 @@ def test_bicubic_input_stage(P, case):
 
 # ---- split-swizzled operand path of the large ViT linears (csrc/gemm_ss.hip) ---------------------------------------------------
 @pytest.mark.parametrize("M,K,N", [(100, 64, 128), (1037, 256, 384), (4100, 1024, 1024), (2500, 384, 1152)])
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["128", "256", "auto"])  # (auto: the library's choice -- 64 x 64 tiles with 2 / 4 LDS stages on the small grids)
 def test_gemm_ss_bit_equal_to_gemm16(P, M, K, N, tile, monkeypatch):
     """gemm_ss_kernel (pre-split operands, LDS-DMA) == gemm16_kernel (fp32 operands split in the kernel), BIT FOR BIT: same
     split, same three products in the same order, same epilogue.  That equality is what lets the host pick the kernel by
     problem size without making results depend on the batch.  Also vs the fp32 reference within the bf16x3 tolerance."""
-    monkeypatch.setenv("PRV2_GEMM_SS_TILE", tile)
+    if tile != "auto":
+        monkeypatch.setenv("PRV2_GEMM_SS_TILE", tile)
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g)
     w, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
