@@ -761,6 +761,8 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
     else PRV2_LAUNCH_NARROW(64, PRV2_PREC_BF16);
     return;
   }
+  // (wider layers as N-tiles of 64 on this kernel -- two workgroups per CU, the halo staged once per N-tile -- are no faster than one
+  //  workgroup with 128 columns: 98->98 272 vs 283 TF, 194->194 336 vs 335, 322->322 376 vs 397)
 #undef PRV2_LAUNCH_NARROW
   if (p.Ncols <= 32 && !p.w_tail && !no_persist) {
     const int tiles = blocks - p.strip_blocks, wgs = tiles < persist_workgroups() ? tiles : persist_workgroups();
