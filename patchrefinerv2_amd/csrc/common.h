@@ -51,6 +51,23 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// GELU for the store loops of the bf16-mode conv kernels (16 rows x 4 channels per thread: VALU-bound; the exact-erf GELU above
+// is ocml's two-branch erff, ~45 instructions under divergence -- +4..9 % on the short-K decoder layers): Abramowitz-Stegun 7.1.26
+// on v_rcp_f32 / v_exp_f32, ~14 instructions.  Max |error| against float64 GELU over [-8, 8]: 4.7e-7 -- the same as the exact
+// formula evaluated in fp32 (4.5e-7).  The f32 mode, the ViT linears and the generic kernels keep act_apply.
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f * t;
+  p = (p - 1.453152027f) * t;
+  p = (p + 1.421413741f) * t;
+  p = (p - 0.284496736f) * t;
+  p = (p + 0.254829592f) * t;
+  const float r = 1.0f - p * __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+  return 0.5f * v * (1.0f + copysignf(r, x));
+}
+__device__ __forceinline__ float act_apply_bf(float v, int act) { return act == PRV2_ACT_GELU ? gelu_fast(v) : act_apply(v, act); }
+
 // bilinear / align_corners=True source coordinate (float32, PyTorch's area_pixel_compute_scale)
 struct AxisTap {
   int i0, i1;

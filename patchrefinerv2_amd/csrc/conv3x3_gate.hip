@@ -518,7 +518,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
       for (int e = 0; e < 4; ++e) {
         float t = cv[e];
         if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[ROWS + rr] * lw[e] + lb[e];
-        ov[e] = act_apply(t, decltype(act_c)::value) + rv[i][e];
+        ov[e] = act_apply_bf(t, decltype(act_c)::value) + rv[i][e];
       }
       if (y0 + rr / TW < p.H && x0 + (rr & (TW - 1)) < p.W) {
         float* dst = ybase + (long long)pix_of(i) * p.ldy;

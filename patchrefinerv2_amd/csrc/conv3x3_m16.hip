@@ -617,7 +617,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           for (int e = 0; e < 4; ++e) {
             float t = cv[e] + ec.bias[e];
             if constexpr (LN) t = (t - ln_stats[rr]) * ln_stats[TH * TW + rr] * ec.lnw[e] + ec.lnb[e];
-            t = act_apply(t, decltype(act_c)::value);
+            t = act_apply_bf(t, decltype(act_c)::value);
             if constexpr (RES) t += rv[e];
             ov[e] = e < ec.nvalid ? t : 0.f;  // pad channels behind cout stay zero
           }
