@@ -52,7 +52,7 @@ def parse():
                          "all-gather (every rank blends); --shard frames: rank0 = final RCCL gather of the per-rank maps to "
                          "rank 0 (SURVEY.md 8e cfg 5), all = every rank keeps its own map (the reference's data parallelism)")
     ap.add_argument("--max-batch", type=int, default=None, help="patches per launch batch (results are batch independent); default: the "
-                    "workload's own (14 unless it names one)")
+                    "workload's own (41 unless it names one)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over")
     ap.add_argument("--no-prefetch-coarse", dest="prefetch_coarse", action="store_false",
                     help="do not enqueue the next frame's coarse forward beside the current frame's tile batches")
@@ -163,7 +163,7 @@ def main():
     name = args.workload or DEFAULT_WORKLOAD
     w = WORKLOADS[name]
     if args.max_batch is None:
-        args.max_batch = int(WORKLOADS[name].get("max_batch", 14))
+        args.max_batch = int(WORKLOADS[name].get("max_batch", 41))
     mc = model_config(name, prec=args.prec, max_batch=args.max_batch, n_streams=args.streams)
     mc["config"]["device"] = str(dev)
     mc["config"]["hip_graph"] = bool(args.hip_graph)

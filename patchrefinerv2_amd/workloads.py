@@ -63,10 +63,10 @@ WORKLOADS["v2_eff_zoeda_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840
 # = the metric-bins head over MiDaS DPT_BEiT_L_384 (:10-17), ResizeZoe -> P = 384 x 512, MNv4-S refiner, BiDirectionalFusion zoe cfg
 ZOE_BEIT_L = dict(ZOE_DA_L, midas_model_type="DPT_BEiT_L_384", img_size=[384, 512])
 WORKLOADS["v2_zoe_4k_r32"] = dict(kind="PatchRefinerPlus", raw=[2160, 3840], split=[4, 4], pps=[384, 512], mode="r32",
-                                  coarse=None, zoe=ZOE_BEIT_L, zoe_type="ZoeDepth", fusion=BIDIR_ZOE, patches=81,
-                                  # tiles per launch batch (results are batch independent): 81 = 41 + 40 on two streams -- the small pyramid
-                                  # levels (48 x 64 and below: 84-336 workgroups per launch at 14 tiles) fill the chip better; 198.5 -> 194.3 ms
-                                  max_batch=41)
+                                  coarse=None, zoe=ZOE_BEIT_L, zoe_type="ZoeDepth", fusion=BIDIR_ZOE, patches=81)
+# (bench.py runs every workload with 41 tiles per launch batch unless an entry names ``max_batch``: 81 = 41 + 40 on two streams -- the
+#  small pyramid levels (48 x 64 and below: 84-336 workgroups per launch at 14 tiles) fill the chip better: 198.5 -> 194.3 ms here,
+#  +1..3 % on the other 81-tile workloads, flat at r64; results are batch independent)
 # configs/patchrefiner_zoedepth/pr_u4k.py (the README's example command): V1 with ZoeDepth / BEiT-L on every tile
 WORKLOADS["v1_zoe_4k_r32"] = dict(kind="PatchRefiner", raw=[2160, 3840], split=[4, 4], pps=[384, 512], mode="r32",
                                   coarse=None, zoe=ZOE_BEIT_L, zoe_type="ZoeDepth", fine_zoe=ZOE_BEIT_L,
