@@ -5,7 +5,7 @@
       [--save] --work-dir OUT --test-type general [--gray-scale] --image-raw-shape H W --patch-split-num h w
 
 CONFIG is an MMEngine-style python config (``model=dict(type=..., config=dict(...))``, ``_base_`` supported).
-Extras: ``--synthetic-weights`` (the reference has not released checkpoints), ``--prec``, ``--process-num``.
+Extras: ``--synthetic-weights`` (the reference has not released checkpoints), ``--prec``, ``--process-num``, ``--max-batch``, ``--streams``.
 Multi-GPU: launch with torch.distributed.run; frames are sharded over ranks like the reference's dist_test.sh.
 """
 import argparse
@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--patch-split-num", nargs=2, type=int, default=[4, 4])
     ap.add_argument("--process-num", type=int, default=4)
     ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--max-batch", type=int, default=41, help="tiles per launch batch (the result does not depend on it; config key max_batch wins)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over (config key n_streams wins)")
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--seed", type=int, default=621)
     ap.add_argument("--consistency", type=int, default=0, metavar="OVERLAP",
@@ -66,6 +68,8 @@ def main():
 
     mcfg = cfg.model.to_dict()
     mcfg["config"]["prec"] = args.prec
+    mcfg["config"].setdefault("max_batch", args.max_batch)  # (the reference's process_num only groups the random tiles of a plan)
+    mcfg["config"].setdefault("n_streams", args.streams)
     model = build_model(mcfg)
     if args.ckp_path:
         sd = torch.load(args.ckp_path, map_location="cpu")
