@@ -67,9 +67,11 @@ def main():
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
 
     mcfg = cfg.model.to_dict()
-    mcfg["config"]["prec"] = args.prec
-    mcfg["config"].setdefault("max_batch", args.max_batch)  # (the reference's process_num only groups the random tiles of a plan)
-    mcfg["config"].setdefault("n_streams", args.streams)
+    # PatchRefiner / PatchRefinerPlus take one ``config`` dict, BaselinePretrain keyword arguments (baseline_pretrain.py:45)
+    mopts = mcfg["config"] if "config" in mcfg else mcfg
+    mopts["prec"] = args.prec
+    mopts.setdefault("max_batch", args.max_batch)  # (the reference's process_num only groups the random tiles of a plan)
+    mopts.setdefault("n_streams", args.streams)
     model = build_model(mcfg)
     if args.ckp_path:
         sd = torch.load(args.ckp_path, map_location="cpu")
