@@ -68,7 +68,9 @@ def main():
 
     mcfg = cfg.model.to_dict()
     # PatchRefiner / PatchRefinerPlus take one ``config`` dict, BaselinePretrain keyword arguments (baseline_pretrain.py:45)
-    mopts = mcfg["config"] if "config" in mcfg else mcfg
+    # (PatchRefinerSemi: the options belong to the student it delegates to, patchrefiner_semi.py:208-210)
+    tgt = mcfg["model_cfg_student"] if "model_cfg_student" in mcfg else mcfg
+    mopts = tgt["config"] if "config" in tgt else tgt
     mopts["prec"] = args.prec
     mopts.setdefault("max_batch", args.max_batch)  # (the reference's process_num only groups the random tiles of a plan)
     mopts.setdefault("n_streams", args.streams)
