@@ -169,6 +169,95 @@ __global__ void __launch_bounds__(256) roi_align_kernel(const float* __restrict_
   }
 }
 
+// The upsampling regime of the path (an ROI is 1/S of the coarse map and comes out at the map's own size: bin < 1 pixel, one
+// sample per bin): R output rows per thread.  Consecutive output rows mostly share their two source rows (a x4 zoom: 4 output
+// rows per source row), so the four taps stay in registers while (y_low, y_high) does not change -- ~1.3 instead of 4 tap loads
+// per output, the SAME arithmetic per output as roi_align_kernel (w1 v1 + w2 v2 + w3 v3 + w4 v4, left to right).  Boxes whose
+// sampling grid is larger than 1 x 1 (down-sampling ROIs) take the general per-pixel loop.
+template <int R>
+__global__ void __launch_bounds__(256) roi_align_rows_kernel(const float* __restrict__ feat, int H, int W, int C, int ldf,
+                                                             const float* __restrict__ boxes, int K, float scale, int oh, int ow,
+                                                             float* __restrict__ out, int ldo) {
+  const unsigned cg = C / 4;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)ow * cg) return;
+  const int px = (int)(t / cg), c = (int)(t - (unsigned)px * cg) * 4;
+  const int py0 = blockIdx.y * R, k = blockIdx.z;
+  const float* b = boxes + 4 * k;
+  const float rsw = b[0] * scale - 0.5f, rsh = b[1] * scale - 0.5f;
+  const float rew = b[2] * scale - 0.5f, reh = b[3] * scale - 0.5f;
+  const float roi_w = rew - rsw, roi_h = reh - rsh;
+  const float bin_h = roi_h / (float)oh, bin_w = roi_w / (float)ow;
+  const int gh = (int)ceilf(roi_h / (float)oh), gw = (int)ceilf(roi_w / (float)ow);
+  if (gh > 1 || gw > 1) {  // block-uniform (a property of box k): the general sampling grid, one output row at a time
+#pragma unroll 1
+    for (int r = 0; r < R && py0 + r < oh; ++r) {
+      const int py = py0 + r;
+      const float count = (float)max(gh * gw, 1);
+      float4 acc = vzero4();
+      for (int iy = 0; iy < gh; ++iy) {
+        const float y = rsh + (float)py * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float x = rsw + (float)px * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+          float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+          int yl = (int)yy, xl = (int)xx, yh, xh;
+          if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+          if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+          const float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+          float4 val = vzero4();
+          vfma(val, hy * hx, *reinterpret_cast<const float4*>(feat + ((int64_t)yl * W + xl) * ldf + c));
+          vfma(val, hy * lx, *reinterpret_cast<const float4*>(feat + ((int64_t)yl * W + xh) * ldf + c));
+          vfma(val, ly * hx, *reinterpret_cast<const float4*>(feat + ((int64_t)yh * W + xl) * ldf + c));
+          vfma(val, ly * lx, *reinterpret_cast<const float4*>(feat + ((int64_t)yh * W + xh) * ldf + c));
+          vfma(acc, 1.0f, val);
+        }
+      }
+      vdiv(acc, count);
+      *reinterpret_cast<float4*>(out + (((int64_t)k * oh + py) * ow + px) * ldo + c) = acc;
+    }
+    return;
+  }
+  // one sample per bin: x is the thread's own, shared by its R rows
+  const float x = rsw + (float)px * bin_w + .5f * bin_w / 1.0f;
+  const bool x_in = !(x < -1.0f || x > (float)W);
+  float xx = x <= 0.f ? 0.f : x;
+  int xl = (int)xx, xh;
+  if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else xh = xl + 1;
+  const float lx = xx - (float)xl, hx = 1.f - lx;
+  int cyl = -1, cyh = -1;  // rows whose taps are in registers (block-uniform: the block's threads share their output rows)
+  float4 v1 = vzero4(), v2 = vzero4(), v3 = vzero4(), v4 = vzero4();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int py = py0 + r;
+    if (py >= oh) break;
+    const float y = rsh + (float)py * bin_h + .5f * bin_h / 1.0f;
+    float4 acc = vzero4();
+    if (x_in && !(y < -1.0f || y > (float)H)) {
+      float yy = y <= 0.f ? 0.f : y;
+      int yl = (int)yy, yh;
+      if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+      const float ly = yy - (float)yl, hy = 1.f - ly;
+      if (yl != cyl || yh != cyh) {
+        v1 = *reinterpret_cast<const float4*>(feat + ((int64_t)yl * W + xl) * ldf + c);
+        v2 = *reinterpret_cast<const float4*>(feat + ((int64_t)yl * W + xh) * ldf + c);
+        v3 = *reinterpret_cast<const float4*>(feat + ((int64_t)yh * W + xl) * ldf + c);
+        v4 = *reinterpret_cast<const float4*>(feat + ((int64_t)yh * W + xh) * ldf + c);
+        cyl = yl;
+        cyh = yh;
+      }
+      float4 val = vzero4();
+      vfma(val, hy * hx, v1);
+      vfma(val, hy * lx, v2);
+      vfma(val, ly * hx, v3);
+      vfma(val, ly * lx, v4);
+      vfma(acc, 1.0f, val);
+    }
+    vdiv(acc, 1.0f);
+    *reinterpret_cast<float4*>(out + (((int64_t)k * oh + py) * ow + px) * ldo + c) = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bilinear align_corners=True upsample, NHWC
 // ---------------------------------------------------------------------------------------------
@@ -348,7 +437,12 @@ extern "C" int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c
   bool vec = (c % 4 == 0) && (ldf % 4 == 0) && (ldo % 4 == 0) && aligned16(feat) && aligned16(out);
   PRV2_REQUIRE(oh <= 65535 && k <= 65535, "roi_align: grid too large");
   const dim3 grid((unsigned)cdiv((int64_t)ow * (vec ? c / 4 : c), 256), oh, k);
-  if (vec)
+  if (vec && oh >= 16) {
+    constexpr int R = 4;
+    const dim3 grid_r((unsigned)cdiv((int64_t)ow * (c / 4), 256), (unsigned)cdiv(oh, R), k);
+    hipLaunchKernelGGL(roi_align_rows_kernel<R>, grid_r, dim3(256), 0, (hipStream_t)stream, feat, h, w, c, ldf, boxes, k, spatial_scale, oh, ow,
+                       out, ldo);
+  } else if (vec)
     hipLaunchKernelGGL(roi_align_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, feat, h, w,
                        c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo);
   else

@@ -345,6 +345,14 @@ def test_roi_align(P):
     ref2 = o_ops.roi_align(feat, big, (5, 7), 24 / 56, aligned=True)
     got2 = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), big[:, 1:].contiguous().to(DEV), 24 / 56, 5, 7)
     close(got2.to_nchw(), ref2, 1e-5, "roi grid")
+    # sampling grid > 1 at >= 16 output rows (the row-cached kernel's general branch), and a box hanging over the map's edge
+    boxes3 = torch.tensor([[0, 0.0, 0.0, 84.0, 56.0], [0, 40.0, 20.0, 100.0, 70.0]])
+    ref3 = o_ops.roi_align(feat.repeat(2, 1, 1, 1), torch.cat([torch.arange(2.0)[:, None], boxes3[:, 1:]], 1), (16, 20), 24 / 56, aligned=True)
+    got3 = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), boxes3[:, 1:].contiguous().to(DEV), 24 / 56, 16, 20)
+    close(got3.to_nchw(), ref3, 1e-5, "roi grid, rows kernel")
+    ref4 = o_ops.roi_align(feat.repeat(2, 1, 1, 1), torch.cat([torch.arange(2.0)[:, None], boxes3[:, 1:]], 1), (48, 64), 24 / 56, aligned=True)
+    got4 = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), boxes3[:, 1:].contiguous().to(DEV), 24 / 56, 48, 64)
+    close(got4.to_nchw(), ref4, 1e-5, "roi zoom, rows kernel, out-of-map samples")
 
 
 @pytest.mark.parametrize("case", [(2, 32, 12, 16, 24, 32), (1, 1, 56, 84, 28, 42), (1, 98, 7, 11, 14, 21), (1, 256, 16, 16, 14, 14)])
