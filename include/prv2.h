@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 7
+#define PRV2_ABI_VERSION 8
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -261,6 +261,13 @@ int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int32_t w, int3
  * pad channels), 16-byte aligned, pixel stride ldy.  Same arithmetic per map as prv2_upsample_bilinear. */
 int prv2_depth_pair_fill(const float* p1, const float* p2, int32_t n, int32_t h, int32_t w, int32_t oh, int32_t ow, float* y,
                          int32_t ldy, void* stream);
+
+/* Border correction of a 3x3 / pad 1 conv whose bias was folded from an upstream constant: GatedFusionBlock's ``out_conv`` (1x1, bias b)
+ * followed by the bilinear x2 and ``output_conv1`` (3x3, W) is ONE 3x3 conv with weights W o out_conv and bias + sum_taps W_tap b
+ * (bi_directional_fusion_model.py:139-142,201: a 1x1 commutes with the interpolation, whose weights sum to one) -- except that at
+ * the image border the zero padding hides some taps from b.  y[n, oy, ox, :c] -= sum of tap_bias[tap][:] over the taps of (oy, ox)
+ * that fall outside the image; tap_bias: [9][c] (ky, kx order), c % 4 == 0. */
+int prv2_conv_border_bias(float* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldy, const float* tap_bias, void* stream);
 
 /* NCHW <-> NHWC layout changes at the boundary (image_lr in, coarse_prediction out) */
 int prv2_nchw_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, float* y, int32_t ldy, void* stream);

@@ -367,6 +367,36 @@ __global__ void __launch_bounds__(256) depth_pair_fill_kernel(const float* __res
   *reinterpret_cast<float4*>(y + (((int64_t)n * oh + oy) * ow + ox) * ldy) = o;
 }
 
+// y[n, oy, ox, :c] -= sum of bt[tap][:] over the taps (ky, kx) of a 3 x 3 / pad 1 conv that fall outside the image at (oy, ox): the
+// border correction of a conv whose bias was folded from an upstream constant (conv3x3(x + b) = conv3x3(x) + sum_taps W_tap b holds
+// only where all nine taps see b; with zero padding the border pixels see fewer).  One thread = one border pixel x 4 channels.
+__global__ void __launch_bounds__(256) conv_border_bias_kernel(float* __restrict__ y, int N, int H, int W, int C, int ldy,
+                                                               const float* __restrict__ bt /* [9][C] */) {
+  const int per_img = 2 * W + 2 * (H - 2 > 0 ? H - 2 : 0), c4n = C / 4;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * per_img * c4n) return;
+  const int c = (int)(t % c4n) * 4;
+  const int b = (int)((t / c4n) % per_img), n = (int)(t / c4n / per_img);
+  int oy, ox;
+  if (b < W) { oy = 0; ox = b; }
+  else if (b < 2 * W) { oy = H - 1; ox = b - W; }
+  else { const int r = b - 2 * W; oy = 1 + (r >> 1); ox = (r & 1) ? W - 1 : 0; }
+  if (H == 1 && b >= W) return;  // (one row: top == bottom, counted once)
+  float4 s = vzero4();
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy + ky - 1, ix = ox + kx - 1;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) continue;
+      vfma(s, 1.0f, *reinterpret_cast<const float4*>(bt + (ky * 3 + kx) * C + c));
+    }
+  float4* q = reinterpret_cast<float4*>(y + (((long long)n * H + oy) * W + ox) * ldy + c);
+  float4 v = *q;
+  v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w;
+  *q = v;
+}
+
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W,
                                                            float* __restrict__ y, int ldy) {
   int64_t total = (int64_t)N * H * W * C;
@@ -472,6 +502,15 @@ extern "C" int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int3
     hipLaunchKernelGGL(upsample_bilinear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, n,
                        h, w, c, ldx, oh, ow, ac_scale(h, oh), ac_scale(w, ow), y, ldy);
   PRV2_LAUNCH_CHECK("upsample_bilinear");
+  return 0;
+}
+
+extern "C" int prv2_conv_border_bias(float* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldy, const float* tap_bias, void* stream) {
+  PRV2_REQUIRE(y && tap_bias && n > 0 && h > 0 && w > 1 && c > 0, "conv_border_bias: bad arguments");
+  PRV2_REQUIRE(c % 4 == 0 && ldy % 4 == 0 && ldy >= c && aligned16(y) && aligned16(tap_bias), "conv_border_bias: 16-byte channel groups (c %d ldy %d)", c, ldy);
+  const long long items = (long long)n * (2 * w + 2 * (h > 2 ? h - 2 : 0)) * (c / 4);
+  hipLaunchKernelGGL(conv_border_bias_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, y, n, h, w, c, ldy, tap_bias);
+  PRV2_LAUNCH_CHECK("conv_border_bias");
   return 0;
 }
 

@@ -23,6 +23,11 @@ from .dav2 import StateDictModule
 from .ops import ACT_GELU, ACT_RELU, ACT_SIGMOID, Feat
 
 
+import os
+
+FOLD_OUT_CONV = os.environ.get("PRV2_FOLD_OUT_CONV", "1") != "0"  # A/B and test switch (BiDirectionalFusion._pack)
+
+
 def as_feat1(t: torch.Tensor) -> Feat:
     """dense [B,1,H,W] tensor == NHWC [B,H,W,1]."""
     B, _, H, Wd = t.shape
@@ -208,6 +213,17 @@ class BiDirectionalFusion(_EncDec):
 
         P["refine"] = {r: block(f"{s}refinenet{r}.") for r in range(1, 6)}
         P["out1"] = self._conv(s + "output_conv1")
+        if self.prec != ops.PREC_F32 and FOLD_OUT_CONV:
+            # refinenet1.out_conv (1x1) -> bilinear x2 -> output_conv1 (3x3) is ONE 3x3 conv on the upsampled gate output: a 1x1
+            # commutes with the interpolation (its weights sum to one), so W' = W1 o W_oc and bias' = b1 + sum_taps W1_tap b_oc -- except
+            # at the image border, where the zero padding hides taps from b_oc (ops.conv_border_bias).  Saves the 256 -> 256 GEMM at
+            # 192 x 256 (2.5 ms per frame); the f32 mode keeps the reference's layer order.
+            w1, b1 = self._sd[s + "output_conv1.weight"].double(), self._sd[s + "output_conv1.bias"].double()
+            woc, boc = self._sd[s + "refinenet1.out_conv.weight"].double()[:, :, 0, 0], self._sd[s + "refinenet1.out_conv.bias"].double()
+            wf = torch.einsum("omyx,mi->oiyx", w1, woc).float()
+            bt = torch.einsum("omyx,m->yxo", w1, boc)  # [3, 3, out]: what each tap contributes from the folded constant
+            P["out1_folded"] = ops.pack_conv(wf, (b1 + bt.sum((0, 1))).float(), pad=1, device=self.device, prec=self.prec)
+            P["out1_tap_bias"] = bt.reshape(9, -1).float().contiguous().to(self.device)
         P["out2_0"] = self._conv(s + "output_conv2.0")
         P["out2_fusion"] = block(s + "output_conv2_fusion.")
         P["out3_w"] = self._dev(s + "output_conv3.0.weight")
@@ -225,7 +241,7 @@ class BiDirectionalFusion(_EncDec):
         fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
         return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])
 
-    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True, dest=None) -> Feat:
+    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True, dest=None, skip_out_conv=False) -> Feat:
         """GatedFusionBlock.forward (bi_directional_fusion_model.py:116-146).  ``coarse`` may have a
         different size (it is resized while being placed).  The 1x1 ``out_conv`` is applied BEFORE the
         bilinear upsample: both are linear and the bilinear weights sum to one, so
@@ -238,7 +254,7 @@ class BiDirectionalFusion(_EncDec):
             out = self._gated_unit(blk["u1"], xs[1], cat, F_, res=xs[0])
         out = self._gated_unit(blk["u2"], out, cat, F_)
         if upscale:
-            y = ops.conv2d(out, blk["out_conv"])
+            y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])  # (skip: folded into the consumer's weights, _pack)
             return ops.upsample_bilinear(y, size[0], size[1], out=dest)
         return ops.conv2d(out, blk["out_conv"], dest)
 
@@ -252,8 +268,13 @@ class BiDirectionalFusion(_EncDec):
         path4 = self._gated_block(R[4], [path5, rn[3]], coarse[4], F_, size=(rn[2].h, rn[2].w), dest=dests[3])
         path3 = self._gated_block(R[3], [path4, rn[2]], coarse[3], F_, size=(rn[1].h, rn[1].w), dest=dests[2])
         path2 = self._gated_block(R[2], [path3, rn[1]], coarse[2], F_, size=(rn[0].h, rn[0].w), dest=dests[1])
-        path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=(rn[0].h * 2, rn[0].w * 2))
-        out = ops.conv2d(path1, P["out1"])
+        folded = "out1_folded" in P
+        path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=(rn[0].h * 2, rn[0].w * 2), skip_out_conv=folded)
+        if folded:
+            out = ops.conv2d(path1, P["out1_folded"])
+            ops.conv_border_bias(out, P["out1_tap_bias"])
+        else:
+            out = ops.conv2d(path1, P["out1"])
         last = ops.conv2d(out, P["out2_0"], act=ACT_RELU)
         last = self._gated_block(P["out2_fusion"], [last], coarse[0], self.coarse_chl[0], upscale=False, dest=dests[0])
         depth = ops.conv2d_cout1(last, P["out3_w"], P["out3_b"], 1)

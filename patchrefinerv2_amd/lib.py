@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(C.Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "prv2_gate_weight_bytes": (C.c_int64, [_I]),
     "prv2_pack_gate_weight": (_I, [_P, _P, _I, _I, _P]),
     "prv2_conv3x3_ln_gate": (_I, [_P] * 12),
+    "prv2_conv_border_bias": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "prv2_depth_pair_fill": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

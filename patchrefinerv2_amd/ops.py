@@ -633,6 +633,14 @@ class RoiSource:
         return self._mat
 
 
+def conv_border_bias(y: Feat, tap_bias: torch.Tensor):
+    """y -= the folded bias of the 3x3 taps that the zero padding hides at the image border (include/prv2.h::prv2_conv_border_bias)"""
+    assert tap_bias.shape == (9, y.c) and tap_bias.is_contiguous()
+    PROFILER.launch_aux("conv_border_bias", 8.0 * y.n * 2 * (y.h + y.w) * y.c,
+                        lambda: L.check(L.load().prv2_conv_border_bias(y.ptr, y.n, y.h, y.w, y.c, y.ld, tap_bias.data_ptr(), _stream()),
+                                        "conv_border_bias"), f"{y.c}ch {y.n}x{y.h}x{y.w}")
+
+
 def depth_pair_fill(p1: Feat, p2: Feat, buf: Feat, c0: int):
     """channels c0, c0 + 1 of ``buf`` <- (p1, p2) resized to the buffer's size, channels c0 + 2, c0 + 3 (the pad) <- 0"""
     assert p1.c == 1 and p2.c == 1 and p1.ld == 1 and p2.ld == 1 and (p1.n, p1.h, p1.w) == (p2.n, p2.h, p2.w) == (buf.n, p1.h, p1.w)

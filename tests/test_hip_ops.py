@@ -174,6 +174,26 @@ def test_conv3x3_ln_gate_rejects_what_it_does_not_cover(P):
         P.conv3x3_ln_gate(x, cw, ln, None, None)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_out_conv_folds_into_the_following_3x3(P, prec):
+    """GatedFusionBlock.out_conv (1x1 + bias) -> bilinear x2 -> output_conv1 (3x3 + bias) (bi_directional_fusion_model.py:139-142,201) ==
+    ONE 3x3 conv with composed weights on the upsampled input + the border correction of the folded bias (prv2_conv_border_bias)"""
+    x = rnd(1, 2, 64, 12, 16)
+    woc, boc = rnd(2, 64, 64, 1, 1) / 8, rnd(3, 64)
+    w1, b1 = rnd(4, 32, 64, 3, 3) / 24, rnd(5, 32)
+    ref = F.conv2d(F.interpolate(F.conv2d(x, woc, boc), size=(24, 32), mode="bilinear", align_corners=True), w1, b1, padding=1)
+    wf = torch.einsum("omyx,mi->oiyx", w1.double(), woc.double()[:, :, 0, 0]).float()
+    bt = torch.einsum("omyx,m->yxo", w1.double(), boc.double())
+    PR = P.L.PREC_NAMES[prec]
+    cw = P.pack_conv(wf.to(DEV), (b1.double() + bt.sum((0, 1))).float().to(DEV), pad=1, prec=PR)
+    up = P.upsample_bilinear(P.Feat.from_nchw(x.to(DEV)), 24, 32)
+    out = P.conv2d(up, cw)
+    wrong = float((out.to_nchw().cpu() - ref).abs().max())
+    P.conv_border_bias(out, bt.reshape(9, -1).float().contiguous().to(DEV))
+    close(out.to_nchw(), ref, 1e-5 if prec == "f32" else 3e-5, "folded out_conv")
+    assert wrong > 1e-2  # (the border pixels do need the correction)
+
+
 def test_conv_into_concat_slice(P):
     """producer writes into a channel slice of a wider buffer == torch.cat"""
     x = rnd(1, 1, 32, 10, 12)
