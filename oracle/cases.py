@@ -296,3 +296,29 @@ def e2e_v2b_sd(seed: int = 89):
     spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"],
                                     f["fine_chl_after_coarse2fine"], f["temp_chl"], f["dec_chl"]))
     return W.synth_state_dict(spec, seed=seed)
+
+
+# -- full-width parity on synthetic weights: make the depth RANGE exercise the bins ------------------------------------------
+def widen_depth_range(sd, prefix: str = "coarse_branch.", gain: float = 4.0, lo: float = 0.5, hi: float = 60.0,
+                      offset_gain: float = 6.0, fusion_prefix: str = "refiner_fusion_model."):
+    """Synthetic weights leave the ZoeDepth metric-bins head nearly constant (bin centres 0.1 .. 5 m, a flat log-binomial:
+    depth 0.9 .. 1.6 of max_depth 80) and the refinement offset ~0.07 m, so an AbsRel on coarse + offset is blind to the
+    per-patch network.  This re-scales the HEADS only (same shapes, same graph): the 64 seed bin centres spread geometrically
+    over lo .. hi metres (softplus^-1 into the regressor's bias, its input-dependent part damped), the log-binomial
+    probability logits x gain (the mode then moves over the bins from pixel to pixel: 1 % .. 99 % quantiles of the coarse
+    depth ~5 .. 49 m at 384 x 512) and the fusion net's final 3 x 3 conv x offset_gain (offsets of metres).  Returns a new
+    state dict; the product and the oracle both load it."""
+    import numpy as np
+    sd = OrderedDict(sd)
+    k = prefix + "seed_bin_regressor._net.2."
+    if k + "bias" in sd:
+        nb = sd[k + "bias"].numel()
+        c = torch.from_numpy(np.geomspace(lo, hi, nb).astype(np.float32))
+        sd[k + "bias"] = torch.log(torch.expm1(c))
+        sd[k + "weight"] = sd[k + "weight"] * 0.1
+        wt = sd[prefix + "conditional_log_binomial.mlp.2.weight"].clone()
+        wt[:2] *= gain
+        sd[prefix + "conditional_log_binomial.mlp.2.weight"] = wt
+    if fusion_prefix + "final_conv.weight" in sd:
+        sd[fusion_prefix + "final_conv.weight"] = sd[fusion_prefix + "final_conv.weight"] * offset_gain
+    return sd

@@ -14,6 +14,8 @@ import torch.nn.functional as F
 
 from .ops import bilinear_ac
 
+TRACE = None  # tests set this to a dict: intermediate maps of the last call (c2f_depth, dec_last, offset)
+
 
 def ln_cf(x, w, b, eps=1e-6):
     """channels-first LayerNorm (convs.py:24-29)."""
@@ -56,6 +58,8 @@ def _encode_decode(sd, p, enc1, enc2, dec, c_feat, f_feat, pred1, pred2, update_
         dec_feat = upsample_hardcode(sd, f"{p}{dec}.{j}.", _feat, feat, pred1, pred2)
         _feat = dec_feat
     off = F.conv2d(dec_feat, sd[p + "final_conv.weight"], None, padding=1)
+    if TRACE is not None:
+        TRACE["dec_last"], TRACE["offset"] = dec_feat, off
     if update_base is not None:
         return torch.clamp(update_base + off, min=0)
     return off
@@ -113,5 +117,7 @@ def bidirectional_fusion(sd, p, c_feat, f_feat, pred1, pred2, update_base=None):
         c_feat = [bilinear_ac(c, f.shape[-2:]) for c, f in zip(c_feat, f_feat)]
     f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat)
     f_feat, pred2 = f_feat[::-1], out_depth
+    if TRACE is not None:
+        TRACE["c2f_depth"], TRACE["c2f_last"] = out_depth, f_feat[0]
     return _encode_decode(sd, p, "fusion_layers_1", "fusion_layers_2", "f2r_agg",
                           c_feat, f_feat, pred1, pred2, update_base)

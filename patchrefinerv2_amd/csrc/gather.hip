@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(256) roi_align_rows_kernel(const float* __rest
   const float roi_w = rew - rsw, roi_h = reh - rsh;
   const float bin_h = roi_h / (float)oh, bin_w = roi_w / (float)ow;
   const int gh = (int)ceilf(roi_h / (float)oh), gw = (int)ceilf(roi_w / (float)ow);
-  if (gh > 1 || gw > 1) {  // block-uniform (a property of box k): the general sampling grid, one output row at a time
+  if (gh != 1 || gw != 1) {  // block-uniform (a property of box k): the general sampling grid, one output row at a time
+    // (gh or gw == 0: a degenerate box with roi_h / roi_w <= 0 -- zero samples, output 0, like roi_align_kernel and torchvision)
 #pragma unroll 1
     for (int r = 0; r < R && py0 + r < oh; ++r) {
       const int py = py0 + r;

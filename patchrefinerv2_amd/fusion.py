@@ -68,6 +68,7 @@ class _EncDec(StateDictModule):
     """Shared fine2coarse encoder + decoder of FusionUnet / BiDirectionalFusion."""
 
     ENC1 = ENC2 = DEC = ""
+    trace = None  # tests set this to a dict: intermediate maps of the last call (c2f_depth, c2f_last, dec_last, offset)
 
     def _init_encdec(self, in_chl: Sequence[int], temp_chl: Sequence[int], dec_chl: Sequence[int]):
         self.in_chl, self.temp_chl, self.dec_chl = list(in_chl), list(temp_chl), list(dec_chl)
@@ -131,6 +132,9 @@ class _EncDec(StateDictModule):
             c0w, c2w = P[f"{self.DEC}.{j}"]
             t = ops.conv2d(buf, c0w, act=ACT_GELU)
             feat = ops.conv2d(t, c2w, act=ACT_GELU)
+        if self.trace is not None:  # tests: the last decoder stage, as the oracle sees it
+            self.trace["dec_last"] = feat.to_nchw()
+            self.trace["offset"] = ops.conv2d_cout1(feat, P["final_w"], None, 3)
         # final_conv 3x3 -> 1 ; clamp(update_base + offset, min=0)
         return ops.conv2d_cout1(feat, P["final_w"], None, 3, res=update_base, clamp0=update_base is not None, out=out)
 
@@ -303,6 +307,8 @@ class BiDirectionalFusion(_EncDec):
         cat1 = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l], dev) for l in range(6)]
         dests = [cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]
         out_depth = self._c2f(P, list(f_feat[1:]), c_feat, dests)
+        if self.trace is not None:
+            self.trace["c2f_depth"], self.trace["c2f_last"] = out_depth.clone(), dests[0].to_nchw()
 
         def fill(l):
             def fn(cat: Feat):

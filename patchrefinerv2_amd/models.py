@@ -316,6 +316,9 @@ class _PatchModel(StateDictModule):
         patch_raw_shape-sized crops, no blending: what the reference's ``mode='train'`` forward computes for given crops /
         bboxs (coarse forward + ROI of the crop + refiner; patchrefinerplus.py:405-467) -- the building block of
         Tester.run_consistency (tester.py:211-321)."""
+        if not hasattr(self, "infer_forward") or (not self.needs_coarse and getattr(self, "target", "fine") == "coarse"):
+            raise NotImplementedError(f"{type(self).__name__}(target='coarse') has no per-tile path (one backbone forward on image_lr, "
+                                      "baseline_pretrain.py:409-411): predict_tiles / run_consistency need a tiling model")
         tile_cfg = self.tile_cfg if tile_cfg is None else self.prepare_tile_cfg(tile_cfg["image_raw_shape"], tile_cfg["patch_split_num"])
         dev = image_hr.device
         ph, pw = self.patch_process_shape
@@ -428,12 +431,16 @@ class _PatchModel(StateDictModule):
                 st["depth"], st["coarse"] = self._device_frame(st["lr"], st["hr"], st["tiles"], st["boxes"], plan, tile_cfg, process_num)
             st["graph"] = g
             cache[key] = ent = st
+        if ent.get("staged") is not None:
+            ent["staged"].synchronize()  # the previous replay's H2D copies out of the pinned buffers rewritten below
         ent["h_tiles"].copy_(tiles_i)
         ent["h_boxes"].copy_(boxes_f)
         ent["lr"].copy_(image_lr, non_blocking=True)
         ent["hr"].copy_(image_hr, non_blocking=True)
         ent["tiles"].copy_(ent["h_tiles"], non_blocking=True)
         ent["boxes"].copy_(ent["h_boxes"], non_blocking=True)
+        ent["staged"] = torch.cuda.Event()
+        ent["staged"].record(torch.cuda.current_stream(dev))
         ent["graph"].replay()
         return ent["depth"], (ent["coarse"].clone() if ent["coarse"] is not None else None)
 
@@ -473,14 +480,12 @@ class _PatchModel(StateDictModule):
         return box[0]
 
     # -- coarse forward of the NEXT frame beside this frame's tile batches (forward(next_image_lr=...)) -----------------------
-    @staticmethod
-    def _lr_key(t):
-        return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
-
     def _coarse_of(self, image_lr):
-        """this frame's coarse pyramid: the one prefetched by the previous call if it was made for this very tensor"""
+        """this frame's coarse pyramid: the one prefetched by the previous call if it was made for this very tensor OBJECT,
+        unmodified since (the prefetch entry holds the tensor itself: that keeps it alive while the side stream reads it, and
+        an address the caching allocator hands out again for another image can never match)"""
         pf = self.__dict__.pop("_coarse_prefetched", None)
-        if pf is not None and pf["key"] == self._lr_key(image_lr):
+        if pf is not None and pf["lr"] is image_lr and pf["version"] == image_lr._version:
             torch.cuda.current_stream(image_lr.device).wait_event(pf["done"])
             for t in pf["tensors"]:  # allocated on the prefetch stream, consumed on this frame's streams from here on
                 t.record_stream(torch.cuda.current_stream(image_lr.device))
@@ -501,7 +506,18 @@ class _PatchModel(StateDictModule):
             done = torch.cuda.Event()
             done.record(st)
         tensors = [f.buf for f in feats] + [pred]
-        self._coarse_prefetched = dict(key=self._lr_key(next_lr), feats=feats, pred=pred, done=done, tensors=tensors)
+        self._coarse_prefetched = dict(lr=next_lr, version=next_lr._version, feats=feats, pred=pred, done=done, tensors=tensors)
+
+    def _invalidate_frame_caches(self):
+        """whatever was derived from the weights that have just been replaced: the next frame's prefetched coarse pyramid and
+        the captured hipGraphs (they hold raw pointers to the packed weights, relative-position biases and blend masks)"""
+        for k in ("_coarse_prefetched", "_coarse_hold", "_graphs"):
+            self.__dict__.pop(k, None)
+
+    def load_state_dict(self, sd, strict: bool = True):
+        res = super().load_state_dict(sd, strict=strict)
+        self._invalidate_frame_caches()
+        return res
 
     def _streams(self, dev, n):
         cache = self.__dict__.setdefault("_stream_cache", {})
@@ -676,6 +692,7 @@ class BaselinePretrain(_PatchModel):
 
     # baseline_pretrain.py:126-142: checkpoints hold the bare branch
     def load_dict(self, sd):
+        self._invalidate_frame_caches()
         return self._branch.load_state_dict(sd, strict=False)
 
     def get_save_dict(self):

@@ -437,6 +437,29 @@ def test_next_frame_coarse_prefetch_is_bit_identical(P):
     run(0, frames[2][1])          # prefetched for frame 2 ...
     d, cp = run(1, None)          # ... but frame 1 arrives: computed inline
     assert torch.equal(d, ref[1][0]) and torch.equal(cp, ref[1][1])
+    # the announced frame is dropped and ANOTHER image lands at the same address (what the caching allocator does with a freed
+    # block): the prefetch entry is keyed by the tensor object, so the stale pyramid must not be used
+    ghost = frames[2][1].clone()
+    run(0, ghost)
+    ghost_ptr = ghost.data_ptr()
+    del ghost
+    other = frames[1][1].clone()
+    if other.data_ptr() == ghost_ptr:
+        assert other._version == 0
+    frames.append((frames[1][0], other))
+    d, cp = run(3, None)
+    assert torch.equal(d, ref[1][0]) and torch.equal(cp, ref[1][1])
+    # in-place modification of the announced tensor invalidates the prefetch as well
+    lr2 = frames[2][1].clone()
+    run(0, lr2)
+    lr2.copy_(frames[1][1])
+    frames.append((frames[1][0], lr2))
+    d, cp = run(4, None)
+    assert torch.equal(d, ref[1][0]) and torch.equal(cp, ref[1][1])
+    # weights replaced between two calls: nothing derived from the old ones survives
+    run(0, frames[1][1])
+    m.load_state_dict(e2e_v2_sd(), strict=True)
+    assert "_coarse_prefetched" not in m.__dict__
 
 
 def test_rejects_cpu_inputs_and_bad_shapes(P):

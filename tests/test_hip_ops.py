@@ -373,6 +373,13 @@ def test_roi_align(P):
     ref4 = o_ops.roi_align(feat.repeat(2, 1, 1, 1), torch.cat([torch.arange(2.0)[:, None], boxes3[:, 1:]], 1), (48, 64), 24 / 56, aligned=True)
     got4 = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), boxes3[:, 1:].contiguous().to(DEV), 24 / 56, 48, 64)
     close(got4.to_nchw(), ref4, 1e-5, "roi zoom, rows kernel, out-of-map samples")
+    # degenerate boxes (roi_w or roi_h <= 0: an empty sampling grid) give zeros whatever kernel the output height selects
+    boxes5 = torch.tensor([[0, 30.0, 10.0, 30.0, 40.0], [0, 10.0, 30.0, 50.0, 20.0], [0, 0.0, 0.0, 84.0, 56.0]])
+    for oh, ow in ((8, 8), (16, 20), (48, 64)):
+        ref5 = o_ops.roi_align(feat.repeat(3, 1, 1, 1), torch.cat([torch.arange(3.0)[:, None], boxes5[:, 1:]], 1), (oh, ow), 24 / 56, aligned=True)
+        got5 = P.roi_align(P.Feat.from_nchw(feat.to(DEV)), boxes5[:, 1:].contiguous().to(DEV), 24 / 56, oh, ow)
+        assert float(ref5[:2].abs().max()) == 0.0 and float(got5.to_nchw()[:2].abs().max()) == 0.0
+        close(got5.to_nchw(), ref5, 1e-5, f"roi degenerate boxes {oh}x{ow}")
 
 
 @pytest.mark.parametrize("case", [(2, 32, 12, 16, 24, 32), (1, 1, 56, 84, 28, 42), (1, 98, 7, 11, 14, 21), (1, 256, 16, 16, 14, 14)])
