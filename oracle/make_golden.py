@@ -320,10 +320,8 @@ def _patch_torch_load(sd_for):
     return real
 
 
-def g_e2e_v1():
-    print("[e2e_v1]")
-    c = E2E_V1
-    sd = e2e_v1_sd()
+def _build_ref_e2e_v1(c, sd):
+    """the reference's PatchRefiner class over reduced DA2 backbones, synthetic weights loaded by name"""
     dpt = refharness.ref_module("external.depth_anything_v2.dpt")
     # reduced DA2 dims: the reference class is built by name, so swap its ctor for the reduced builder
     orig = dpt.DepthAnythingV2
@@ -350,6 +348,14 @@ def g_e2e_v1():
         pr_mod.DepthAnythingV2 = orig
     missing = m.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys and not missing.missing_keys, missing
+    return m
+
+
+def g_e2e_v1():
+    print("[e2e_v1]")
+    c = E2E_V1
+    sd = e2e_v1_sd()
+    m = _build_ref_e2e_v1(c, sd)
     ora = o_tiling.OraclePatchRefiner(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
                                       W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
                                       patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
@@ -800,6 +806,124 @@ def g_baseline():
             assert d < 1e-4 and sorted(log) == sorted(olog), (d, sorted(log), sorted(olog))
             res[f"{target}_{mode}"] = ref
     save("baseline", **res)
+
+
+def g_consistency():
+    """The reference's own ``Tester.run_consistency`` (estimator/tester/tester.py:211-321) driven over the reference's
+    PatchRefiner (E2E_V1 reduced backbones) on one synthetic 2160 x 3840 frame prepared exactly as the U4K consistency dataset
+    does (u4k_dataset.py:62-65,158-185: 16 crops of 540 x 960 shifted towards the centre by multiples of overlap / 2, each
+    resized with the dataset's ResizeDA, pre-normalised bboxs): pins ``oracle.tiling.run_consistency`` and gives the product's
+    ``Tester.run_consistency`` a known answer (tests/golden/consistency.npz)."""
+    print("[consistency]")
+    import types
+    c = E2E_V1
+    sd = e2e_v1_sd()
+    m = _build_ref_e2e_v1(c, sd)
+    # -- the modules tester.py imports at its top and never needs on this path ------------------------------------------
+    class _PB:
+        def __init__(self, *a, **k):
+            pass
+
+        def update(self):
+            pass
+    mm = sys.modules["mmengine"]
+    for name in ("mmengine.analysis", "mmengine.optim", "mmengine.dist", "mmengine.utils", "mmengine.fileio", "wandb", "tqdm",
+                 "skimage", "skimage.io", "kornia", "PIL", "PIL.Image", "matplotlib.pyplot"):
+        if name not in sys.modules:
+            sys.modules[name] = refharness._AnyAttr(name)
+    sys.modules["mmengine.dist"].get_dist_info = lambda: (0, 1)
+    sys.modules["mmengine.dist"].collect_results_gpu = lambda results, n: results
+    sys.modules["mmengine.dist"].collect_results_cpu = lambda results, n: results
+    sys.modules["mmengine.utils"].ProgressBar = _PB
+    sys.modules["mmengine.utils"].mkdir_or_exist = lambda p: os.makedirs(p, exist_ok=True)
+    for sub in ("analysis", "optim", "dist", "utils", "fileio"):
+        setattr(mm, sub, sys.modules["mmengine." + sub])
+    sys.modules["mmengine.optim"].build_optim_wrapper = None
+    sys.modules["mmengine.fileio"].dump = None
+    sys.modules["tqdm"].tqdm = lambda x, *a, **k: x
+    sys.modules["skimage"].io = sys.modules["skimage.io"]
+    sys.modules["PIL"].Image = sys.modules["PIL.Image"]
+    u = types.ModuleType("estimator.utils")
+    for n in ("colorize", "colorize_infer_pfv1", "colorize_rescale", "extract_edges", "rescale_tensor"):
+        setattr(u, n, None)
+    sys.modules["estimator.utils"] = u
+    mu = refharness.ref_module("estimator.models.utils")
+    if not hasattr(mu, "HookTool"):
+        mu.HookTool = None
+    tp = types.ModuleType("estimator.tester")
+    tp.__path__ = [os.path.join(refharness.REF, "estimator/tester")]
+    sys.modules["estimator.tester"] = tp
+    import importlib
+    ref_tester = importlib.import_module("estimator.tester.tester")
+
+    # -- one frame, prepared as U4KDataset.__getitem__ does in consistency mode -----------------------------------------
+    overlap, H, Wd, h, w = 270, 2160, 3840, 540, 960
+    ph, pw = c["pps"]
+    image = rand_image(c["seed"] + 5, 1, H, Wd)[0]
+    h_start_list = [int(0 + 3 * overlap / 2), int(540 + overlap / 2), int(1080 - overlap / 2), int(1620 - 3 * overlap / 2)]
+    w_start_list = [int(0 + 3 * overlap / 2), int(960 + overlap / 2), int(1920 - overlap / 2), int(2880 - 3 * overlap / 2)]
+    crops, bboxs = [], []
+    for hs in h_start_list:
+        for ws in w_start_list:
+            crops.append(m.resizer(image[:, hs:hs + h, ws:ws + w].unsqueeze(0)).squeeze(0))
+            bbox = torch.tensor([ws, hs, ws + w, hs + h])
+            bboxs.append(torch.tensor([bbox[0] / Wd * pw, bbox[1] / H * ph, bbox[2] / Wd * pw, bbox[3] / H * ph]))
+    batch = dict(image_lr=m.resizer(image.unsqueeze(0)), image_hr=torch.tensor([[H, Wd]]), crops_image_hr=torch.stack(crops)[None],
+                 depth_gt=torch.ones(1, 1, 8, 8), crop_depths=torch.ones(1, 16, 1, ph, pw), bboxs=torch.stack(bboxs)[None],
+                 img_file_basename=["frame0"])
+
+    class _DS:
+        def __len__(self):
+            return 1
+
+        def evaluate_consistency(self, results):
+            return results
+    ds = _DS()
+    ds.h_start_list, ds.w_start_list = h_start_list, w_start_list
+
+    class _DL:
+        dataset = ds
+        batch_sampler = [[0]]
+
+        def __iter__(self):
+            return iter([batch])
+    cfg = refharness.AttrDict(collect_input_args=["image_lr", "image_hr", "crops_image_hr", "depth_gt", "crop_depths", "bboxs"])
+    t = ref_tester.Tester(cfg, refharness.AttrDict(rank=0, save=False, work_dir="/tmp"), _DL(), m)
+    got = {}
+    real_cat = torch.cat
+    real_cuda = torch.Tensor.cuda
+    # capture what the reference computes (it only hands the scalars to dataset.evaluate_consistency)
+    ds.evaluate_consistency = lambda results: got.setdefault("results", results)
+    crops_seen = []
+    real_interp = torch.nn.functional.interpolate
+
+    def spy_interp(x, size=None, **k):
+        y = real_interp(x, size, **k)
+        if size is not None and tuple(size) == (540, 960):
+            crops_seen.append(y.squeeze().clone())
+        return y
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    ref_tester.F.interpolate = spy_interp
+    try:
+        t.run_consistency()
+    finally:
+        torch.Tensor.cuda = real_cuda
+        ref_tester.F.interpolate = real_interp
+    assert torch.cat is real_cat
+    ce_ref = float(got["results"][0]["consistency_error"])
+    ref_crops = torch.stack(crops_seen[:16])
+
+    ora = o_tiling.OraclePatchRefiner(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                      W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}),
+                                      patch_process_shape=c["pps"], image_raw_shape=[H, Wd], patch_split_num=[4, 4])
+    ce, o_crops = o_tiling.run_consistency(ora, image.unsqueeze(0), overlap=overlap)
+    d = maxdiff(ref_crops, o_crops)
+    print(f"  reference consistency_error {ce_ref:.6f}, oracle {ce:.6f}; crops oracle-vs-ref max|d| {d:.2e} (crop depth "
+          f"{float(ref_crops.min()):.3f}..{float(ref_crops.max()):.3f})")
+    assert d < 2e-4 and abs(ce - ce_ref) < 1e-6 * max(1.0, ce_ref), (d, ce, ce_ref)
+    np.savez_compressed(os.path.join(OUT, "consistency.npz"), consistency_error=np.float64(ce_ref), overlap=np.int64(overlap),
+                        image_seed=np.int64(c["seed"] + 5), crops_strided=ref_crops[:, ::9, ::16].numpy())
+    print("  wrote consistency.npz")
 
 
 if __name__ == "__main__":

@@ -210,6 +210,57 @@ class OracleRefiner:
         return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=None, coarse_prediction=coarse_pred)
 
 
+def consistency_starts(n, size, overlap):
+    """u4k_dataset.py:62-65 / eth_dataset.py:92-93 generalised: crop i of n is shifted by ((n - 1) - 2 i) * overlap / 2 towards
+    the centre, so that neighbours share ``overlap`` pixels"""
+    return [int(i * size + ((n - 1) - 2 * i) * overlap / 2) for i in range(n)]
+
+
+def prenorm_bbox(ws, hs, w, h, image_raw_shape, patch_process_shape):
+    """the dataset's pre_norm_bbox arithmetic (u4k_dataset.py:171-176): int64 tensor / int * int -> float32, which is NOT the
+    infer path's ``bboxs.int() * (1 / W * pw)`` (baseline_pretrain.py:289-296) to the last bit"""
+    H, W = image_raw_shape
+    ph, pw = patch_process_shape
+    b = torch.tensor([ws, hs, ws + w, hs + h])
+    return torch.tensor([b[0] / W * pw, b[1] / H * ph, b[2] / W * pw, b[3] / H * ph])
+
+
+@torch.no_grad()
+def run_consistency(ora: "OracleRefiner", image_hr, overlap=270):
+    """Tester.run_consistency (estimator/tester/tester.py:211-321) over the consistency crops of the U4K / ETH3D datasets:
+    each crop through the model's ``mode='train'`` forward (coarse forward on the whole frame + the crop's ROI with the
+    dataset's pre-normalised bbox + the per-patch network; patchrefiner.py:300-340), bilinear(align_corners) to the crop's raw
+    size, mean |difference| over the strips shared with the left and the upper neighbour.
+    Returns (consistency_error, crops [sh*sw, rh, rw])."""
+    from .ops import bilinear_ac
+    tc = ora.tile_cfg
+    H, W = tc["image_raw_shape"]
+    sh, sw = tc["patch_split_num"]
+    rh, rw = tc["patch_raw_shape"]
+    ph = ora.patch_process_shape[0]
+    image = image_hr[0]
+    feats, cp = ora.coarse_forward(ora.resizer(image_hr))
+    crops = []
+    for hs in consistency_starts(sh, rh, overlap):
+        for ws in consistency_starts(sw, rw, overlap):
+            crop = ora.resizer(image[:, hs:hs + rh, ws:ws + rw].unsqueeze(0))
+            bf = torch.cat((torch.zeros(1, 1), prenorm_bbox(ws, hs, rw, rh, (H, W), ora.patch_process_shape)[None]), dim=-1)
+            # coarse_postprocess_train (patchrefiner.py:187-197): batch 1, no repeat
+            rois = [roi_align(f, bf, f.shape[-2:], f.shape[-2] / ph, aligned=True) for f in feats]
+            droi = roi_align(cp, bf, cp.shape[-2:], cp.shape[-2] / ph, aligned=True)
+            pred = ora.infer_forward(crop, dict(coarse_depth_roi=droi, coarse_feats_roi=rois))
+            crops.append(bilinear_ac(pred, (rh, rw)).squeeze())
+    errs = []
+    for ii in range(sh):
+        for jj in range(sw):
+            cur = crops[ii * sw + jj]
+            if jj > 0:
+                errs.append((crops[ii * sw + jj - 1][:, -overlap:] - cur[:, :overlap]).abs().flatten())
+            if ii > 0:
+                errs.append((crops[(ii - 1) * sw + jj][-overlap:, :] - cur[:overlap, :]).abs().flatten())
+    return float(torch.cat(errs).mean()), torch.stack(crops)
+
+
 class OraclePatchRefiner(OracleRefiner):
     """V1: DA2 coarse + DA2 per-patch + FusionUnet (configs/patchrefiner_dav2/pr_u4k.py)."""
 

@@ -310,12 +310,23 @@ class _PatchModel(StateDictModule):
             depth = depth.clone()  # the graph's own output buffer is rewritten by the next replay
         return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
 
+    def _boxes_prenorm(self, tiles, tile_cfg) -> np.ndarray:
+        """the DATASET's pre-normalised bboxs (pre_norm_bbox=True, u4k_dataset.py:171-176: int64 tensor / W * pw in float32) --
+        what the reference's ``mode='train'`` forward receives; differs from the infer path's ``bboxs.int() * (1 / W * pw)``
+        (``_boxes``) in the last bit"""
+        H, W = (np.float32(v) for v in tile_cfg["image_raw_shape"])
+        rh, rw = tile_cfg["patch_raw_shape"]
+        ph, pw = (np.float32(v) for v in self.patch_process_shape)
+        f = np.float32
+        return np.array([[f(w) / W * pw, f(h) / H * ph, f(w + rw) / W * pw, f(h + rh) / H * ph] for h, w in tiles], dtype=np.float32)
+
     @torch.no_grad()
-    def predict_tiles(self, image_lr, image_hr, tiles, tile_cfg=None):
+    def predict_tiles(self, image_lr, image_hr, tiles, tile_cfg=None, prenorm_bbox=False):
         """Per-tile predictions [K, 1, ph, pw] (device) for explicit tile origins ``tiles`` = [(h_start, w_start), ...] of
         patch_raw_shape-sized crops, no blending: what the reference's ``mode='train'`` forward computes for given crops /
         bboxs (coarse forward + ROI of the crop + refiner; patchrefinerplus.py:405-467) -- the building block of
-        Tester.run_consistency (tester.py:211-321)."""
+        Tester.run_consistency (tester.py:211-321).  ``prenorm_bbox``: ROI boxes in the dataset's arithmetic (``_boxes_prenorm``)
+        instead of the infer path's."""
         if not hasattr(self, "infer_forward") or (not self.needs_coarse and getattr(self, "target", "fine") == "coarse"):
             raise NotImplementedError(f"{type(self).__name__}(target='coarse') has no per-tile path (one backbone forward on image_lr, "
                                       "baseline_pretrain.py:409-411): predict_tiles / run_consistency need a tiling model")
@@ -329,7 +340,8 @@ class _PatchModel(StateDictModule):
             else:
                 feats = cd = None
             t_dev = torch.tensor(list(tiles), dtype=torch.int32).view(-1, 2).to(dev)
-            boxes = torch.from_numpy(self._boxes(list(tiles), tile_cfg)).to(dev) if self.needs_coarse else None
+            mk = self._boxes_prenorm if prenorm_bbox else self._boxes
+            boxes = torch.from_numpy(mk(list(tiles), tile_cfg)).to(dev) if self.needs_coarse else None
             preds = torch.empty((len(tiles), 1, ph, pw), device=dev)
             bs = max(1, int(getattr(self, "max_batch", None) or 4))
             image_chw = image_hr[0].contiguous().float()

@@ -214,7 +214,9 @@ class Tester:
         for idx in range(rank, len(self.dataloader), world):
             item = self.dataloader[idx]
             hr = item["image_hr"].unsqueeze(0).cuda()
-            preds = self.model.predict_tiles(self.model.resizer(hr), hr, tiles, tile_cfg)
+            # the consistency dataset hands the model pre-normalised bboxs (pre_norm_bbox=True in every shipped config)
+            pre = bool(getattr(getattr(self.model, "config", None), "get", lambda k, d: d)("pre_norm_bbox", True))
+            preds = self.model.predict_tiles(self.model.resizer(hr), hr, tiles, tile_cfg, prenorm_bbox=pre)
             up = torch.empty((len(tiles), rh, rw, 1), device=preds.device)  # dense 1-channel NHWC == [K, rh, rw]
             ops.upsample_bilinear(ops.Feat(preds.view(len(tiles), preds.shape[-2], preds.shape[-1], 1)), rh, rw, out=ops.Feat(up))
             up = up.view(len(tiles), rh, rw)
@@ -228,6 +230,7 @@ class Tester:
                         errs.append((up[(ii - 1) * sw + jj][-overlap:, :] - cur[:overlap, :]).abs().flatten())
             ce = float(torch.cat(errs).mean()) if errs else 0.0
             entry = dict(name=item["img_file_basename"], consistency_error=ce)
+            self.last_crops = up  # [sh * sw, rh, rw] on the device (tests compare them with the reference's)
             if self.runner_info.save:  # the stitched centres (tester.py:243-247) as a colour map
                 os.makedirs(self.runner_info.work_dir, exist_ok=True)
                 full = torch.zeros((H, W))

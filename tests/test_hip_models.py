@@ -382,6 +382,56 @@ def test_predict_tiles_and_run_consistency(P, tmp_path):
     assert t.last_eval["consistency_error"] == res[0]["consistency_error"] and (tmp_path / "out" / "f0.png").exists()
 
 
+def test_run_consistency_vs_reference_golden(P, golden, tmp_path):
+    """Tester.run_consistency against the REFERENCE's own Tester.run_consistency (tester.py:211-321), which
+    oracle/make_golden.py::g_consistency ran over the reference's PatchRefiner on the same synthetic 2160 x 3840 frame prepared
+    as the U4K consistency dataset does (16 crops of 540 x 960, overlap 270, pre-normalised bboxs): the 16 resized crop
+    predictions and the consistency error"""
+    import numpy as np
+    from oracle import tiling as o_tiling
+    from patchrefinerv2_amd.tester import ImageDataset, RunnerInfo, Tester
+    c, g = E2E_V1, golden("consistency")
+    raw, split, overlap = [2160, 3840], [4, 4], int(g["overlap"])
+    m = _build("PatchRefiner", c, e2e_v1_sd(), image_raw_shape=raw, patch_split_num=split, max_batch=8)
+    img = rand_image(int(g["image_seed"]), 1, *raw)
+    d = tmp_path / "rgb"
+    d.mkdir()
+    np.save(str(d / "frame0.npy"), img[0].permute(1, 2, 0).contiguous().numpy())
+    ds = ImageDataset(str(d), image_resolution=raw, network_process_size=c["pps"])
+    assert torch.equal(ds[0]["image_hr"].cpu(), img[0])       # same-size bicubic(align_corners) is the identity
+    t = Tester(None, RunnerInfo(save=False, work_dir=str(tmp_path / "out")), ds, m)
+    res = t.run_consistency(image_raw_shape=raw, patch_split_num=split, overlap=overlap)
+    ce_ref = float(g["consistency_error"])
+    crops = t.last_crops.cpu()
+    assert tuple(crops.shape) == (16, 540, 960)
+    err = float((crops[:, ::9, ::16] - torch.from_numpy(g["crops_strided"])).abs().max())
+    print(f"run_consistency vs reference: consistency_error {res[0]['consistency_error']:.6f} (reference {ce_ref:.6f}); crops max|d| {err:.2e}")
+    assert err < 1e-3 and abs(res[0]["consistency_error"] - ce_ref) < 2e-5 * ce_ref
+    # and against the oracle's restatement run here on the full crops
+    dcfg = W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]})
+    ora = o_tiling.OraclePatchRefiner(e2e_v1_sd(), dcfg, dcfg, patch_process_shape=c["pps"], image_raw_shape=raw, patch_split_num=split)
+    ce_o, crops_o = o_tiling.run_consistency(ora, img, overlap=overlap)
+    assert abs(ce_o - ce_ref) < 1e-6 and float((crops - crops_o).abs().max()) < 1e-3
+
+
+def test_compute_metrics_device_on_the_gpu_vs_reference_golden(P, golden):
+    """metrics.compute_metrics_device -- how Tester.run scores a frame with ground truth -- on CUDA tensors against the
+    reference's compute_metrics outputs (tests/golden/output_stage.npz, estimator/utils/metric.py:87-149), incl. the NaN / inf
+    pixels, the garg crop, the resized prediction and the soft-edge error"""
+    import numpy as np
+    from patchrefinerv2_amd import metrics as M
+    g = golden("output_stage")
+    gt, pred, pred_lo, edges = (torch.from_numpy(g[k]) for k in ("gt", "pred", "pred_lo", "edges"))
+    d1 = M.compute_metrics_device(gt.to(DEV), pred.to(DEV), garg_crop=False, eigen_crop=False, dataset="u4k", min_depth_eval=0.1,
+                                  max_depth_eval=10, disp_gt_edges=edges.to(DEV))
+    d2 = M.compute_metrics_device(gt, pred_lo.to(DEV), garg_crop=True, eigen_crop=False, dataset="kitti", min_depth_eval=0.1, max_depth_eval=10)
+    for tag, d in (("m1", d1), ("m2", d2)):
+        keys = [k[len(tag) + 1:] for k in g.files if k.startswith(tag + "_")]
+        assert set(keys) == set(d), (sorted(keys), sorted(d))
+        for k in keys:
+            np.testing.assert_allclose(float(d[k]), float(g[f"{tag}_{k}"]), rtol=2e-5, atol=1e-7, err_msg=f"{tag} {k}")
+
+
 def test_models_through_torch_custom_ops(P):
     """ops.DISPATCH = 'torch': the host mirror reaches the kernels through the PyTorch custom ops torch.ops.prv2.* (conv2d / linear,
     layernorm, attention, crop+resize, ROI gather, upsample, blend, ZoeDepth head ops) instead of ctypes -- whole frames of V1, V2
