@@ -251,10 +251,13 @@ def main():
     if world > 1:
         nt = w["patches"]
         if shard is not None:
-            per = (nt + world - 1) // world
-            result["multi_gpu"] = dict(mode="patches", gather=args.gather, tiles_per_rank=[len(range(r, nt, world)) for r in range(world)],
-                                       collective=("gather->rank0" if gather_dst is not None else "all_gather"),
-                                       collective_bytes_per_frame=per * w["pps"][0] * w["pps"][1] * 4 * (world - 1))
+            groups = model.last_shard_layout  # (models._PatchModel.shard_layout: gather groups, tiles per rank)
+            result["multi_gpu"] = dict(mode="patches", gather=args.gather,
+                                       tiles_per_rank=[sum(g["share"][r] for g in groups) for r in range(world)],
+                                       gather_groups=[dict(tiles=g["n"], per_rank=g["share"], padded_to=g["per"]) for g in groups],
+                                       collective=("async gather->rank0 per group" if gather_dst is not None else "async all_gather per group"),
+                                       plan_sync="int32 tile tensor, RCCL broadcast from rank 0 per frame",
+                                       collective_bytes_per_frame=sum(g["per"] for g in groups) * w["pps"][0] * w["pps"][1] * 4 * (world - 1))
         else:
             result["multi_gpu"] = dict(mode="frames", gather=args.gather, tiles_per_rank=[nt] * world,
                                        collective=("gather->rank0 of the per-rank depth maps" if frame_gather else "none"),

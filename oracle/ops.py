@@ -152,7 +152,7 @@ def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size, spatial_scale
         bin_h, bin_w = f32(roi_h / f32(oh)), f32(roi_w / f32(ow))
         gh = int(math.ceil(float(roi_h) / oh))
         gw = int(math.ceil(float(roi_w) / ow))
-        gh, gw = max(gh, 1), max(gw, 1)
+        # (no clamp of the grid: torchvision's "when the grid is empty, output zeros" -- a degenerate box, roi_w or roi_h <= 0)
         count = f32(max(gh * gw, 1))
         acc = feat.new_zeros((C, oh, ow))
         ph = np.arange(oh, dtype=np.float32)

@@ -242,8 +242,8 @@ class _PatchModel(StateDictModule):
     def forward(self, mode=None, image_lr=None, image_hr=None, crops_image_hr=None, depth_gt=None, crop_depths=None,
                 bboxs=None, tile_cfg=None, cai_mode="m1", process_num=4, select_patch=-1, shard=None,
                 return_device=False, gather_dst=None, next_image_lr=None, **kwargs):
-        """``shard=(rank, world)``: this process computes tiles rank, rank+world, ... and the predictions are exchanged
-        (RCCL): all-gather when ``gather_dst`` is None (every rank blends and returns the map), gather to rank
+        """``shard=(rank, world)``: this process computes its share of the frame's tiles (``shard_layout``) and the predictions
+        are exchanged (RCCL): all-gather when ``gather_dst`` is None (every rank blends and returns the map), gather to rank
         ``gather_dst`` otherwise (only that rank blends; the others return ``depth=None``).
         ``next_image_lr``: the low-resolution image of the frame the caller will submit NEXT (a video / dataset loop knows
         it): its coarse forward -- one image through the backbone, ~10 ms of kernels that cover a fraction of the chip -- is
@@ -273,12 +273,10 @@ class _PatchModel(StateDictModule):
         dev = image_hr.device
         # ---- host: the frame's tile plan (consumes Python's ``random`` in the reference's order) ----------------------
         passes = self.plan_tiles(tile_cfg, cai_mode, process_num)
-        if shard is not None and shard[1] > 1:
-            # every rank consumed ``random`` identically above; the plan that counts is rank 0's (a rank seeded
-            # differently would otherwise blend the others' predictions at its own coordinates)
-            passes = self._sync_plan(passes)
-        flat = [t for p in passes for t in p["raw"]]
         self.last_plan = passes
+        if shard is not None and shard[1] > 1:
+            return self._infer_sharded(image_lr, image_hr, depth_gt, passes, tile_cfg, process_num, shard, return_device, gather_dst)
+        flat = [t for p in passes for t in p["raw"]]
         idx = list(range(len(flat)))
         if shard is not None:
             idx = idx[shard[0]::shard[1]]
@@ -300,15 +298,243 @@ class _PatchModel(StateDictModule):
             if depth is None:  # gather-to-one: this rank's part of the frame is done
                 return None, dict(rgb=image_lr, depth_pred=None, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
         if not return_device:
-            # the reference returns a fresh CPU tensor; through torch's caching pinned-memory allocator the 33 MB D2H runs at
-            # PCIe rate instead of being staged through a pageable buffer (3.4 -> ~1 ms per 4K frame)
-            hostd = torch.empty(depth.shape, dtype=depth.dtype, pin_memory=True)
-            hostd.copy_(depth, non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()
-            depth = hostd
+            depth = self._to_host(depth)
         elif use_graph:
             depth = depth.clone()  # the graph's own output buffer is rewritten by the next replay
         return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+
+    @staticmethod
+    def _to_host(depth):
+        """the reference returns a fresh CPU tensor; through torch's caching pinned-memory allocator the 33 MB D2H runs at
+        PCIe rate instead of being staged through a pageable buffer (3.4 -> ~1 ms per 4K frame)"""
+        hostd = torch.empty(depth.shape, dtype=depth.dtype, pin_memory=True)
+        hostd.copy_(depth, non_blocking=True)
+        torch.cuda.current_stream(depth.device).synchronize()
+        return hostd
+
+    # ==============================================================================================================
+    # patch-sharded mode (SURVEY.md 8e): tiles of ONE frame over the ranks, one process per GPU, RCCL over xGMI
+    # ==============================================================================================================
+    def _infer_sharded(self, image_lr, image_hr, depth_gt, passes, tile_cfg, process_num, shard, return_device, gather_dst):
+        """The frame's plan as ONE int32 tensor [2 * n_all, 2] = (every tile's crop origin | every tile's blend origin), moved to
+        the device and overwritten there by rank 0's (an RCCL broadcast enqueued on the stream: no pickling, no host blocking --
+        a rank whose ``random`` state differs would otherwise blend the others' predictions at its own coordinates).  Everything
+        that depends on coordinates (crops, ROI boxes, blend) reads the device copy; everything the host needs (pass kinds and
+        counts, who owns which tile) follows from (cai_mode, process_num, patch_split_num) alone."""
+        dev = image_hr.device
+        n_all = sum(len(p["raw"]) for p in passes)
+        plan_t = torch.tensor([t for p in passes for t in p["raw"]] + [t for p in passes for t in p["proc"]],
+                              dtype=torch.int32).view(2 * n_all, 2).to(dev, non_blocking=True)
+        plan_t = self._sync_plan_tensor(plan_t)
+        plan = dict(kinds=[p["kind"] for p in passes], counts=[len(p["raw"]) for p in passes], n_all=n_all)
+        depth, coarse_prediction = self._device_frame_sharded(image_lr, image_hr, plan_t, plan, tile_cfg, shard, gather_dst)
+        if depth is None:  # gather-to-one: this rank's part of the frame is done
+            return None, dict(rgb=image_lr, depth_pred=None, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+        if not return_device:
+            depth = self._to_host(depth)
+        return depth, dict(rgb=image_lr, depth_pred=depth, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
+
+    @staticmethod
+    def _sync_plan_tensor(plan_t):
+        """rank 0's tile coordinates on every rank (in place; device tensors over RCCL, CPU tensors over gloo in the tests)"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(plan_t, src=0)
+        return plan_t
+
+    def _boxes_dev(self, tiles_dev, tile_cfg):
+        """``_boxes`` on the device from int32 tile origins [k, 2] (h, w): int -> float32 is exact and the one multiplication by
+        the float32 factor is the same IEEE operation, so the boxes equal the host version bit for bit (tested)."""
+        H, W = tile_cfg["image_raw_shape"]
+        rh, rw = tile_cfg["patch_raw_shape"]
+        ph, pw = self.patch_process_shape
+        fac = torch.tensor([1 / W * pw, 1 / H * ph, 1 / W * pw, 1 / H * ph], dtype=torch.float32, device=tiles_dev.device)
+        h, w = tiles_dev[:, 0], tiles_dev[:, 1]
+        bb = torch.stack([w, h, w + rw, h + rh], dim=1).to(torch.float32)
+        return bb * fac[None]
+
+    SHARD_DST_COST = 1.5  # what the blending rank does BEHIND the last group (receive, blend, D2H of the map: ~3-4 ms at 4K),
+    #                       in tile-times: tiles of the last group move from it to other ranks while that shortens the modelled
+    #                       critical path max(others' tiles, its tiles + cost); config key shard_dst_cost
+
+    def shard_layout(self, kinds, counts, world, dst=None):
+        """Who computes which tile, and what is exchanged when (pure host arithmetic on the plan's pass structure; cached).
+        Passes form GATHER GROUPS -- [init + half-offset grids] and [random tiles] -- so that the receiving rank pastes /
+        blends the first group (at the re-ensemble resolution) while every rank still computes the second.  Inside a group the
+        tiles are dealt round-robin over the ranks; in the LAST group the blending rank ``dst`` hands tiles to the others while
+        that shortens max(others' tiles, its tiles + shard_dst_cost) -- its receive + blend + D2H tail.
+        Returns a list of groups: dict(passes=[pass indices], base, n, per, owner=[rank per tile], mine=[[tile offsets in the
+        group] per rank], perm=[position of every tile of the group in the rank-major [world * per] gathered stack])."""
+        key = (tuple(kinds), tuple(counts), int(world), dst, float(getattr(self, "shard_dst_cost", self.SHARD_DST_COST)))
+        cache = self.__dict__.setdefault("_shard_layouts", {})
+        if key in cache:
+            return cache[key]
+        cost = key[4]
+        fixed = [i for i, k in enumerate(kinds) if k != "random"]
+        rnd = [i for i, k in enumerate(kinds) if k == "random" and counts[i] > 0]
+        groups = []
+        id_groups = [ids for ids in (fixed, rnd) if ids]
+        for ids in id_groups:
+            n = sum(counts[i] for i in ids)
+            share = [n // world] * world
+            order = [r for r in range(world - 1, -1, -1) if r != dst] + ([dst] if dst is not None else [])
+            for r in order[:n % world]:         # the remainder: highest ranks first, the blending rank last
+                share[r] += 1
+            if dst is not None and world > 1 and ids is id_groups[-1]:
+                others = [r for r in range(world) if r != dst]
+                while share[dst] > 0:           # hand a tile to the rank with the fewest while the critical path shrinks
+                    r = min(others, key=lambda q: (share[q], q))
+                    now = max(max(share[q] for q in others), share[dst] + cost)
+                    then = max(max(share[q] + (q == r) for q in others), share[dst] - 1 + cost)
+                    if then >= now:
+                        break
+                    share[dst] -= 1
+                    share[r] += 1
+            owner, left, r = [], list(share), 0
+            for _ in range(n):                  # round-robin deal, skipping ranks that are full
+                while left[r % world] == 0:
+                    r += 1
+                owner.append(r % world)
+                left[r % world] -= 1
+                r += 1
+            mine = [[i for i, o in enumerate(owner) if o == q] for q in range(world)]
+            per = max(share)
+            slot = {}
+            for q in range(world):
+                for sl, i in enumerate(mine[q]):
+                    slot[i] = q * per + sl
+            groups.append(dict(passes=ids, base=sum(counts[:ids[0]]), n=n, per=per, owner=owner, mine=mine, share=share,
+                               perm=[slot[i] for i in range(n)]))
+        cache[key] = groups
+        return groups
+
+    def _device_frame_sharded(self, image_lr, image_hr, plan_t, plan, tile_cfg, shard, gather_dst):
+        """A frame on rank ``shard[0]`` of ``shard[1]``: coarse forward (every rank; next frame's beside the tiles when
+        announced), this rank's tiles group by group (``shard_layout``), the group's prediction stacks exchanged ASYNCHRONOUSLY
+        (RCCL gather to ``gather_dst`` / all-gather on the collective's own stream) while the next group computes, and on the
+        receiving rank(s) the overlap blend of a group as soon as its stacks have arrived -- in the reference's order, so the
+        map is bit-identical to the unsharded one.  No host synchronisation inside."""
+        rank, world = shard
+        dev = image_hr.device
+        ph, pw = self.patch_process_shape
+        rh, rw = tile_cfg["patch_raw_shape"]
+        RH, RW = tile_cfg["patch_reensemble_shape"]
+        n_all = plan["n_all"]
+        groups = self.shard_layout(plan["kinds"], plan["counts"], world, gather_dst)
+        self.last_shard_layout = groups
+        if self.needs_coarse:
+            coarse_feats, coarse_prediction = self._coarse_of(image_lr)
+            coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
+        else:
+            coarse_feats = coarse_prediction = coarse_depth = None
+        image_chw = image_hr[0].contiguous().float()
+        raw_all, proc_all = plan_t[:n_all], plan_t[n_all:]
+        bs = max(1, int(getattr(self, "max_batch", None) or 4))
+        n_streams = max(1, int(getattr(self, "n_streams", None) or 1))
+        main = torch.cuda.current_stream(dev)
+        streams = [main] if n_streams == 1 else self._streams(dev, n_streams)
+        # per group: the (padded) stack this rank sends and its tiles' coordinates, allocated before the worker streams start
+        stacks, coords = [], []
+        for g in groups:
+            stacks.append(torch.zeros((g["per"], 1, ph, pw), device=dev))
+            idx = torch.tensor([g["base"] + i for i in g["mine"][rank]], dtype=torch.int64, device=dev)
+            t = raw_all.index_select(0, idx)
+            coords.append((t, self._boxes_dev(t, tile_cfg) if self.needs_coarse else None))
+        if n_streams > 1:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in streams:
+                st.wait_event(ready)
+        receiver = gather_dst is None or rank == gather_dst
+        ram = DeviceRunningAverageMap(RH, RW, dev) if receiver else None
+        mask = blend_mask((ph, pw), self.blend_border, 0.0, dev) if receiver else None
+        self.last_exchange_bytes = 0
+        bi = 0
+
+        def launch(gi):
+            nonlocal bi
+            t, boxes = coords[gi]
+            k = t.shape[0]
+            used = []
+            for s0 in range(0, k, bs):
+                e = min(s0 + bs, k)
+                st = streams[bi % len(streams)]
+                bi += 1
+                used.append(st)
+                with torch.cuda.stream(st):
+                    crops, rois, depth_roi = self._prepare_batch(image_chw, t[s0:e], boxes[s0:e] if boxes is not None else None,
+                                                                 tile_cfg, coarse_feats, coarse_depth)
+                    self.infer_forward(crops, rois, depth_roi, out=stacks[gi][s0:e])
+            return used
+
+        def blend(gi, allp):
+            g = groups[gi]
+            perm = torch.tensor(g["perm"], dtype=torch.int64, device=dev)
+            preds = allp.view(world * g["per"], ph, pw).index_select(0, perm)
+            o = 0
+            for pi in g["passes"]:
+                kind, k = plan["kinds"][pi], plan["counts"][pi]
+                pr = preds[o:o + k]
+                tdev = proc_all[g["base"] + o:g["base"] + o + k]
+                o += k
+                if kind == "init":
+                    ram.paste(pr, mask, tdev, ph, pw)
+                elif kind == "grid":
+                    ram.update(pr, mask, tdev, ph, pw)
+                else:
+                    ram.resize(tile_cfg["image_raw_shape"])
+                    ram.update(pr, blend_mask((rh, rw), self.blend_border, 1e-3, dev), tdev, rh, rw)
+
+        pending = None  # (group index, exchange handle) whose stacks are on their way
+        for gi in range(len(groups)):
+            used = launch(gi)
+            if gi == 0:
+                self._prefetch_coarse(getattr(self, "_next_lr", None), main)
+            if pending is not None and receiver:   # blend the previous group on the main stream while this one computes
+                allp = pending[1]()
+                receiver = allp is not None        # (None on a receiving rank: the tests' recording pass of the shard emulation)
+                if receiver:
+                    blend(pending[0], allp)
+            for st in used:
+                if st is not main:
+                    main.wait_stream(st)
+            pending = (gi, self._exchange_begin(stacks[gi], shard, gather_dst, gi))
+        if pending is not None:
+            allp = pending[1]()
+            receiver = receiver and allp is not None
+            if receiver:
+                blend(pending[0], allp)
+        if receiver and "random" in plan["kinds"] and not any(plan["kinds"][i] == "random" for g in groups for i in g["passes"]):
+            ram.resize(tile_cfg["image_raw_shape"])  # an r-mode whose N // process_num is 0: the resize still happens
+        if not receiver:
+            return None, coarse_prediction
+        return ram.avg[None, None], coarse_prediction
+
+    def _exchange_begin(self, mine, shard, dst, group=0):
+        """start the exchange of equally sized stacks; returns a callable that makes the current stream wait for it and gives
+        the rank-major [world * per, ...] result (None on ranks that do not receive).  RCCL: asynchronous on the collective's
+        stream.  A patched ``_exchange`` (tests: single-GPU emulation of the ranks) is called synchronously."""
+        self.last_exchange_bytes = getattr(self, "last_exchange_bytes", 0) + mine.numel() * 4 * (shard[1] - 1)
+        if "_exchange" in self.__dict__:
+            res = self._exchange(mine, shard, dst, group)
+            return lambda: res
+        import torch.distributed as dist
+        rank, world = shard
+        if dst is None:
+            allp = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), device=mine.device)
+            work = dist.all_gather_into_tensor(allp, mine, async_op=True)
+            parts = None
+        else:
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+            work = dist.gather(mine, parts, dst=dst, async_op=True)
+            allp = None
+
+        def result():
+            work.wait()  # (RCCL: the current stream waits; gloo: the host does)
+            if dst is None:
+                return allp
+            return torch.cat(parts, dim=0) if parts is not None else None
+        return result
 
     def _boxes_prenorm(self, tiles, tile_cfg) -> np.ndarray:
         """the DATASET's pre-normalised bboxs (pre_norm_bbox=True, u4k_dataset.py:171-176: int64 tensor / W * pw in float32) --
@@ -392,10 +618,6 @@ class _PatchModel(StateDictModule):
         if n_streams > 1:
             for st in streams:
                 main.wait_stream(st)
-        if shard is not None and shard[1] > 1:
-            preds = self._gather_predictions(preds, n_all, shard, gather_dst)
-            if preds is None:
-                return None, coarse_prediction
         preds = preds.view(n_all, ph, pw)
 
         # ---- overlap blend, in the reference's order ----------------------------------------------
@@ -456,40 +678,11 @@ class _PatchModel(StateDictModule):
         ent["graph"].replay()
         return ent["depth"], (ent["coarse"].clone() if ent["coarse"] is not None else None)
 
-    def _gather_predictions(self, preds, n_total, shard, dst=None):
-        """The path's only exchange step (RCCL over xGMI): the per-rank prediction stacks, padded to a common length.
-        Rank r holds tiles r, r+world, ...; the gathered [world, per] stack read column-major is tile order.
-        Returns None on the ranks that do not receive (gather to ``dst``)."""
-        rank, world = shard
-        per = (n_total + world - 1) // world
-        mine = torch.zeros((per,) + tuple(preds.shape[1:]), device=preds.device)
-        mine[:preds.shape[0]] = preds
-        allp = self._exchange(mine, shard, dst)
-        if allp is None:
-            return None
-        allp = allp.view((world, per) + tuple(mine.shape[1:]))
-        return allp.transpose(0, 1).reshape((per * world,) + tuple(preds.shape[1:]))[:n_total].contiguous()
-
-    def _exchange(self, mine, shard, dst):
-        """all-gather (dst None) or gather-to-dst of equally sized stacks -> [world * per, ...] (rank-major) or None."""
-        import torch.distributed as dist
-        rank, world = shard
-        self.last_exchange_bytes = mine.numel() * 4 * (world - 1)  # bytes this frame moves into one receiving rank
-        if dst is None:
-            allp = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), device=mine.device)
-            dist.all_gather_into_tensor(allp, mine)
-            return allp
-        parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
-        dist.gather(mine, parts, dst=dst)
-        return torch.cat(parts, dim=0) if rank == dst else None
-
-    def _sync_plan(self, passes):
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return passes  # single-process emulation of the sharded path (tests)
-        box = [passes]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
+    def _exchange(self, mine, shard, dst, group=0):
+        """blocking form of ``_exchange_begin`` (all-gather when dst is None, gather-to-dst otherwise) -> rank-major
+        [world * per, ...] or None.  The single-GPU shard emulation of the tests replaces it on the instance."""
+        self.__dict__.setdefault("last_exchange_bytes", 0)
+        return self._exchange_begin(mine, shard, dst, group)()
 
     # -- coarse forward of the NEXT frame beside this frame's tile batches (forward(next_image_lr=...)) -----------------------
     def _coarse_of(self, image_lr):
@@ -618,6 +811,7 @@ class _PatchModel(StateDictModule):
         self.max_batch = config.get("max_batch", None)
         self.n_streams = config.get("n_streams", 1)
         self.hip_graph = bool(config.get("hip_graph", False))  # capture + replay the device side of a frame (_graph_frame)
+        self.shard_dst_cost = float(config.get("shard_dst_cost", self.SHARD_DST_COST))  # patch-sharded mode (shard_layout)
         self.strategy_refiner_target = config.strategy_refiner_target
         self.fusion_feat_level = config.fusion_feat_level
         ctype = config.coarse_branch["type"]

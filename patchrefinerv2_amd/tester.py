@@ -138,6 +138,23 @@ class RunnerInfo:
         self.__dict__.update(kw)
 
 
+def collect_results(results, size):
+    """mmengine.dist.collect_results_gpu as Tester.run uses it (estimator/tester/tester.py:124-127): the per-rank result lists
+    of a frame-sharded run (frame f on rank f mod world) all-gathered as pickled objects and interleaved back into dataset
+    order on rank 0 (the other ranks get None); a single process returns its own list."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return results
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, results)
+    if dist.get_rank() != 0:
+        return None
+    ordered = []
+    for i in range(max(len(p) for p in parts)):
+        ordered.extend(p[i] for p in parts if i < len(p))
+    return ordered[:size]
+
+
 class Tester:
     """``Tester(config, runner_info, dataloader, model).run(cai_mode, process_num, image_raw_shape, patch_split_num)``"""
 
@@ -145,21 +162,40 @@ class Tester:
         self.config, self.runner_info, self.dataloader, self.model = config, runner_info, dataloader, model
 
     @torch.no_grad()
-    def run(self, cai_mode="m1", process_num=4, image_raw_shape=(2160, 3840), patch_split_num=(4, 4), seed=None):
+    def run(self, cai_mode="m1", process_num=4, image_raw_shape=(2160, 3840), patch_split_num=(4, 4), seed=None, shard="frames"):
+        """``shard='frames'`` (the reference's data parallelism, tester.py:58: frame f on rank f mod world) or ``'patches'`` (every
+        rank works on EVERY frame: its tiles are sharded over the ranks and gathered to rank 0, which blends, saves and scores --
+        models._PatchModel.forward(shard=...)).  The loop knows its next frame: its low-resolution image is announced to the
+        model, which runs that coarse forward beside the current frame's tiles (``next_image_lr``)."""
         import random
         results = []
         rank, world = self.runner_info.rank, getattr(self.runner_info, "world_size", 1)
-        for idx in range(rank, len(self.dataloader), world):  # frame-sharded data parallelism (tester.py:58)
+        patches = shard == "patches" and world > 1
+        prefetch = bool(getattr(self.model, "needs_coarse", False))
+        todo = list(range(len(self.dataloader))) if patches else list(range(rank, len(self.dataloader), world))
+
+        def load(idx):
             item = self.dataloader[idx]
             hr = item["image_hr"].unsqueeze(0).cuda()
-            lr = self.model.resizer(hr)
+            return item, hr, self.model.resizer(hr)
+
+        nxt = load(todo[0]) if todo else None
+        for n, idx in enumerate(todo):
+            item, hr, lr = nxt
+            nxt = load(todo[n + 1]) if n + 1 < len(todo) else None
             if seed is not None:
                 random.seed(seed)
             tile_cfg = dict(image_raw_shape=list(image_raw_shape), patch_split_num=list(patch_split_num))
             # with ground truth the frame is scored on the device (metrics.compute_metrics_device): ask for the device map
             kw = dict(return_device=True) if item.get("depth_gt") is not None and getattr(self.model, "supports_return_device", False) else {}
+            if patches:
+                kw.update(shard=(rank, world), gather_dst=0)
+            if prefetch and nxt is not None:
+                kw["next_image_lr"] = nxt[2]
             result, log = self.model(mode="infer", cai_mode=cai_mode, process_num=process_num, tile_cfg=tile_cfg,
                                      image_lr=lr, image_hr=hr, **kw)
+            if result is None:  # patch-sharded: only rank 0 holds the map
+                continue
             result_dev = result if result.is_cuda else None
             result = result.cpu()  # BaselinePretrain(target='coarse') hands back the device tensor (baseline_pretrain.py:464)
             if self.runner_info.save:
@@ -184,7 +220,11 @@ class Tester:
                 entry["metrics"] = self.dataloader.get_metrics(item["depth_gt"], result if result_dev is None else result_dev,
                                                                disp_gt_edges=item.get("boundary"))
             results.append(entry)
-        if results and "metrics" in results[0]:
+        if not patches:
+            # collect results from all ranks (tester.py:124-127: collect_results_gpu); rank 0 evaluates the whole dataset
+            allr = collect_results(results, len(self.dataloader))
+            results = allr if allr is not None else results
+        if results and "metrics" in results[0] and rank == 0:
             from .metrics import evaluate
             self.last_eval = evaluate([r["metrics"] for r in results])
         return results

@@ -1,7 +1,10 @@
-"""CPU, world_size 2 over gloo: the patch-sharded mode's exchange step (all-gather or gather-to-rank-0 of the
-per-rank prediction stacks + reorder to tile order) reproduces the single-process ordering, and the tile plan
-is rank 0's on every rank.  (The sharded FORWARD itself is emulated on one GPU in tests/test_hip_models.py.)"""
+"""CPU, world_size 2 over gloo: the patch-sharded mode's host / exchange logic -- the tile-to-rank layout with its gather
+groups, the asynchronous exchange of the per-rank prediction stacks (all-gather or gather-to-rank-0) and the permutation back
+to tile order reproduce the single-process ordering; the tile plan tensor is rank 0's on every rank; Tester's cross-rank
+result collection keeps the dataset order.  (The sharded FORWARD itself is emulated on one GPU in tests/test_hip_models.py
+and tests/test_headline_parity.py.)"""
 import os
+import random
 
 import pytest
 import torch
@@ -20,57 +23,110 @@ class _Host(M._PatchModel):
         pass
 
 
-def _worker(rank, world, port, n_tiles, out):
+def _plan(h, mode, pn=4, raw=(2160, 3840), split=(4, 4)):
+    passes = h.plan_tiles(h.prepare_tile_cfg(list(raw), list(split)), mode, pn)
+    return [p["kind"] for p in passes], [len(p["raw"]) for p in passes], passes
+
+
+def _worker(rank, world, port, mode, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        full = torch.arange(n_tiles * 24, dtype=torch.float32).view(n_tiles, 1, 4, 6)
-        mine = full[rank::world].contiguous()  # tile i -> rank i mod world
         h = _Host()
-        got = h._gather_predictions(mine, n_tiles, (rank, world))              # all-gather: every rank gets the frame
-        ok = torch.equal(got, full)
-        got0 = h._gather_predictions(mine, n_tiles, (rank, world), dst=0)      # gather-to-rank-0: only rank 0 does
-        ok = ok and ((torch.equal(got0, full)) if rank == 0 else got0 is None)
-        # the tile plan that counts is rank 0's: a rank whose ``random`` state differs is overruled
-        import random
-        random.seed(621 + rank)
         h.patch_process_shape = (448, 448)
-        plan = h._sync_plan(h.plan_tiles(h.prepare_tile_cfg([2160, 3840], [4, 4]), "r8", 4))
-        import zlib
-        sig = torch.tensor([zlib.crc32(str(plan).encode())])
-        both = [torch.zeros_like(sig) for _ in range(world)]
-        dist.all_gather(both, sig)
-        ok = ok and all(int(b) == int(both[0]) for b in both)
+        random.seed(621 + rank)          # every rank draws ANOTHER plan ...
+        kinds, counts, passes = _plan(h, mode)
+        n_all = sum(counts)
+        plan_t = torch.tensor([t for p in passes for t in p["raw"]] + [t for p in passes for t in p["proc"]], dtype=torch.int32).view(-1, 2)
+        mine_before = plan_t.clone()
+        plan_t = h._sync_plan_tensor(plan_t)   # ... and rank 0's overrules
+        both = [torch.zeros_like(plan_t) for _ in range(world)]
+        dist.all_gather(both, plan_t)
+        ok = all(torch.equal(b, both[0]) for b in both)
+        if rank == 0:
+            ok = ok and torch.equal(plan_t, mine_before)
+        h.patch_process_shape = (4, 6)
+        full = torch.arange(n_all * 24, dtype=torch.float32).view(n_all, 1, 4, 6)   # "prediction" of tile i
+        for dst in (None, 0):
+            groups = h.shard_layout(kinds, counts, world, dst)
+            assert sum(g["n"] for g in groups) == n_all
+            got = []
+            for gi, g in enumerate(groups):
+                stack = torch.zeros((g["per"], 1, 4, 6))
+                for sl, i in enumerate(g["mine"][rank]):
+                    stack[sl] = full[g["base"] + i]
+                allp = h._exchange_begin(stack, (rank, world), dst, gi)()      # async collective + wait
+                if allp is not None:
+                    got.append(allp.view(world * g["per"], 1, 4, 6).index_select(0, torch.tensor(g["perm"])))
+            if dst is None or rank == dst:
+                ok = ok and torch.equal(torch.cat(got), full)
+            else:
+                ok = ok and not got
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        # Tester's cross-rank collection (tester.py:124-127, collect_results_gpu): frame f ran on rank f % world
+        from patchrefinerv2_amd.tester import collect_results
+        n = 5
+        part = [dict(name=f"f{i}", rank=rank) for i in range(rank, n, world)]
+        allr = collect_results(part, n)
         if rank == 0:
-            out.put(int(flag.item()))
+            ok2 = [r["name"] for r in allr] == [f"f{i}" for i in range(n)] and [r["rank"] for r in allr] == [i % world for i in range(n)]
+            out.put(int(flag.item()) * int(ok2))
+        else:
+            assert allr is None
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_tiles", [81, 16, 5])
-def test_patch_shard_gather_world2(n_tiles):
+@pytest.mark.parametrize("mode", ["r32", "m1", "r8"])
+def test_patch_shard_exchange_world2(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + n_tiles
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_tiles, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + len(mode) + ord(mode[-1])
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 1
 
 
-def test_shard_assignment_covers_every_tile_once():
-    import random
+@pytest.mark.parametrize("mode,n", [("r32", 81), ("r64", 113), ("r128", 177), ("m2", 49), ("m1", 16), ("r3", 49)])
+def test_shard_layout_covers_every_tile_once(mode, n):
     h = _Host()
     h.patch_process_shape = (448, 448)
-    tc = h.prepare_tile_cfg([2160, 3840], [4, 4])
     random.seed(621)
-    flat = [t for p in h.plan_tiles(tc, "r32", 4) for t in p["raw"]]
-    for world in (2, 4, 8):
-        parts = [list(range(len(flat)))[r::world] for r in range(world)]
-        assert sorted(i for p in parts for i in p) == list(range(81))
-        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    kinds, counts, _ = _plan(h, mode)
+    assert sum(counts) == n
+    for world in (1, 2, 4, 8):
+        for dst in (None, 0, world - 1):
+            groups = h.shard_layout(kinds, counts, world, dst)
+            assert len(groups) == (2 if mode[0] == "r" and int(mode[1:]) >= 4 else 1)
+            seen = []
+            for g in groups:
+                assert sorted(i for m in g["mine"] for i in m) == list(range(g["n"]))          # every tile exactly once
+                assert sorted(g["perm"]) == sorted(q * g["per"] + s for q in range(world) for s in range(len(g["mine"][q])))
+                assert all(len(g["mine"][q]) == g["share"][q] <= g["per"] for q in range(world))
+                others = [g["share"][q] for q in range(world) if q != dst]
+                if others:
+                    assert max(others) - min(others) <= 1
+                    if dst is not None and world > 1:                # the blending rank never computes more; fewer in the last group
+                        assert g["share"][dst] <= min(others) and g["share"][dst] >= min(others) - 3
+                        if g is groups[-1] and g["n"] >= 2 * world:
+                            assert g["share"][dst] < max(others)
+                seen += [g["base"] + i for m in g["mine"] for i in m]
+            assert sorted(seen) == list(range(n))
+
+
+def test_boxes_on_device_equal_host_boxes():
+    """_boxes_dev (patch-sharded mode: boxes from the broadcast plan tensor) == _boxes (host numpy) bit for bit"""
+    h = _Host()
+    for pps, raw, split in (((384, 512), (2160, 3840), (4, 4)), ((448, 448), (2160, 3840), (4, 4)), ((392, 518), (1080, 1920), (2, 2))):
+        h.patch_process_shape = pps
+        tc = h.prepare_tile_cfg(list(raw), list(split))
+        random.seed(5)
+        tiles = [(random.randint(0, raw[0] - tc["patch_raw_shape"][0] - 1), random.randint(0, raw[1] - tc["patch_raw_shape"][1] - 1)) for _ in range(300)]
+        want = torch.from_numpy(h._boxes(tiles, tc))
+        got = h._boxes_dev(torch.tensor(tiles, dtype=torch.int32), tc)
+        assert torch.equal(got, want)

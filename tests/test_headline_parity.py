@@ -192,10 +192,23 @@ def test_headline_4k_r32_bench_batching_properties_and_shards():
     assert torch.equal(a, run(0))
     assert torch.equal(b1, run(1))      # the prefetched coarse pyramid == the one computed inline
     model.max_batch, model.n_streams = 41, 3
-    stacks = {}
-    model._exchange = lambda mine, shard, d: stacks.__setitem__(shard[0], mine.clone())
+    from conftest import ShardEmulation
+    emu = ShardEmulation(model, 8)
+    emu.record()
     for r in range(8):
         assert run(0, shard=(r, 8), gather_dst=0) is None
-    assert all(s.shape[0] == 11 for s in stacks.values())          # ceil(81 / 8), padded
-    model._exchange = lambda mine, shard, d: torch.cat([stacks[r] for r in range(8)], dim=0)
+    groups = model.last_shard_layout
+    assert [g["n"] for g in groups] == [49, 32] and [g["per"] for g in groups] == [7, 5]
+    assert groups[1]["share"][0] == 3       # the blending rank computes fewer tiles of the last group
+    emu.deliver()
     assert torch.equal(a, run(0, shard=(0, 8), gather_dst=0))
+    # ... with the next frame's coarse forward prefetched beside the sharded tiles, too
+    emu.restore()
+    emu = ShardEmulation(model, 2)
+    emu.record()
+    for r in range(2):
+        assert run(0, shard=(r, 2), gather_dst=0) is None
+    emu.deliver()
+    assert torch.equal(a, run(0, nxt=frames[1][1], shard=(0, 2), gather_dst=0))
+    emu.restore()
+    assert torch.equal(b1, run(1))

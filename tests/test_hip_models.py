@@ -770,29 +770,35 @@ def test_patch_shard_emulation_equals_unsharded(P, world, dst):
     """run ``shard=(r, N)`` for r = 0..N-1 sequentially on one GPU, hand rank 0 the stacks exactly as all_gather / gather
     would deliver them (rank-major), and require the blended frame to be bit-identical to the unsharded one
     (tile i -> rank i mod N, blend in the reference's order)."""
+    from conftest import ShardEmulation
     c = E2E_V1
     m = _build("PatchRefiner", c, e2e_v1_sd())
     full, _ = _run(m, c, "r8")
-    stacks = {}
-
-    def record(mine, shard, d):
-        assert d == dst
-        stacks[shard[0]] = mine.clone()
-        return None                                   # "this rank does not receive": forward returns depth None
-    m._exchange = record
+    emu = ShardEmulation(m, world)
+    emu.record()
     for r in range(world):
         depth, log = _run(m, c, "r8", shard=(r, world), gather_dst=dst)
         assert depth is None and log["coarse_prediction"] is not None
     n_tiles = sum(len(p["raw"]) for p in m.last_plan)
-    assert sorted(stacks) == list(range(world)) and n_tiles == 17
-    assert all(s.shape[0] == -(-n_tiles // world) for s in stacks.values())  # padded to a common length
-
-    def deliver(mine, shard, d):
-        assert torch.equal(mine, stacks[shard[0]])    # deterministic per-rank work
-        return torch.cat([stacks[r] for r in range(world)], dim=0)
-    m._exchange = deliver
-    got, _ = _run(m, c, "r8", shard=(0, world), gather_dst=dst)
-    assert torch.equal(got, full)
+    groups = m.last_shard_layout
+    assert n_tiles == 17 and [g["n"] for g in groups] == [9, 8]          # [init + 3 grids | random]: two exchanges per frame
+    assert sorted(emu.stacks) == [(r, g) for r in range(world) for g in range(2)]
+    assert all(emu.stacks[(r, gi)].shape[0] == g["per"] for r in range(world) for gi, g in enumerate(groups))  # padded to a common length
+    emu.deliver()
+    for r in ([0] if dst is not None else range(world)):                   # all-gather: every rank blends the same map
+        got, _ = _run(m, c, "r8", shard=(r, world), gather_dst=dst)
+        assert torch.equal(got, full)
+    # a rank seeded differently still blends at rank 0's coordinates only through the broadcast plan (tests/test_distributed.py);
+    # modes without random tiles have a single gather group
+    emu.restore()
+    full_m2, _ = _run(m, c, "m2")
+    emu = ShardEmulation(m, world)
+    emu.record()
+    for r in range(world):
+        assert _run(m, c, "m2", shard=(r, world), gather_dst=0)[0] is None
+    assert len(m.last_shard_layout) == 1
+    emu.deliver()
+    assert torch.equal(_run(m, c, "m2", shard=(0, world), gather_dst=0)[0], full_m2)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -919,9 +925,10 @@ def test_baseline_config3_config4_single_gpu_properties(P, name, tiles):
     assert float(a.min()) >= 0.0 and float(a.max()) <= 80.0 * 1.0001
     model.max_batch, model.n_streams = 10, 2
     assert torch.equal(a, run())
-    stacks = {}
-    model._exchange = lambda mine, shard, d: stacks.__setitem__(shard[0], mine.clone())
+    from conftest import ShardEmulation
+    emu = ShardEmulation(model, 8)
+    emu.record()
     for r in range(8):
         assert run(shard=(r, 8), gather_dst=0) is None
-    model._exchange = lambda mine, shard, d: torch.cat([stacks[r] for r in range(8)], dim=0)
+    emu.deliver()
     assert torch.equal(a, run(shard=(0, 8), gather_dst=0))

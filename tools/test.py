@@ -6,7 +6,8 @@
 
 CONFIG is an MMEngine-style python config (``model=dict(type=..., config=dict(...))``, ``_base_`` supported).
 Extras: ``--synthetic-weights`` (the reference has not released checkpoints), ``--prec``, ``--process-num``, ``--max-batch``, ``--streams``.
-Multi-GPU: launch with torch.distributed.run; frames are sharded over ranks like the reference's dist_test.sh.
+Multi-GPU: ``sh tools/dist_test.sh CONFIG GPUS [arguments]`` (docs/user_infer.md:113-130): one process per GPU over RCCL;
+``--shard frames`` (default, the reference's data parallelism) or ``--shard patches`` (tiles of every frame over the ranks).
 """
 import argparse
 import ast
@@ -52,6 +53,11 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over (config key n_streams wins)")
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--seed", type=int, default=621)
+    ap.add_argument("--launcher", default="none", choices=["none", "pytorch"],
+                    help="pytorch: started by torch.distributed.run (tools/dist_test.sh): one process per GPU, RCCL process group")
+    ap.add_argument("--shard", default="frames", choices=["frames", "patches"],
+                    help="multi-GPU: frames = frame f on rank f mod N (the reference's dist_test.sh), patches = the tiles of every "
+                         "frame sharded over the ranks, gathered to rank 0 over RCCL")
     ap.add_argument("--consistency", type=int, default=0, metavar="OVERLAP",
                     help="Tester.run_consistency (estimator/tester/tester.py:211): seam error over crops overlapping by OVERLAP pixels (reference: 270)")
     ap.add_argument("--benchmark", action="store_true", help="Tester.benchmark (estimator/tester/tester.py:325) instead of run")
@@ -65,6 +71,10 @@ def main():
     cfg.merge_from_dict(parse_opts(args.cfg_option))
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    if world > 1:  # estimator/utils/dist.py:31-33 (init_dist(launcher, backend='nccl')); nccl == RCCL on ROCm
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))))
 
     mcfg = cfg.model.to_dict()
     # PatchRefiner / PatchRefinerPlus take one ``config`` dict, BaselinePretrain keyword arguments (baseline_pretrain.py:45)
@@ -101,11 +111,17 @@ def main():
         print(f"The variance of {args.repeat_times} evaluations: {b['fps_variance']}")
         print(f"Model Flops: {b['flops'] / 1e12:.3f} T  Model Parameters: {b['params'] / 1e6:.1f} M")
         return
-    for r in tester.run(cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
-                        patch_split_num=args.patch_split_num, seed=args.seed):
-        print(f"[rank {rank}] {r['name']}: depth {r['shape']} mean {r['mean']:.4f}")
-    if getattr(tester, "last_eval", None):  # frames that came with ground truth (dataset gt_dir)
-        print(f"[rank {rank}] " + ", ".join(f"{k} {v:.4f}" for k, v in tester.last_eval.items()))
+    results = tester.run(cai_mode=args.cai_mode, process_num=args.process_num, image_raw_shape=args.image_raw_shape,
+                         patch_split_num=args.patch_split_num, seed=args.seed, shard=args.shard)
+    if rank == 0 or world == 1:  # (frame-sharded runs: rank 0 holds every rank's results, collected like collect_results_gpu)
+        for r in results:
+            print(f"[rank {rank}] {r['name']}: depth {r['shape']} mean {r['mean']:.4f}")
+        if getattr(tester, "last_eval", None):  # frames that came with ground truth (dataset gt_dir)
+            print(f"[rank {rank}] " + ", ".join(f"{k} {v:.4f}" for k, v in tester.last_eval.items()))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
