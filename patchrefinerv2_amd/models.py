@@ -732,7 +732,23 @@ class _PatchModel(StateDictModule):
 
     # -- checkpoint contract (patchrefinerplus.py:212-216) ------------------------------------------
     def load_dict(self, sd):
-        return self.load_state_dict(sd, strict=False)
+        """patchrefinerplus.py:212-213 (``load_state_dict(strict=False)``) made checkpoint-ready: key variants of the two
+        un-vendored packages (timm's flattened / unflattened feature-net names, a DDP ``module.`` prefix, BatchNorm bookkeeping
+        buffers) are rewritten by ``weights.remap_state_dict``; whatever still does not match is REPORTED, grouped by module
+        (``weights.diagnose_state_dict``) -- the reference prints the bare key lists -- and a forward with parameters still
+        missing raises 'weights not loaded' instead of running on garbage.  The report is kept in ``self.last_load_report``."""
+        import warnings
+        from . import weights as W_
+        spec = self.spec()
+        sd, applied = W_.remap_state_dict(sd, spec)
+        res = self.load_state_dict(sd, strict=False)
+        diag = W_.diagnose_state_dict(spec, sd)
+        self.last_load_report = dict(diag, remapped=applied)
+        if applied:
+            warnings.warn("load_dict: renamed checkpoint keys -- " + ", ".join(f"{k}: {v}" for k, v in applied.items()))
+        if res["missing_keys"] or res["unexpected_keys"] or diag["shape_mismatch"]:
+            warnings.warn("load_dict: " + W_.format_diagnosis(diag))
+        return res
 
     def get_save_dict(self):
         return self.state_dict()

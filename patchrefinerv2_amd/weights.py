@@ -632,3 +632,89 @@ def synth_state_dict(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tenso
         if k.endswith("K_minus_1"):
             sd[k] = torch.tensor([float(sd[k[:-len("K_minus_1")] + "k_idx"].numel() - 1)]).view(sd[k].shape)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# checkpoint readiness: what to do when a released checkpoint's key names differ from this build's table
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's own modules (estimator/*, external/depth_anything*, external/zoedepth) are checked name by name against the
+# imported reference (oracle/make_golden.py).  Two un-vendored packages contribute names that could only be restated from their
+# published conventions: timm (``refiner_encoder.*``: MobileNetV4 / ConvNeXt / EfficientNet under ``features_only=True``, whose
+# FeatureListNet flattens the top-level Sequentials -- ``blocks.3`` may appear as ``blocks_3``, ``stem.0`` as ``stem_0``,
+# ``stages.2`` as ``stages_2``) and the torch.hub MiDaS fork (``core.core.pretrained.model.*`` = timm's BEiT).  These rules
+# rewrite such variants; ``diagnose_state_dict`` reports what they cannot explain.
+REMAP_RULES = (
+    ("DistributedDataParallel prefix", r"^module\.", ""),
+    ("timm FeatureListNet flattening (blocks_N -> blocks.N)", r"(^|\.)blocks_(\d+)(\.|$)", r"\1blocks.\2\3"),
+    ("timm unflattened stem (stem.N -> stem_N)", r"(^|\.)stem\.(\d+)\.", r"\1stem_\2."),
+    ("timm unflattened stages (stages.N -> stages_N)", r"(^|\.)stages\.(\d+)\.", r"\1stages_\2."),
+    ("timm BEiT fused-qkv naming (attn.qkv.bias split kept by timm as q_bias / v_bias)", r"\.attn\.qkv_bias$", ".attn.q_bias"),
+)
+IGNORABLE = (r"\.num_batches_tracked$", r"\.relative_position_index$", r"\.attn\.k_bias$")  # bookkeeping / derived buffers
+
+
+def remap_state_dict(sd, spec: Spec):
+    """Apply REMAP_RULES to the keys of ``sd`` that are not in ``spec`` (a rule is used for a key only if the rewritten name IS
+    in ``spec`` with the same shape); drop IGNORABLE bookkeeping keys.  Returns (new_sd, applied) with applied = {rule: count}."""
+    out, applied = OrderedDict(), {}
+    for k, v in sd.items():
+        if k in spec:
+            out[k] = v
+            continue
+        if any(re.search(p, k) for p in IGNORABLE):
+            applied["dropped bookkeeping buffers"] = applied.get("dropped bookkeeping buffers", 0) + 1
+            continue
+        cands, names = [k], [[]]
+        for name, pat, rep in REMAP_RULES:  # rules compose (a DDP prefix on top of a flattened name)
+            for c, used in list(zip(cands, names)):
+                n = re.sub(pat, rep, c)
+                if n != c and n not in cands:
+                    cands.append(n)
+                    names.append(used + [name])
+        hit = next(((c, used) for c, used in zip(cands, names) if c in spec and tuple(spec[c]) == tuple(v.shape)), None)
+        if hit is None:
+            out[k] = v
+        else:
+            out[hit[0]] = v
+            for name in hit[1]:
+                applied[name] = applied.get(name, 0) + 1
+    return out, applied
+
+
+def diagnose_state_dict(spec: Spec, sd, depth: int = 4) -> dict:
+    """What of ``sd`` this build can and cannot use: matched / missing / unexpected / shape-mismatched keys grouped by module
+    prefix (``depth`` name components, indices folded to N), plus, for every unexpected key, the missing keys with the same
+    leaf name and shape inside the same top-level module (candidate renames a maintainer can turn into a REMAP_RULES line)."""
+    def group(keys):
+        g = OrderedDict()
+        for k in keys:
+            p = ".".join(re.sub(r"\.\d+(?=\.|$)", ".N", k).split(".")[:depth])
+            g.setdefault(p, []).append(k)
+        return OrderedDict((p, dict(count=len(ks), example=ks[0])) for p, ks in g.items())
+    missing = [k for k in spec if k not in sd]
+    unexpected = [k for k in sd if k not in spec]
+    mism = [(k, tuple(sd[k].shape), tuple(spec[k])) for k in spec if k in sd and tuple(sd[k].shape) != tuple(spec[k])]
+    cands = OrderedDict()
+    by_leaf = {}
+    for k in missing:
+        by_leaf.setdefault((k.split(".")[0], k.rsplit(".", 1)[-1], tuple(spec[k])), []).append(k)
+    for k in unexpected:
+        c = by_leaf.get((k.split(".")[0], k.rsplit(".", 1)[-1], tuple(sd[k].shape)), [])
+        if c:
+            cands[k] = c[:3]
+    return dict(matched=len(spec) - len(missing) - len(mism), total=len(spec), missing=group(missing), unexpected=group(unexpected),
+                shape_mismatch=mism[:20], rename_candidates=OrderedDict(list(cands.items())[:40]))
+
+
+def format_diagnosis(d: dict) -> str:
+    lines = [f"state dict: {d['matched']} of {d['total']} parameters matched"]
+    for title, key in (("MISSING (in this model, not in the checkpoint)", "missing"), ("UNEXPECTED (in the checkpoint, unknown here)", "unexpected")):
+        if d[key]:
+            lines.append(f"  {title}:")
+            lines += [f"    {v['count']:5d}  {p}.*   e.g. {v['example']}" for p, v in d[key].items()]
+    if d["shape_mismatch"]:
+        lines.append("  SHAPE MISMATCH: " + "; ".join(f"{k}: checkpoint {a} vs model {b}" for k, a, b in d["shape_mismatch"][:8]))
+    if d["rename_candidates"]:
+        lines.append("  rename candidates (same leaf name + shape inside the same top-level module; add a rule to weights.REMAP_RULES):")
+        lines += [f"    {k}  ->  {' | '.join(c)}" for k, c in list(d["rename_candidates"].items())[:12]]
+    return "\n".join(lines)

@@ -224,3 +224,36 @@ def test_canny_edge_map_of_the_output_stage():
     assert not canny(np.full((32, 32), 3.0, np.float32)).any()            # constant image: the zero border is corrected for
     d = depth_edges(torch.tensor(np.exp(img))[None, None])
     assert d.shape == (64, 96) and d.sum() > e.sum() and (d | ~e).all()    # dilation contains the thin edges
+
+
+def test_checkpoint_key_remap_and_diagnosis():
+    """checkpoint readiness (patchrefinerplus.py:105-124,202-205): a state dict saved with a DDP prefix, timm's FLATTENED feature-net
+    names and BatchNorm bookkeeping buffers is rewritten onto this build's table; what cannot be explained is reported grouped by
+    module with rename candidates"""
+    import re
+    import torch
+    from patchrefinerv2_amd import weights as W
+    spec = W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4)
+    spec["refiner_fusion_model.final_conv.weight"] = (1, 32, 3, 3)
+    sd = {k: torch.zeros(shp) for k, shp in spec.items()}
+    odd = {}
+    for k, v in sd.items():
+        k2 = "module." + re.sub(r"\.blocks\.(\d+)\.", r".blocks_\1.", k)
+        odd[k2] = v
+        if k.endswith("running_var"):
+            odd[k2.replace("running_var", "num_batches_tracked")] = torch.zeros(())
+    odd["module.refiner_fusion_model.final_conv.weight"] = odd.pop("module.refiner_fusion_model.final_conv.weight")
+    new, applied = W.remap_state_dict(odd, spec)
+    assert sorted(new) == sorted(spec) and applied["DistributedDataParallel prefix"] == len(spec)
+    assert applied["dropped bookkeeping buffers"] > 0 and applied["timm FeatureListNet flattening (blocks_N -> blocks.N)"] > 100
+    # an unknown naming: reported, with the right rename candidate
+    bad = dict(sd)
+    v = bad.pop("refiner_fine_branch.refiner_encoder.conv_stem.weight")
+    bad["refiner_fine_branch.refiner_encoder.stem.conv.weight"] = v
+    bad["totally.unrelated"] = torch.zeros(3)
+    new, applied = W.remap_state_dict(bad, spec)
+    d = W.diagnose_state_dict(spec, new)
+    assert d["matched"] == len(spec) - 1 and list(d["missing"]) == ["refiner_fine_branch.refiner_encoder.conv_stem.weight"]
+    assert d["rename_candidates"]["refiner_fine_branch.refiner_encoder.stem.conv.weight"] == ["refiner_fine_branch.refiner_encoder.conv_stem.weight"]
+    txt = W.format_diagnosis(d)
+    assert "MISSING" in txt and "UNEXPECTED" in txt and "totally" in txt and "rename candidates" in txt
