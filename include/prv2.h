@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 8
+#define PRV2_ABI_VERSION 9
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -98,6 +98,26 @@ int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, void* w_pac
 int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
                 const float* ln_weight, const float* ln_bias, const float* gamma, const float* mul, const float* res,
                 const float* res2, float* y, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution whose first ``channels`` input channels are a bilinear(align_corners=True) UPSAMPLE of a
+ * low-resolution tensor, interpolated while the conv stages its input tile -- the upsampled tensor is never written:
+ *   UpSample.forward_hardcode   estimator/models/blocks/fusion_model.py:15-24   x = cat[interpolate(x1, size, 'bilinear',
+ *                               align_corners=True), x2, pred1, pred2] -> DoubleConv: the first conv reads channels [0, c1) from x1
+ *   C2FModule output_conv1      bi_directional_fusion_model.py:139-142,201      conv3x3(interpolate(path_1, scale 2, align_corners))
+ * x (NHWC, d->ldx) supplies the channels [channels, d->cin) at their usual offsets (its first ``channels`` channels are not
+ * read; x may equal u->x when channels == d->cin).  Same arithmetic, bit for bit, as prv2_upsample_bilinear into x followed by
+ * prv2_conv2d.  Contract (prv2_conv2d_ups_supported(d, u) != 0): bf16 modes, 3x3 s1 p1, cout > 64 and != 256-with-cin%32==0 routing
+ * aside the layer must be one the 128-column halo kernel takes (width >= 24 ...), channels % 32 == 0, 0 < channels <= cin,
+ * u->ld % 4 == 0, 16-byte aligned, no input ReLU. */
+typedef struct prv2_ups_src {
+  const float* x;        /* low-resolution source, NHWC [n, h, w, ld], channels [0, channels) used */
+  int32_t h, w, ld;
+  int32_t channels;
+  int64_t bstride;       /* image stride in floats (0 => h*w*ld) */
+} prv2_ups_src;
+int prv2_conv2d_ups_supported(const prv2_conv_desc* d, const prv2_ups_src* u);
+int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src* u, const void* w_packed, const float* bias,
+                    const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream);
 
 /* GatedConvUnit tail in one kernel (estimator/models/blocks/bi_directional_fusion_model.py:44-51 ``fusion_conv`` =
  * Conv3x3(2F -> F) . LayerNorm(channels_first) . ReLU . Conv1x1(F -> F) . Sigmoid, and :70-80 ``out * fusion (+ xs[0])``):

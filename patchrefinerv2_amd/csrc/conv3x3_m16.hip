@@ -64,9 +64,17 @@ constexpr int halo16_smem_floats() {
 // with the 1x1 gate on the tile -- normalise + activate + bf16 split of the C tile in place, gate GEMM from LDS with the (small)
 // weight fragments in registers, sigmoid * mul (+ res) in the store loop -- see conv3x3_gate.hip, which does the same at 256
 // channels on tiles of its own.
-template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false, bool SINGLE = false, bool GATE = false>
+// UPS (BN = 128): the first p.ups_c input channels are bilinear(align_corners=True) samples of the low-resolution tensor p.xu,
+// formed while the halo is staged: an item = 4 tap loads (hardware zero fill outside the image) combined with
+// upsample_bilinear_kernel's exact arithmetic, so the layer equals "upsample into the concat buffer, then conv" bit for bit
+// without the upsampled tensor ever being written (fusion_model.py:15-24, bi_directional_fusion_model.py:139-142,201).  Slabs behind
+// ups_c keep the plain loader; their three extra tap slots are out-of-range loads (zeros, no memory traffic), so that every
+// item is four VMEM instructions and the counted waits stay compile-time constants.
+template <int BN, int PREC, bool TAIL, bool TALL, bool PERSIST = false, bool SINGLE = false, bool GATE = false, bool UPS = false>
 __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, int bid, const int nwg) {
   using namespace m16;
+  static_assert(!UPS || (!PERSIST && !SINGLE && !GATE && BN == 128), "UPS: the 128-column kernel");
+  constexpr int LPI = UPS ? 4 : 1;  // buffer loads per halo item
   // Tile = 8 rows x 32 pixels, or (TALL) 32 rows x 8 pixels for the remainder strip of images whose width is
   // 32k + (1..8): same pixel count, same halo size, a pixel run of 16 is then 2 rows x 8 pixels.
   constexpr int TH = TALL ? 32 : 8, TW = TALL ? 8 : 32, HW_ = TW + 2;
@@ -160,6 +168,40 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   };
   Halo hcur = halo_of(tl);
   Halo hnxt = hcur;  // PERSIST: the next tile of this workgroup (loaded from during the last slab)
+  // UPS: per item the byte offset of tap (y0, x0) in the low-resolution image (or OOB), whether x1 / y1 are the next pixel /
+  // row (align_corners clamps them at the far edge), and the two fractional weights -- ac_tap's values
+  struct HaloU {
+    i32x4 rsrc;
+    unsigned off[A_IT];
+    float wy[A_IT], wx[A_IT];
+    unsigned edge;  // bit 2 it: x1 = x0 + 1, bit 2 it + 1: y1 = y0 + 1
+  };
+  HaloU hu;
+  const int ups_slabs = UPS ? p.ups_c / BK : 0;
+  unsigned u_dx = 0, u_dy = 0;
+  if constexpr (UPS) {
+    const unsigned long long ub = (unsigned long long)(size_t)(p.xu + (long long)tl.n_img * p.xu_bstride);
+    hu.rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub);
+    hu.rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((ub >> 32) & 0xffffu));
+    hu.rsrc.z = __builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)p.uH * p.uW - 1) * p.ldxu + p.ups_c) * 4));
+    hu.rsrc.w = 0x00020000;
+    hu.edge = 0;
+    u_dx = (unsigned)(p.ldxu * 4);
+    u_dy = (unsigned)(p.uW * p.ldxu * 4);
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int hp = prow + 64 * it;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = tl.y0 - 1 + hy, ix = tl.x0 - 1 + hx;
+      const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const AxisTap ty = ac_tap(ok ? iy : 0, p.usy, p.uH), tx = ac_tap(ok ? ix : 0, p.usx, p.uW);
+      hu.off[it] = ok ? (unsigned)(((ty.i0 * p.uW + tx.i0) * p.ldxu + chunk * 4) * 4) : OOB;
+      hu.wy[it] = ty.w1;
+      hu.wx[it] = tx.w1;
+      hu.edge |= (tx.i1 != tx.i0 ? 1u : 0u) << (2 * it);
+      hu.edge |= (ty.i1 != ty.i0 ? 2u : 0u) << (2 * it);
+    }
+  }
   const long long w_row_stride = 9LL * p.Cin_pad;
   // With a tail tile (igemm.h: has_tail_tile) the last slab -- 2 real channels -- is not walked tap by tap: its
   // 9 taps x 2 channels are ONE extra step (k = 2*tap + c) after the full slabs.
@@ -170,7 +212,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   const int cin4 = (p.Cin + 3) & ~3;
   const int relu_floor = p.relu_in ? 0 : (int)0x80000000;  // fused input ReLU as an integer max on the float bits
 
-  f32x4 ra[A_IT];
+  f32x4 ra[A_IT][LPI];
   auto a_voff = [&](const Halo& hl, int cc, int it) {  // (2^31 + cc*128 stays out of range: no wrap)
     return cc * BK + chunk * 4 < cin4 ? hl.off[it] + (unsigned)(cc * BK * 4) : OOB;
   };
@@ -178,13 +220,54 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   // waits vmcnt(0) in front of the first use; the value is handed back by the counted wait (its "+v" operand);
   // (b) the buffer form with hardware range checking.
   auto load_a_async = [&](const Halo& hl, int cc, int it) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it]) : "v"(a_voff(hl, cc, it)), "s"(hl.rsrc) : "memory");
+    if constexpr (!UPS) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][0]) : "v"(a_voff(hl, cc, it)), "s"(hl.rsrc) : "memory");
+    } else {
+      const bool ups = cc < ups_slabs;  // block-uniform
+      i32x4 rs;
+      rs.x = ups ? hu.rsrc.x : hl.rsrc.x;
+      rs.y = ups ? hu.rsrc.y : hl.rsrc.y;
+      rs.z = ups ? hu.rsrc.z : hl.rsrc.z;
+      rs.w = hl.rsrc.w;
+      // (an OOB base stays out of range with the tap offsets added: image extents are < 2^29 floats)
+      const unsigned o0 = ups ? hu.off[it] + (unsigned)(cc * BK * 4) : a_voff(hl, cc, it);
+      const unsigned dx = ((hu.edge >> (2 * it)) & 1u) ? u_dx : 0u, dy = ((hu.edge >> (2 * it + 1)) & 1u) ? u_dy : 0u;
+      const unsigned o1 = ups ? o0 + dx : OOB, o2 = ups ? o0 + dy : OOB, o3 = ups ? o0 + dx + dy : OOB;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][0]) : "v"(o0), "s"(rs) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][LPI - 3]) : "v"(o1), "s"(rs) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][LPI - 2]) : "v"(o2), "s"(rs) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][LPI - 1]) : "v"(o3), "s"(rs) : "memory");
+    }
   };
-  auto store_a = [&](int abuf, int it) {
+  // the counted wait that hands item `it` back (its registers are the asm's in/out operands: nothing may be scheduled across)
+#define PRV2_WAIT_ITEM(newer, it)                                                                                                     \
+  do {                                                                                                                              \
+    if constexpr (!UPS) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[it][0]) : "n"(newer) : "memory");                                \
+    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[it][0]), "+v"(ra[it][LPI - 3]), "+v"(ra[it][LPI - 2]), "+v"(ra[it][LPI - 1]) : "n"(newer) : "memory"); \
+  } while (0)
+  // cc_item: the slab the item was loaded for (UPS: decides whether its four taps are interpolated)
+  auto store_a = [&](int abuf, int it, int cc_item) {
     const int hp = prow + 64 * it;
     if (hp >= HALO) return;
+    f32x4 v_in = ra[it][0];
+    if constexpr (UPS) {
+      if (cc_item < ups_slabs) {  // block-uniform; upsample_bilinear_kernel's operation order (gather.hip), element by element
+        const float w1x = hu.wx[it], w0x = 1.0f - w1x, w1y = hu.wy[it], w0y = 1.0f - w1y;
+        f32x4 top = {0.f, 0.f, 0.f, 0.f}, bot = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          top[e] += w0x * ra[it][0][e];
+          top[e] += w1x * ra[it][LPI - 3][e];
+          bot[e] += w0x * ra[it][LPI - 2][e];
+          bot[e] += w1x * ra[it][LPI - 1][e];
+          r[e] += w0y * top[e];
+          r[e] += w1y * bot[e];
+        }
+        v_in = r;
+      }
+    }
     typedef int i32x4v __attribute__((ext_vector_type(4)));
-    i32x4v vi = __builtin_bit_cast(i32x4v, ra[it]);
+    i32x4v vi = __builtin_bit_cast(i32x4v, v_in);
     vi.x = max(vi.x, relu_floor);  // ReLU on the bits: negative floats are negative ints; floor INT_MIN = identity
     vi.y = max(vi.y, relu_floor);
     vi.z = max(vi.z, relu_floor);
@@ -277,8 +360,8 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   }
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[it])::"memory");
-    store_a(0, it);
+    PRV2_WAIT_ITEM(0, it);
+    store_a(0, it, 0);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // full fence: lgkmcnt for the asm stores, vmcnt(0) for the DMAs
@@ -334,9 +417,9 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
 #ifndef PRV2_ABL_NOA
             if constexpr (!SINGLE && tap >= 2 && tap - 2 < A_IT) {
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
-              constexpr int newer = 2 * ND + Lm1 + L0;
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
-              store_a(ab ^ 1, tap - 2);  // other halo buffer: last read in the previous slab
+              constexpr int newer = 2 * ND + LPI * (Lm1 + L0);
+              PRV2_WAIT_ITEM(newer, tap - 2);
+              store_a(ab ^ 1, tap - 2, ccn);  // other halo buffer: last read in the previous slab
             }
 #endif
           }
@@ -347,9 +430,9 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
       // tap 8, of this slab's halo; the DMA of step s+1 (issued two barriers ago) has landed: newer than it are
       // the halo loads of steps s-1 and s and the DMA issued at the previous barrier.
 #ifdef PRV2_ABL_NOBAR
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ND + Lm1 + L0) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ND + LPI * (Lm1 + L0)) : "memory");
 #else
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ND + Lm1 + L0) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ND + LPI * (Lm1 + L0)) : "memory");
 #endif
       read_b(NJ & 1, (tap + 1) % 3, 0);  // column 0 of the next step (the last column sits in slot (NJ-1)&1)
       __builtin_amdgcn_sched_barrier(0);
@@ -370,8 +453,8 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
               // VMEM instructions issued since the last halo load (tap A_IT - 1): the DMAs of taps A_IT - 1 .. 7
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[it]) : "n"((8 - (A_IT - 1)) * ND) : "memory");
-              store_a(0, it);
+              PRV2_WAIT_ITEM((8 - (A_IT - 1)) * ND, it);
+              store_a(0, it, ccn);
             }
           }
         } else {
@@ -674,6 +757,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_halo16_kernel(const IgemmParam
   else halo16_body<BN, PREC, TAIL, false>(p, smem, blockIdx.x - strip, gridDim.x - strip);
 }
 
+// the same with the fused-upsample loader (p.xu: the first p.ups_c input channels are bilinear samples of a low-resolution tensor)
+template <int BN, int PREC, bool TAIL>
+__global__ void __launch_bounds__(512, 2) conv3x3_halo16_ups_kernel(const IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[halo16_smem_floats<BN>()];
+  const int strip = p.strip_blocks;  // block-uniform
+  if ((int)blockIdx.x < strip) halo16_body<BN, PREC, TAIL, true, false, false, false, true>(p, smem, blockIdx.x, strip);
+  else halo16_body<BN, PREC, TAIL, false, false, false, false, true>(p, smem, blockIdx.x - strip, gridDim.x - strip);
+}
+
+bool conv3x3_halo16_ups_usable(const IgemmParams& p, int prec) {
+  return p.xu && conv3x3_halo16_usable(p, prec) && p.Ncols > 64 && p.ups_c > 0 && p.ups_c % 32 == 0 && p.ups_c <= p.Cin && !p.relu_in && p.ldxu % 4 == 0 &&
+         p.ldxu >= p.ups_c && (reinterpret_cast<uintptr_t>(p.xu) & 15) == 0 && p.xu_bstride % 4 == 0 && (long long)p.uH * p.uW * p.ldxu < (1LL << 29) &&
+         p.uH >= 1 && p.uW >= 1;
+}
+
 // BN = 32 without tail tile: the 8 x 32 tiles are walked by persistent workgroups (one per CU: 160 KB of LDS), the strip
 // tiles stay ordinary leading workgroups.
 template <int PREC>
@@ -742,6 +840,18 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;
   p.strip_blocks = p.rw > 0 ? p.N * (int)cdiv(p.H, 32) * p.tiles_n : 0;
   const int blocks = p.N * (int)cdiv(p.H, 8) * p.tiles_x * p.tiles_n + p.strip_blocks;
+  if (p.xu) {  // fused-upsample loader: the 128-column kernel (conv2d_impl checked conv3x3_halo16_ups_usable)
+    set_kernel("conv3x3_halo16_ups_kernel", 128, prec);
+#define PRV2_LAUNCH_UPS(PREC_)                                                                                             \
+  do {                                                                                                                   \
+    if (p.w_tail) hipLaunchKernelGGL((conv3x3_halo16_ups_kernel<128, PREC_, true>), dim3(blocks), dim3(512), 0, s, p);   \
+    else hipLaunchKernelGGL((conv3x3_halo16_ups_kernel<128, PREC_, false>), dim3(blocks), dim3(512), 0, s, p);           \
+  } while (0)
+    if (prec == PRV2_PREC_BF16X3) PRV2_LAUNCH_UPS(PRV2_PREC_BF16X3);
+    else PRV2_LAUNCH_UPS(PRV2_PREC_BF16);
+#undef PRV2_LAUNCH_UPS
+    return;
+  }
   static const bool no_persist = getenv("PRV2_HALO_NO_PERSIST") != nullptr;  // A/B switches
   static const int n32_mode = getenv("PRV2_HALO_N32") ? atoi(getenv("PRV2_HALO_N32")) : 1;  // 1: two single-halo workgroups per CU; 0: round-1 paths
   set_kernel("conv3x3_halo16_kernel", p.Ncols > 64 ? 128 : (p.Ncols > 32 ? 64 : 32), prec);

@@ -40,6 +40,12 @@ struct IgemmParams {
   // GatedConvUnit tail (conv3x3_m16.hip GATE / conv3x3_gate.hip): y = mul * sigmoid(W_g act(LN(conv + bias)) + gate_bias) (+ res)
   const void* gate_w;  // fragment-major Cout x Cout gate weights (prv2_pack_gate_weight), or null
   const float* gate_bias;
+  // conv3x3_m16.hip UPS: input channels [0, ups_c) are bilinear(align_corners=True) samples of the low-resolution NHWC tensor xu
+  // (uH x uW, pixel stride ldxu) taken while the halo is staged; channels [ups_c, Cin) come from x as usual.  null: none.
+  const float* xu;
+  int uH, uW, ldxu, ups_c;
+  long long xu_bstride;
+  float usy, usx;      // ac_scale(uH, H), ac_scale(uW, W)
 };
 
 // fragment-major gate weights: [16-column block cb][32-channel slab ks][hi, lo][lane 64] x 16 B, lane (m = lane & 15, g = lane >> 4)
@@ -300,7 +306,9 @@ bool conv3x3_halo16_usable(const IgemmParams& p, int prec);
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t stream);  // tiles [0, tiles_x) + strip [rx0, rx0 + rw)
 int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
                 const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
-                const float* gate_bias);  // igemm.hip: prv2_conv2d, with the optional gate stage of the 32 / 128-channel layers
+                const float* gate_bias, const prv2_ups_src* ups = nullptr);  // igemm.hip: prv2_conv2d, with the optional gate stage of
+                                                                             // the 32 / 128-channel layers / the fused-upsample loader
+bool conv3x3_halo16_ups_usable(const IgemmParams& p, int prec);  // p.xu layers (prv2_conv2d_ups): the 128-column 16x16x32 halo kernel
 bool conv3x3_halo16_gate_usable(const IgemmParams& p, int prec);                 // p.gate_w layers: Cout == 32 or 128, Cin % 32 == 0
 void launch_conv3x3_halo16_gate(IgemmParams& p, int prec, hipStream_t stream);
 // conv3x3_gate.hip: 3x3 convs with 256 output channels (8 x 16 pixel tiles x all channels; fused LayerNorm / gate tail)

@@ -361,20 +361,37 @@ extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, 
 namespace prv2 {
 int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
                 const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
-                const float* gate_bias);
+                const float* gate_bias, const prv2_ups_src* ups);
 }
 
 extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
                            const float* ln_weight, const float* ln_bias, const float* gamma, const float* mul,
                            const float* res, const float* res2, float* y, void* stream) {
-  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, gamma, mul, res, res2, y, stream, nullptr, nullptr);
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, gamma, mul, res, res2, y, stream, nullptr, nullptr, nullptr);
 }
 
 // gate_w != null: the GatedConvUnit tail at 32 / 128 channels (prv2_conv3x3_ln_gate routes here; conv3x3_m16.hip GATE): mul / res then
 // belong to the final stage y = mul * sigmoid(W_g act(LN(conv + bias)) + gate_bias) (+ res)
+// fused-upsample loader (prv2.h): the layer's shape contract, checked on the descriptor alone
+static bool ups_shape_ok(const prv2_conv_desc* d, const prv2_ups_src* u) {
+  return d && u && u->x && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->convt_k == 0 && !d->same_pad && d->prec != PRV2_PREC_F32 &&
+         !d->force_generic && d->part == 0 && d->cout > 64 && d->w >= 24 && d->h >= 4 && !d->relu_in && u->channels > 0 && u->channels % 32 == 0 &&
+         u->channels <= d->cin && u->ld % 4 == 0 && u->ld >= u->channels && u->h >= 1 && u->w >= 1 && (long long)u->h * u->w * u->ld < (1LL << 29) &&
+         (long long)d->h * d->w * d->ldx < (1LL << 29) && !(getenv("PRV2_HALO_MFMA32") && getenv("PRV2_HALO_MFMA32")[0] == '1');
+}
+
+extern "C" int prv2_conv2d_ups_supported(const prv2_conv_desc* d, const prv2_ups_src* u) { return ups_shape_ok(d, u) ? 1 : 0; }
+
+extern "C" int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src* u, const void* w_packed, const float* bias,
+                               const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream) {
+  PRV2_REQUIRE(ups_shape_ok(d, u), "conv2d_ups: layer / source not covered (3x3 s1 p1, bf16 modes, cout > 64, width >= 24, channels %% 32 == 0, no input ReLU)");
+  PRV2_REQUIRE(aligned16(u->x) && (u->bstride % 4 == 0), "conv2d_ups: source must be 16-byte aligned");
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, res, nullptr, y, stream, nullptr, nullptr, u);
+}
+
 int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
                       const float* ln_bias, const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream,
-                      const void* gate_w, const float* gate_bias) {
+                      const void* gate_w, const float* gate_bias, const prv2_ups_src* ups) {
   PRV2_REQUIRE(d && x && w_packed && y, "conv2d: null pointer");
   PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -385,13 +402,18 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
   PRV2_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "conv2d: ln_weight and ln_bias go together");
   // 3x3 convs with 256 output channels (a layer property: the choice never depends on the batch): the workgroup holds the whole
   // channel row, so the LayerNorm is fused for this width too
-  if (!gate_w && !d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
+  if (!ups && !gate_w && !d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
     return prv2_conv3x3_ln_gate(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, nullptr, res, y, stream);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps;
   p.gate_w = gate_w; p.gate_bias = gate_bias;
+  if (ups) {
+    p.xu = ups->x; p.uH = ups->h; p.uW = ups->w; p.ldxu = ups->ld; p.ups_c = ups->channels;
+    p.xu_bstride = ups->bstride ? ups->bstride : (long long)ups->h * ups->w * ups->ld;
+    p.usy = ac_scale(ups->h, d->h); p.usx = ac_scale(ups->w, d->w);
+  }
   PRV2_REQUIRE(!ln_weight || (d->cout <= 128 && d->convt_k == 0), "conv2d: fused LayerNorm needs cout <= 128 (got %d)", d->cout);
   p.N = d->n; p.H = d->h; p.W = d->w;
   p.Cin = d->cin; p.Cin_pad = (int)roundup(d->cin, BK); p.Cout = d->cout;
@@ -465,6 +487,8 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
       PRV2_LAUNCH_CHECK("conv3x3_ln_gate(halo16)");
       return 0;
     }
+    PRV2_REQUIRE(!ups || conv3x3_halo16_ups_usable(p, d->prec), "conv2d_ups: layer not covered by the 128-column halo kernel (%d->%d, %dx%d, prec %d)",
+                 d->cin, d->cout, d->h, d->w, d->prec);
     if (strip && conv3x3_halo16_usable(p, d->prec)) {  // bf16 modes: tiles and strip are one launch
       PRV2_REQUIRE(d->part == 0, "conv2d: part=%d is only meaningful when the strip is a launch of its own (f32 mode)", d->part);
       p.rx0 = p.W - rem;
@@ -485,8 +509,8 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
     p.M = (long long)d->n * p.OH * rem;
     p.tiles_m = (int)cdiv(p.M, BM);
   } else
-  if (gate_w) {
-    PRV2_REQUIRE(false, "conv3x3_ln_gate: layer not covered by the gate kernel (%d->%d k%d, %dx%d)", d->cin, d->cout, d->kh, d->h, d->w);
+  if (gate_w || ups) {
+    PRV2_REQUIRE(false, "%s: layer not covered by the halo kernels (%d->%d k%d, %dx%d)", ups ? "conv2d_ups" : "conv3x3_ln_gate", d->cin, d->cout, d->kh, d->h, d->w);
   } else
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;

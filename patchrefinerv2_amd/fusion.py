@@ -127,10 +127,15 @@ class _EncDec(StateDictModule):
         feat = temps[L_ - 1] if nd > 0 else temps[0]
         for j, (c1, c2, dc) in enumerate(self.dec_in):
             buf = dec_bufs[j]
-            place(feat, buf.slice(0, c1))
             place_preds(pred1, pred2, buf, c1 + c2)
             c0w, c2w = P[f"{self.DEC}.{j}"]
-            t = ops.conv2d(buf, c0w, act=ACT_GELU)
+            if isinstance(feat, Feat) and ops.conv2d_ups_supported(buf, feat, c0w):
+                # bilinear(x1 -> size of x2) is formed inside the conv's tile loader (fusion_model.py:16-18): the upsampled x1 is
+                # never written; channels [0, c1) of ``buf`` stay unused
+                t = ops.conv2d_ups(buf, feat, c0w, act=ACT_GELU)
+            else:
+                place(feat, buf.slice(0, c1))
+                t = ops.conv2d(buf, c0w, act=ACT_GELU)
             feat = ops.conv2d(t, c2w, act=ACT_GELU)
         if self.trace is not None:  # tests: the last decoder stage, as the oracle sees it
             self.trace["dec_last"] = feat.to_nchw()
@@ -245,7 +250,8 @@ class BiDirectionalFusion(_EncDec):
         fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
         return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])
 
-    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True, dest=None, skip_out_conv=False) -> Feat:
+    def _gated_block(self, blk, xs: List[Feat], coarse: Feat, F_: int, size=None, upscale=True, dest=None, skip_out_conv=False,
+                     defer_upsample=None) -> Feat:
         """GatedFusionBlock.forward (bi_directional_fusion_model.py:116-146).  ``coarse`` may have a
         different size (it is resized while being placed).  The 1x1 ``out_conv`` is applied BEFORE the
         bilinear upsample: both are linear and the bilinear weights sum to one, so
@@ -259,6 +265,8 @@ class BiDirectionalFusion(_EncDec):
         out = self._gated_unit(blk["u2"], out, cat, F_)
         if upscale:
             y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])  # (skip: folded into the consumer's weights, _pack)
+            if defer_upsample is not None and ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample):
+                return y  # the consumer (a 3x3 conv) interpolates while it stages its tiles: ops.conv2d_ups
             return ops.upsample_bilinear(y, size[0], size[1], out=dest)
         return ops.conv2d(out, blk["out_conv"], dest)
 
@@ -273,12 +281,15 @@ class BiDirectionalFusion(_EncDec):
         path3 = self._gated_block(R[3], [path4, rn[2]], coarse[3], F_, size=(rn[1].h, rn[1].w), dest=dests[2])
         path2 = self._gated_block(R[2], [path3, rn[1]], coarse[2], F_, size=(rn[0].h, rn[0].w), dest=dests[1])
         folded = "out1_folded" in P
-        path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=(rn[0].h * 2, rn[0].w * 2), skip_out_conv=folded)
-        if folded:
-            out = ops.conv2d(path1, P["out1_folded"])
-            ops.conv_border_bias(out, P["out1_tap_bias"])
+        w1 = P["out1_folded"] if folded else P["out1"]
+        size1 = (rn[0].h * 2, rn[0].w * 2)
+        path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=size1, skip_out_conv=folded, defer_upsample=w1)
+        if (path1.h, path1.w) != size1:  # not upsampled yet: output_conv1 samples it bilinearly inside its loader (:139-142, :201)
+            out = ops.conv2d_ups(ops.UpsOnly(path1, *size1), path1, w1)
         else:
-            out = ops.conv2d(path1, P["out1"])
+            out = ops.conv2d(path1, w1)
+        if folded:
+            ops.conv_border_bias(out, P["out1_tap_bias"])
         last = ops.conv2d(out, P["out2_0"], act=ACT_RELU)
         last = self._gated_block(P["out2_fusion"], [last], coarse[0], self.coarse_chl[0], upscale=False, dest=dests[0])
         depth = ops.conv2d_cout1(last, P["out3_w"], P["out3_b"], 1)

@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvDesc(C.Structure):
@@ -33,6 +33,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class UpsSrc(C.Structure):  # prv2_ups_src
+    _fields_ = [("x", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("ld", C.c_int32), ("channels", C.c_int32), ("bstride", C.c_int64)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/prv2.h declares
@@ -43,6 +47,8 @@ SIGNATURES = {
     "prv2_packed_weight_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "prv2_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prv2_conv2d_ups_supported": (_I, [C.POINTER(ConvDesc), C.POINTER(UpsSrc)]),
+    "prv2_conv2d_ups": (_I, [C.POINTER(ConvDesc), _P, C.POINTER(UpsSrc), _P, _P, _P, _P, _P, _P, _P]),
     "prv2_conv2d_cout1": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _P]),
     "prv2_dwconv2d": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "prv2_dwconv2d_ex": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),

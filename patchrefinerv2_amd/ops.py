@@ -292,6 +292,55 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     return out
 
 
+UPS_FUSION = os.environ.get("PRV2_UPS_FUSION", "1") != "0"  # A/B and test switch: bilinear upsample fused into the consumer conv's loader
+
+
+def _ups_desc(x: Feat, u: Feat, cw: ConvW, out_ld: int, act: int, res_ld: int, ln_eps: float):
+    d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=x.ld, ldy=out_ld,
+                   x_bstride=0, y_bstride=0, relu_in=0, act=act, convt_k=cw.convt_k, ld_mul=0, ld_res=res_ld, ld_res2=0, prec=cw.prec,
+                   force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+    us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
+    return d, us
+
+
+class UpsOnly:
+    """the ``x`` of ``conv2d_ups`` when EVERY input channel comes from the upsampled source (u.c == cin): only the output size"""
+
+    def __init__(self, u: Feat, h: int, w: int):
+        self.n, self.h, self.w, self.c, self.ld, self.ptr, self.device = u.n, h, w, u.c, u.ld, u.ptr, u.device
+
+
+def conv2d_ups_supported(x, u: Feat, cw: ConvW) -> bool:
+    """can ``conv2d_ups`` fuse the upsample of ``u`` (the first u.c input channels) into this 3x3 conv's loader?  A property of the
+    layer (channels, per-image size, arithmetic mode) -- never of the batch."""
+    if not UPS_FUSION or DISPATCH == "torch" or type(x) not in (Feat, UpsOnly) or type(u) is not Feat or x.n != u.n or (x.h, x.w) == (u.h, u.w):
+        return False
+    d, us = _ups_desc(x, u, cw, roundup(cw.cout, 4), ACT_NONE, 0, 1e-6)
+    return bool(L.load().prv2_conv2d_ups_supported(C.byref(d), C.byref(us)))
+
+
+def conv2d_ups(x: Feat, u: Feat, cw: ConvW, out: Optional[Feat] = None, *, act: int = ACT_NONE, res: Optional[Feat] = None, ln=None,
+               ln_eps: float = 1e-6) -> Feat:
+    """3x3 conv over the VIRTUAL concat [bilinear_align_corners(u -> x.h x x.w) | x[..., u.c:]]: channels [0, u.c) are interpolated
+    from the low-resolution ``u`` inside the conv's tile loader (include/prv2.h::prv2_conv2d_ups); ``x`` supplies the rest at
+    their usual channel offsets (its first u.c channels are never read).  Bit-identical to upsample_bilinear(u, out=x.slice(0, u.c))
+    followed by conv2d(x, cw)."""
+    assert x.c == cw.cin and u.c <= x.c and (u.n, x.n) == (x.n, u.n)
+    oh, ow = conv_out_hw(cw, x.h, x.w)
+    if out is None:
+        out = Feat.alloc(x.n, oh, ow, cw.cout, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, oh, ow, cw.cout)
+    d, us = _ups_desc(x, u, cw, out.ld, act, res.ld if res is not None else 0, ln_eps)
+
+    def call():
+        L.check(L.load().prv2_conv2d_ups(C.byref(d), x.ptr, C.byref(us), cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
+                                         _ptr(ln[1]) if ln is not None else None, _ptr(res), out.ptr, _stream()), "conv2d_ups")
+
+    shape = f"{cw.cin}->{cw.cout} k3s1 {x.n}x{x.h}x{x.w} (+up {u.c}ch {u.h}x{u.w})"
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), 2.0 * x.n * oh * ow * cw.cout * cw.cin * 9, call, shape=shape)
+    return out
+
+
 GATE_FUSION = os.environ.get("PRV2_GATE_FUSION", "1") != "0"  # A/B and test switch: GatedConvUnit tail as one kernel
 # widths F of a GatedConvUnit the library fuses (prv2_conv3x3_ln_gate); PRV2_GATE_CHANNELS=256 restricts them for A/B runs
 GATE_CHANNELS = tuple(int(c) for c in os.environ.get("PRV2_GATE_CHANNELS", "32,128,256").split(","))

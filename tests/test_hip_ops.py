@@ -749,3 +749,64 @@ def test_layernorm_ss_and_attention_ss_feed_gemm_ss_bit_equal(P):
     a = P.attention(qkv, B, N, H, P.L.PREC_BF16X3)
     a_ss = P.attention(qkv, B, N, H, P.L.PREC_BF16X3, out_ss=True)
     assert torch.equal(P.linear(a, cwp), P.gemm_ss(a_ss, cwp))
+
+
+UPS_CASES = [
+    # n, (h, w) of the low-resolution source, (H, W) of the conv, source channels c1, cin, cout
+    (2, (24, 32), (48, 64), 256, 256, 128),      # output_conv1: every channel comes from the upsampled path_1 (x2)
+    (1, (20, 33), (40, 66), 64, 98, 98),         # f2r_agg: [up(x1) 64 | x2 32 | pred1 | pred2], tail tile, width 64 + a 2-column strip
+    (2, (13, 17), (25, 33), 128, 194, 194),      # ragged pyramid sizes (not x2), ragged rows
+    (1, (12, 16), (24, 32), 512, 770, 770),      # the lowest decoder stage
+    (1, (6, 9), (29, 70), 32, 66, 130),          # strong zoom, strip of 6 columns, cout over one 128-column tile
+]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", UPS_CASES)
+def test_conv2d_ups_equals_upsample_then_conv(P, case, prec):
+    """prv2_conv2d_ups (bilinear(align_corners) upsample of the first c1 input channels formed inside the 3x3 conv's tile loader:
+    fusion_model.py:15-24, bi_directional_fusion_model.py:139-142,201) == prv2_upsample_bilinear into the concat buffer followed by
+    prv2_conv2d, BIT FOR BIT; the first c1 channels of the concat buffer are never read (NaN-filled here)"""
+    n, (h, w), (H, W), c1, cin, cout = case
+    PR = P.L.PREC_NAMES[prec]
+    u = P.Feat.from_nchw(rnd(1, n, c1, h, w).to(DEV))
+    rest = rnd(2, n, cin - c1, H, W).to(DEV) if cin > c1 else None
+    cw = P.pack_conv((rnd(3, cout, cin, 3, 3) / np.sqrt(9 * cin)).to(DEV), rnd(4, cout).to(DEV), pad=1, prec=PR)
+    res = P.Feat.from_nchw(rnd(5, n, cout, H, W).to(DEV))
+
+    def concat(fill_nan):
+        x = P.Feat.alloc(n, H, W, cin, DEV)
+        if rest is not None:
+            x.buf[..., c1:cin] = rest.permute(0, 2, 3, 1)
+        if fill_nan:
+            x.buf[..., :c1] = float("nan")
+        return x
+
+    xr = concat(False)
+    P.upsample_bilinear(u, H, W, out=xr.slice(0, c1))
+    ref = P.conv2d(xr, cw, act=P.ACT_GELU, res=res)
+    ref_kernel = P.L.load().prv2_last_kernel().decode()
+    x = concat(True) if cin > c1 else P.UpsOnly(u, H, W)
+    assert P.conv2d_ups_supported(x, u, cw)
+    got = P.conv2d_ups(x, u, cw, act=P.ACT_GELU, res=res)
+    assert "ups" in P.L.load().prv2_last_kernel().decode() and "ups" not in ref_kernel
+    assert bool(torch.isfinite(got.buf).all())
+    assert torch.equal(got.buf, ref.buf), float((got.buf - ref.buf).abs().max())
+    # and against plain torch (fp32): the layer itself
+    want = F.gelu(F.conv2d(torch.cat([F.interpolate(u.to_nchw().cpu(), (H, W), mode="bilinear", align_corners=True)] +
+                                     ([rest.cpu()] if rest is not None else []), 1), rnd(3, cout, cin, 3, 3) / np.sqrt(9 * cin), rnd(4, cout), padding=1)) + res.to_nchw().cpu()
+    close(got.to_nchw(), want, 3e-5 if prec == "bf16x3" else 2e-2, "conv2d_ups vs torch")
+
+
+def test_conv2d_ups_rejects_what_it_does_not_cover(P):
+    PR = P.L.PREC_NAMES["bf16x3"]
+    u = P.Feat.from_nchw(rnd(1, 1, 64, 12, 16).to(DEV))
+    x = P.Feat.alloc(1, 24, 32, 98, DEV)
+    ok = P.pack_conv(rnd(2, 98, 98, 3, 3).to(DEV), None, pad=1, prec=PR)
+    assert P.conv2d_ups_supported(x, u, ok)
+    assert not P.conv2d_ups_supported(x, u, P.pack_conv(rnd(2, 32, 98, 3, 3).to(DEV), None, pad=1, prec=PR))             # narrow kernels
+    assert not P.conv2d_ups_supported(x, u, P.pack_conv(rnd(2, 98, 98, 3, 3).to(DEV), None, pad=1, prec=P.L.PREC_NAMES["f32"]))
+    assert not P.conv2d_ups_supported(x, P.Feat.from_nchw(rnd(1, 1, 48, 12, 16).to(DEV)), ok)                            # channels % 32
+    assert not P.conv2d_ups_supported(P.Feat.alloc(1, 24, 16, 98, DEV), P.Feat.from_nchw(rnd(1, 1, 64, 12, 8).to(DEV)), ok)  # width < 24
+    with pytest.raises(RuntimeError):
+        P.conv2d_ups(P.Feat.alloc(1, 24, 16, 98, DEV), P.Feat.from_nchw(rnd(1, 1, 64, 12, 8).to(DEV)), ok)
