@@ -231,7 +231,9 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
       rs.w = hl.rsrc.w;
       // (an OOB base stays out of range with the tap offsets added: image extents are < 2^29 floats)
       const unsigned o0 = ups ? hu.off[it] + (unsigned)(cc * BK * 4) : a_voff(hl, cc, it);
-      const unsigned dx = ((hu.edge >> (2 * it)) & 1u) ? u_dx : 0u, dy = ((hu.edge >> (2 * it + 1)) & 1u) ? u_dy : 0u;
+      unsigned edge = hu.edge;
+      asm volatile("" : "+v"(edge));  // opaque: the tap offsets are formed here, per load -- hoisted out of the slab loop they cost 18 registers
+      const unsigned dx = ((edge >> (2 * it)) & 1u) ? u_dx : 0u, dy = ((edge >> (2 * it + 1)) & 1u) ? u_dy : 0u;
       const unsigned o1 = ups ? o0 + dx : OOB, o2 = ups ? o0 + dy : OOB, o3 = ups ? o0 + dx + dy : OOB;
       asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][0]) : "v"(o0), "s"(rs) : "memory");
       asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][LPI - 3]) : "v"(o1), "s"(rs) : "memory");
@@ -252,7 +254,9 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
     f32x4 v_in = ra[it][0];
     if constexpr (UPS) {
       if (cc_item < ups_slabs) {  // block-uniform; upsample_bilinear_kernel's operation order (gather.hip), element by element
-        const float w1x = hu.wx[it], w0x = 1.0f - w1x, w1y = hu.wy[it], w0y = 1.0f - w1y;
+        float w1x = hu.wx[it], w1y = hu.wy[it];
+        asm volatile("" : "+v"(w1x), "+v"(w1y));  // opaque: 1 - w is recomputed per item instead of living in 12 more registers
+        const float w0x = 1.0f - w1x, w0y = 1.0f - w1y;
         f32x4 top = {0.f, 0.f, 0.f, 0.f}, bot = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
