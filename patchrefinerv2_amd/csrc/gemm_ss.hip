@@ -151,8 +151,14 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
     for (int k = 0; k < p.kslabs; ++k) {
       // my DMAs of slab k have landed; behind the barrier everyone's have, and everyone is done reading the other stage
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PRV2_GSS_NODMA  // timing ablation (results wrong; profiles/r03_experiments.txt): only the first two slabs are ever fetched
+      if (k + 1 < p.kslabs && k < 1) issue((k + 1) & 1, k + 1);
+#else
       if (k + 1 < p.kslabs) issue((k + 1) & 1, k + 1);
+#endif
+#ifndef PRV2_GSS_NOMMA  // timing ablation (results wrong): the DMA stream alone
       compute(k & 1);
+#endif
     }
     asm volatile("s_barrier" ::: "memory");  // the staging memory becomes the epilogue strips
   } else {
@@ -324,6 +330,16 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
     }                                                                                                                                  \
   } while (0)
   const char* const be = getenv("PRV2_GEMM_SS_BLOCKED");  // A/B switch
+  if (force == 2563 || force == 1283) {  // experiments (profiles/r03_experiments.txt): 256 x 128 / 128 x 256 tiles, three 48 KB stages
+    const int tm = force == 1283 ? 128 : 256, tn = force == 1283 ? 256 : 128;
+    p.tiles_n = (int)cdiv(n, tn);
+    p.tiles_m = (int)cdiv(m, tm);
+    p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
+    const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
+    if (force == 2563) PRV2_GSS(2, 4, 8, 2, 512, 3);
+    else PRV2_GSS(2, 4, 4, 4, 512, 3);
+    set_kernel("gemm_ss_kernel", 256, PRV2_PREC_BF16X3);
+  } else
   if (big) {
     p.tiles_n = (int)cdiv(n, 256);
     p.tiles_m = (int)cdiv(m, 256);
