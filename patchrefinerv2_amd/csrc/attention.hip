@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
 
   // Q fragments (B operand of S^T): lane (q = r32, half) holds Q[q][16ks + 8half + j]
   const int q_row = qt * AT_BQ + wave * 32 + r32;
+  const bool wave_active = qt * AT_BQ + wave * 32 < N;  // wave-uniform
   bf16x8 qh[4], ql[4];
   {
     const __bf16* qp = Qs + (bh * N + (q_row < N ? q_row : 0)) * 128 + half * 8;
@@ -368,6 +369,10 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
     }
     __syncthreads();
     if (k0 + AT_BK < N) fetch(k0 + AT_BK);
+    // A wave without a single valid query only helps staging K / V: 1025 (DINOv2) and 769 (BEiT) tokens are 8 resp. 6 full
+    // query tiles plus ONE query -- three of the last workgroup's four waves would otherwise run all 96 MFMAs per key tile on
+    // garbage (a ninth / seventh of the launch's matrix work)
+    if (!wave_active) return;
 
     // S^T tiles: rows = keys (t*32 + row), cols = this wave's 32 queries
     f32x16 st[2];
