@@ -368,7 +368,9 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
         *reinterpret_cast<uint2*>(Vt + ld_row * AB_VP + ld_q * 64 + i * 8) = vreg[i];
     }
     __syncthreads();
+#ifndef PRV2_ATT_ABL_NOFETCH
     if (k0 + AT_BK < N) fetch(k0 + AT_BK);
+#endif
     // A wave without a single valid query only helps staging K / V: 1025 (DINOv2) and 769 (BEiT) tokens are 8 resp. 6 full
     // query tiles plus ONE query -- three of the last workgroup's four waves would otherwise run all 96 MFMAs per key tile on
     // garbage (a ninth / seventh of the launch's matrix work)
@@ -408,6 +410,7 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
           st[t][e] = key < N ? st[t][e] : -INFINITY;
         }
     }
+#ifndef PRV2_ATT_ABL_NOSOFTMAX  // timing ablation (results wrong; profiles/r03_experiments.txt)
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -429,6 +432,9 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
     m_run = m_new;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o_acc[0][e] *= corr; o_acc[1][e] *= corr; }
+#else
+    l_run += st[0][0];
+#endif
 
     // O^T += V^T P^T : B fragments straight from the P^T accumulators, A = V^T rows from LDS
 #pragma unroll
@@ -438,8 +444,13 @@ __global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* 
         f32x4 p0 = {st[t][8 * s], st[t][8 * s + 1], st[t][8 * s + 2], st[t][8 * s + 3]};
         f32x4 p1 = {st[t][8 * s + 4], st[t][8 * s + 5], st[t][8 * s + 6], st[t][8 * s + 7]};
         bf16x4 h0, l0, h1, l1;
+#ifndef PRV2_ATT_ABL_NOSPLIT
         split4(p0, h0, l0);
         split4(p1, h1, l1);
+#else
+        h0 = __builtin_bit_cast(bf16x4, __builtin_shufflevector(p0, p0, 0, 1)); l0 = __builtin_bit_cast(bf16x4, __builtin_shufflevector(p0, p0, 2, 3));
+        h1 = __builtin_bit_cast(bf16x4, __builtin_shufflevector(p1, p1, 0, 1)); l1 = __builtin_bit_cast(bf16x4, __builtin_shufflevector(p1, p1, 2, 3));
+#endif
         const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         const int koff = (t * 32 + s * 16 + half * 4) * 2;  // bytes; element j -> key + 8*(j>>2) + (j&3)
