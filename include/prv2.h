@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 9
+#define PRV2_ABI_VERSION 10
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -118,6 +118,18 @@ typedef struct prv2_ups_src {
 int prv2_conv2d_ups_supported(const prv2_conv_desc* d, const prv2_ups_src* u);
 int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src* u, const void* w_packed, const float* bias,
                     const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream);
+
+/* prv2_conv2d (3x3 / stride 1 / pad 1, bias, [LayerNorm,] activation, [+ res]) that ALSO writes the two depth maps every fusion
+ * level appends to its features behind its own output channels: y[pixel][cout .. cout + 3] = (p1, p2, 0, 0), p1 / p2 dense
+ * [n, ph, pw] resized bilinear(align_corners=True) to the output size -- the ``torch.cat([f, pred1, pred2])`` of
+ * fusion_model.py:91-118 / bi_directional_fusion_model.py:424-436 closed by the conv that fills the rest of the row, instead of a
+ * prv2_depth_pair_fill launch of 16-byte stores into 400-byte rows.  Same arithmetic as prv2_conv2d + prv2_depth_pair_fill.
+ * Contract (prv2_conv2d_tail_supported(d) != 0): bf16 modes, 3x3 s1 p1, width >= 24, height >= 4, cout % 4 == 0 and <= 128 (the
+ * widths whose LayerNorm the halo kernels fuse), ldy >= cout + 4, LayerNorm or residual but not both. */
+int prv2_conv2d_tail_supported(const prv2_conv_desc* d);
+int prv2_conv2d_tail(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
+                     const float* ln_bias, const float* res, const float* p1, const float* p2, int32_t ph, int32_t pw, float* y,
+                     void* stream);
 
 /* GatedConvUnit tail in one kernel (estimator/models/blocks/bi_directional_fusion_model.py:44-51 ``fusion_conv`` =
  * Conv3x3(2F -> F) . LayerNorm(channels_first) . ReLU . Conv1x1(F -> F) . Sigmoid, and :70-80 ``out * fusion (+ xs[0])``):

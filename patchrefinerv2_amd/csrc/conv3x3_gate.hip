@@ -616,7 +616,7 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
     PRV2_REQUIRE(gate_narrow_shape_ok(d) && ln_weight, "conv3x3_ln_gate: 3x3 s1 p1, cout 32 / 128 / 256, cin %% 32 == 0, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
                  d->h, d->w, d->cin, d->cout, d->kh, d->stride, d->prec);
     PRV2_REQUIRE(d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate: ReLU or no activation in front of the gate (act %d)", d->act);
-    return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, mul, res, nullptr, y, stream, gate_w_packed, gate_bias, nullptr);
+    return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, mul, res, nullptr, y, stream, gate_w_packed, gate_bias, nullptr, nullptr, nullptr, 0, 0);
   }
   PRV2_REQUIRE(ln_weight || !gate_w_packed, "conv3x3_ln_gate: the gate stage sits behind the LayerNorm");
   PRV2_REQUIRE(gate_conv_shape_ok(d), "conv3x3_ln_gate: 3x3 s1 p1, cout 256, cin %% 32 == 0, width >= 16, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",

@@ -712,6 +712,34 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
         }
       };
+      if (p.tail1 && col4 == 0 && c.tile_n == p.tiles_n - 1) {
+        // [pred1 | pred2 | 0 | 0] behind the Cout channels of this thread's rows: depth_pair_fill_kernel's arithmetic (gather.hip),
+        // one 16-byte store per pixel that completes the row the loop below writes (fusion_model.py:91-118)
+        float* const tbase = p.y + (long long)c.n_img * p.y_bstride + p.Cout;
+        const float* const t1 = p.tail1 + (long long)c.n_img * p.tH * p.tW;
+        const float* const t2 = p.tail2 + (long long)c.n_img * p.tH * p.tW;
+        for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+          const int py = rr / TW, px = rr - py * TW;
+          const int oy = c.y0 + py, ox = c.x0 + px;
+          if (oy >= p.H || ox >= p.W) continue;
+          const AxisTap ty = ac_tap(oy, p.tsy, p.tH), tx = ac_tap(ox, p.tsx, p.tW);
+          auto interp = [&](const float* q) {
+            const float v00 = q[ty.i0 * p.tW + tx.i0], v01 = q[ty.i0 * p.tW + tx.i1];
+            const float v10 = q[ty.i1 * p.tW + tx.i0], v11 = q[ty.i1 * p.tW + tx.i1];
+            float top = 0.f, bot = 0.f, r = 0.f;
+            top += tx.w0 * v00;
+            top += tx.w1 * v01;
+            bot += tx.w0 * v10;
+            bot += tx.w1 * v11;
+            r += ty.w0 * top;
+            r += ty.w1 * bot;
+            return r;
+          };
+          const f32x4 ov = {interp(t1), interp(t2), 0.f, 0.f};
+          float* dst = tbase + (unsigned)((oy * p.W + ox) * p.ldy);
+          asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+        }
+      }
       using T_ = std::true_type;
       using F_ = std::false_type;
       dispatch_act(p.act, [&](auto act_c) {

@@ -46,6 +46,12 @@ struct IgemmParams {
   int uH, uW, ldxu, ups_c;
   long long xu_bstride;
   float usy, usx;      // ac_scale(uH, H), ac_scale(uW, W)
+  // conv3x3_m16.hip: [pred1 | pred2 | 0 | 0] written behind the Cout channels of every output pixel (prv2_conv2d_tail): the two
+  // dense 1-channel maps tail1 / tail2 [N, tH, tW] resized bilinear(align_corners=True) to the output size.  null: none.
+  const float* tail1;
+  const float* tail2;
+  int tH, tW;
+  float tsy, tsx;
 };
 
 // fragment-major gate weights: [16-column block cb][32-channel slab ks][hi, lo][lane 64] x 16 B, lane (m = lane & 15, g = lane >> 4)
@@ -306,8 +312,9 @@ bool conv3x3_halo16_usable(const IgemmParams& p, int prec);
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t stream);  // tiles [0, tiles_x) + strip [rx0, rx0 + rw)
 int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
                 const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
-                const float* gate_bias, const prv2_ups_src* ups = nullptr);  // igemm.hip: prv2_conv2d, with the optional gate stage of
-                                                                             // the 32 / 128-channel layers / the fused-upsample loader
+                const float* gate_bias, const prv2_ups_src* ups = nullptr, const float* tail1 = nullptr, const float* tail2 = nullptr,
+                int tail_h = 0, int tail_w = 0);  // igemm.hip: prv2_conv2d, with the optional gate stage of the 32 / 128-channel layers /
+                                                  // the fused-upsample loader / the depth-pair tail
 bool conv3x3_halo16_ups_usable(const IgemmParams& p, int prec);  // p.xu layers (prv2_conv2d_ups): the 128-column 16x16x32 halo kernel
 bool conv3x3_halo16_gate_usable(const IgemmParams& p, int prec);                 // p.gate_w layers: Cout == 32 or 128, Cin % 32 == 0
 void launch_conv3x3_halo16_gate(IgemmParams& p, int prec, hipStream_t stream);

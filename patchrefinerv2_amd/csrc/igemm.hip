@@ -361,13 +361,13 @@ extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, 
 namespace prv2 {
 int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
                 const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
-                const float* gate_bias, const prv2_ups_src* ups);
+                const float* gate_bias, const prv2_ups_src* ups, const float* tail1, const float* tail2, int tail_h, int tail_w);
 }
 
 extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
                            const float* ln_weight, const float* ln_bias, const float* gamma, const float* mul,
                            const float* res, const float* res2, float* y, void* stream) {
-  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, gamma, mul, res, res2, y, stream, nullptr, nullptr, nullptr);
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, gamma, mul, res, res2, y, stream, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0);
 }
 
 // gate_w != null: the GatedConvUnit tail at 32 / 128 channels (prv2_conv3x3_ln_gate routes here; conv3x3_m16.hip GATE): mul / res then
@@ -386,12 +386,31 @@ extern "C" int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const pr
                                const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream) {
   PRV2_REQUIRE(ups_shape_ok(d, u), "conv2d_ups: layer / source not covered (3x3 s1 p1, bf16 modes, cout > 64, width >= 24, channels %% 32 == 0, no input ReLU)");
   PRV2_REQUIRE(aligned16(u->x) && (u->bstride % 4 == 0), "conv2d_ups: source must be 16-byte aligned");
-  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, res, nullptr, y, stream, nullptr, nullptr, u);
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, res, nullptr, y, stream, nullptr, nullptr, u, nullptr, nullptr, 0, 0);
+}
+
+// depth-pair tail (prv2.h): the layer must end in the lean store loop of the 16x16x32 halo kernels
+static bool tail_shape_ok(const prv2_conv_desc* d) {
+  return d && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->convt_k == 0 && !d->same_pad && d->prec != PRV2_PREC_F32 &&
+         !d->force_generic && d->part == 0 && d->w >= 24 && d->h >= 4 && d->cout % 4 == 0 && d->ldy >= d->cout + 4 && d->ldy % 4 == 0 &&
+         d->cout <= 128 && (long long)d->h * d->w * d->ldx < (1LL << 29) && (long long)d->h * d->w * d->ldy < (1LL << 31) &&
+         !(getenv("PRV2_HALO_MFMA32") && getenv("PRV2_HALO_MFMA32")[0] == '1');
+}
+
+extern "C" int prv2_conv2d_tail_supported(const prv2_conv_desc* d) { return tail_shape_ok(d) ? 1 : 0; }
+
+extern "C" int prv2_conv2d_tail(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
+                                const float* ln_bias, const float* res, const float* p1, const float* p2, int32_t ph, int32_t pw, float* y,
+                                void* stream) {
+  PRV2_REQUIRE(tail_shape_ok(d) && p1 && p2 && ph > 0 && pw > 0 && !(ln_weight && res),
+               "conv2d_tail: layer not covered (3x3 s1 p1, bf16 modes, width >= 24, cout %% 4 == 0 and <= 128, ldy >= cout + 4, LayerNorm or residual but not both)");
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, res, nullptr, y, stream, nullptr, nullptr, nullptr, p1, p2, ph, pw);
 }
 
 int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
                       const float* ln_bias, const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream,
-                      const void* gate_w, const float* gate_bias, const prv2_ups_src* ups) {
+                      const void* gate_w, const float* gate_bias, const prv2_ups_src* ups, const float* tail1, const float* tail2, int tail_h,
+                      int tail_w) {
   PRV2_REQUIRE(d && x && w_packed && y, "conv2d: null pointer");
   PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -409,6 +428,10 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps;
   p.gate_w = gate_w; p.gate_bias = gate_bias;
+  if (tail1) {
+    p.tail1 = tail1; p.tail2 = tail2; p.tH = tail_h; p.tW = tail_w;
+    p.tsy = ac_scale(tail_h, d->h); p.tsx = ac_scale(tail_w, d->w);
+  }
   if (ups) {
     p.xu = ups->x; p.uH = ups->h; p.uW = ups->w; p.ldxu = ups->ld; p.ups_c = ups->channels;
     p.xu_bstride = ups->bstride ? ups->bstride : (long long)ups->h * ups->w * ups->ld;
@@ -489,6 +512,8 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
     }
     PRV2_REQUIRE(!ups || conv3x3_halo16_ups_usable(p, d->prec), "conv2d_ups: layer not covered by the 128-column halo kernel (%d->%d, %dx%d, prec %d)",
                  d->cin, d->cout, d->h, d->w, d->prec);
+    PRV2_REQUIRE(!tail1 || (conv3x3_halo16_usable(p, d->prec) && p.vec_epi), "conv2d_tail: layer not covered by the 16x16x32 halo kernels (%d->%d, %dx%d, prec %d)",
+                 d->cin, d->cout, d->h, d->w, d->prec);
     if (strip && conv3x3_halo16_usable(p, d->prec)) {  // bf16 modes: tiles and strip are one launch
       PRV2_REQUIRE(d->part == 0, "conv2d: part=%d is only meaningful when the strip is a launch of its own (f32 mode)", d->part);
       p.rx0 = p.W - rem;
@@ -509,8 +534,8 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
     p.M = (long long)d->n * p.OH * rem;
     p.tiles_m = (int)cdiv(p.M, BM);
   } else
-  if (gate_w || ups) {
-    PRV2_REQUIRE(false, "%s: layer not covered by the halo kernels (%d->%d k%d, %dx%d)", ups ? "conv2d_ups" : "conv3x3_ln_gate", d->cin, d->cout, d->kh, d->h, d->w);
+  if (gate_w || ups || tail1) {
+    PRV2_REQUIRE(false, "%s: layer not covered by the halo kernels (%d->%d k%d, %dx%d)", ups ? "conv2d_ups" : (tail1 ? "conv2d_tail" : "conv3x3_ln_gate"), d->cin, d->cout, d->kh, d->h, d->w);
   } else
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;

@@ -106,6 +106,17 @@ class _EncDec(StateDictModule):
             h, w = sizes[L_ - 2 - j]
             dec_bufs.append(alloc_with_pred_tail(B, h, w, c1 + c2, dev))
         temps = [None] * L_
+        dec_tail_done = [False] * nd  # decoder concat buffers whose [pred1 | pred2] tail the conv that fills x2 has written
+
+        def conv_ln_gelu(x, conv, lnw, lnb, dst, tail_c0=None, buf=None):
+            """conv -> LN -> GELU (convs.py:67-72) into ``dst``; when dst's row ends in the [pred1 | pred2] tail and the library fuses
+            it, the same launch writes the tail (ops.conv2d_tail); returns whether it did"""
+            if tail_c0 is not None and _fused_tail(tail_c0) and ops.conv2d_tail_supported(x, conv, dst):
+                ops.conv2d_tail(x, conv, dst, pred1, pred2, act=ACT_GELU, ln=(lnw, lnb))
+                return True
+            ops.conv2d(x, conv, dst, act=ACT_GELU, ln=(lnw, lnb))
+            return False
+
         for l in range(L_):
             h, w = sizes[l]
             tc = self.temp_chl[l]
@@ -113,21 +124,24 @@ class _EncDec(StateDictModule):
             pairs[l](cat1)
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
             cat2 = alloc_with_pred_tail(B, h, w, tc, dev)
-            ops.conv2d(cat1, conv, cat2.slice(0, tc), act=ACT_GELU, ln=(lnw, lnb))  # conv -> LN -> GELU (convs.py:67-72)
-            place_preds(pred1, pred2, cat2, tc)
+            if not conv_ln_gelu(cat1, conv, lnw, lnb, cat2.slice(0, tc), tail_c0=tc):
+                place_preds(pred1, pred2, cat2, tc)
             conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
             j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
             if 0 <= j < nd:
                 c1, c2, _ = self.dec_in[j]
                 assert c2 == tc
                 dst = dec_bufs[j].slice(c1, c2)
+                dec_tail_done[j] = conv_ln_gelu(cat2, conv, lnw, lnb, dst, tail_c0=c1 + c2)
             else:
                 dst = Feat.alloc(B, h, w, tc, dev)
-            temps[l] = ops.conv2d(cat2, conv, dst, act=ACT_GELU, ln=(lnw, lnb))
+                ops.conv2d(cat2, conv, dst, act=ACT_GELU, ln=(lnw, lnb))
+            temps[l] = dst
         feat = temps[L_ - 1] if nd > 0 else temps[0]
         for j, (c1, c2, dc) in enumerate(self.dec_in):
             buf = dec_bufs[j]
-            place_preds(pred1, pred2, buf, c1 + c2)
+            if not dec_tail_done[j]:
+                place_preds(pred1, pred2, buf, c1 + c2)
             c0w, c2w = P[f"{self.DEC}.{j}"]
             if isinstance(feat, Feat) and ops.conv2d_ups_supported(buf, feat, c0w):
                 # bilinear(x1 -> size of x2) is formed inside the conv's tile loader (fusion_model.py:16-18): the upsampled x1 is

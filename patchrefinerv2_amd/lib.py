@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(C.Structure):
@@ -49,6 +49,8 @@ SIGNATURES = {
     "prv2_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prv2_conv2d_ups_supported": (_I, [C.POINTER(ConvDesc), C.POINTER(UpsSrc)]),
     "prv2_conv2d_ups": (_I, [C.POINTER(ConvDesc), _P, C.POINTER(UpsSrc), _P, _P, _P, _P, _P, _P, _P]),
+    "prv2_conv2d_tail_supported": (_I, [C.POINTER(ConvDesc)]),
+    "prv2_conv2d_tail": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "prv2_conv2d_cout1": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _F, _P, _I, _P, _P]),
     "prv2_dwconv2d": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "prv2_dwconv2d_ex": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),

@@ -341,6 +341,40 @@ def conv2d_ups(x: Feat, u: Feat, cw: ConvW, out: Optional[Feat] = None, *, act: 
     return out
 
 
+TAIL_FUSION = os.environ.get("PRV2_TAIL_FUSION", "1") != "0"  # A/B and test switch: [pred1 | pred2] tails written by the conv that fills the row
+
+
+def _tail_desc(x: Feat, cw: ConvW, out: Feat, act: int, res_ld: int, ln_eps: float):
+    return L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=x.ld, ldy=out.ld,
+                      x_bstride=0, y_bstride=0, relu_in=0, act=act, convt_k=cw.convt_k, ld_mul=0, ld_res=res_ld, ld_res2=0, prec=cw.prec,
+                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+
+
+def conv2d_tail_supported(x: Feat, cw: ConvW, out: Feat) -> bool:
+    """can ``conv2d_tail`` close the [.. | pred1 | pred2 | 0 | 0] row behind this conv's output slice?  (a property of the layer)"""
+    if not TAIL_FUSION or not DIRECT_PLACEMENT or DISPATCH == "torch" or type(x) is not Feat or out.ld != out.c0 + cw.cout + 4 or (out.c0 + cw.cout) % 4:
+        return False
+    d = _tail_desc(x, cw, out, ACT_NONE, 0, 1e-6)
+    return bool(L.load().prv2_conv2d_tail_supported(C.byref(d)))
+
+
+def conv2d_tail(x: Feat, cw: ConvW, out: Feat, p1: Feat, p2: Feat, *, act: int = ACT_NONE, ln=None, ln_eps: float = 1e-6) -> Feat:
+    """conv2d(x, cw, out, act=, ln=) that also writes (p1, p2, 0, 0) -- the two dense depth maps resized bilinear(align_corners) to
+    the output size -- into the four channels behind ``out``'s slice (include/prv2.h::prv2_conv2d_tail); bit-identical to
+    conv2d + depth_pair_fill"""
+    assert x.c == cw.cin and (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and out.ld == out.c0 + cw.cout + 4
+    assert p1.c == 1 and p2.c == 1 and p1.ld == 1 and p2.ld == 1 and (p1.n, p1.h, p1.w) == (p2.n, p2.h, p2.w) and p1.n == x.n
+    d = _tail_desc(x, cw, out, act, 0, ln_eps)
+
+    def call():
+        L.check(L.load().prv2_conv2d_tail(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
+                                          _ptr(ln[1]) if ln is not None else None, None, p1.ptr, p2.ptr, p1.h, p1.w, out.ptr, _stream()), "conv2d_tail")
+
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), 2.0 * x.n * x.h * x.w * cw.cout * cw.cin * 9, call,
+                    shape=f"{cw.cin}->{cw.cout} k3s1 {x.n}x{x.h}x{x.w} (+tail)")
+    return out
+
+
 GATE_FUSION = os.environ.get("PRV2_GATE_FUSION", "1") != "0"  # A/B and test switch: GatedConvUnit tail as one kernel
 # widths F of a GatedConvUnit the library fuses (prv2_conv3x3_ln_gate); PRV2_GATE_CHANNELS=256 restricts them for A/B runs
 GATE_CHANNELS = tuple(int(c) for c in os.environ.get("PRV2_GATE_CHANNELS", "32,128,256").split(","))

@@ -810,3 +810,32 @@ def test_conv2d_ups_rejects_what_it_does_not_cover(P):
     assert not P.conv2d_ups_supported(P.Feat.alloc(1, 24, 16, 98, DEV), P.Feat.from_nchw(rnd(1, 1, 64, 12, 8).to(DEV)), ok)  # width < 24
     with pytest.raises(RuntimeError):
         P.conv2d_ups(P.Feat.alloc(1, 24, 16, 98, DEV), P.Feat.from_nchw(rnd(1, 1, 64, 12, 8).to(DEV)), ok)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 66, 64, 32, 14, 18), (1, 25, 33, 130, 64, 25, 33), (2, 24, 32, 258, 128, 48, 64), (1, 29, 70, 66, 100, 8, 9)])
+def test_conv2d_tail_equals_conv_then_depth_pair_fill(P, case):
+    """prv2_conv2d_tail (conv + LayerNorm + GELU that also closes the row with [pred1 | pred2 | 0 | 0], fusion_model.py:91-118) ==
+    prv2_conv2d followed by prv2_depth_pair_fill, bit for bit -- as a slice of a wider concat buffer too"""
+    n, H, W, cin, cout, ph, pw = case
+    PR = P.L.PREC_NAMES["bf16x3"]
+    x = P.Feat.from_nchw(rnd(1, n, cin, H, W).to(DEV))
+    cw = P.pack_conv((rnd(2, cout, cin, 3, 3) / np.sqrt(9 * cin)).to(DEV), None, pad=1, prec=PR)
+    ln = ((torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5).to(DEV), (rnd(4, cout) * 0.1).to(DEV))
+    p1, p2 = (P.Feat(rnd(s, n, ph, pw, 1).abs().to(DEV).contiguous()) for s in (5, 6))
+    for c_before in (0, 32):   # the conv's slice starts at channel c_before of the buffer (decoder concat: [up(x1) | x2 | p1 p2])
+        def run(fused):
+            buf = P.Feat.alloc_raw(n, H, W, c_before + cout + 2, DEV)
+            buf.buf.fill_(float("nan"))
+            dst = buf.slice(c_before, cout)
+            if fused:
+                assert P.conv2d_tail_supported(x, cw, dst)
+                P.conv2d_tail(x, cw, dst, p1, p2, act=P.ACT_GELU, ln=ln)
+            else:
+                P.conv2d(x, cw, dst, act=P.ACT_GELU, ln=ln)
+                P.depth_pair_fill(p1, p2, buf, c_before + cout)
+            return buf.buf[..., c_before:]
+        a, b = run(True), run(False)
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b), (c_before, float((a - b).abs().max()))
+    assert not P.conv2d_tail_supported(x, cw, P.Feat.alloc(n, H, W, cout, DEV))                       # no room behind the slice
+    c256 = P.pack_conv(rnd(2, 256, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
+    assert not P.conv2d_tail_supported(P.Feat.alloc(1, 24, 32, 64, DEV), c256, P.Feat.alloc_raw(1, 24, 32, 258, DEV).slice(0, 256))  # LayerNorm fused up to 128 columns

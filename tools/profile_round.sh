@@ -2,7 +2,7 @@
 # Run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): regenerates the profiles/ evidence of the default
 # bench workload into gpurun_out/profiles/ (copy what should be judged into profiles/ afterwards).
 set -u
-TAG=${1:-r02}; PREC=${2:-bf16x3}
+TAG=${1:-r03}; PREC=${2:-bf16x3}
 R=$(pwd); O=$R/gpurun_out/profiles; mkdir -p $O
 WL=$(python3 -c "from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD as w; print(w)")
 export TMPDIR=/tmp
@@ -12,6 +12,12 @@ for W2 in v1_zoe_4k_r32 v1_dav2l_4k_r32 v2_zoeda_4k_r32 v2_dav2l_4k_r64 v1_dav2s
 done
 python3 bench.py --prec f32 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_f32_bench_${WL}.json 2>> $O/bench.err
 python3 bench.py --layer-report $O/${TAG}_${PREC}_layers_${WL}.csv --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/bench.err
+# layer reports of the f32 mode and of the ViT-heavy README example
+python3 bench.py --prec f32 --layer-report $O/${TAG}_f32_layers_${WL}.csv --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>> $O/bench.err
+python3 bench.py --workload v1_zoe_4k_r32 --layer-report $O/${TAG}_${PREC}_layers_v1_zoe_4k_r32.csv --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>> $O/bench.err
+# the bench's cpu_baseline extrapolation against a fully timed oracle frame (m1, 16 tiles)
+python3 tools/cpu_baseline_validate.py > $O/${TAG}_cpu_baseline_validation.json 2>> $O/bench.err
+python3 tools/shard_model.py > $O/${TAG}_shard_model.json 2>> $O/bench.err
 # kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline > /tmp/kt.log 2>&1
@@ -20,4 +26,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python3 $R/bench.py --steps 1 --warmup 0 --streams 1 --no-roofline --no-cpu-baseline > /tmp/pmc_$C.log 2>&1
 done
 python3 $R/tools/pmc_to_json.py $O/${TAG}_${PREC}_pmc_frame_${WL}.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
+# kernel stats of one ViT-heavy workload (BEiT-L on every tile)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --workload v1_zoe_4k_r32 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline > /tmp/kt2.log 2>&1
+cp $(find /tmp/kt2 -name '*kernel_stats.csv' | head -1) $O/${TAG}_${PREC}_kernel_stats_v1_zoe_4k_r32.csv
+cd $R
+bash tools/pmc_vit.sh 14 1 > $O/${TAG}_${PREC}_pmc_vit_blocks_b14.txt 2>&1
+bash tools/pmc_gate.sh > $O/${TAG}_${PREC}_pmc_sq_dominant_kernel.txt 2>&1
 ls -la $O
