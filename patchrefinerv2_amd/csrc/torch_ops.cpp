@@ -129,6 +129,41 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
   return y;
 }
 
+// include/prv2.h::prv2_conv2d_ups: 3x3 conv over the virtual concat [bilinear_align_corners(u -> oh x ow) | x[..., u.c:]] -- the upsample
+// of UpSample.forward_hardcode (fusion_model.py:15-24) / of output_conv1's input (bi_directional_fusion_model.py:139-142,201) formed
+// inside the conv's tile loader.  x: NHWC [n, oh, ow, cin] whose first u.size(3) channels are not read, or None when every input
+// channel comes from u (oh, ow give the output size either way).
+Tensor conv3x3_ups(const optional<Tensor>& x_in, const Tensor& u, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout,
+                   int64_t oh, int64_t ow, int64_t act, const optional<Tensor>& ln_weight, const optional<Tensor>& ln_bias,
+                   const optional<Tensor>& res, int64_t prec, double ln_eps, const optional<Tensor>& out) {
+  const int64_t ldu = nhwc_ld(u, "u");
+  const int64_t n = u.size(0), cu = u.size(3);
+  const Tensor& x = x_in.has_value() ? *x_in : u;
+  const int64_t ldx = x_in.has_value() ? nhwc_ld(x, "x") : ldu;
+  const int64_t cin = x_in.has_value() ? x.size(3) : cu;
+  if (x_in.has_value()) TORCH_CHECK(x.size(0) == n && x.size(1) == oh && x.size(2) == ow, "prv2::conv3x3_ups: x must be [n, oh, ow, cin]");
+  dev_f32(w_packed, "w_packed");
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_packed_weight_bytes((int)cout, (int)cin, 3, 3, 0, (int)prec), "prv2::conv3x3_ups: w_packed does not match (cout, cin, prec)");
+  TORCH_CHECK(ln_weight.has_value() == ln_bias.has_value(), "prv2::conv3x3_ups: ln_weight and ln_bias go together");
+  Tensor y = out_or_alloc(out, u, n, oh, ow, cout, "conv3x3_ups");
+  prv2_conv_desc d = {};
+  d.n = (int)n; d.h = (int)oh; d.w = (int)ow; d.cin = (int)cin; d.cout = (int)cout; d.kh = 3; d.kw = 3; d.stride = 1; d.pad = 1;
+  d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out"); d.act = (int)act; d.prec = (int)prec; d.ln_eps = (float)ln_eps;
+  const float* pr = nullptr;
+  if (res.has_value()) {
+    d.ld_res = (int32_t)nhwc_ld(*res, "res");
+    TORCH_CHECK(res->sizes() == y.sizes(), "prv2::conv3x3_ups: res must have the output's shape");
+    pr = res->data_ptr<float>();
+  }
+  prv2_ups_src us = {};
+  us.x = u.data_ptr<float>(); us.h = (int)u.size(1); us.w = (int)u.size(2); us.ld = (int)ldu; us.channels = (int)cu; us.bstride = 0;
+  TORCH_CHECK(prv2_conv2d_ups_supported(&d, &us), "prv2::conv3x3_ups: layer not covered (bf16 modes, cout > 64, width >= 24, u channels % 32 == 0, 16-byte aligned rows)");
+  Launch L(u);
+  ok(prv2_conv2d_ups(&d, x.data_ptr<float>(), &us, w_packed.data_ptr(), opt_ptr(bias, "bias", cout), opt_ptr(ln_weight, "ln_weight", cout),
+                     opt_ptr(ln_bias, "ln_bias", cout), pr, y.data_ptr<float>(), L.stream), "conv3x3_ups");
+  return y;
+}
+
 // include/prv2.h::prv2_pack_gate_weight / prv2_conv3x3_ln_gate: the GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80)
 Tensor pack_gate_weight(const Tensor& w) {
   dev_f32(w, "weight");
@@ -358,6 +393,8 @@ TORCH_LIBRARY(prv2, m) {
   m.def("conv2d(Tensor x, Tensor w_packed, Tensor? bias, int cout, int kh, int kw, int stride=1, int pad=0, int act=0, bool relu_in=False, "
         "Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? gamma=None, Tensor? mul=None, Tensor? res=None, Tensor? res2=None, int convt_k=0, "
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None) -> Tensor");
+  m.def("conv3x3_ups(Tensor? x, Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, Tensor? ln_weight=None, "
+        "Tensor? ln_bias=None, Tensor? res=None, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
   m.def("pack_gate_weight(Tensor weight) -> Tensor");
   m.def("conv3x3_ln_gate(Tensor x, Tensor w_packed, Tensor? bias, Tensor ln_weight, Tensor ln_bias, Tensor? gate_w_packed=None, Tensor? gate_bias=None, "
         "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
@@ -382,6 +419,7 @@ TORCH_LIBRARY(prv2, m) {
 TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("pack_conv_weight", &pack_conv_weight);
   m.impl("conv2d", &conv2d);
+  m.impl("conv3x3_ups", &conv3x3_ups);
   m.impl("pack_gate_weight", &pack_gate_weight);
   m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
   m.impl("layernorm", &layernorm);

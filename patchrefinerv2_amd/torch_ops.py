@@ -19,7 +19,7 @@ from .lib import (ABI_VERSION, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SI
                   PREC_F32)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprv2_torch.so")
-OPS = ("abi_version", "pack_conv_weight", "conv2d", "pack_gate_weight", "conv3x3_ln_gate", "layernorm", "attention_fwd", "crop_resize_bilinear", "roi_gather_pyramid", "roi_align",
+OPS = ("abi_version", "pack_conv_weight", "conv2d", "conv3x3_ups", "pack_gate_weight", "conv3x3_ln_gate", "layernorm", "attention_fwd", "crop_resize_bilinear", "roi_gather_pyramid", "roi_align",
        "upsample_bilinear_ac", "blend_init", "blend_update", "blend_resize", "zoe_attractor", "zoe_bins_head", "nchw_to_nhwc",
        "nhwc_to_nchw")
 _loaded = False

@@ -198,3 +198,38 @@ def test_zoe_head_ops_and_layout(T):
     d = ops.zoe_bins_head(pt.to(DEV), bins.to(DEV), 0.0212, 50.0)
     assert tuple(d.shape) == (1, 1, 6, 8) and bool(torch.isfinite(d).all())
     assert float(d.min()) >= float(bins.min()) - 1e-4 and float(d.max()) <= float(bins.max()) + 1e-4  # an expectation over the bins
+
+
+@gpu
+def test_conv3x3_ups_equals_interpolate_then_conv(T):
+    """torch.ops.prv2.conv3x3_ups: the bilinear(align_corners=True) upsample of UpSample.forward_hardcode (fusion_model.py:15-24) /
+    of output_conv1's input (bi_directional_fusion_model.py:139-142,201) formed inside the conv's tile loader -- against
+    F.interpolate + F.conv2d in fp32, with and without pass-through channels, and bit-equal to the unfused ops of this library"""
+    import torch.nn.functional as F
+    ops, mod = T
+    n, h, w, H, W, cu, crest, cout = 2, 12, 17, 24, 33, 64, 34, 96
+    u = randn(1, n, h, w, cu).to(DEV)
+    rest = randn(2, n, H, W, crest).to(DEV)
+    wt = randn(3, cout, cu + crest, 3, 3) / (9 * (cu + crest)) ** 0.5
+    bias = randn(4, cout)
+    wp = ops.pack_conv_weight(wt.to(DEV), None, 0, mod.PREC_BF16X3)
+    xbuf = torch.full((n, H, W, cu + crest + 2), float("nan"), device=DEV)     # (padded row stride; the first cu channels are never read)
+    x = xbuf[..., :cu + crest]
+    x[..., cu:] = rest
+    got = ops.conv3x3_ups(x, u, wp, bias.to(DEV), cout, H, W, act=mod.ACT_GELU, prec=mod.PREC_BF16X3)
+    up = F.interpolate(u.permute(0, 3, 1, 2).cpu(), (H, W), mode="bilinear", align_corners=True)
+    want = F.gelu(F.conv2d(torch.cat([up, rest.permute(0, 3, 1, 2).cpu()], 1), wt, bias, padding=1))
+    err = float((got.permute(0, 3, 1, 2).cpu() - want).abs().max())
+    assert err < 3e-5 * max(1.0, float(want.abs().max())), err
+    x2 = torch.zeros_like(xbuf)[..., :cu + crest]
+    x2[..., cu:] = rest
+    ops.upsample_bilinear_ac(u, H, W, out=x2[..., :cu])
+    ref = ops.conv2d(x2, wp, bias.to(DEV), cout, 3, 3, pad=1, act=mod.ACT_GELU, prec=mod.PREC_BF16X3)
+    assert torch.equal(got, ref)
+    # every channel from the upsampled source (x = None)
+    wp2 = ops.pack_conv_weight(wt[:, :cu].contiguous().to(DEV), None, 0, mod.PREC_BF16X3)
+    got2 = ops.conv3x3_ups(None, u, wp2, None, cout, H, W, prec=mod.PREC_BF16X3)
+    want2 = F.conv2d(up, wt[:, :cu], None, padding=1)
+    assert float((got2.permute(0, 3, 1, 2).cpu() - want2).abs().max()) < 3e-5 * max(1.0, float(want2.abs().max()))
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_ups(None, u, ops.pack_conv_weight(wt[:32, :cu].contiguous().to(DEV), None, 0, mod.PREC_BF16X3), None, 32, H, W, prec=mod.PREC_BF16X3)  # cout <= 64
