@@ -297,8 +297,10 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
+// (launch bounds: THREE workgroups per CU -- the kernel needed 169 (with bias 202) registers, one more than three waves per SIMD
+//  allow; asking for 168 costs nothing and a third independent wave per SIMD fills the softmax / staging gaps of the other two)
 template <bool HAS_BIAS>
-__global__ void __launch_bounds__(256, 2) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
+__global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
                                                                   const __bf16* __restrict__ Ks,
                                                                   const __bf16* __restrict__ VtH,
                                                                   const __bf16* __restrict__ VtL, int N, int Npad,
