@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 10
+#define PRV2_ABI_VERSION 11
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -84,8 +84,16 @@ typedef struct prv2_conv_desc {
   int32_t same_pad;      /* != 0: TensorFlow "SAME" padding as timm's Conv2dSame (the reference's stem surgery builds one,
                           * patchrefinerplus.py:152-158): out = ceil(in / stride), total = max((out-1)*stride + k - in, 0),
                           * low = total / 2, the rest goes to the high side; ``pad`` is ignored.  Not for convt_k.          */
-  int32_t reserved;
+  int32_t fmt;           /* PRV2_FMT_* bits: operands in the pre-split "X2" activation format -- per 8 channels
+                          * [8 x bf16 hi | 8 x bf16 lo] (32 bytes = the bytes of 8 floats; hi = RNE bf16 of v, lo = RNE bf16 of v - hi),
+                          * i.e. exactly what the bf16x3 kernels' loaders make of an fp32 input, stored by the producer so that the
+                          * consumer only copies.  Taken by the 256-column kernels (prv2_conv3x3_ln_gate / prv2_conv2d layers it routes
+                          * there): X_X2 + MUL_X2 by the gate kernel, Y_X2 by the plain conv without LayerNorm.  A layer's result does not
+                          * depend on the format (``mul`` counts as hi + lo either way).  0 everywhere else.                        */
 } prv2_conv_desc;
+#define PRV2_FMT_X_X2 1   /* x is X2 (gate kernel: the GatedConvUnit's [out | coarse ROI] concat)            */
+#define PRV2_FMT_MUL_X2 2 /* mul is X2 (gate kernel: ``out``, the first half of that concat; goes together with X_X2) */
+#define PRV2_FMT_Y_X2 4   /* y is written X2 (256-column conv, no LayerNorm: GatedConvUnit.conv writing ``out``) */
 
 /* host-side helpers: sizes of the packed weight buffers (in bytes) */
 int64_t prv2_packed_weight_bytes(int32_t cout, int32_t cin, int32_t kh, int32_t kw, int32_t convt_k, int32_t prec);
@@ -282,6 +290,11 @@ int prv2_crop_resize(const float* img_chw, int32_t img_h, int32_t img_w, const i
  * feat NHWC [1, h, w, c]; boxes device fp32 [k][4] = (x1, y1, x2, y2) in lr-frame pixels. */
 int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes, int32_t k,
                    float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo, void* stream);
+
+/* prv2_roi_align writing the pre-split "X2" format of prv2_conv_desc.fmt (c % 8 == 0): the coarse half of a GatedConvUnit's concat
+ * buffer, whose only consumer is the gate kernel.  Same arithmetic; out[...] = X2(roi value). */
+int prv2_roi_align_x2(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes, int32_t k,
+                      float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo, void* stream);
 
 /* F.interpolate(mode='bilinear', align_corners=True) on NHWC (every decoder upsample; Appendix C row 1) */
 int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t oh,

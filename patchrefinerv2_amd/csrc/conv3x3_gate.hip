@@ -25,12 +25,22 @@
 
 #include "igemm.h"
 
+// Pre-split activations ("X2", round 3).  The halo stream costs the main loop 6-8 % (ablation): every fp32 element is ReLU'd, rounded
+// to bf16 hi, subtracted, rounded to bf16 lo and written to LDS as two 8-byte halves.  A tensor whose ONLY consumers are these
+// kernels is therefore stored by its producer in the operand format itself: per 8 channels [8 x bf16 hi | 8 x bf16 lo] = 32 bytes,
+// the bytes of 8 floats -- same pixel stride, same buffers, channel slices at multiples of 8 stay valid.  hi = RNE bf16 of v,
+// lo = RNE bf16 of v - hi (split_bf16): exactly what the consumer's loader computes from fp32, so a layer's result does not depend on
+// which format its input arrived in.  The loader then only copies (two 16-byte loads -> two ds_write_b128 per 8 channels); operands of
+// the final stage read in this format are hi + lo (the gate's ``mul`` is ALWAYS taken as hi + lo, whatever format it arrives in, for
+// the same reason).  In this file: x / mul of the gate kernel (the [out | coarse ROI] concat of a GatedConvUnit), y of the plain
+// 256-column conv (GatedConvUnit.conv writes ``out`` into that concat); prv2_roi_align_x2 writes the other half.
 namespace prv2 {
 
 namespace g256 {
 constexpr int BN = 256, TH = 8, TW = 16, HW_ = TW + 2;
 constexpr int HALO = (TH + 2) * HW_;            // 180 halo pixels
 constexpr int A_IT = (HALO * 8 + 511) / 512;    // float4 loads per thread per slab (3)
+constexpr int A_IT2 = (HALO * 4 + 511) / 512;   // X2 input: 32-byte items (8 channels: hi, lo) per thread per slab (2)
 constexpr int AROW = 160;                       // bytes per halo pixel in LDS (32 bf16 hi | 32 bf16 lo | 32 B pad)
 constexpr int A_BYTES = HALO * AROW, B_BYTES = BN * 128, NBUF = 3;
 constexpr int CLD = BN + 4;                     // C tile row pitch (floats): rows shift by 16 B over the banks
@@ -52,6 +62,7 @@ struct GateConvParams {
   IgemmParams c;           // the 3x3 conv: x, w, bias, ln_w, ln_b, ln_eps, act; final stage: mul, res, y (+ their strides)
   const void* gate_w;      // fragment-major packed 256 x 256 gate weights, or null: y = act(LN(conv + bias))
   const float* gate_bias;
+  int x_x2, mul_x2, y_x2;  // operand formats (X2 = pre-split, see the head of this file); y_x2: the no-gate, no-LayerNorm kernel
   long long* stamps;       // -DPRV2_GATE_STAMPS builds (tools/probes/gate_phase_stamps.sh): 10 s_memtime stamps per wave
 };
 
@@ -64,9 +75,11 @@ struct GateConvParams {
 #define PRV2_STAMP(i)
 #endif
 
-template <int PREC, bool GATE>
+template <int PREC, bool GATE, bool X2IN = false>
 __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem) {
   using namespace g256;
+  constexpr int NIT = X2IN ? A_IT2 : A_IT;  // halo items per thread per slab
+  constexpr int LPI = X2IN ? 2 : 1;         // 16-byte loads per item
   const IgemmParams& p = gp.c;
   char* const As_b = reinterpret_cast<char*>(smem);
   char* const Bs_b = As_b + 2 * A_BYTES;
@@ -96,7 +109,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   constexpr unsigned OOB = 0x80000000u;
   i32x4 rsrc;
-  unsigned hoff[A_IT];
+  unsigned hoff[NIT];
   {
     const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)n_img * p.x_bstride);
     rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)img_base);
@@ -104,12 +117,13 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     rsrc.z = __builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + p.Cin) * 4));
     rsrc.w = 0x00020000;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int hp = prow + 64 * it;
+    for (int it = 0; it < NIT; ++it) {
+      // fp32 input: item = (halo pixel prow + 64 it, 4 channels `chunk`); X2: item tid + 512 it = (halo pixel, 8-channel group)
+      const int hp = X2IN ? (tid + 512 * it) >> 2 : prow + 64 * it;
       const int hy = hp / HW_, hx = hp - hy * HW_;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
       const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      hoff[it] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + chunk * 4) * 4) : OOB;
+      hoff[it] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + (X2IN ? (tid & 3) * 8 : chunk * 4)) * 4) : OOB;
     }
   }
   const long long w_row_stride = 9LL * p.Cin_pad;
@@ -117,16 +131,29 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   const int nsteps = 9 * cslabs;
   const int relu_floor = p.relu_in ? 0 : (int)0x80000000;
 
-  f32x4 ra[A_IT];
+  f32x4 ra[NIT][LPI];
   auto load_a_async = [&](int cc, int it) {
     const unsigned voff = hoff[it] + (unsigned)(cc * BK * 4);  // (2^31 + cc*128 stays out of range: no wrap)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it]) : "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra[it][0]) : "v"(voff), "s"(rsrc) : "memory");
+    if constexpr (X2IN) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(ra[it][LPI - 1]) : "v"(voff), "s"(rsrc) : "memory");
   };
+#define PRV2_WAIT_A(newer, it)                                                                                              \
+  do {                                                                                                                    \
+    if constexpr (!X2IN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[it][0]) : "n"(newer) : "memory");                    \
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[it][0]), "+v"(ra[it][LPI - 1]) : "n"(newer) : "memory");            \
+  } while (0)
   auto store_a = [&](int abuf, int it) {
+    if constexpr (X2IN) {  // pre-split input: the 8 channels' hi / lo halves go to the two planes of the LDS row as they are
+      const int item = tid + 512 * it, hp = item >> 2;
+      if (hp >= HALO) return;
+      const unsigned addr = (unsigned)(size_t)(As_b + abuf * A_BYTES + hp * AROW) + (item & 3) * 16;
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:64" ::"v"(addr), "v"(ra[it][0]), "v"(ra[it][LPI - 1]) : "memory");
+      return;
+    }
     const int hp = prow + 64 * it;
     if (hp >= HALO) return;
     typedef int i32x4v __attribute__((ext_vector_type(4)));
-    i32x4v vi = __builtin_bit_cast(i32x4v, ra[it]);
+    i32x4v vi = __builtin_bit_cast(i32x4v, ra[it][0]);
     vi.x = max(vi.x, relu_floor);
     vi.y = max(vi.y, relu_floor);
     vi.z = max(vi.z, relu_floor);
@@ -200,7 +227,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   // ---- prologue ---------------------------------------------------------------------------------------------
   PRV2_STAMP(0);
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) load_a_async(0, it);
+  for (int it = 0; it < NIT; ++it) load_a_async(0, it);
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     dma_b(0, 0, i);
@@ -208,8 +235,8 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     dma_b(2, 2, i);
   }
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[it])::"memory");
+  for (int it = 0; it < NIT; ++it) {
+    PRV2_WAIT_A(0, it);
     store_a(0, it);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -224,7 +251,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     const int ab = cc & 1;
     auto step = [&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
-      constexpr int L0 = tap < A_IT ? 1 : 0, Lm1 = (tap >= 1 && tap - 1 < A_IT) ? 1 : 0;
+      constexpr int L0 = tap < NIT ? LPI : 0, Lm1 = (tap >= 1 && tap - 1 < NIT) ? LPI : 0;  // halo loads issued at this / the previous tap
       const int s = cc * 9 + tap;
       const int s3 = s + 3 < nsteps ? s + 3 : nsteps - 1;
       constexpr int bb = tap % 3;
@@ -242,15 +269,15 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
           __builtin_amdgcn_sched_barrier(0);
 #ifndef PRV2_ABL_NOA  // (timing ablations of tools/probes/gate_phase_stamps.sh: results are wrong with any of them)
           if (j == 0 && a == 0) {
-            if constexpr (tap < A_IT) load_a_async(ccn, tap);
+            if constexpr (tap < NIT) load_a_async(ccn, tap);
           }
 #endif
           if (j == 1 && a == NA - 2) {
 #ifndef PRV2_ABL_NOA
-            if constexpr (tap >= 2 && tap - 2 < A_IT) {
+            if constexpr (tap >= 2 && tap - 2 < NIT) {
               // VMEM instructions issued since load_a_async(tap - 2): DMAs of steps tap-2 and tap-1, loads tap-1, tap
               constexpr int newer = 2 * ND + Lm1 + L0;
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[tap - 2]) : "n"(newer) : "memory");
+              PRV2_WAIT_A(newer, tap - 2);
               store_a(ab ^ 1, tap - 2);
             }
 #endif
@@ -403,16 +430,11 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (bare: the weight fragments stay in flight)
     PRV2_STAMP(5);
-    // ---- operands of the final stage y = mul * sigmoid(gate + bias) + res: 64 threads x float4 = one 1 KB pixel row, 16 rows per
-    // thread, ALL requested long before their use: with one workgroup per CU nothing else hides this traffic, and a CU only
-    // reaches its memory rate with a whole operand tile (128 KB) in flight (4 rows in flight: 19 k cycles for the store loop;
-    // phase stamps of tools/probes/gate_phase_stamps.sh)
-    constexpr int C4 = BN / 4, RPP = 512 / C4, NR = ROWS / RPP;
-    const int col4 = tid % C4;
-    auto pix_of = [&](int i) {  // (rows below the image: clamped address, never stored)
-      const int rr = tid / C4 + i * RPP;
-      return min(y0 + rr / TW, p.H - 1) * p.W + min(x0 + (rr & (TW - 1)), p.W - 1);
-    };
+    // ---- operands of the final stage y = mul * sigmoid(gate + bias) + res, ALL requested long before their use: with one workgroup
+    // per CU nothing else hides this traffic, and a CU only reaches its memory rate with a whole operand tile (128 KB) in flight
+    // (4 rows in flight: 19 k cycles for the store loop; phase stamps of tools/probes/gate_phase_stamps.sh).  Thread = NC channels of
+    // a pixel: fp32 mul: 4 channels (64 threads x float4 = one 1 KB pixel row, 16 rows per thread); pre-split (X2) mul: 8 channels =
+    // one [8 hi | 8 lo] group (32 threads per row, 8 rows per thread) -- 16-byte accesses either way.
     // buffer loads (per-image base, 32-bit offsets; an absent operand is a resource of zero records: the hardware returns zeros,
     // no branches around the loads)
     const long long img_m = (long long)n_img * p.H * p.W;
@@ -422,63 +444,104 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.res ? p.res + img_m * p.ld_res : p.x), 0, p.res ? (int)((img_px * p.ld_res + BN) * 4u) : 0, 0x00020000);
     const bool has_mul = p.mul != nullptr;  // block-uniform
-    f32x4 mv[NR], rv[NR];
+    auto final_stage = [&](auto nc_c) {
+      constexpr int NC = decltype(nc_c)::value, NV = NC / 4;  // channels per thread, float4 per thread and row
+      constexpr bool MX2 = NC == 8;                            // mul arrives pre-split
+      constexpr int CG = BN / NC, RPP = 512 / CG, NR = ROWS / RPP;
+      const int colg = tid % CG;
+      auto pix_of = [&](int i) {  // (rows below the image: clamped address, never stored)
+        const int rr = tid / CG + i * RPP;
+        return min(y0 + rr / TW, p.H - 1) * p.W + min(x0 + (rr & (TW - 1)), p.W - 1);
+      };
+      f32x4 mv[NR][NV], rv[NR][NV];
 #pragma unroll
-    for (int ks = 0; ks < KS2; ++ks) {
-      if (ks == KS2 - 3) {  // five slabs of weight registers are free again: the mul rows fly during the rest of the GEMM
+      for (int ks = 0; ks < KS2; ++ks) {
+        if (ks == KS2 - 3) {  // five slabs of weight registers are free again: the mul rows fly during the rest of the GEMM
 #pragma unroll
-        for (int i = 0; i < NR; ++i) mv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mul_rs, (pix_of(i) * p.ld_mul + col4 * 4) * 4, 0, 0));
-      }
+          for (int i = 0; i < NR; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {  // four pixel runs at a time (their fragments: 32 registers)
-        bf16x8 xh[4], xl[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const float* q = csm + ((4 * h + a) * TW + m16) * CLD + ks * 32 + 8 * g;
-          xh[a] = *reinterpret_cast<const bf16x8*>(q);
-          xl[a] = *reinterpret_cast<const bf16x8*>(q + 4);
+            for (int v = 0; v < NV; ++v)  // (X2: v = 0 the group's hi half, v = 1 its lo half -- adjacent 16-byte pieces, like two float4)
+              mv[i][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mul_rs, (pix_of(i) * p.ld_mul + colg * NC + 4 * v) * 4, 0, 0));
         }
 #pragma unroll
-        for (int j = 0; j < NJ2; ++j) {
-          const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[ks][j][0]);
-          const bf16x8 wl = __builtin_bit_cast(bf16x8, wf[ks][j][1]);
+        for (int h = 0; h < 2; ++h) {  // four pixel runs at a time (their fragments: 32 registers)
+          bf16x8 xh[4], xl[4];
 #pragma unroll
-          for (int pr = 0; pr < NP; ++pr)
+          for (int a = 0; a < 4; ++a) {
+            const float* q = csm + ((4 * h + a) * TW + m16) * CLD + ks * 32 + 8 * g;
+            xh[a] = *reinterpret_cast<const bf16x8*>(q);
+            xl[a] = *reinterpret_cast<const bf16x8*>(q + 4);
+          }
 #pragma unroll
-            for (int a = 0; a < 4; ++a) mma(acc2[4 * h + a][j], xh[a], xl[a], wh, wl, pr);
+          for (int j = 0; j < NJ2; ++j) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wf[ks][j][0]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, wf[ks][j][1]);
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+              for (int a = 0; a < 4; ++a) mma(acc2[4 * h + a][j], xh[a], xl[a], wh, wl, pr);
+          }
         }
       }
-    }
-    PRV2_STAMP(6);
+      PRV2_STAMP(6);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (pix_of(i) * p.ld_res + col4 * 4) * 4, 0, 0));
-    // (bare barriers: __syncthreads() would first drain vmcnt, i.e. wait for the rows just requested)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read its rows of the C tile
+      for (int i = 0; i < NR; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ2; ++j) {
-      const int col = wave * 32 + j * 16 + m16;
+        for (int v = 0; v < NV; ++v)
+          rv[i][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (pix_of(i) * p.ld_res + colg * NC + 4 * v) * 4, 0, 0));
+      // (bare barriers: __syncthreads() would first drain vmcnt, i.e. wait for the rows just requested)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read its rows of the C tile
 #pragma unroll
-      for (int a = 0; a < NA2; ++a)
+      for (int j = 0; j < NJ2; ++j) {
+        const int col = wave * 32 + j * 16 + m16;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) csm[(a * TW + 4 * g + e) * CLD + col] = acc2[a][j][e];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    PRV2_STAMP(7);
-    f32x4 gb = {0.f, 0.f, 0.f, 0.f};
-    if (gp.gate_bias) gb = *reinterpret_cast<const f32x4*>(gp.gate_bias + col4 * 4);
-    float* const ybase = p.y + (long long)n_img * p.y_bstride + col4 * 4;
+        for (int a = 0; a < NA2; ++a)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int rr = tid / C4 + i * RPP;
-      const f32x4 cv = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + col4 * 4]);
-      f32x4 ov;
+          for (int e = 0; e < 4; ++e) csm[(a * TW + 4 * g + e) * CLD + col] = acc2[a][j][e];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PRV2_STAMP(7);
+      f32x4 gb[NV];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (has_mul ? mv[i][e] : 1.0f) * sigmoid_fast(cv[e] + gb[e]) + rv[i][e];
-      if (y0 + rr / TW < p.H && x0 + (rr & (TW - 1)) < p.W) {
+      for (int v = 0; v < NV; ++v) gb[v] = gp.gate_bias ? *reinterpret_cast<const f32x4*>(gp.gate_bias + colg * NC + 4 * v) : f32x4{0.f, 0.f, 0.f, 0.f};
+      float* const ybase = p.y + (long long)n_img * p.y_bstride + colg * NC;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int rr = tid / CG + i * RPP;
+        // ``mul`` counts as hi + lo of its bf16 split in EITHER format (this unit's conv input is the same tensor and sees exactly
+        // these 16 bits): the result does not depend on the format the producer chose
+        f32x4 mf[NV];
+        if constexpr (MX2) {
+          typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+          const u32x4v hh = __builtin_bit_cast(u32x4v, mv[i][0]), ll = __builtin_bit_cast(u32x4v, mv[i][NV - 1]);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            mf[v][0] = __builtin_bit_cast(float, hh[2 * v] << 16) + __builtin_bit_cast(float, ll[2 * v] << 16);
+            mf[v][1] = __builtin_bit_cast(float, hh[2 * v] & 0xffff0000u) + __builtin_bit_cast(float, ll[2 * v] & 0xffff0000u);
+            mf[v][2] = __builtin_bit_cast(float, hh[2 * v + 1] << 16) + __builtin_bit_cast(float, ll[2 * v + 1] << 16);
+            mf[v][3] = __builtin_bit_cast(float, hh[2 * v + 1] & 0xffff0000u) + __builtin_bit_cast(float, ll[2 * v + 1] & 0xffff0000u);
+          }
+        } else {
+          bf16x4 mh, ml;
+          split_bf16(mv[i][0], mh, ml);
+          mf[0] = __builtin_convertvector(mh, f32x4) + __builtin_convertvector(ml, f32x4);
+        }
+        const bool inside = y0 + rr / TW < p.H && x0 + (rr & (TW - 1)) < p.W;
         float* dst = ybase + (long long)pix_of(i) * p.ldy;
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + colg * NC + 4 * v]);
+          f32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = (has_mul ? mf[v][e] : 1.0f) * sigmoid_fast(cv[e] + gb[v][e]) + rv[i][v][e];
+          if (inside) {
+            float* d2 = dst + 4 * v;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(d2), "v"(ov) : "memory");
+          }
+        }
       }
-    }
+    };
+    final_stage(std::integral_constant<int, X2IN ? 8 : 4>{});  // (host: mul comes in the format of x -- it IS the first half of x)
     PRV2_STAMP(8);
 #ifdef PRV2_GATE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -487,6 +550,49 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     return;
   }
 
+  if (gp.y_x2) {  // block-uniform (host: no LayerNorm)
+    // ---- no gate, pre-split output: y = X2(act(conv + bias) + res) -- GatedConvUnit.conv writing ``out`` into the unit's concat
+    // buffer in the operand format of its only consumer (the gate kernel).  32 threads x 8 channels = one 1 KB pixel row
+    // ([8 hi | 8 lo] per thread: two adjacent 16-byte stores), 8 rows per thread, residual rows requested up front
+    constexpr int C8 = BN / 8, RPP8 = 512 / C8, NR8 = ROWS / RPP8;
+    const int col8 = tid % C8;
+    auto pix8 = [&](int i) {
+      const int rr = tid / C8 + i * RPP8;
+      return min(y0 + rr / TW, p.H - 1) * p.W + min(x0 + (rr & (TW - 1)), p.W - 1);
+    };
+    const __amdgpu_buffer_rsrc_t res_rs8 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res ? p.res + (long long)n_img * p.H * p.W * p.ld_res : p.x), 0, p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + BN) * 4u) : 0,
+        0x00020000);
+    f32x4 rv8[NR8][2];
+#pragma unroll
+    for (int i = 0; i < NR8; ++i) {
+      rv8[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs8, (pix8(i) * p.ld_res + col8 * 8) * 4, 0, 0));
+      rv8[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs8, (pix8(i) * p.ld_res + col8 * 8 + 4) * 4, 0, 0));
+    }
+    float* const ybase8 = p.y + (long long)n_img * p.y_bstride + col8 * 8;
+    dispatch_act(p.act, [&](auto act_c) {
+#pragma unroll
+      for (int i = 0; i < NR8; ++i) {
+        const int rr = tid / C8 + i * RPP8;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + col8 * 8]), v1 = *reinterpret_cast<const f32x4*>(&csm[rr * CLD + col8 * 8 + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = act_apply_bf(v0[e], decltype(act_c)::value) + rv8[i][0][e];
+          v1[e] = act_apply_bf(v1[e], decltype(act_c)::value) + rv8[i][1][e];
+        }
+        bf16x4 h0, l0, h1, l1;
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (y0 + rr / TW < p.H && x0 + (rr & (TW - 1)) < p.W) {
+          float* dst = ybase8 + (long long)pix8(i) * p.ldy;
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 1" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
+        }
+      }
+    });
+    return;
+  }
   // ---- no gate: y = act([LN](conv + bias)) (+ res); 64 threads x float4 = one 1 KB pixel row, 16 rows per thread; the residual
   // rows are all requested up front (see the gate stage)
   constexpr int C4 = BN / 4, RPP = 512 / C4, NR = ROWS / RPP;
@@ -544,6 +650,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_kernel(const GateCon
   static_assert(BN_ == g256::BN, "one tile width");
   __shared__ __attribute__((aligned(16))) float smem[g256::SMEM_FLOATS];
   c256_body<PREC, true>(gp, smem);
+}
+// the gate kernel on a pre-split (X2) input: the halo loader only copies
+template <int BN_, int PREC>
+__global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_x2_kernel(const GateConvParams gp) {
+  static_assert(BN_ == g256::BN, "one tile width");
+  __shared__ __attribute__((aligned(16))) float smem[g256::SMEM_FLOATS];
+  c256_body<PREC, true, true>(gp, smem);
 }
 
 // C x C gate weights (PyTorch [cout][cin][1][1]; C = 32, 128, 256) -> the fragment-major image of igemm.h::gate_frag_index
@@ -613,6 +726,7 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
                                     float* y, void* stream) {
   PRV2_REQUIRE(d && x && w_packed && y && (ln_weight != nullptr) == (ln_bias != nullptr), "conv3x3_ln_gate: null pointer");
   if (gate_w_packed && d->cout != g256::BN) {  // 32 / 128 channels: conv3x3_m16.hip's kernels with the gate stage in their epilogue
+    PRV2_REQUIRE(d->fmt == 0, "conv3x3_ln_gate: pre-split (X2) operands are taken at 256 channels only");
     PRV2_REQUIRE(gate_narrow_shape_ok(d) && ln_weight, "conv3x3_ln_gate: 3x3 s1 p1, cout 32 / 128 / 256, cin %% 32 == 0, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
                  d->h, d->w, d->cin, d->cout, d->kh, d->stride, d->prec);
     PRV2_REQUIRE(d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate: ReLU or no activation in front of the gate (act %d)", d->act);
@@ -643,6 +757,14 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
   p.vec_ok = 1; p.vec_epi = 1;
   gp.gate_w = gate_w_packed;
   gp.gate_bias = gate_bias;
+  gp.x_x2 = (d->fmt & PRV2_FMT_X_X2) != 0;
+  gp.mul_x2 = (d->fmt & PRV2_FMT_MUL_X2) != 0;
+  gp.y_x2 = (d->fmt & PRV2_FMT_Y_X2) != 0;
+  PRV2_REQUIRE(!(d->fmt & ~(PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2 | PRV2_FMT_Y_X2)), "conv3x3_ln_gate: unknown format bits %d", d->fmt);
+  PRV2_REQUIRE(!gp.x_x2 || (gate_w_packed && d->cin % 8 == 0 && !d->relu_in), "conv3x3_ln_gate: a pre-split (X2) input is taken by the gate kernel only (no input ReLU)");
+  PRV2_REQUIRE(!gate_w_packed || !mul || gp.mul_x2 == gp.x_x2, "conv3x3_ln_gate: the gate kernel takes mul in the format of x (PRV2_FMT_X_X2 and PRV2_FMT_MUL_X2 go together)");
+  PRV2_REQUIRE(!gp.mul_x2 || (gate_w_packed && mul), "conv3x3_ln_gate: PRV2_FMT_MUL_X2 without a gate stage / mul operand");
+  PRV2_REQUIRE(!gp.y_x2 || (!gate_w_packed && !ln_weight), "conv3x3_ln_gate: a pre-split (X2) output is written by the plain 256-column conv (no LayerNorm, no gate)");
 #ifdef PRV2_GATE_STAMPS
   gp.stamps = getenv("PRV2_STAMP_PTR") ? (long long*)strtoull(getenv("PRV2_STAMP_PTR"), nullptr, 16) : nullptr;
 #endif
@@ -650,6 +772,13 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
   PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate: grid too large");
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = d->prec == PRV2_PREC_BF16X3;
+  if (gate_w_packed && gp.x_x2) {
+    if (x3) hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(512), 0, s, gp);
+    else hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16>), dim3((unsigned)blocks), dim3(512), 0, s, gp);
+    set_kernel("conv3x3_c256_gate_x2_kernel", 256, d->prec);
+    PRV2_LAUNCH_CHECK("conv3x3_ln_gate");
+    return 0;
+  }
   if (gate_w_packed) {
     if (x3) hipLaunchKernelGGL((conv3x3_c256_gate_kernel<256, PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(512), 0, s, gp);
     else hipLaunchKernelGGL((conv3x3_c256_gate_kernel<256, PRV2_PREC_BF16>), dim3((unsigned)blocks), dim3(512), 0, s, gp);

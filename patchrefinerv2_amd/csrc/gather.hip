@@ -117,7 +117,25 @@ __device__ __forceinline__ void vdiv(float4& a, float s) {
 }
 __device__ __forceinline__ void vdiv(float& a, float s) { a /= s; }
 
-template <int VEC>
+// one thread's 4 consecutive channels c .. c + 3 of an output pixel: fp32, or (X2) the pre-split format of prv2_conv_desc.fmt --
+// per 8 channels [8 x bf16 hi | 8 x bf16 lo]: the 4 channels are 8 bytes of the group's hi half and 8 bytes of its lo half
+template <bool X2>
+__device__ __forceinline__ void store4_fmt(float* pix_base, int c, const float4 v) {
+  if constexpr (!X2) {
+    *reinterpret_cast<float4*>(pix_base + c) = v;
+  } else {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t f = {v.x, v.y, v.z, v.w};
+    const bf16x4_t hi = __builtin_convertvector(f, bf16x4_t);
+    const bf16x4_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, f32x4_t), bf16x4_t);
+    char* g = reinterpret_cast<char*>(pix_base + (c & ~7)) + ((c >> 2) & 1) * 8;
+    *reinterpret_cast<bf16x4_t*>(g) = hi;
+    *reinterpret_cast<bf16x4_t*>(g + 16) = lo;
+  }
+}
+
+template <int VEC, bool X2 = false>
 __global__ void __launch_bounds__(256) roi_align_kernel(const float* __restrict__ feat, int H, int W, int C, int ldf,
                                                         const float* __restrict__ boxes, int K, float scale, int oh,
                                                         int ow, float* __restrict__ out, int ldo) {
@@ -165,7 +183,8 @@ __global__ void __launch_bounds__(256) roi_align_kernel(const float* __restrict_
       }
     }
     vdiv(acc, count);
-    *reinterpret_cast<V*>(out + pix * ldo + c) = acc;
+    if constexpr (VEC == 4) store4_fmt<X2>(out + pix * ldo, c, acc);
+    else *reinterpret_cast<V*>(out + pix * ldo + c) = acc;
   }
 }
 
@@ -174,7 +193,7 @@ __global__ void __launch_bounds__(256) roi_align_kernel(const float* __restrict_
 // rows per source row), so the four taps stay in registers while (y_low, y_high) does not change -- ~1.3 instead of 4 tap loads
 // per output, the SAME arithmetic per output as roi_align_kernel (w1 v1 + w2 v2 + w3 v3 + w4 v4, left to right).  Boxes whose
 // sampling grid is larger than 1 x 1 (down-sampling ROIs) take the general per-pixel loop.
-template <int R>
+template <int R, bool X2 = false>
 __global__ void __launch_bounds__(256) roi_align_rows_kernel(const float* __restrict__ feat, int H, int W, int C, int ldf,
                                                              const float* __restrict__ boxes, int K, float scale, int oh, int ow,
                                                              float* __restrict__ out, int ldo) {
@@ -215,7 +234,7 @@ __global__ void __launch_bounds__(256) roi_align_rows_kernel(const float* __rest
         }
       }
       vdiv(acc, count);
-      *reinterpret_cast<float4*>(out + (((int64_t)k * oh + py) * ow + px) * ldo + c) = acc;
+      store4_fmt<X2>(out + (((int64_t)k * oh + py) * ow + px) * ldo, c, acc);
     }
     return;
   }
@@ -255,7 +274,7 @@ __global__ void __launch_bounds__(256) roi_align_rows_kernel(const float* __rest
       vfma(acc, 1.0f, val);
     }
     vdiv(acc, 1.0f);
-    *reinterpret_cast<float4*>(out + (((int64_t)k * oh + py) * ow + px) * ldo + c) = acc;
+    store4_fmt<X2>(out + (((int64_t)k * oh + py) * ow + px) * ldo, c, acc);
   }
 }
 
@@ -460,14 +479,41 @@ extern "C" int prv2_bicubic_resize(const void* src_hwc, int32_t src_is_u8, int32
   return 0;
 }
 
+static int roi_align_impl(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes, int32_t k, float spatial_scale,
+                          int32_t oh, int32_t ow, float* out, int32_t ldo, void* stream, bool x2);
+
 extern "C" int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes,
                               int32_t k, float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo,
                               void* stream) {
+  return roi_align_impl(feat, h, w, c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo, stream, false);
+}
+
+extern "C" int prv2_roi_align_x2(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes,
+                                 int32_t k, float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo,
+                                 void* stream) {
+  PRV2_REQUIRE(feat && out && c > 0 && c % 8 == 0 && ldf % 4 == 0 && ldo % 8 == 0 && aligned16(feat) && (reinterpret_cast<uintptr_t>(out) & 31) == 0,
+               "roi_align_x2: c %% 8 == 0, ldo %% 8 == 0, 32-byte aligned output (c=%d ldo=%d)", c, ldo);
+  return roi_align_impl(feat, h, w, c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo, stream, true);
+}
+
+static int roi_align_impl(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes, int32_t k, float spatial_scale,
+                          int32_t oh, int32_t ow, float* out, int32_t ldo, void* stream, bool x2) {
   PRV2_REQUIRE(feat && boxes && out, "roi_align: null pointer");
   PRV2_REQUIRE(h > 0 && w > 0 && c > 0 && k > 0 && oh > 0 && ow > 0 && ldf >= c && ldo >= c, "roi_align: bad geometry");
   bool vec = (c % 4 == 0) && (ldf % 4 == 0) && (ldo % 4 == 0) && aligned16(feat) && aligned16(out);
   PRV2_REQUIRE(oh <= 65535 && k <= 65535, "roi_align: grid too large");
   const dim3 grid((unsigned)cdiv((int64_t)ow * (vec ? c / 4 : c), 256), oh, k);
+  if (x2) {  // (vec holds: checked by the caller)
+    if (oh >= 16) {
+      constexpr int R = 4;
+      const dim3 grid_r((unsigned)cdiv((int64_t)ow * (c / 4), 256), (unsigned)cdiv(oh, R), k);
+      hipLaunchKernelGGL((roi_align_rows_kernel<R, true>), grid_r, dim3(256), 0, (hipStream_t)stream, feat, h, w, c, ldf, boxes, k, spatial_scale, oh, ow,
+                         out, ldo);
+    } else
+      hipLaunchKernelGGL((roi_align_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, feat, h, w, c, ldf, boxes, k, spatial_scale, oh, ow, out, ldo);
+    PRV2_LAUNCH_CHECK("roi_align_x2");
+    return 0;
+  }
   if (vec && oh >= 16) {
     constexpr int R = 4;
     const dim3 grid_r((unsigned)cdiv((int64_t)ow * (c / 4), 256), (unsigned)cdiv(oh, R), k);

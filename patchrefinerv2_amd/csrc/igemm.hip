@@ -423,6 +423,7 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
   // channel row, so the LayerNorm is fused for this width too
   if (!ups && !gate_w && !d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
     return prv2_conv3x3_ln_gate(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, nullptr, res, y, stream);
+  PRV2_REQUIRE(d->fmt == 0, "conv2d: pre-split (X2) operands are only taken by the 256-column 3x3 kernels (fmt %d, %d->%d k%d)", d->fmt, d->cin, d->cout, d->kh);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;

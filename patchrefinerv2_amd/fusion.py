@@ -272,6 +272,14 @@ class BiDirectionalFusion(_EncDec):
         out_conv(up(x)) == up(out_conv(x)) up to rounding -- 4x fewer FLOPs and no upsampled temporary."""
         ref = xs[-1]
         cat = Feat.alloc(ref.n, ref.h, ref.w, 2 * F_, ref.device)
+        # The concat [out | coarse ROI] is read by the fused gate kernel only (as its conv input and, first half, as ``mul``): when
+        # every writer can produce it -- the ROI gather and the 256-column conv of GatedConvUnit.conv -- it is kept in the kernel's
+        # own pre-split operand format (ops.Feat.x2; include/prv2.h PRV2_FMT_*): the halo loader then only copies.  Same results.
+        units = [blk["u2"]] + ([blk["u1"]] if len(xs) == 2 else [])
+        cat.x2 = bool(ops.X2_FORMAT and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and F_ % 8 == 0 and
+                      isinstance(coarse, ops.RoiSource) and ops.DIRECT_PLACEMENT and (coarse.h, coarse.w) == (ref.h, ref.w) and
+                      all("f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]) and ops._c256(ref, u["conv"]) and u["conv"].cout == 256
+                          for u in units))
         place(coarse, cat.slice(F_, F_))
         out = xs[0]
         if len(xs) == 2:

@@ -16,7 +16,8 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
-ABI_VERSION = 10
+FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
+ABI_VERSION = 11
 
 
 class ConvDesc(C.Structure):
@@ -29,7 +30,7 @@ class ConvDesc(C.Structure):
         ("relu_in", C.c_int32), ("act", C.c_int32), ("convt_k", C.c_int32),
         ("ld_mul", C.c_int32), ("ld_res", C.c_int32), ("ld_res2", C.c_int32),
         ("prec", C.c_int32), ("force_generic", C.c_int32), ("ln_eps", C.c_float), ("part", C.c_int32),
-        ("same_pad", C.c_int32), ("reserved", C.c_int32),
+        ("same_pad", C.c_int32), ("fmt", C.c_int32),
     ]
 
 
@@ -75,6 +76,7 @@ SIGNATURES = {
     "prv2_zoe_logbinom_depth": (_I, [_P, _I, _P, _I, _I, _F, _F, _L, _P, _P]),
     "prv2_crop_resize": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _I, _P]),
     "prv2_roi_align": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P, _I, _P]),
+    "prv2_roi_align_x2": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P, _I, _P]),
     "prv2_upsample_bilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_conv3x3_ln_gate_supported": (_I, [_P]),
     "prv2_gate_weight_bytes": (C.c_int64, [_I]),

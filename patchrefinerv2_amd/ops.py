@@ -115,12 +115,15 @@ def roundup(a: int, b: int) -> int:
 class Feat:
     """NHWC fp32 activation [n, h, w, c] living in ``buf`` ([n, h, w, ld]) at channel offset c0."""
 
-    __slots__ = ("buf", "n", "h", "w", "c", "c0")
+    __slots__ = ("buf", "n", "h", "w", "c", "c0", "x2")
 
-    def __init__(self, buf: torch.Tensor, c: Optional[int] = None, c0: int = 0):
+    def __init__(self, buf: torch.Tensor, c: Optional[int] = None, c0: int = 0, x2: bool = False):
         assert buf.dim() == 4 and buf.is_contiguous()
         _require_dev(buf)
         self.buf = buf
+        # x2: the bytes are the pre-split "X2" operand format of include/prv2.h (per 8 channels [8 bf16 hi | 8 bf16 lo]) instead of
+        # fp32 -- written by a producer for the 256-column conv kernels, its only readers (csrc/conv3x3_gate.hip)
+        self.x2 = x2
         self.n, self.h, self.w = buf.shape[0], buf.shape[1], buf.shape[2]
         self.c = buf.shape[3] - c0 if c is None else c
         self.c0 = c0
@@ -153,14 +156,28 @@ class Feat:
         return self.buf.device
 
     def slice(self, c0: int, c: int) -> "Feat":
-        return Feat(self.buf, c, self.c0 + c0)
+        assert not self.x2 or (c0 % 8 == 0 and c % 8 == 0)
+        return Feat(self.buf, c, self.c0 + c0, self.x2)
 
     def view(self) -> torch.Tensor:
         """this activation as a (strided) torch tensor [n, h, w, c]: what the torch.ops.prv2 operators take"""
+        assert not self.x2, "a pre-split (X2) buffer is not an fp32 tensor"
         return self.buf[..., self.c0:self.c0 + self.c]
 
     def batch(self, b0: int, b1: int) -> "Feat":
-        return Feat(self.buf[b0:b1], self.c, self.c0)
+        return Feat(self.buf[b0:b1], self.c, self.c0, self.x2)
+
+    def x2_to_float(self) -> "Feat":
+        """tests / debugging: the fp32 values an X2 buffer stands for (hi + lo per element)"""
+        assert self.x2 and self.c0 % 8 == 0 and self.c % 8 == 0
+        raw = self.buf[..., self.c0:self.c0 + self.c].contiguous().view(torch.int32)              # [n, h, w, c] dwords
+        g = raw.view(self.n, self.h, self.w, self.c // 8, 2, 4)                                   # [.., group, hi | lo, 4 dwords = 8 bf16]
+        def unpack(d):                                                                            # 4 dwords -> 8 floats (element 2i = low half)
+            lo16 = (d << 16).view(torch.float32)
+            hi16 = (d & -65536).view(torch.float32)
+            return torch.stack([lo16, hi16], dim=-1).flatten(-2)
+        v = unpack(g[..., 0, :]) + unpack(g[..., 1, :])
+        return Feat(v.reshape(self.n, self.h, self.w, self.c).contiguous())
 
     def to_nchw(self) -> torch.Tensor:
         """Debug / boundary helper: dense NCHW copy (through the HIP layout kernel)."""
@@ -254,16 +271,20 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
                    ldx=x.ld, ldy=out.ld, x_bstride=x_bstride, y_bstride=0, relu_in=int(relu_in), act=act,
                    convt_k=cw.convt_k, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0,
                    ld_res2=res2.ld if res2 is not None else 0, prec=cw.prec, force_generic=int(force_generic),
-                   ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+                   ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), fmt=0)
     for aux in (mul, res, res2):
         if aux is not None:
-            assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
+            assert (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c) and not aux.x2
+    assert not getattr(x, "x2", False), "conv2d reads fp32 activations (X2 inputs: conv3x3_ln_gate)"
+    if out.x2:  # pre-split output: written by the 256-column conv without LayerNorm (GatedConvUnit.conv -> the unit's concat buffer)
+        assert ln is None and gamma is None and mul is None and res2 is None and not force_generic and not x_bstride and _c256(x, cw)
+        d.fmt = L.FMT_Y_X2
     ncols = cw.cout * (cw.convt_k ** 2 if cw.convt_k else 1)
     taps = 1 if cw.convt_k else cw.kh * cw.kw
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
     halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and (cw.pad == 1 or cw.same_pad) and not cw.convt_k and x.w >= 24 and x.h >= 4
             and not force_generic)  # only for the f32-mode strip split below; kernel names come from prv2_last_kernel()
-    via_torch = DISPATCH == "torch" and type(x) is Feat and not x_bstride and not force_generic
+    via_torch = DISPATCH == "torch" and type(x) is Feat and not x_bstride and not force_generic and not out.x2
 
     def call():
         if via_torch and d.part == 0:
@@ -298,7 +319,7 @@ UPS_FUSION = os.environ.get("PRV2_UPS_FUSION", "1") != "0"  # A/B and test switc
 def _ups_desc(x: Feat, u: Feat, cw: ConvW, out_ld: int, act: int, res_ld: int, ln_eps: float):
     d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=x.ld, ldy=out_ld,
                    x_bstride=0, y_bstride=0, relu_in=0, act=act, convt_k=cw.convt_k, ld_mul=0, ld_res=res_ld, ld_res2=0, prec=cw.prec,
-                   force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+                   force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), fmt=0)
     us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
     return d, us
 
@@ -347,7 +368,7 @@ TAIL_FUSION = os.environ.get("PRV2_TAIL_FUSION", "1") != "0"  # A/B and test swi
 def _tail_desc(x: Feat, cw: ConvW, out: Feat, act: int, res_ld: int, ln_eps: float):
     return L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=x.ld, ldy=out.ld,
                       x_bstride=0, y_bstride=0, relu_in=0, act=act, convt_k=cw.convt_k, ld_mul=0, ld_res=res_ld, ld_res2=0, prec=cw.prec,
-                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), fmt=0)
 
 
 def conv2d_tail_supported(x: Feat, cw: ConvW, out: Feat) -> bool:
@@ -376,6 +397,7 @@ def conv2d_tail(x: Feat, cw: ConvW, out: Feat, p1: Feat, p2: Feat, *, act: int =
 
 
 GATE_FUSION = os.environ.get("PRV2_GATE_FUSION", "1") != "0"  # A/B and test switch: GatedConvUnit tail as one kernel
+X2_FORMAT = os.environ.get("PRV2_X2", "1") != "0"  # A/B and test switch: the GatedConvUnit's concat buffer in the pre-split operand format
 # widths F of a GatedConvUnit the library fuses (prv2_conv3x3_ln_gate); PRV2_GATE_CHANNELS=256 restricts them for A/B runs
 GATE_CHANNELS = tuple(int(c) for c in os.environ.get("PRV2_GATE_CHANNELS", "32,128,256").split(","))
 
@@ -394,10 +416,11 @@ def pack_gate(weight: torch.Tensor) -> torch.Tensor:
 
 
 def _gate_desc(x: Feat, cw: ConvW, out_ld: int, relu_in, act, mul, res, ln_eps):
+    fmt = (L.FMT_X_X2 if getattr(x, "x2", False) else 0) | (L.FMT_MUL_X2 if mul is not None and mul.x2 else 0)
     return L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad,
                       ldx=x.ld, ldy=out_ld, x_bstride=0, y_bstride=0, relu_in=int(relu_in), act=act, convt_k=cw.convt_k,
                       ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0, ld_res2=0, prec=cw.prec,
-                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), reserved=0)
+                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), fmt=fmt)
 
 
 def conv3x3_ln_gate_supported(x: Feat, cw: ConvW) -> bool:
@@ -418,8 +441,9 @@ def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate
     for aux in (mul, res):
         assert aux is None or (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
     d = _gate_desc(x, cw, out.ld, relu_in, act, mul, res, ln_eps)
+    assert not out.x2 and (res is None or not res.x2)
     flops = 2.0 * x.n * x.h * x.w * cw.cout * (cw.cin * 9 + (cw.cout if gate_w is not None else 0))
-    if DISPATCH == "torch" and type(x) is Feat:
+    if DISPATCH == "torch" and type(x) is Feat and not d.fmt:
         v = lambda f: None if f is None else f.view()  # noqa: E731
         PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
                         lambda: _tops().conv3x3_ln_gate(x.view(), cw.w, cw.bias, ln[0], ln[1], gate_w, gate_bias, v(mul), v(res), act, relu_in, cw.prec,
@@ -659,15 +683,16 @@ def roi_align(feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow
     k = boxes.shape[0]
     if out is None:
         out = Feat.alloc(k, oh, ow, feat.c, feat.device)
-    if DISPATCH == "torch":
+    if DISPATCH == "torch" and not out.x2:
         PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
                             lambda: _tops().roi_align(feat.view(), boxes.contiguous(), float(spatial_scale), oh, ow, out.view()),
                             f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}")
         return out
+    fn = L.load().prv2_roi_align_x2 if out.x2 else L.load().prv2_roi_align  # (x2: the pre-split format of the gate kernel's input)
     PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
-                        lambda: L.check(L.load().prv2_roi_align(feat.ptr, feat.h, feat.w, feat.c, feat.ld, boxes.data_ptr(), k,
-                                                                 spatial_scale, oh, ow, out.ptr, out.ld, _stream()), "roi_align"),
-                        f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}")
+                        lambda: L.check(fn(feat.ptr, feat.h, feat.w, feat.c, feat.ld, boxes.data_ptr(), k,
+                                           spatial_scale, oh, ow, out.ptr, out.ld, _stream()), "roi_align"),
+                        f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}{' x2' if out.x2 else ''}")
     return out
 
 

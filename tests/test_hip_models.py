@@ -140,6 +140,49 @@ def test_bidir_fusion(P, golden):
         close(out, g[tag], 3e-5, tag)
 
 
+def test_bidir_fusion_x2_format_is_bit_identical(P):
+    """BiDirectionalFusion with the GatedConvUnits' concat buffers in the pre-split X2 operand format (default when the coarse
+    pyramid arrives as ROI sources at the refiner's sizes) == the same network on fp32 buffers (PRV2_X2=0), bit for bit"""
+    from patchrefinerv2_amd import ops
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    c = TINY_BIDIR
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"],
+                                                c["dec_chl"]), seed=c["seed"])
+    m = BiDirectionalFusion(coarse2fine_type="coarse-gated", coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                            fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec="bf16x3")
+    m.load_state_dict(sd)
+    i = c["make_inputs"]("same")
+    ff = [P.Feat.from_nchw(t.to(DEV)) for t in i["f_feat"]]
+    sizes = [(t.shape[-2], t.shape[-1]) for t in i["f_feat"]]
+    K = i["pred1"].shape[0]
+    # the coarse pyramid as ROI sources (what the frame driver hands over): whole-map boxes at each level's own size
+    frame = [P.Feat.from_nchw(t[:1].to(DEV)) for t in i["c_feat"]]
+    boxes = torch.tensor([[0.0, 0.0, float(sizes[0][1]), float(sizes[0][0])]] * K, device=DEV)
+    rois = lambda: [ops.RoiSource(f, boxes, f.h / sizes[0][0], f.h, f.w) for f in frame]  # noqa: E731
+
+    def run():
+        return m(rois(), [None] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV), f_sizes=sizes).clone()
+
+    used = []
+    real = ops.conv3x3_ln_gate
+
+    def spy(x, *a, **k):
+        used.append(bool(x.x2))
+        return real(x, *a, **k)
+    ops.conv3x3_ln_gate = spy
+    try:
+        a = run()
+        assert any(used), "the X2 path was not taken"
+        ops.X2_FORMAT = False
+        used.clear()
+        b = run()
+        assert not any(used)
+    finally:
+        ops.X2_FORMAT = True
+        ops.conv3x3_ln_gate = real
+    assert torch.equal(a, b)
+
+
 def test_lightweight_refiner(P):
     from patchrefinerv2_amd.refiner import LightWeightRefiner
     sd = W.synth_state_dict(W.mnv4_spec("refiner_encoder.", in_chans=4), seed=9)

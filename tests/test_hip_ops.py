@@ -93,6 +93,13 @@ GATE_CASES = [  # n, h, w, cin, channels F, gate, residual
 ]
 
 
+def _x2_reconstruct(v: torch.Tensor) -> torch.Tensor:
+    """what an X2 element stands for: bf16 hi (RNE) + bf16 lo (RNE of the remainder), as split_bf16 computes them"""
+    hi = v.to(torch.bfloat16).float()
+    lo = (v - hi).to(torch.bfloat16).float()
+    return hi + lo
+
+
 @pytest.mark.parametrize("case", GATE_CASES)
 @pytest.mark.parametrize("prec", ["bf16x3", "f32ref"])
 def test_conv3x3_ln_gate_fused_tail(P, case, prec):
@@ -123,8 +130,8 @@ def test_conv3x3_ln_gate_fused_tail(P, case, prec):
         close(got.to_nchw(), ref, 2e-5, f"fused tail {case}")
         return
     t = P.conv2d(xf, cw0, act=P.ACT_RELU, ln=ln)
-    if gate:
-        t = P.conv2d(t, cw3, act=P.ACT_SIGMOID, mul=f(mul), res=f(res) if with_res else None)
+    if gate:  # (the 256-channel gate kernel multiplies by the bf16 pair hi + lo of ``mul`` -- the operand its conv reads, in either format)
+        t = P.conv2d(t, cw3, act=P.ACT_SIGMOID, mul=f(_x2_reconstruct(mul) if C_ == 256 else mul), res=f(res) if with_res else None)
     close(got.to_nchw(), t.to_nchw().cpu(), 2e-6, f"fused vs unfused {case}")
 
 
@@ -839,3 +846,47 @@ def test_conv2d_tail_equals_conv_then_depth_pair_fill(P, case):
     assert not P.conv2d_tail_supported(x, cw, P.Feat.alloc(n, H, W, cout, DEV))                       # no room behind the slice
     c256 = P.pack_conv(rnd(2, 256, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
     assert not P.conv2d_tail_supported(P.Feat.alloc(1, 24, 32, 64, DEV), c256, P.Feat.alloc_raw(1, 24, 32, 258, DEV).slice(0, 256))  # LayerNorm fused up to 128 columns
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", [(2, 24, 32, 512), (1, 17, 29, 512), (3, 12, 16, 512)])
+def test_x2_presplit_format_gate_unit(P, case, prec):
+    """The pre-split "X2" activation format (include/prv2.h PRV2_FMT_*; csrc/conv3x3_gate.hip): a GatedConvUnit's concat buffer
+    [out | coarse ROI] written by its producers in the gate kernel's operand format -- prv2_roi_align_x2 and the 256-column conv
+    with an X2 output hold exactly hi + lo of what the fp32 versions write, and the fused gate kernel gives the SAME BITS on the X2
+    buffer (x and mul) as on the fp32 one (bi_directional_fusion_model.py:56-82)"""
+    n, h, w, cin = case
+    F_ = cin // 2
+    PR = P.L.PREC_NAMES[prec]
+    g = torch.Generator().manual_seed(11)
+    x = P.Feat.from_nchw(torch.randn(n, F_, h, w, generator=g).to(DEV))                                  # the unit's input
+    coarse = P.Feat.from_nchw(torch.randn(1, F_, 2 * h, 2 * w, generator=g).to(DEV))                     # a coarse pyramid level
+    boxes = torch.tensor([[1.0 + 3 * i, 2.0 + i, 1.0 + 3 * i + w / 2.0, 2.0 + i + h / 2.0] for i in range(n)], device=DEV)
+    cw_c = P.pack_conv((torch.randn(F_, F_, 3, 3, generator=g) / (3 * F_ ** 0.5)).to(DEV), torch.randn(F_, generator=g).to(DEV) * 0.1, pad=1, prec=PR)
+    cw_f = P.pack_conv((torch.randn(F_, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(DEV), torch.randn(F_, generator=g).to(DEV) * 0.1, pad=1, prec=PR)
+    w3 = (torch.randn(F_, F_, 1, 1, generator=g) / 16).to(DEV)
+    gw, gb = P.pack_gate(w3), torch.randn(F_, generator=g).to(DEV) * 0.1
+    ln = ((torch.rand(F_, generator=g) + 0.5).to(DEV), (torch.randn(F_, generator=g) * 0.1).to(DEV))
+    res = P.Feat.from_nchw(torch.randn(n, F_, h, w, generator=g).to(DEV))
+
+    def unit(x2):
+        cat = P.Feat.alloc(n, h, w, cin, DEV)
+        cat.x2 = x2
+        P.roi_align(coarse, boxes, 1.0, h, w, out=cat.slice(F_, F_))
+        out = P.conv2d(x, cw_c, cat.slice(0, F_), relu_in=True, res=x)                                  # GatedConvUnit.conv: conv(relu(x)) + x
+        y = P.conv3x3_ln_gate(cat, cw_f, ln, gw, gb, act=P.ACT_RELU, mul=out, res=res)
+        return cat, y, P.L.load().prv2_last_kernel().decode()
+
+    cat32, y32, k32 = unit(False)
+    catx2, yx2, kx2 = unit(True)
+    assert "x2" in kx2 and "x2" not in k32
+    assert torch.equal(catx2.x2_to_float().buf, _x2_reconstruct(cat32.buf))
+    assert bool(torch.isfinite(yx2.buf).all()) and torch.equal(yx2.buf, y32.buf)
+    # the formats are only taken where they are implemented
+    with pytest.raises((RuntimeError, AssertionError)):
+        P.conv2d(catx2, cw_f)
+    narrow = P.pack_conv(torch.randn(64, F_, 3, 3, generator=g).to(DEV), None, pad=1, prec=PR)
+    dst = P.Feat.alloc(n, h, w, 64, DEV)
+    dst.x2 = True
+    with pytest.raises((RuntimeError, AssertionError)):
+        P.conv2d(x, narrow, dst)
