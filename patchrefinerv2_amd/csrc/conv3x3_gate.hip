@@ -71,8 +71,19 @@ struct GateConvParams {
   do {                                                                                                     \
     if (gp.stamps && (threadIdx.x & 63) == 0) gp.stamps[((long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 10 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+// in-kernel clock (MI355X_MICROARCH.md 'DVFS give-back' item 6): s_memtime / s_memrealtime at the start and the end of a workgroup,
+// into a region of the stamp buffer of their own
+#define PRV2_CLK_STAMP(i)                                                                                  \
+  do {                                                                                                     \
+    if (gp.stamps && threadIdx.x == 0) {                                                                   \
+      long long* q_ = gp.stamps + 8000000 + ((long long)blockIdx.x * 2 + (i)) * 2;                         \
+      q_[0] = __builtin_amdgcn_s_memtime();                                                                \
+      q_[1] = __builtin_amdgcn_s_memrealtime();                                                            \
+    }                                                                                                      \
+  } while (0)
 #else
 #define PRV2_STAMP(i)
+#define PRV2_CLK_STAMP(i)
 #endif
 
 template <int PREC, bool GATE, bool X2IN = false>
@@ -226,6 +237,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
 
   // ---- prologue ---------------------------------------------------------------------------------------------
   PRV2_STAMP(0);
+  PRV2_CLK_STAMP(0);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) load_a_async(0, it);
 #pragma unroll
@@ -546,6 +558,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
 #ifdef PRV2_GATE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PRV2_STAMP(9);
+    PRV2_CLK_STAMP(1);
 #endif
     return;
   }
@@ -658,6 +671,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_x2_kernel(const Gate
   __shared__ __attribute__((aligned(16))) float smem[g256::SMEM_FLOATS];
   c256_body<PREC, true, true>(gp, smem);
 }
+
+}  // namespace prv2
+#include "conv3x3_w4.h"
+namespace prv2 {
 
 // C x C gate weights (PyTorch [cout][cin][1][1]; C = 32, 128, 256) -> the fragment-major image of igemm.h::gate_frag_index
 __global__ void __launch_bounds__(256) pack_gate_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c) {
@@ -772,6 +789,17 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
   PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate: grid too large");
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = d->prec == PRV2_PREC_BF16X3;
+  // PRV2_W4=1: the four-wave kernel of conv3x3_w4.h (two workgroups per CU).  NOT the default: it needs 7 % fewer shader cycles per tile
+  // (all-zero operands, where the chip holds 2.39 GHz: 646 vs 607 TF), but on real operands the chip is at its power limit -- the clock
+  // falls from 1.94 to 1.81 GHz and the launch takes the same 3.48 ms; inside a frame (two streams) it is 1 % slower
+  // (tools/probes/gate_clock.sh, profiles/r03_power_wall.txt)
+  static const int use_w4 = getenv("PRV2_W4") ? atoi(getenv("PRV2_W4")) : 0;
+  if (gate_w_packed && gp.x_x2 && x3 && use_w4 && (!mul || gp.mul_x2)) {
+    hipLaunchKernelGGL((conv3x3_w4_gate_kernel<PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(256), 0, s, gp);
+    set_kernel("conv3x3_w4_gate_kernel", 256, d->prec);
+    PRV2_LAUNCH_CHECK("conv3x3_ln_gate");
+    return 0;
+  }
   if (gate_w_packed && gp.x_x2) {
     if (x3) hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(512), 0, s, gp);
     else hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16>), dim3((unsigned)blocks), dim3(512), 0, s, gp);

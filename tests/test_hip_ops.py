@@ -879,7 +879,7 @@ def test_x2_presplit_format_gate_unit(P, case, prec):
 
     cat32, y32, k32 = unit(False)
     catx2, yx2, kx2 = unit(True)
-    assert "x2" in kx2 and "x2" not in k32
+    assert ("x2" in kx2 or "w4" in kx2) and "x2" not in k32 and "w4" not in k32
     assert torch.equal(catx2.x2_to_float().buf, _x2_reconstruct(cat32.buf))
     assert bool(torch.isfinite(yx2.buf).all()) and torch.equal(yx2.buf, y32.buf)
     # the formats are only taken where they are implemented
@@ -890,3 +890,23 @@ def test_x2_presplit_format_gate_unit(P, case, prec):
     dst.x2 = True
     with pytest.raises((RuntimeError, AssertionError)):
         P.conv2d(x, narrow, dst)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 32), (1, 17, 29)])
+def test_w4_gate_kernel_matches_the_eight_wave_kernel(shape):
+    """csrc/conv3x3_w4.h (opt-in, PRV2_W4=1: four waves, two workgroups per CU, halo by buffer_load ... lds, wave-local LayerNorm and
+    gate GEMM) against the 8-wave kernel on the same GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80), ragged tiles
+    included: the same products in the same order, LayerNorm partial sums in another order -- ~1e-6 relative.  (The switch is read
+    once per process: the comparison runs in a child.)"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRV2_W4="1", PRV2_X2="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "w4_check.py"), *map(str, shape)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "conv3x3_w4_gate_kernel<256,bf16x3>" in r.stdout and "conv3x3_c256_gate_kernel<256,bf16x3>" in r.stdout, r.stdout
+    m = re.search(r"max\|d\| (\S+) scale (\S+) .* finite (\S+)", r.stdout)
+    assert m and m.group(3) == "True", r.stdout
+    assert float(m.group(1)) <= 3e-6 * float(m.group(2)), r.stdout

@@ -33,6 +33,12 @@ gw = P.pack_gate(torch.randn(F_, F_, 1, 1, device=DEV, generator=g) / 16)
 gb = torch.randn(F_, device=DEV, generator=g)
 ln = (torch.rand(F_, device=DEV, generator=g) + 0.5, torch.randn(F_, device=DEV, generator=g) * 0.1)
 res = P.Feat(torch.randn(n, h, w, F_, device=DEV, generator=g))
+if os.environ.get("PROBE_ZERO"):  # all-zero operands: the chip holds its full clock -- ranks kernels by CYCLES, not by what they deliver
+    for t_ in (x, coarse, res):
+        t_.buf.zero_()
+    cw_c = P.pack_conv(torch.zeros(F_, F_, 3, 3, device=DEV), torch.zeros(F_, device=DEV), pad=1, prec=PR)
+    cw_f = P.pack_conv(torch.zeros(F_, 2 * F_, 3, 3, device=DEV), torch.zeros(F_, device=DEV), pad=1, prec=PR)
+    gw = P.pack_gate(torch.zeros(F_, F_, 1, 1, device=DEV))
 for rnd in range(2):
     for x2 in (False, True):
         cat = P.Feat.alloc(n, h, w, 2 * F_, DEV)
