@@ -257,3 +257,25 @@ def test_checkpoint_key_remap_and_diagnosis():
     assert d["rename_candidates"]["refiner_fine_branch.refiner_encoder.stem.conv.weight"] == ["refiner_fine_branch.refiner_encoder.conv_stem.weight"]
     txt = W.format_diagnosis(d)
     assert "MISSING" in txt and "UNEXPECTED" in txt and "totally" in txt and "rename candidates" in txt
+
+
+def test_split_arithmetic_study_orders_the_schemes():
+    """tools/studies/split_arith_study.py (numpy emulation against float64): bf16x3 -- the shipped arithmetic --
+    is fp32-grade (< 1e-5 per dot product), and the candidate of the next round, one fp16 product + two block-scaled e2m3 corrections,
+    stays within 4 x of it and 15 x under a single fp16 product"""
+    import importlib.util
+    import os
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("split_arith_study", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "studies",
+                                                                                    "split_arith_study.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((32, 1152)).astype(np.float32)
+    w = (rng.standard_normal((48, 1152)) / 34.0).astype(np.float32)
+    ref, out = mod.dots(x, w)
+    den = np.sqrt((ref ** 2).mean())
+    err = {k: float(np.sqrt(((v - ref) ** 2).mean()) / den) for k, v in out.items()}
+    assert err["bf16x3"] < 1e-5 < err["f16"] and err["bf16"] > 1e-3
+    assert err["f16+f6x2"] < 4 * err["bf16x3"] and err["f16+f6x2"] * 15 < err["f16"]
+    assert err["f16+f6x2"] <= err["f16+f8x2"] < err["f16+f4x2"]

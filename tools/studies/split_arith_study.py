@@ -62,13 +62,18 @@ def dots(x, w):
     return ref, out
 
 
-for label, mkx in (("x ~ N(0,1)", lambda m, k: rng.standard_normal((m, k))),
-                   ("x = relu(N(0,1)) (half zeros)", lambda m, k: np.maximum(rng.standard_normal((m, k)), 0)),
-                   ("x heavy-tailed (N * lognormal)", lambda m, k: rng.standard_normal((m, k)) * np.exp(rng.standard_normal((m, k)))),
-                   ("x ~ N(3, 0.1) (large mean: cancellation-free)", lambda m, k: 3 + 0.1 * rng.standard_normal((m, k)))):
-    for K in (288, 4608):
-        x = mkx(64, K).astype(np.float32)
-        w = (rng.standard_normal((96, K)) / np.sqrt(K)).astype(np.float32)
-        ref, out = dots(x, w)
-        den = np.sqrt((ref ** 2).mean())
-        print(f"{label}, K = {K}: rms error / rms result   " + "   ".join(f"{k} {np.sqrt(((v - ref) ** 2).mean()) / den:.2e}" for k, v in out.items()))
+def main():
+    for label, mkx in (("x ~ N(0,1)", lambda m, k: rng.standard_normal((m, k))),
+                       ("x = relu(N(0,1)) (half zeros)", lambda m, k: np.maximum(rng.standard_normal((m, k)), 0)),
+                       ("x heavy-tailed (N * lognormal)", lambda m, k: rng.standard_normal((m, k)) * np.exp(rng.standard_normal((m, k)))),
+                       ("x ~ N(3, 0.1) (large mean: cancellation-free)", lambda m, k: 3 + 0.1 * rng.standard_normal((m, k)))):
+        for K in (288, 4608):
+            x = mkx(64, K).astype(np.float32)
+            w = (rng.standard_normal((96, K)) / np.sqrt(K)).astype(np.float32)
+            ref, out = dots(x, w)
+            den = np.sqrt((ref ** 2).mean())
+            print(f"{label}, K = {K}: rms error / rms result   " + "   ".join(f"{k} {np.sqrt(((v - ref) ** 2).mean()) / den:.2e}" for k, v in out.items()))
+
+
+if __name__ == "__main__":
+    main()
