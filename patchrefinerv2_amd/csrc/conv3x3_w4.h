@@ -7,7 +7,7 @@
 //
 // conv3x3_c256_gate[_x2]_kernel keeps one 8-wave workgroup per CU (153 KB of LDS): its epilogue -- LayerNorm statistics, normalise,
 // gate GEMM, store loop, 16 % of a tile's cycles -- and every barrier / DMA wait of its main loop run with the MFMA pipe idle
-// (74.7 % busy over the kernel).  Here the same tile (8 x 16 pixels x all 256 output channels) belongs to 4 waves with 80 KB of LDS,
+// (74.7 % busy over the kernel).  Here the same tile (8 x 16 pixels x all 256 output channels) belongs to 4 waves with 76.5 KB of LDS,
 // so that a CU holds two workgroups in different phases: one's epilogue and stalls are the other's MFMA time.
 //
 //   * wave w = image rows 2w, 2w + 1 of the tile (2 pixel runs of 16) x ALL 256 output channels: 2 x 16 accumulators of
@@ -16,13 +16,14 @@
 //     LayerNorm statistics are therefore lane sums + two cross-lane adds, the normalised values are split to bf16 hi / lo in
 //     registers and ARE the B operand of the gate GEMM (its k index = the channel, by the output-channel order chosen below): no C
 //     tile in LDS, no barrier in the epilogue except the weight pipeline's.
-//   * a step = (32-channel slab, tap, half of the output channels): weight tile 128 rows x 128 B = 16 KB by LDS-DMA into two
-//     alternating buffers (the DMA of step s + 1 is issued behind the barrier of step s); 48 MFMAs per wave and step, 18 steps per
-//     slab.  The gate GEMM is 16 more steps of the same pipeline (k = 256 normalised channels from registers, weight tiles gathered
+//   * a step = (32-channel slab, tap, half of the output channels): weight tile 128 rows x 128 B = 16 KB by LDS-DMA into three
+//     rotating buffers (the DMA of step s + 2 is issued behind the barrier of step s; one step of lookahead cost 3 %); 48 MFMAs per
+//     wave and step, 18 steps per slab.  The gate GEMM is 16 more steps of the same pipeline (k = 256 normalised channels from registers, weight tiles gathered
 //     by the DMA from the fragment-major image of prv2_pack_gate_weight).
 //   * the halo slab (10 x 18 pixels x 32 channels, pre-split "X2" input: see the head of conv3x3_gate.hip) goes global -> LDS by
-//     `buffer_load_dwordx4 ... lds`: per-lane gather addresses, hardware zero fill outside the image, no registers, no VALU; two
-//     buffers, the next slab's DMA issued at the first step of the current one.  LDS rows are 128 B, the 16-byte slot q of halo
+//     `buffer_load_dwordx4 ... lds`: per-lane gather addresses, hardware zero fill outside the image, no registers, no VALU; ONE
+//     buffer: the last tap's fragments are read at the end of step 15, the next slab's DMA is issued behind the barrier of step 16
+//     (its per-lane offsets wait in LDS: 6 registers the loop does not have).  LDS rows are 128 B, the 16-byte slot q of halo
 //     pixel hp at q ^ (hp & 7) (slots 0-3: bf16 hi of channels 8q..8q+7, 4-7: lo): conflict free for ds_read_b128 at every tap.
 //   * output channel order: accumulator j (0..15), row m = 4g + e of the MFMA result is channel 32 (j >> 1) + 8 g + 4 (j & 1) + e,
 //     i.e. a lane's accumulators 2s, 2s + 1 are the 8 CONSECUTIVE channels 32 s + 8 g .. + 7: one k-group of the gate GEMM's slab s,
