@@ -287,21 +287,30 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
 }
 
 // Row statistics for the fused LayerNorm: the C tile sits in LDS as [rows][cld]; thread t (< rows) owns row t.
-// Two passes (mean, then biased variance of the centred values) exactly like convs.py:25-27.
+// Two passes (mean, then biased variance of the centred values) exactly like convs.py:25-27.  Summation order: four partial sums --
+// partial g over the channels 32 s + 8 g + i (i < 8, ascending) -- combined as (p0 + p1) + (p2 + p3): the order in which the four
+// lanes of a pixel hold and reduce the channels in conv3x3_q4.h's wave-local epilogue, so that a layer's result does not depend on
+// which of the kernels took it.
 __device__ __forceinline__ void ln_row_stats(const IgemmParams& p, const float* ctile, int cld, int rows, int tid,
                                              float* stats /* [2*rows] in LDS */) {
   if (tid < rows) {
     const float* r = ctile + tid * cld;
-    float s = 0.f;
-    for (int c = 0; c < p.Cout; ++c) s += r[c] + (p.bias ? p.bias[c] : 0.f);
-    const float mean = s / (float)p.Cout;
-    float q = 0.f;
-    for (int c = 0; c < p.Cout; ++c) {
-      float d = r[c] + (p.bias ? p.bias[c] : 0.f) - mean;
-      q += d * d;
-    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < p.Cout; c0 += 32)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        for (int c = c0 + 8 * g; c < c0 + 8 * g + 8 && c < p.Cout; ++c) s[g] += r[c] + (p.bias ? p.bias[c] : 0.f);
+    const float mean = ((s[0] + s[1]) + (s[2] + s[3])) / (float)p.Cout;
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < p.Cout; c0 += 32)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        for (int c = c0 + 8 * g; c < c0 + 8 * g + 8 && c < p.Cout; ++c) {
+          const float d = r[c] + (p.bias ? p.bias[c] : 0.f) - mean;
+          q[g] += d * d;
+        }
     stats[tid] = mean;
-    stats[rows + tid] = 1.0f / sqrtf(q / (float)p.Cout + p.ln_eps);
+    stats[rows + tid] = 1.0f / sqrtf(((q[0] + q[1]) + (q[2] + q[3])) / (float)p.Cout + p.ln_eps);
   }
 }
 

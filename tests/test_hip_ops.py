@@ -910,3 +910,23 @@ def test_w4_gate_kernel_matches_the_eight_wave_kernel(shape):
     m = re.search(r"max\|d\| (\S+) scale (\S+) .* finite (\S+)", r.stdout)
     assert m and m.group(3) == "True", r.stdout
     assert float(m.group(1)) <= 3e-6 * float(m.group(2)), r.stdout
+
+
+def test_q4_kernels_pass_the_conv_tests():
+    """csrc/conv3x3_q4.h (opt-in, PRV2_Q4=2: four-wave workgroups, two per CU, for every 3x3 layer with 65 .. 128-column tiles it covers):
+    the fused-upsample, tail-tile and plain conv tests of this file pass bit for bit with it switched on (the switch is read once per
+    process: a child runs them)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, PRV2_Q4="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-k", "conv2d_ups_equals or conv2d_tail_equals or fused_tail or halo16", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    chk = subprocess.run([sys.executable, "-c", "import torch, numpy as np\nfrom patchrefinerv2_amd import ops as P\n"
+                          "x = P.Feat(torch.randn(1, 24, 32, 64, device='cuda'))\n"
+                          "cw = P.pack_conv(torch.randn(128, 64, 3, 3, device='cuda') / 24, None, pad=1, prec=P.L.PREC_NAMES['bf16x3'])\n"
+                          "P.conv2d(x, cw)\nprint(P.L.load().prv2_last_kernel().decode())"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(here)))
+    assert "conv3x3_q4_kernel" in chk.stdout, chk.stdout + chk.stderr[-2000:]

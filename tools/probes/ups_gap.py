@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, "/root/repo")
 import torch
 from patchrefinerv2_amd import ops as P
-DEV="cuda"; N=14; PR=P.L.PREC_NAMES["bf16x3"]
+DEV="cuda"; N=int(sys.argv[1]) if len(sys.argv) > 1 else 14; PR=P.L.PREC_NAMES["bf16x3"]
 def timeit(fn, it=8):
     for _ in range(4): fn()
     torch.cuda.synchronize()
@@ -11,7 +11,7 @@ def timeit(fn, it=8):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
-for h, w, cin, cout, upc in [(384,512,256,128,256),(384,512,98,98,64),(192,256,194,194,128),(96,128,322,322,256),(48,64,642,642,512)]:
+for h, w, cin, cout, upc in [(384,512,256,128,256),(384,512,98,98,64),(192,256,194,194,128),(96,128,322,322,256),(48,64,642,642,512)][:int(os.environ.get("NL", 5))]:
     x = P.Feat.alloc(N, h, w, cin, DEV); x.buf[..., :cin] = torch.randn(N, h, w, cin, device=DEV)
     cw = P.pack_conv(torch.randn(cout, cin, 3, 3, device=DEV) / (3 * cin ** 0.5), torch.randn(cout, device=DEV), pad=1, prec=PR)
     lnp = (torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)) if cout <= 128 else None
