@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 11
+#define PRV2_ABI_VERSION 12
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -157,6 +157,13 @@ int prv2_pack_gate_weight(const float* w_src, void* w_packed, int32_t cout, int3
 int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
                          const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul, const float* res,
                          float* y, void* stream);
+
+/* prv2_conv3x3_ln_gate with a pre-LayerNorm addend: fused = act(LN(conv3x3(x) + bias + pre)), pre NHWC fp32 [n, h, w, ld_pre >= cout]
+ * (ld_pre % 4 == 0, 16-byte aligned) -- the coarse half of the unit's ``fusion_conv.0`` from prv2_coarse_tap_gather, x being the fine
+ * half only (cin = F instead of 2F).  cout == 256 only.  pre == NULL: prv2_conv3x3_ln_gate. */
+int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre,
+                             int32_t ld_pre, const float* ln_weight, const float* ln_bias, const void* gate_w_packed, const float* gate_bias,
+                             const float* mul, const float* res, float* y, void* stream);
 
 /* Convolution with ONE output channel (direct, HBM-bound):
  *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118
@@ -295,6 +302,29 @@ int prv2_roi_align(const float* feat, int32_t h, int32_t w, int32_t c, int32_t l
  * buffer, whose only consumer is the gate kernel.  Same arithmetic; out[...] = X2(roi value). */
 int prv2_roi_align_x2(const float* feat, int32_t h, int32_t w, int32_t c, int32_t ldf, const float* boxes, int32_t k,
                       float spatial_scale, int32_t oh, int32_t ow, float* out, int32_t ldo, void* stream);
+
+/* The coarse half of a ``cat([fine, coarse_roi])`` 3x3 convolution, once per frame at coarse resolution (csrc/coarse_taps.hip):
+ *   GatedConvUnit.forward        bi_directional_fusion_model.py:70-73    fusion_conv.0(cat([out, c_feat]))    (no activation in front)
+ *   BiDirectionalFusion.forward  bi_directional_fusion_model.py:424-426  fusion_layers_1[l](cat([c, f]))
+ *   with c_feat = roi_align(feat.repeat(K), boxes, (h, w), h / P) of the per-frame pyramid level (patchrefinerplus.py:263-283).
+ * The conv is linear and its coarse input is a bilinear zoom of ``feat``, so
+ *     conv3x3(c_feat; W_c)(p) = sum_tap [p + d_tap inside the tile] Bil(G_tap; s(p + d_tap)),   G_tap = W_c[:, :, tap] . feat
+ * (s = roi_align's sample position, Bil = its clamped bilinear sample).  G is a 1x1 GEMM at COARSE resolution (prv2_conv2d with the
+ * weights [tap * c + co][ci]); the reference spends 9 * cin * cout MACs per output pixel of each of the frame's tiles on it.
+ *
+ * prv2_coarse_tap_knots: tiles of one frame share their size, i.e. consecutive output pixels are knot_b = tile / frame (per axis,
+ *   <= 1/2) apart in coarse coordinates; U(y, x) = sum_tap Bil(G_tap; y + dy knot_bh, x + dx knot_bw) is then piecewise bilinear on
+ *   the knot grid {k - b, k, k + b} and this call tabulates it there: g [h, w, ldg] (channel tap * c + co) -> v [3h, 3w, ldv].
+ * prv2_coarse_tap_gather: out[k, i, j, :] = U(s(i, j)) - the taps the zero padding hides on the tile's border pixels (sampled from
+ *   g): the pre-LayerNorm addend of prv2_conv3x3_ln_gate_pre / the pre-activation addend of the level's fusion conv.  A 4-tap
+ *   gather, like the prv2_roi_align of c_feat it replaces.  boxes / spatial_scale as prv2_roi_align; every box must lie inside the
+ *   frame and yield one sample per bin (roi extent <= output size).  Exact algebra; rounding differs from the reference's order by
+ *   ~1e-7 relative. */
+int prv2_coarse_tap_knots(const float* g, int32_t h, int32_t w, int32_t c, int32_t ldg, float knot_bh, float knot_bw, float* v,
+                          int32_t ldv, void* stream);
+int prv2_coarse_tap_gather(const float* v, const float* g, int32_t h, int32_t w, int32_t c, int32_t ldv, int32_t ldg, float knot_bh,
+                           float knot_bw, const float* boxes, int32_t k, float spatial_scale, int32_t oh, int32_t ow, float* out,
+                           int32_t ldo, void* stream);
 
 /* F.interpolate(mode='bilinear', align_corners=True) on NHWC (every decoder upsample; Appendix C row 1) */
 int prv2_upsample_bilinear(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t ldx, int32_t oh,

@@ -63,6 +63,8 @@ struct GateConvParams {
   const void* gate_w;      // fragment-major packed 256 x 256 gate weights, or null: y = act(LN(conv + bias))
   const float* gate_bias;
   int x_x2, mul_x2, y_x2;  // operand formats (X2 = pre-split, see the head of this file); y_x2: the no-gate, no-LayerNorm kernel
+  const float* pre;        // pre-LayerNorm addend [n, h, w, ld_pre] (prv2_conv3x3_ln_gate_pre: the conv's coarse half, coarse_taps.hip), or null
+  int ld_pre;
   long long* stamps;       // -DPRV2_GATE_STAMPS builds (tools/probes/gate_phase_stamps.sh): 10 s_memtime stamps per wave
 };
 
@@ -335,6 +337,21 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   PRV2_STAMP(2);
 
+  // ---- pre-LayerNorm addend (the conv's coarse half, gathered per tile by coarse_taps.hip): 64 threads x float4 = one 1 KB pixel
+  // row, 16 rows per thread, all requested here -- they land while the C tile is written -- and added to the C tile in LDS
+  constexpr int PC4 = BN / 4, PRPP = 512 / PC4, PNR = ROWS / PRPP;
+  const bool has_pre = gp.pre != nullptr;  // block-uniform
+  f32x4 pv[PNR];
+  if (has_pre) {
+    const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(gp.pre + (long long)n_img * p.H * p.W * gp.ld_pre), 0, (int)(((unsigned)(p.H * p.W - 1) * gp.ld_pre + BN) * 4u), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PNR; ++i) {
+      const int rr = tid / PC4 + i * PRPP;
+      const int pix = min(y0 + rr / TW, p.H - 1) * p.W + min(x0 + (rr & (TW - 1)), p.W - 1);
+      pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pre_rs, (pix * gp.ld_pre + (tid % PC4) * 4) * 4, 0, 0));
+    }
+  }
   // ---- C tile (conv + bias) -> LDS; LayerNorm parameters beside it ----------------------------------------------
   float* const ln_stats = csm + ROWS * CLD;   // [mean | rstd]
   float* const ln_par = ln_stats + 2 * ROWS;  // [weight | bias]
@@ -353,6 +370,14 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     ln_par[BN + tid] = p.ln_b[tid];
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (bare barriers from here on: __syncthreads() also drains vmcnt)
+  if (has_pre) {
+#pragma unroll
+    for (int i = 0; i < PNR; ++i) {
+      f32x4* q = reinterpret_cast<f32x4*>(&csm[(tid / PC4 + i * PRPP) * CLD + (tid % PC4) * 4]);
+      *q = *q + pv[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   PRV2_STAMP(3);
   // Gate weights: wave w multiplies ALL 128 pixels with gate columns 32w .. 32w + 31, so that every weight fragment is fetched
   // by exactly one wave (256 KB per tile from L2; 64 x 64 wave tiles fetched 512 KB and the GEMM ran at half the MFMA rate).
@@ -673,7 +698,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_x2_kernel(const Gate
 }
 
 }  // namespace prv2
+#ifdef PRV2_EXPERIMENTS  // (make EXPERIMENTS=1: the round-3 power-wall experiment; not part of the default build)
 #include "conv3x3_w4.h"
+#endif
 namespace prv2 {
 
 // C x C gate weights (PyTorch [cout][cin][1][1]; C = 32, 128, 256) -> the fragment-major image of igemm.h::gate_frag_index
@@ -741,7 +768,16 @@ extern "C" int prv2_pack_gate_weight(const float* w_src, void* w_packed, int32_t
 extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
                                     const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul, const float* res,
                                     float* y, void* stream) {
+  return prv2_conv3x3_ln_gate_pre(d, x, w_packed, bias, nullptr, 0, ln_weight, ln_bias, gate_w_packed, gate_bias, mul, res, y, stream);
+}
+
+extern "C" int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre,
+                                        int32_t ld_pre, const float* ln_weight, const float* ln_bias, const void* gate_w_packed,
+                                        const float* gate_bias, const float* mul, const float* res, float* y, void* stream) {
   PRV2_REQUIRE(d && x && w_packed && y && (ln_weight != nullptr) == (ln_bias != nullptr), "conv3x3_ln_gate: null pointer");
+  PRV2_REQUIRE(!pre || (d->cout == g256::BN && ln_weight && ld_pre >= d->cout && ld_pre % 4 == 0 && aligned16(pre) &&
+                        (long long)d->h * d->w * ld_pre < (1LL << 29)),
+               "conv3x3_ln_gate_pre: the pre-LayerNorm addend is taken at cout == 256 in front of a LayerNorm; [n, h, w, ld_pre >= cout], ld_pre %% 4 == 0, 16-byte aligned");
   if (gate_w_packed && d->cout != g256::BN) {  // 32 / 128 channels: conv3x3_m16.hip's kernels with the gate stage in their epilogue
     PRV2_REQUIRE(d->fmt == 0, "conv3x3_ln_gate: pre-split (X2) operands are taken at 256 channels only");
     PRV2_REQUIRE(gate_narrow_shape_ok(d) && ln_weight, "conv3x3_ln_gate: 3x3 s1 p1, cout 32 / 128 / 256, cin %% 32 == 0, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
@@ -774,6 +810,8 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
   p.vec_ok = 1; p.vec_epi = 1;
   gp.gate_w = gate_w_packed;
   gp.gate_bias = gate_bias;
+  gp.pre = pre;
+  gp.ld_pre = ld_pre;
   gp.x_x2 = (d->fmt & PRV2_FMT_X_X2) != 0;
   gp.mul_x2 = (d->fmt & PRV2_FMT_MUL_X2) != 0;
   gp.y_x2 = (d->fmt & PRV2_FMT_Y_X2) != 0;
@@ -793,13 +831,15 @@ extern "C" int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, con
   // (all-zero operands, where the chip holds 2.39 GHz: 646 vs 607 TF), but on real operands the chip is at its power limit -- the clock
   // falls from 1.94 to 1.81 GHz and the launch takes the same 3.48 ms; inside a frame (two streams) it is 1 % slower
   // (tools/probes/gate_clock.sh, profiles/r03_power_wall.txt)
+#ifdef PRV2_EXPERIMENTS
   static const int use_w4 = getenv("PRV2_W4") ? atoi(getenv("PRV2_W4")) : 0;
-  if (gate_w_packed && gp.x_x2 && x3 && use_w4 && (!mul || gp.mul_x2)) {
+  if (gate_w_packed && gp.x_x2 && x3 && use_w4 && (!mul || gp.mul_x2) && !pre) {
     hipLaunchKernelGGL((conv3x3_w4_gate_kernel<PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(256), 0, s, gp);
     set_kernel("conv3x3_w4_gate_kernel", 256, d->prec);
     PRV2_LAUNCH_CHECK("conv3x3_ln_gate");
     return 0;
   }
+#endif
   if (gate_w_packed && gp.x_x2) {
     if (x3) hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(512), 0, s, gp);
     else hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16>), dim3((unsigned)blocks), dim3(512), 0, s, gp);

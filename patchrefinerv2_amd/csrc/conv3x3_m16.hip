@@ -866,6 +866,7 @@ static int persist_workgroups() {  // one persistent workgroup per CU of the CUR
 }
 
 }  // namespace prv2
+#ifdef PRV2_EXPERIMENTS  // (make EXPERIMENTS=1: round-3 experiment, slower inside the frame; not part of the default build)
 #include "conv3x3_q4.h"
 namespace prv2 {
 
@@ -901,13 +902,18 @@ static void launch_conv3x3_q4(IgemmParams& p, int prec, hipStream_t s) {
     else hipLaunchKernelGGL((conv3x3_q4_kernel<false, false>), dim3(blocks), dim3(256), 0, s, p);
   }
 }
+}  // namespace prv2
+#endif
+namespace prv2 {
 
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   using namespace m16;
+#ifdef PRV2_EXPERIMENTS
   if (conv3x3_q4_usable(p, prec)) {
     launch_conv3x3_q4(p, prec, s);
     return;
   }
+#endif
   static const int wave_map = getenv("PRV2_HALO_WAVE_MAP") ? atoi(getenv("PRV2_HALO_WAVE_MAP")) : 1;  // A/B switch
   p.wave_map = wave_map;
   p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;

@@ -228,6 +228,15 @@ class BiDirectionalFusion(_EncDec):
             w3 = self._sd[b + "fusion_conv.3.weight"]
             if self.prec != ops.PREC_F32 and w3.shape[0] == w3.shape[1] and w3.shape[0] in ops.GATE_CHANNELS:  # fused tail kernel (ops.conv3x3_ln_gate)
                 u["f3g"] = ops.pack_gate(w3.to(self.device))
+                w0 = self._sd[b + "fusion_conv.0.weight"]
+                F_ = w3.shape[0]
+                if F_ == self.FEATURES and w0.shape[1] == 2 * F_:
+                    # fusion_conv.0 over cat([out, c_feat]) (:70-73) = conv3x3(out; W[:, :F]) + conv3x3(c_feat; W[:, F:]); the second
+                    # term is linear in the per-frame pyramid level and is computed once per frame at coarse resolution
+                    # (prepare_frame / ops.CoarseTaps): ``f0a`` = the fine half (with the bias), ``tapw`` = the coarse half as the
+                    # 1x1 GEMM weights of the nine tap maps
+                    u["f0a"] = ops.pack_conv(w0[:, :F_], self._sd.get(b + "fusion_conv.0.bias"), device=self.device, prec=self.prec)
+                    u["tapw"] = ops.coarse_tap_weight(w0[:, F_:])
             return u
 
         def block(b):
@@ -235,6 +244,12 @@ class BiDirectionalFusion(_EncDec):
                         u2=unit(b + "GateresConfUnit2."))
 
         P["refine"] = {r: block(f"{s}refinenet{r}.") for r in range(1, 6)}
+        # per level: the coarse-half GEMM of the block's GatedConvUnits in ONE 1x1 conv (unit 2 first; refinenet5 runs unit 2 only, :125-129)
+        P["taps"] = {}
+        for r in range(1, 6):
+            us = [P["refine"][r]["u2"]] + ([P["refine"][r]["u1"]] if r < 5 else [])
+            if all("tapw" in u for u in us):
+                P["taps"][r] = ops.pack_conv(torch.cat([u["tapw"] for u in us], 0), None, device=self.device, prec=self.prec)
         P["out1"] = self._conv(s + "output_conv1")
         if self.prec != ops.PREC_F32 and FOLD_OUT_CONV:
             # refinenet1.out_conv (1x1) -> bilinear x2 -> output_conv1 (3x3) is ONE 3x3 conv on the upsampled gate output: a 1x1
@@ -253,7 +268,47 @@ class BiDirectionalFusion(_EncDec):
         P["out3_b"] = self._dev(s + "output_conv3.0.bias")
         self._packed = P
 
+    # -- once per frame ------------------------------------------------------------------------
+    def prepare_frame(self, c_feat: List[Feat], knot_b):
+        """Per-frame part of the fusion network: the coarse half of every GatedConvUnit's ``fusion_conv.0`` (the pyramid level through
+        the conv's coarse weights: one 1x1 GEMM per level at COARSE resolution + its knot table, ops.CoarseTaps) -- the reference
+        convolves the x``split`` zoom of the same map once per tile.  c_feat: the 6 pyramid levels high -> low (as ``forward`` takes
+        their ROIs); knot_b = (tile height / frame height, tile width / frame width).  Attached to the maps (``Feat.aux``): ``forward``
+        finds it through its ``ops.RoiSource``s.  A no-op when the arithmetic mode / widths have no fused gate kernel."""
+        P = self._packed
+        if P is None or not ops.COARSE_TAPS or not P.get("taps") or max(knot_b) > 0.5 or min(knot_b) <= 0:
+            return
+        F_ = self.FEATURES
+        kb = (float(knot_b[0]), float(knot_b[1]))
+        for r, tw in P["taps"].items():
+            f = c_feat[r]
+            if f.c != F_ or f.n != 1 or (f.aux is not None and f.aux.get("kb") == kb):
+                continue
+            g = ops.conv2d(f, tw, algo=0.0)  # [1, H, W, units * 9 * F]
+            names = ["u2"] + (["u1"] if r < 5 else [])
+            f.aux = dict(kb=kb, g=g, taps={n: ops.CoarseTaps(g.slice(i * 9 * F_, 9 * F_), F_, kb) for i, n in enumerate(names)})
+
+    @staticmethod
+    def frame_tensors(c_feat: List[Feat]):
+        """the device tensors ``prepare_frame`` attached (for stream bookkeeping by the caller)"""
+        out = []
+        for f in c_feat:
+            if f.aux is not None:
+                out.append(f.aux["g"].buf)
+                out.extend(t.v.buf for t in f.aux["taps"].values())
+        return out
+
     # -- coarse2fine ---------------------------------------------------------------------------
+    @staticmethod
+    def _gated_unit_taps(u, x: Feat, taps: "ops.CoarseTaps", coarse: "ops.RoiSource", F_: int, res: Optional[Feat] = None) -> Feat:
+        """GatedConvUnit.forward with the coarse half of ``fusion_conv.0`` taken from the per-frame tap table: the 3x3 conv runs over
+        ``out`` only (K = F instead of 2F), ``c_feat`` is never gathered."""
+        out = Feat(torch.empty((x.n, x.h, x.w, F_), device=x.device, dtype=torch.float32), x2=True)  # the gate kernel's operand format
+        ops.conv2d(x, u["conv"], out, relu_in=True, res=x)                                          # conv(relu(x)) + x
+        pre = taps.gather(coarse.boxes, coarse.scale, x.h, x.w)                                      # conv3x3(c_feat; W[:, F:]) per tile
+        return ops.conv3x3_ln_gate(out, u["f0a"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res, pre=pre,
+                                   pre_cin=F_)
+
     @staticmethod
     def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None) -> Feat:
         """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
@@ -271,11 +326,24 @@ class BiDirectionalFusion(_EncDec):
         bilinear upsample: both are linear and the bilinear weights sum to one, so
         out_conv(up(x)) == up(out_conv(x)) up to rounding -- 4x fewer FLOPs and no upsampled temporary."""
         ref = xs[-1]
+        units = [blk["u2"]] + ([blk["u1"]] if len(xs) == 2 else [])
+        aux = coarse.feat.aux if isinstance(coarse, ops.RoiSource) else None
+        if (aux is not None and ops.COARSE_TAPS and ops.X2_FORMAT and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and F_ == self.FEATURES
+                and (coarse.h, coarse.w) == (ref.h, ref.w) and upscale
+                and all("f0a" in u and ops.conv3x3_ln_gate_supported(ref, u["f0a"]) and ops._c256(ref, u["conv"]) and u["conv"].cout == 256 for u in units)):
+            # the coarse half of both units comes from the per-frame tap tables (prepare_frame): no concat buffer, no ROI gather
+            out = xs[0]
+            if len(xs) == 2:
+                out = self._gated_unit_taps(blk["u1"], xs[1], aux["taps"]["u1"], coarse, F_, res=xs[0])
+            out = self._gated_unit_taps(blk["u2"], out, aux["taps"]["u2"], coarse, F_)
+            y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])
+            if defer_upsample is not None and ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample):
+                return y
+            return ops.upsample_bilinear(y, size[0], size[1], out=dest)
         cat = Feat.alloc(ref.n, ref.h, ref.w, 2 * F_, ref.device)
         # The concat [out | coarse ROI] is read by the fused gate kernel only (as its conv input and, first half, as ``mul``): when
         # every writer can produce it -- the ROI gather and the 256-column conv of GatedConvUnit.conv -- it is kept in the kernel's
         # own pre-split operand format (ops.Feat.x2; include/prv2.h PRV2_FMT_*): the halo loader then only copies.  Same results.
-        units = [blk["u2"]] + ([blk["u1"]] if len(xs) == 2 else [])
         cat.x2 = bool(ops.X2_FORMAT and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and F_ % 8 == 0 and
                       isinstance(coarse, ops.RoiSource) and ops.DIRECT_PLACEMENT and (coarse.h, coarse.w) == (ref.h, ref.w) and
                       all("f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]) and ops._c256(ref, u["conv"]) and u["conv"].cout == 256

@@ -423,7 +423,7 @@ class _PatchModel(StateDictModule):
         groups = self.shard_layout(plan["kinds"], plan["counts"], world, gather_dst)
         self.last_shard_layout = groups
         if self.needs_coarse:
-            coarse_feats, coarse_prediction = self._coarse_of(image_lr)
+            coarse_feats, coarse_prediction = self._coarse_of(image_lr, tile_cfg)
             coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
         else:
             coarse_feats = coarse_prediction = coarse_depth = None
@@ -489,7 +489,7 @@ class _PatchModel(StateDictModule):
         for gi in range(len(groups)):
             used = launch(gi)
             if gi == 0:
-                self._prefetch_coarse(getattr(self, "_next_lr", None), main)
+                self._prefetch_coarse(getattr(self, "_next_lr", None), main, tile_cfg)
             if pending is not None and receiver:   # blend the previous group on the main stream while this one computes
                 allp = pending[1]()
                 receiver = allp is not None        # (None on a receiving rank: the tests' recording pass of the shard emulation)
@@ -562,6 +562,7 @@ class _PatchModel(StateDictModule):
         with torch.cuda.device(dev):
             if self.needs_coarse:
                 feats, cp = self.coarse_forward(image_lr)
+                self._prepare_frame(feats, tile_cfg)
                 cd = Feat(cp.view(1, cp.shape[-2], cp.shape[-1], 1))
             else:
                 feats = cd = None
@@ -588,7 +589,7 @@ class _PatchModel(StateDictModule):
         RH, RW = tile_cfg["patch_reensemble_shape"]
         n_mine, n_all = plan["n_mine"], plan["n_all"]
         if self.needs_coarse:
-            coarse_feats, coarse_prediction = self._coarse_of(image_lr)
+            coarse_feats, coarse_prediction = self._coarse_of(image_lr, tile_cfg)
             coarse_depth = Feat(coarse_prediction.view(1, coarse_prediction.shape[-2], coarse_prediction.shape[-1], 1))
         else:
             coarse_feats = coarse_prediction = coarse_depth = None
@@ -614,7 +615,7 @@ class _PatchModel(StateDictModule):
                 crops, rois, depth_roi = self._prepare_batch(image_chw, tiles_dev[s:e], boxes_dev[s:e], tile_cfg, coarse_feats,
                                                              coarse_depth)
                 self.infer_forward(crops, rois, depth_roi, out=preds[s:e])
-        self._prefetch_coarse(getattr(self, "_next_lr", None), main)
+        self._prefetch_coarse(getattr(self, "_next_lr", None), main, tile_cfg)
         if n_streams > 1:
             for st in streams:
                 main.wait_stream(st)
@@ -685,7 +686,12 @@ class _PatchModel(StateDictModule):
         return self._exchange_begin(mine, shard, dst, group)()
 
     # -- coarse forward of the NEXT frame beside this frame's tile batches (forward(next_image_lr=...)) -----------------------
-    def _coarse_of(self, image_lr):
+    def _prepare_frame(self, coarse_feats, tile_cfg):
+        """per-frame work of the per-patch networks that depends on the coarse pyramid only (PatchRefinerPlus: the coarse half of
+        the fusion convs, fusion.BiDirectionalFusion.prepare_frame) -> the device tensors it created"""
+        return []
+
+    def _coarse_of(self, image_lr, tile_cfg=None):
         """this frame's coarse pyramid: the one prefetched by the previous call if it was made for this very tensor OBJECT,
         unmodified since (the prefetch entry holds the tensor itself: that keeps it alive while the side stream reads it, and
         an address the caching allocator hands out again for another image can never match)"""
@@ -695,10 +701,15 @@ class _PatchModel(StateDictModule):
             for t in pf["tensors"]:  # allocated on the prefetch stream, consumed on this frame's streams from here on
                 t.record_stream(torch.cuda.current_stream(image_lr.device))
             self._coarse_hold = pf  # (alive until the next frame replaces it: every consumer stream is long done by then)
+            if tile_cfg is not None:
+                self._prepare_frame(pf["feats"], tile_cfg)  # (a no-op when the prefetch prepared it for this tiling)
             return pf["feats"], pf["pred"]
-        return self.coarse_forward(image_lr)
+        feats, pred = self.coarse_forward(image_lr)
+        if tile_cfg is not None:
+            self._prepare_frame(feats, tile_cfg)
+        return feats, pred
 
-    def _prefetch_coarse(self, next_lr, main):
+    def _prefetch_coarse(self, next_lr, main, tile_cfg=None):
         if next_lr is None or not self.needs_coarse or ops.PROFILER.enabled or torch.cuda.is_current_stream_capturing():
             return
         dev = next_lr.device
@@ -708,9 +719,10 @@ class _PatchModel(StateDictModule):
         st.wait_stream(main)  # (the image may have been produced on the caller's stream)
         with torch.cuda.stream(st):
             feats, pred = self.coarse_forward(next_lr)
+            extra = self._prepare_frame(feats, tile_cfg) if tile_cfg is not None else []
             done = torch.cuda.Event()
             done.record(st)
-        tensors = [f.buf for f in feats] + [pred]
+        tensors = [f.buf for f in feats] + [pred] + list(extra)
         self._coarse_prefetched = dict(lr=next_lr, version=next_lr._version, feats=feats, pred=pred, done=done, tensors=tensors)
 
     def _invalidate_frame_caches(self):
@@ -1055,6 +1067,15 @@ class PatchRefinerPlus(_PatchModel):
 
     def _pack(self):
         pass
+
+    def _prepare_frame(self, coarse_feats, tile_cfg):
+        fm = self.refiner_fusion_model
+        if not hasattr(fm, "prepare_frame"):
+            return []
+        (rh, rw), (H, W) = tile_cfg["patch_raw_shape"], tile_cfg["image_raw_shape"]
+        c_feat = coarse_feats[-self.fusion_feat_level:][::-1]
+        fm.prepare_frame(c_feat, (rh / H, rw / W))
+        return fm.frame_tensors(c_feat)
 
     def infer_forward(self, crops: Feat, rois: List[Feat], depth_roi: Feat, out=None):
         """patchrefinerplus.py:330-365: encoder on [norm(rgb), coarse depth roi] then BiDirectionalFusion."""

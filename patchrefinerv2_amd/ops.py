@@ -41,7 +41,7 @@ class Profiler:
         self.enabled = False
         self.timed = False
         self.by_shape = False
-        self.records = []  # (kernel tag, algorithmic flops, start event, end event)
+        self.records = []  # (kernel tag, executed flops, start event, end event, reference-graph flops)
 
     def start(self, timed=False, by_shape=False):
         self.enabled, self.timed, self.by_shape, self.records = True, timed, by_shape, []
@@ -50,8 +50,10 @@ class Profiler:
         self.enabled = False
         return self.records
 
-    def launch(self, tag, flops, fn, shape=None):
-        """``tag``: a string, or a callable evaluated AFTER the launch (the library reports which kernel it dispatched)"""
+    def launch(self, tag, flops, fn, shape=None, algo=None):
+        """``tag``: a string, or a callable evaluated AFTER the launch (the library reports which kernel it dispatched).
+        ``flops``: the 2*MAC the launch EXECUTES; ``algo``: the 2*MAC the reference graph spends on the same step when that differs
+        (the coarse half of a cat([fine, coarse_roi]) conv is computed once per frame here: coarse_tap_*) -- default: the same."""
         if not self.enabled:
             return fn()
         e0 = e1 = None
@@ -66,7 +68,7 @@ class Profiler:
             tag = tag()
         if self.by_shape and shape is not None:
             tag = f"{tag} {shape}"
-        self.records.append((tag, flops, e0, e1))
+        self.records.append((tag, flops, e0, e1, flops if algo is None else algo))
 
     def launch_aux(self, tag, nbytes, fn, shape):
         """memory-bound kernels: only itemised in the per-layer report (by_shape); bytes go into the tag"""
@@ -75,12 +77,13 @@ class Profiler:
         return self.launch(tag, 0.0, fn, f"{shape} {nbytes / 1e6:.0f}MB")
 
     def summary(self):
-        """{tag: dict(launches, flops, ms)} (call after torch.cuda.synchronize())."""
+        """{tag: dict(launches, flops (executed), algo (reference graph), ms)} (call after torch.cuda.synchronize())."""
         out = {}
-        for tag, fl, e0, e1 in self.records:
-            d = out.setdefault(tag, dict(launches=0, flops=0.0, ms=0.0))
+        for tag, fl, e0, e1, al in self.records:
+            d = out.setdefault(tag, dict(launches=0, flops=0.0, ms=0.0, algo=0.0))
             d["launches"] += 1
             d["flops"] += fl
+            d["algo"] += al
             if e0 is not None:
                 d["ms"] += e0.elapsed_time(e1)
         return out
@@ -115,7 +118,7 @@ def roundup(a: int, b: int) -> int:
 class Feat:
     """NHWC fp32 activation [n, h, w, c] living in ``buf`` ([n, h, w, ld]) at channel offset c0."""
 
-    __slots__ = ("buf", "n", "h", "w", "c", "c0", "x2")
+    __slots__ = ("buf", "n", "h", "w", "c", "c0", "x2", "aux")
 
     def __init__(self, buf: torch.Tensor, c: Optional[int] = None, c0: int = 0, x2: bool = False):
         assert buf.dim() == 4 and buf.is_contiguous()
@@ -124,6 +127,7 @@ class Feat:
         # x2: the bytes are the pre-split "X2" operand format of include/prv2.h (per 8 channels [8 bf16 hi | 8 bf16 lo]) instead of
         # fp32 -- written by a producer for the 256-column conv kernels, its only readers (csrc/conv3x3_gate.hip)
         self.x2 = x2
+        self.aux = None  # per-frame derived tensors a consumer attached to this map (fusion.BiDirectionalFusion.prepare_frame)
         self.n, self.h, self.w = buf.shape[0], buf.shape[1], buf.shape[2]
         self.c = buf.shape[3] - c0 if c is None else c
         self.c0 = c0
@@ -254,9 +258,10 @@ def _c256(x: Feat, cw: ConvW) -> bool:
 def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = False, act: int = ACT_NONE,
            gamma: Optional[torch.Tensor] = None, mul: Optional[Feat] = None, res: Optional[Feat] = None,
            res2: Optional[Feat] = None, x_bstride: int = 0, force_generic: bool = False, ln=None,
-           ln_eps: float = 1e-6) -> Feat:
+           ln_eps: float = 1e-6, algo: Optional[float] = None) -> Feat:
     """y = epilogue(conv(x)); see include/prv2.h::prv2_conv2d.  ``ln`` = (weight, bias) of a channels-first
-    LayerNorm applied between the bias and the activation (fused when cout <= 128, else a separate row-LN pass)."""
+    LayerNorm applied between the bias and the activation (fused when cout <= 128, else a separate row-LN pass).
+    ``algo``: the reference graph's FLOPs for this step when they differ from the executed ones (Profiler.launch)."""
     if ln is not None and cw.cout > 128 and not (gamma is None and mul is None and res2 is None and not force_generic and not x_bstride
                                                  and _c256(x, cw)):
         y = conv2d(x, cw, out, relu_in=relu_in, x_bstride=x_bstride, force_generic=force_generic)
@@ -309,7 +314,7 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
         d.part = 2
         PROFILER.launch(tag, full * rem / x.w, call, shape=shape + f" strip{rem}")
         return out
-    PROFILER.launch(tag, 2.0 * m_rows * ncols * cw.cin * taps, call, shape=shape)
+    PROFILER.launch(tag, 2.0 * m_rows * ncols * cw.cin * taps, call, shape=shape, algo=algo)
     return out
 
 
@@ -432,9 +437,10 @@ def conv3x3_ln_gate_supported(x: Feat, cw: ConvW) -> bool:
 
 def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate_bias: Optional[torch.Tensor], out: Optional[Feat] = None,
                     *, act: int = ACT_RELU, mul: Optional[Feat] = None, res: Optional[Feat] = None, relu_in: bool = False,
-                    ln_eps: float = 1e-6) -> Feat:
+                    ln_eps: float = 1e-6, pre: Optional[Feat] = None, pre_cin: int = 0) -> Feat:
     """y = mul * sigmoid(conv1x1(act(LN(conv3x3(x) + b))) + gate_bias) (+ res) in one kernel (include/prv2.h::prv2_conv3x3_ln_gate);
-    ``gate_w`` None: y = act(LN(conv3x3(x) + b))."""
+    ``gate_w`` None: y = act(LN(conv3x3(x) + b)).  ``pre``: pre-LayerNorm addend [n, h, w, cout] -- the conv's coarse half from
+    ``CoarseTaps.gather`` (prv2_conv3x3_ln_gate_pre), standing for ``pre_cin`` further input channels of the reference's conv."""
     if out is None:
         out = Feat.alloc(x.n, x.h, x.w, cw.cout, x.device)
     assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and x.c == cw.cin
@@ -443,6 +449,15 @@ def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate
     d = _gate_desc(x, cw, out.ld, relu_in, act, mul, res, ln_eps)
     assert not out.x2 and (res is None or not res.x2)
     flops = 2.0 * x.n * x.h * x.w * cw.cout * (cw.cin * 9 + (cw.cout if gate_w is not None else 0))
+    if pre is not None:
+        assert (pre.n, pre.h, pre.w, pre.c) == (out.n, out.h, out.w, out.c) and not pre.x2
+        PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
+                        lambda: L.check(L.load().prv2_conv3x3_ln_gate_pre(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), pre.ptr, pre.ld, _ptr(ln[0]),
+                                                                          _ptr(ln[1]), _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), out.ptr, _stream()),
+                                        "conv3x3_ln_gate_pre"),
+                        shape=f"{cw.cin}(+{pre_cin} coarse)->{cw.cout}{'->' + str(cw.cout) + ' gate' if gate_w is not None else ''} k3s1 {x.n}x{x.h}x{x.w}",
+                        algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9)
+        return out
     if DISPATCH == "torch" and type(x) is Feat and not d.fmt:
         v = lambda f: None if f is None else f.view()  # noqa: E731
         PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
@@ -709,6 +724,45 @@ def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> 
                                                                          out.ld, _stream()), "upsample_bilinear"),
                         f"{x.c}ch {x.n}x{x.h}x{x.w}->{oh}x{ow}")
     return out
+
+
+COARSE_TAPS = os.environ.get("PRV2_COARSE_TAPS", "1") != "0"  # A/B and test switch: coarse half of the cat([fine, coarse_roi]) convs once per frame
+
+
+class CoarseTaps:
+    """The coarse half of one ``cat([fine, coarse_roi])`` 3x3 conv, tabulated once per frame (include/prv2.h::prv2_coarse_tap_knots):
+    ``g`` [1, H, W, 9 * cout] = the level's map through the conv's coarse weights, tap-major (a 1x1 GEMM at coarse resolution),
+    ``v`` [1, 3H, 3W, cout] = the unmasked tap sum on the knot grid, ``kb`` = (tile height / frame height, tile width / frame width)."""
+
+    def __init__(self, g: Feat, cout: int, kb):
+        assert g.n == 1 and g.c == 9 * cout and 0 < kb[0] <= 0.5 and 0 < kb[1] <= 0.5
+        self.g, self.cout, self.kb = g, cout, (float(kb[0]), float(kb[1]))
+        self.v = Feat(torch.empty((1, 3 * g.h, 3 * g.w, cout), device=g.device, dtype=torch.float32))
+        PROFILER.launch_aux("coarse_tap_knots", 4.0 * g.h * g.w * 18 * cout,
+                            lambda: L.check(L.load().prv2_coarse_tap_knots(g.ptr, g.h, g.w, cout, g.ld, self.kb[0], self.kb[1], self.v.ptr, self.v.ld,
+                                                                           _stream()), "coarse_tap_knots"), f"{cout}ch {g.h}x{g.w}")
+
+    def gather(self, boxes: torch.Tensor, spatial_scale: float, oh: int, ow: int, out: Optional[Feat] = None) -> Feat:
+        """the conv's coarse half for the tiles ``boxes`` (as roi_align takes them): [k, oh, ow, cout], zero padding at the tile border
+        included (prv2_coarse_tap_gather)"""
+        assert boxes.dtype == torch.float32 and boxes.is_cuda and boxes.shape[1] == 4
+        k = boxes.shape[0]
+        if out is None:
+            out = Feat(torch.empty((k, oh, ow, self.cout), device=self.g.device, dtype=torch.float32))
+        assert (out.n, out.h, out.w, out.c) == (k, oh, ow, self.cout) and not out.x2
+        g, v = self.g, self.v
+        PROFILER.launch_aux("coarse_tap_gather", 4.0 * self.cout * (9 * g.h * g.w + k * oh * ow),
+                            lambda: L.check(L.load().prv2_coarse_tap_gather(v.ptr, g.ptr, g.h, g.w, self.cout, v.ld, g.ld, self.kb[0], self.kb[1],
+                                                                            boxes.data_ptr(), k, spatial_scale, oh, ow, out.ptr, out.ld, _stream()),
+                                            "coarse_tap_gather"), f"{self.cout}ch {g.h}x{g.w}->{k}x{oh}x{ow}")
+        return out
+
+
+def coarse_tap_weight(w_coarse: torch.Tensor) -> torch.Tensor:
+    """[cout, cin, 3, 3] coarse-half weights of a conv -> the 1x1 GEMM weights [9 * cout, cin] whose output is tap-major
+    (row tap * cout + co = w[co, :, ky, kx]): G of ``CoarseTaps``"""
+    co, ci = w_coarse.shape[:2]
+    return w_coarse.permute(2, 3, 0, 1).reshape(9 * co, ci).contiguous()
 
 
 DIRECT_PLACEMENT = os.environ.get("PRV2_DIRECT_PLACEMENT", "1") != "0"  # A/B and test switch: ROI levels / depth pairs written by their producers

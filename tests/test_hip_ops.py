@@ -892,6 +892,17 @@ def test_x2_presplit_format_gate_unit(P, case, prec):
         P.conv2d(x, narrow, dst)
 
 
+def _built_with_experiments():
+    """the opt-in round-3 kernels (csrc/conv3x3_w4.h, conv3x3_q4.h) are only in builds made with ``make EXPERIMENTS=1``"""
+    from patchrefinerv2_amd import lib
+    with open(lib.LIB_PATH, "rb") as f:
+        return b"conv3x3_w4_gate_kernel" in f.read()
+
+
+needs_experiments = pytest.mark.skipif(not _built_with_experiments(), reason="library built without EXPERIMENTS=1 (conv3x3_w4.h / conv3x3_q4.h)")
+
+
+@needs_experiments
 @pytest.mark.parametrize("shape", [(2, 24, 32), (1, 17, 29)])
 def test_w4_gate_kernel_matches_the_eight_wave_kernel(shape):
     """csrc/conv3x3_w4.h (opt-in, PRV2_W4=1: four waves, two workgroups per CU, halo by buffer_load ... lds, wave-local LayerNorm and
@@ -912,6 +923,7 @@ def test_w4_gate_kernel_matches_the_eight_wave_kernel(shape):
     assert float(m.group(1)) <= 3e-6 * float(m.group(2)), r.stdout
 
 
+@needs_experiments
 def test_q4_kernels_pass_the_conv_tests():
     """csrc/conv3x3_q4.h (opt-in, PRV2_Q4=2: four-wave workgroups, two per CU, for every 3x3 layer with 65 .. 128-column tiles it covers):
     the fused-upsample, tail-tile and plain conv tests of this file pass bit for bit with it switched on (the switch is read once per
@@ -930,3 +942,90 @@ def test_q4_kernels_pass_the_conv_tests():
                           "P.conv2d(x, cw)\nprint(P.L.load().prv2_last_kernel().decode())"],
                          env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(here)))
     assert "conv3x3_q4_kernel" in chk.stdout, chk.stdout + chk.stderr[-2000:]
+
+
+def _frame_boxes(split, P_hw, k_random, seed):
+    """lr-frame ROI boxes [k, 4] (x1, y1, x2, y2) of tiles 1/split of the frame: the four frame corners, then random positions"""
+    ph, pw = P_hw
+    th, tw = ph / split[0], pw / split[1]
+    rng = np.random.default_rng(seed)
+    org = [(0.0, 0.0), (pw - tw, 0.0), (0.0, ph - th), (pw - tw, ph - th)]
+    org += [(float(rng.uniform(0, pw - tw)), float(rng.uniform(0, ph - th))) for _ in range(k_random)]
+    return torch.tensor([[x, y, x + tw, y + th] for x, y in org], dtype=torch.float32)
+
+
+@pytest.mark.parametrize("case", [((4, 4), 24, 32, 32, 16), ((2, 2), 12, 16, 8, 8), ((4, 4), 13, 18, 16, 12), ((3, 5), 12, 20, 8, 4)])
+def test_coarse_tap_gather_is_conv_of_the_roi(P, case):
+    """csrc/coarse_taps.hip (prv2_coarse_tap_knots / prv2_coarse_tap_gather): the coarse half of a cat([fine, coarse_roi]) 3x3 conv
+    from a per-frame tap table == conv3x3(roi_align(feat, boxes), W, zero padding) (bi_directional_fusion_model.py:70-73 over
+    patchrefinerplus.py:263-283), for tiles in the frame's corners (clamped samples) and at random sub-pixel phases; the frame-level
+    G is formed in float64 here so that the test isolates the two gather kernels"""
+    split, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(1, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    Pshape = (4 * H, 4 * W)  # patch_process_shape: spatial_scale = H / P_h
+    boxes = _frame_boxes(split, Pshape, 6, 3)
+    scale = H / Pshape[0]
+    roi = o_ops.roi_align(feat, torch.cat([torch.zeros(len(boxes), 1), boxes], 1), (H, W), scale)
+    ref = F.conv2d(roi.double(), wt.double(), padding=1).float()                                             # [k, cout, H, W]
+    G = torch.einsum("oikl,ihw->hwklo", wt.double(), feat[0].double()).reshape(1, H, W, 9 * cout).float()   # tap-major
+    taps = P.CoarseTaps(P.Feat(G.contiguous().to(DEV)), cout, (1.0 / split[0], 1.0 / split[1]))
+    got = taps.gather(boxes.to(DEV), scale, H, W)
+    close(got.to_nchw(), ref, 3e-6, "coarse_tap_gather")
+    # the knot table alone: U on the knots of an interior pixel == the unmasked tap sum there (spot check of the table's layout)
+    assert taps.v.buf.shape == (1, 3 * H, 3 * W, cout) and bool(torch.isfinite(taps.v.buf).all())
+
+
+@pytest.mark.parametrize("prec", ["bf16x3"])
+@pytest.mark.parametrize("case", [(5, 24, 32), (6, 17, 29)])
+def test_gated_unit_with_coarse_taps_vs_fp32_reference(P, case, prec):
+    """GatedConvUnit (bi_directional_fusion_model.py:56-82) restructured: conv3x3 over ``out`` only (K = F) + the per-frame coarse
+    half as the gate kernel's pre-LayerNorm addend (prv2_conv3x3_ln_gate_pre) against the reference's order of operations in fp32 --
+    roi_align -> cat -> conv3x3(2F -> F) -> LN -> ReLU -> 1x1 -> sigmoid gate (+ res) -- incl. tiles touching the frame border and
+    random-phase boxes; and against the unrestructured HIP unit (same tolerance class)"""
+    k, h, w = case
+    F_ = 256
+    PR = P.L.PREC_NAMES[prec]
+    g = torch.Generator().manual_seed(17)
+    split = (4, 4)
+    boxes = _frame_boxes(split, (4 * h, 4 * w), k - 4, 9)
+    scale = 0.25
+    x_t = torch.randn(k, F_, h, w, generator=g)
+    coarse_t = torch.randn(1, F_, h, w, generator=g)
+    wc, bc = torch.randn(F_, F_, 3, 3, generator=g) / (3 * F_ ** 0.5), torch.randn(F_, generator=g) * 0.1
+    wf, bf = torch.randn(F_, 2 * F_, 3, 3, generator=g) / (3 * (2 * F_) ** 0.5), torch.randn(F_, generator=g) * 0.1
+    w3, gb = torch.randn(F_, F_, 1, 1, generator=g) / 16, torch.randn(F_, generator=g) * 0.1
+    lnw, lnb = torch.rand(F_, generator=g) + 0.5, torch.randn(F_, generator=g) * 0.1
+    res_t = torch.randn(k, F_, h, w, generator=g)
+    # fp32 reference in the reference's order
+    roi = o_ops.roi_align(coarse_t, torch.cat([torch.zeros(k, 1), boxes], 1), (h, w), scale)
+    out_r = F.conv2d(F.relu(x_t), wc, bc, padding=1) + x_t
+    fused = F.conv2d(torch.cat([out_r, roi], 1), wf, bf, padding=1)
+    mu = fused.mean(1, keepdim=True)
+    var = ((fused - mu) ** 2).mean(1, keepdim=True)
+    fused = F.relu((fused - mu) / torch.sqrt(var + 1e-6) * lnw[None, :, None, None] + lnb[None, :, None, None])
+    ref = out_r * torch.sigmoid(F.conv2d(fused, w3, gb)) + res_t
+    # HIP: restructured unit
+    x, coarse, res = P.Feat.from_nchw(x_t.to(DEV)), P.Feat.from_nchw(coarse_t.to(DEV)), P.Feat.from_nchw(res_t.to(DEV))
+    cw_c = P.pack_conv(wc.to(DEV), bc.to(DEV), pad=1, prec=PR)
+    cw_a = P.pack_conv(wf[:, :F_].contiguous().to(DEV), bf.to(DEV), pad=1, prec=PR)
+    cw_t = P.pack_conv(P.coarse_tap_weight(wf[:, F_:]).to(DEV), None, prec=PR)
+    gw = P.pack_gate(w3.to(DEV))
+    ln = (lnw.to(DEV), lnb.to(DEV))
+    taps = P.CoarseTaps(P.conv2d(coarse, cw_t), F_, (0.25, 0.25))
+    out = P.Feat(torch.empty((k, h, w, F_), device=DEV), x2=True)
+    P.conv2d(x, cw_c, out, relu_in=True, res=x)
+    pre = taps.gather(boxes.to(DEV), scale, h, w)
+    y = P.conv3x3_ln_gate(out, cw_a, ln, gw, gb.to(DEV), act=P.ACT_RELU, mul=out, res=res, pre=pre, pre_cin=F_)
+    assert "gate_x2" in P.L.load().prv2_last_kernel().decode()
+    close(y.to_nchw(), ref, 4e-5, "restructured GatedConvUnit vs fp32 reference")
+    # HIP: the unit as the reference orders it (concat buffer + ROI gather), same arithmetic mode
+    cat = P.Feat.alloc(k, h, w, 2 * F_, DEV)
+    cat.x2 = True
+    P.roi_align(coarse, boxes.to(DEV), scale, h, w, out=cat.slice(F_, F_))
+    out2 = P.conv2d(x, cw_c, cat.slice(0, F_), relu_in=True, res=x)
+    cw_f = P.pack_conv(wf.to(DEV), bf.to(DEV), pad=1, prec=PR)
+    y2 = P.conv3x3_ln_gate(cat, cw_f, ln, gw, gb.to(DEV), act=P.ACT_RELU, mul=out2, res=res)
+    close(y2.to_nchw(), ref, 4e-5, "concat-order GatedConvUnit vs fp32 reference")
+    close(y.to_nchw(), y2.to_nchw().cpu(), 2e-5, "restructured vs concat-order unit")
