@@ -17,9 +17,14 @@ predictions to rank 0, which blends (strong scaling; ``--gather all`` = all-gath
 In ``--shard frames`` mode the per-rank depth maps are gathered to rank 0 over xGMI at the end of every step
 (SURVEY.md 8e cfg 5; ``--gather all`` keeps them on their ranks like the reference's data parallelism).
 
+``--gpus N`` with N > 1 started WITHOUT a launcher (no WORLD_SIZE in the environment) launches itself: the parent -- before any
+GPU call -- starts ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...`` as a child process, relays rank 0's
+JSON line and exits with the child's code (the reference's launcher contract: docs/user_infer.md:124-129, tools/dist_test.sh).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` (dominant kernel,
 HIP-event timed on its launch stream) and ``cpu_baseline`` (the oracle restatement on host cores,
-bounded sample).
+bounded sample).  ``operating_point``: shader clock / board power sampled while the timed frames run (the frame is power-limited:
+its throughput depends on how much the operands toggle -- ``--data zeros|rand`` fixes the two ends of that range).
 """
 from __future__ import annotations
 
@@ -27,7 +32,9 @@ import argparse
 import json
 import os
 import random
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -60,7 +67,71 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layer-report", default=None, help="write a per-layer-shape timing table (extra instrumented frame)")
+    ap.add_argument("--data", default="rand", choices=["rand", "zeros"],
+                    help="synthetic frames: uniform random pixels (default) or all-zero frames -- the frame is power-limited, so its "
+                         "rate depends on operand toggling; zeros is the upper end of that range (not a headline number)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)  # gloo + --stub-model: the CPU launcher test
+    ap.add_argument("--stub-model", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """``--gpus N`` (N > 1) without a launcher: start the N ranks as a FRESH child process tree (torch.distributed.run) -- this parent
+    has not touched the GPU (no torch.cuda call, package not imported) and never re-execs; relay the child's stdout (rank 0's JSON
+    line) and return its exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank child job failed with exit code {proc.returncode}\n")
+    return proc.returncode
+
+
+class OperatingPoint(threading.Thread):
+    """shader clock (MHz) and board power (W) of one GPU sampled from sysfs (hwmon) while the timed frames run: the frame is
+    power-limited, so a throughput number is only comparable together with its operating point.  Values are None when the box
+    does not expose the files to this user."""
+
+    def __init__(self, index: int, period: float = 0.05):
+        super().__init__(daemon=True)
+        self.period, self.samples, self._stop_ev = period, [], threading.Event()
+        self.power_f = self.clk_f = None
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"), key=lambda q: int(q.split("/card")[1].split("/")[0]))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+        if index < len(cards):
+            h = cards[index]
+            self.power_f = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            self.clk_f = os.path.join(h, "freq1_input") if os.path.exists(os.path.join(h, "freq1_input")) else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def run(self):
+        while not self._stop_ev.is_set():
+            self.samples.append((self._read(self.power_f), self._read(self.clk_f)))
+            self._stop_ev.wait(self.period)
+
+    def finish(self):
+        self._stop_ev.set()
+        self.join(timeout=1.0)
+        pw = [p / 1e6 for p, _ in self.samples if p is not None]
+        ck = [c / 1e9 for _, c in self.samples if c is not None]
+        mean = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
+        return dict(clock_ghz=mean(ck), clock_ghz_min=min(ck) if ck else None, power_w=mean(pw), power_w_max=max(pw) if pw else None,
+                    samples=len(self.samples), source="sysfs hwmon (freq1_input, power1_average)" if (pw or ck) else None)
 
 
 def cpu_baseline(name, sd, frame_seed):
@@ -144,16 +215,20 @@ def pmc_traffic(kernel_tag, workload, prec):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))  # (nothing below has run: no GPU call was made in this process)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks -- refusing to report a number under the wrong n_gpus")
+    if args.stub_model:
+        return stub_main(args, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, device_id=dev)
 
     from patchrefinerv2_amd import ops, weights as W
     from patchrefinerv2_amd.registry import build_model
@@ -177,7 +252,10 @@ def main():
 
     def frame(i):
         seed = i if shard is not None else rank * 100003 + i
-        hr = torch.rand(1, 3, *w["raw"], generator=torch.Generator().manual_seed(seed)).to(dev)
+        if args.data == "zeros":
+            hr = torch.zeros(1, 3, *w["raw"], device=dev)
+        else:
+            hr = torch.rand(1, 3, *w["raw"], generator=torch.Generator().manual_seed(seed)).to(dev)
         return hr, model.resizer(hr)
 
     frames = [frame(i) for i in range(min(n_frames, 2))]  # resident inputs (2 alternating frames)
@@ -227,11 +305,15 @@ def main():
     for i in range(args.warmup):
         step(i, last=i == args.warmup - 1)  # (no prefetch across t0: the timed region does exactly K coarse forwards)
     barrier()
+    op = OperatingPoint(local) if rank == 0 else None
+    if op is not None:
+        op.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i, timed=True, last=i == args.steps - 1)
     barrier()
     elapsed = time.perf_counter() - t0
+    operating_point = op.finish() if op is not None else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -242,11 +324,15 @@ def main():
         metric="4K depth maps/sec (cai-mode r32)" if w["mode"] == "r32" else f"depth maps/sec (cai-mode {w['mode']})",
         value=frames_done / elapsed, unit="depth maps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak" if shard is None else "strong",
-        vs_baseline=None, dtype=args.prec, data="synthetic",
+        vs_baseline=None, dtype=args.prec, data="synthetic" if args.data == "rand" else "synthetic (all-zero frames: upper end of the power-limited range, not a headline number)",
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
                     coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else w.get("zoe_type", "DA-ZoeDepth") + "/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
-                    max_batch=args.max_batch, streams=args.streams, hip_graph=bool(args.hip_graph), prefetch_next_coarse=bool(args.prefetch_coarse), out_shape=list(out.shape) if out is not None else None))
+                    max_batch=args.max_batch, streams=args.streams, hip_graph=bool(args.hip_graph), prefetch_next_coarse=bool(args.prefetch_coarse), out_shape=list(out.shape) if out is not None else None,
+                    frames=("torch.rand, seeded" if args.data == "rand" else "zeros"), weights="synthetic (numpy PCG64 keyed by parameter name)",
+                    parity_note=("refiner encoder MobileNetV4-S: parity unpinned (timm absent; two independent transcriptions agree)"
+                                 if w["kind"] == "PatchRefinerPlus" and not w.get("refiner_encoder") else None)))
+    result["operating_point"] = operating_point
 
     if world > 1:
         nt = w["patches"]
@@ -264,6 +350,13 @@ def main():
                                        collective_bytes_per_step=(coll["bytes"] // max(coll["n"], 1) if frame_gather else 0),
                                        collective_ms_per_step=(coll["ms"] / max(coll["n"], 1) if frame_gather else 0.0))
 
+    if world > 1:
+        # the job's collective part is over: every rank leaves the group here, so that nobody sits in a barrier (under RCCL's watchdog)
+        # while rank 0 runs its instrumented single-GPU frames below
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        if rank != 0:
+            return
     if rank == 0 and not args.no_roofline:
         # extra, instrumented frames: HIP events on the launch stream around every matrix-kernel launch
         # rank 0 alone runs these frames: UNSHARDED (a sharded forward would wait in a collective nobody else joins)
@@ -289,12 +382,19 @@ def main():
             bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
             traffic=traffic, traffic_source=traffic_src,
             launches_per_frame=d["launches"], avg_launch_ms=d["ms"] / d["launches"],
-            algorithmic_gflop_per_launch=d["flops"] / d["launches"] / 1e9,
-            frame_algorithmic_tflop=sum(x["flops"] for x in summ.values()) / 1e12,
+            executed_gflop_per_launch=d["flops"] / d["launches"] / 1e9,
+            # FLOP accounting: ``frame_algorithmic_tflop`` = the REFERENCE graph's 2*MAC per frame (what the PyTorch model
+            # spends on conv / linear / attention matmuls); ``executed_tflop`` = what the kernels here multiply -- less, because the coarse
+            # half of every cat([fine, coarse_roi]) conv is computed once per frame at coarse resolution (csrc/coarse_taps.hip) and the
+            # refinenet1 out_conv is folded into output_conv1's weights.  Per-kernel ``achieved`` / ``frac`` are EXECUTED FLOPs / time
+            # (a kernel's frac can never exceed 1); ``whole_frame_frac`` is the algorithmic FLOPs / the timed step.
+            frame_algorithmic_tflop=sum(x["algo"] for x in summ.values()) / 1e12,
+            executed_tflop=sum(x["flops"] for x in summ.values()) / 1e12,
             matrix_kernel_ms_per_frame=tot_ms,
             # the whole frame against the same peak: every algorithmic FLOP of a frame / the TIMED step (all kernels, gathers,
             # blend, D2H and host gaps included) -- what the headline value is worth as a fraction of the MFMA roofline
-            whole_frame_frac=sum(x["flops"] for x in summ.values()) / 1e12 / (elapsed / args.steps) / peak,
+            whole_frame_frac=sum(x["algo"] for x in summ.values()) / 1e12 / (elapsed / args.steps) / peak,
+            whole_frame_frac_executed=sum(x["flops"] for x in summ.values()) / 1e12 / (elapsed / args.steps) / peak,
             kernels={k: dict(launches=v["launches"], ms=round(v["ms"], 3),
                              tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None),
                              frac=(round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None))
@@ -316,9 +416,41 @@ def main():
         result["cpu_baseline"] = cpu_baseline(name, sd, 0)
     if rank == 0:
         print(json.dumps(result))
+
+
+def stub_main(args, rank, world):
+    """``--stub-model`` (the CPU launcher test, tests/test_distributed.py): the rank / timing / reporting skeleton of ``main`` with a
+    model that is a sleep -- no GPU, gloo; proves that ``--gpus N`` without a launcher really runs N ranks and reports n_gpus = N."""
+    import torch.distributed as dist
+    if os.environ.get("PRV2_BENCH_STUB_FAIL") and rank == world - 1:
+        raise SystemExit("stub rank failing on request (launcher test)")
     if world > 1:
-        torch.distributed.barrier()  # the other ranks wait here while rank 0 runs its instrumented frames
-        torch.distributed.destroy_process_group()
+        dist.init_process_group(args.backend)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.tensor([1.0])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+    elapsed = float(t.item())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(metric="stub frames/sec", value=args.steps * world / elapsed, unit="frames/s", n_gpus=world, steps=args.steps,
+                              warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                              dtype="none", data="stub", config=dict(workload="stub", ranks_seen=int(ranks.item())))))
 
 
 if __name__ == "__main__":

@@ -160,10 +160,19 @@ int prv2_conv3x3_ln_gate(const prv2_conv_desc* d, const float* x, const void* w_
 
 /* prv2_conv3x3_ln_gate with a pre-LayerNorm addend: fused = act(LN(conv3x3(x) + bias + pre)), pre NHWC fp32 [n, h, w, ld_pre >= cout]
  * (ld_pre % 4 == 0, 16-byte aligned) -- the coarse half of the unit's ``fusion_conv.0`` from prv2_coarse_tap_gather, x being the fine
- * half only (cin = F instead of 2F).  cout == 256 only.  pre == NULL: prv2_conv3x3_ln_gate. */
+ * half only (cin = F instead of 2F).  pre == NULL: prv2_conv3x3_ln_gate. */
 int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre,
                              int32_t ld_pre, const float* ln_weight, const float* ln_bias, const void* gate_w_packed, const float* gate_bias,
                              const float* mul, const float* res, float* y, void* stream);
+
+/* prv2_conv2d (3x3 / stride 1 / pad 1) with an addend in front of the epilogue: v = acc + pre[m, n] + bias[n]; [LayerNorm;] act; [+ res]
+ * -- ``fusion_layers_1[l](cat([c, f]))`` (bi_directional_fusion_model.py:424-426; FusionUnet encoder_layers_1, fusion_model.py:91-95)
+ * run over the fine half f only, with the coarse half of the conv from prv2_coarse_tap_gather as ``pre`` [n, h, w, ld_pre >= cout].
+ * Contract (prv2_conv2d_pre_supported(d) != 0): bf16 modes, 3x3 s1 p1, width >= 24, height >= 4, cout % 4 == 0 (the layers the
+ * 16x16x32 halo kernels or the 256-column kernel run); a fused LayerNorm needs cout <= 128 or == 256. */
+int prv2_conv2d_pre_supported(const prv2_conv_desc* d);
+int prv2_conv2d_pre(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre, int32_t ld_pre,
+                    const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream);
 
 /* Convolution with ONE output channel (direct, HBM-bound):
  *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118

@@ -15,6 +15,13 @@
 // {k - b, k, k + b}, k integer.  It is therefore fixed by its values on that knot grid (``V``: 3H x 3W knots, the size of G), and a
 // tile's B is a 4-tap gather from V -- the cost of the roi_align it replaces -- minus, on the tile's border pixels only, the taps the
 // conv's zero padding hides (3 per edge pixel, 5 per corner, sampled from G).  Exact algebra; fp32 rounding differs (1e-7 relative).
+//
+// BUILD NOTE: this file is compiled with packed fp32 math OFF (Makefile FLAGS_coarse_taps: -target-feature -packed-fp32-ops).  With
+// hipcc 7.2's v_pk_fma_f32 / v_pk_add_f32 code for tap_gather_kernel the border pixels of a tile came out wrong INTERMITTENTLY --
+// always the low halves of the packed pairs (channels 4k and 4k + 2) of the last quarter-wave (lanes 48-63), values off by one tap
+// term -- but only inside a frame with two tile streams and a third stream busy; never in isolation, and independent of every
+// s_waitcnt / s_nop added around the loads and the store (tools/probes/taps_stage_checksums.py, profiles/r04_experiments.txt).
+// Scalar v_fma_f32 code is bit-stable under the same load; the kernels are HBM-bound, the flag costs nothing measurable.
 #include "common.h"
 
 namespace prv2 {
@@ -161,10 +168,14 @@ __global__ void __launch_bounds__(256) tap_gather_kernel(const float* __restrict
     const float hy = 1.f - ly, hx = 1.f - lx;
     const float* g = G + tap * C + ch;
     float4 r = zero4();
-    fma4(r, hy * hx, *reinterpret_cast<const float4*>(g + ((int64_t)yl * W + xl) * ldg));
-    fma4(r, hy * lx, *reinterpret_cast<const float4*>(g + ((int64_t)yl * W + xh) * ldg));
-    fma4(r, ly * hx, *reinterpret_cast<const float4*>(g + ((int64_t)yh * W + xl) * ldg));
-    fma4(r, ly * lx, *reinterpret_cast<const float4*>(g + ((int64_t)yh * W + xh) * ldg));
+    const float4 a0 = *reinterpret_cast<const float4*>(g + ((int64_t)yl * W + xl) * ldg);
+    const float4 a1 = *reinterpret_cast<const float4*>(g + ((int64_t)yl * W + xh) * ldg);
+    const float4 a2 = *reinterpret_cast<const float4*>(g + ((int64_t)yh * W + xl) * ldg);
+    const float4 a3 = *reinterpret_cast<const float4*>(g + ((int64_t)yh * W + xh) * ldg);
+    fma4(r, hy * hx, a0);
+    fma4(r, hy * lx, a1);
+    fma4(r, ly * hx, a2);
+    fma4(r, ly * lx, a3);
     return r;
   };
 #pragma unroll

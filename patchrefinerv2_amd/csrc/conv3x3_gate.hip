@@ -775,15 +775,15 @@ extern "C" int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x,
                                         int32_t ld_pre, const float* ln_weight, const float* ln_bias, const void* gate_w_packed,
                                         const float* gate_bias, const float* mul, const float* res, float* y, void* stream) {
   PRV2_REQUIRE(d && x && w_packed && y && (ln_weight != nullptr) == (ln_bias != nullptr), "conv3x3_ln_gate: null pointer");
-  PRV2_REQUIRE(!pre || (d->cout == g256::BN && ln_weight && ld_pre >= d->cout && ld_pre % 4 == 0 && aligned16(pre) &&
-                        (long long)d->h * d->w * ld_pre < (1LL << 29)),
-               "conv3x3_ln_gate_pre: the pre-LayerNorm addend is taken at cout == 256 in front of a LayerNorm; [n, h, w, ld_pre >= cout], ld_pre %% 4 == 0, 16-byte aligned");
+  PRV2_REQUIRE(!pre || (ln_weight && ld_pre >= d->cout && ld_pre % 4 == 0 && aligned16(pre) && (long long)d->h * d->w * ld_pre < (1LL << 29)),
+               "conv3x3_ln_gate_pre: the addend goes in front of a LayerNorm; [n, h, w, ld_pre >= cout], ld_pre %% 4 == 0, 16-byte aligned");
   if (gate_w_packed && d->cout != g256::BN) {  // 32 / 128 channels: conv3x3_m16.hip's kernels with the gate stage in their epilogue
     PRV2_REQUIRE(d->fmt == 0, "conv3x3_ln_gate: pre-split (X2) operands are taken at 256 channels only");
     PRV2_REQUIRE(gate_narrow_shape_ok(d) && ln_weight, "conv3x3_ln_gate: 3x3 s1 p1, cout 32 / 128 / 256, cin %% 32 == 0, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",
                  d->h, d->w, d->cin, d->cout, d->kh, d->stride, d->prec);
     PRV2_REQUIRE(d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate: ReLU or no activation in front of the gate (act %d)", d->act);
-    return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, mul, res, nullptr, y, stream, gate_w_packed, gate_bias, nullptr, nullptr, nullptr, 0, 0);
+    return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, mul, res, nullptr, y, stream, gate_w_packed, gate_bias, nullptr, nullptr, nullptr, 0, 0,
+                       pre, ld_pre);
   }
   PRV2_REQUIRE(ln_weight || !gate_w_packed, "conv3x3_ln_gate: the gate stage sits behind the LayerNorm");
   PRV2_REQUIRE(gate_conv_shape_ok(d), "conv3x3_ln_gate: 3x3 s1 p1, cout 256, cin %% 32 == 0, width >= 16, bf16 modes (got %dx%d %d->%d k%d s%d prec %d)",

@@ -545,6 +545,31 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
           csm[row * CLD + wn * (BN / WN) + j * 16 + m16] = acc[a][j][e];
         }
     __syncthreads();
+    if (p.pre) {  // block-uniform: the conv's coarse half (prv2_conv2d_pre) joins the C tile in front of bias / LayerNorm / activation
+      constexpr int PC4 = BN / 4, PRPP = 512 / PC4, PNR = TH * TW / PRPP;
+      const int pc = c.tile_n * BN + (tid % PC4) * 4;
+      if (pc < p.Cout) {  // (host: Cout % 4 == 0)
+        const float* const pbase = p.pre + (long long)c.n_img * p.H * p.W * p.ld_pre + pc;
+        // four rows of the thread requested at a time (the narrow kernels live within 128 registers; rows outside the image: clamped
+        // address, added to rows nobody stores)
+        constexpr int CH = PNR < 4 ? PNR : 4;
+#pragma unroll 1
+        for (int i0 = 0; i0 < PNR; i0 += CH) {
+          f32x4 pv[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int rr = tid / PC4 + (i0 + i) * PRPP, py = rr / TW, px = rr - py * TW;
+            pv[i] = *reinterpret_cast<const f32x4*>(pbase + (long long)(min(c.y0 + py, p.H - 1) * p.W + min(c.x0 + px, p.W - 1)) * p.ld_pre);
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            f32x4* q = reinterpret_cast<f32x4*>(&csm[(tid / PC4 + (i0 + i) * PRPP) * CLD + (tid % PC4) * 4]);
+            *q = *q + pv[i];
+          }
+        }
+      }
+      __syncthreads();
+    }
     float* const ln_stats = csm + TH * TW * CLD;
     if constexpr (GATE) {
       // ---- gate stage (host: p.ln_w != null, Cout == BN, act none / ReLU, 16-byte rows) ----------------------------------

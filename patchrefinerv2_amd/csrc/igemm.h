@@ -52,6 +52,10 @@ struct IgemmParams {
   const float* tail2;
   int tH, tW;
   float tsy, tsx;
+  // conv3x3_m16.hip: addend in front of the bias / LayerNorm / activation stage, [N, H, W, ld_pre >= Cout] (prv2_conv2d_pre: the conv's
+  // coarse half from coarse_taps.hip).  null: none.
+  const float* pre;
+  int ld_pre;
 };
 
 // fragment-major gate weights: [16-column block cb][32-channel slab ks][hi, lo][lane 64] x 16 B, lane (m = lane & 15, g = lane >> 4)
@@ -322,7 +326,7 @@ void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t stream);  // ti
 int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
                 const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
                 const float* gate_bias, const prv2_ups_src* ups = nullptr, const float* tail1 = nullptr, const float* tail2 = nullptr,
-                int tail_h = 0, int tail_w = 0);  // igemm.hip: prv2_conv2d, with the optional gate stage of the 32 / 128-channel layers /
+                int tail_h = 0, int tail_w = 0, const float* pre = nullptr, int ld_pre = 0);  // igemm.hip: prv2_conv2d, with the optional gate stage of the 32 / 128-channel layers /
                                                   // the fused-upsample loader / the depth-pair tail
 bool conv3x3_halo16_ups_usable(const IgemmParams& p, int prec);  // p.xu layers (prv2_conv2d_ups): the 128-column 16x16x32 halo kernel
 bool conv3x3_halo16_gate_usable(const IgemmParams& p, int prec);                 // p.gate_w layers: Cout == 32 or 128, Cin % 32 == 0

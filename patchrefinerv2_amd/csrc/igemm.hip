@@ -361,7 +361,8 @@ extern "C" int prv2_pack_conv_weight(const float* w_src, const float* bn_scale, 
 namespace prv2 {
 int conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight, const float* ln_bias,
                 const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream, const void* gate_w,
-                const float* gate_bias, const prv2_ups_src* ups, const float* tail1, const float* tail2, int tail_h, int tail_w);
+                const float* gate_bias, const prv2_ups_src* ups, const float* tail1, const float* tail2, int tail_h, int tail_w, const float* pre,
+                int ld_pre);
 }
 
 extern "C" int prv2_conv2d(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias,
@@ -407,10 +408,29 @@ extern "C" int prv2_conv2d_tail(const prv2_conv_desc* d, const float* x, const v
   return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, res, nullptr, y, stream, nullptr, nullptr, nullptr, p1, p2, ph, pw);
 }
 
+// pre-stage addend (prv2.h prv2_conv2d_pre): the layer must run on the 16x16x32 halo kernels or on the 256-column kernel
+static bool pre_shape_ok(const prv2_conv_desc* d) {
+  return d && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->convt_k == 0 && !d->same_pad && d->prec != PRV2_PREC_F32 &&
+         !d->force_generic && d->part == 0 && d->w >= 24 && d->h >= 4 && d->cout % 4 == 0 && d->fmt == 0 &&
+         (long long)d->h * d->w * d->ldx < (1LL << 29) && (long long)d->h * d->w * d->ldy < (1LL << 29) &&
+         !(getenv("PRV2_HALO_MFMA32") && getenv("PRV2_HALO_MFMA32")[0] == '1');
+}
+
+extern "C" int prv2_conv2d_pre_supported(const prv2_conv_desc* d) { return pre_shape_ok(d) ? 1 : 0; }
+
+extern "C" int prv2_conv2d_pre(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre, int32_t ld_pre,
+                               const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream) {
+  PRV2_REQUIRE(pre_shape_ok(d) && pre, "conv2d_pre: layer not covered (3x3 s1 p1, bf16 modes, width >= 24, height >= 4, cout %% 4 == 0)");
+  PRV2_REQUIRE(ld_pre >= d->cout && ld_pre % 4 == 0 && aligned16(pre) && (long long)d->h * d->w * ld_pre < (1LL << 29), "conv2d_pre: addend layout");
+  PRV2_REQUIRE(!ln_weight || d->cout <= 128 || d->cout == 256, "conv2d_pre: fused LayerNorm needs cout <= 128 or == 256 (got %d)", d->cout);
+  return conv2d_impl(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, res, nullptr, y, stream, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                     pre, ld_pre);
+}
+
 int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* ln_weight,
                       const float* ln_bias, const float* gamma, const float* mul, const float* res, const float* res2, float* y, void* stream,
                       const void* gate_w, const float* gate_bias, const prv2_ups_src* ups, const float* tail1, const float* tail2, int tail_h,
-                      int tail_w) {
+                      int tail_w, const float* pre, int ld_pre) {
   PRV2_REQUIRE(d && x && w_packed && y, "conv2d: null pointer");
   PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv2d: bad sizes");
   PRV2_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -421,14 +441,15 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
   PRV2_REQUIRE((ln_weight == nullptr) == (ln_bias == nullptr), "conv2d: ln_weight and ln_bias go together");
   // 3x3 convs with 256 output channels (a layer property: the choice never depends on the batch): the workgroup holds the whole
   // channel row, so the LayerNorm is fused for this width too
-  if (!ups && !gate_w && !d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y))
-    return prv2_conv3x3_ln_gate(d, x, w_packed, bias, ln_weight, ln_bias, nullptr, nullptr, nullptr, res, y, stream);
+  if (!ups && !gate_w && !d->force_generic && !gamma && !mul && !res2 && d->part == 0 && conv3x3_c256_eligible(d, x, res, y) && (!pre || ln_weight))
+    return prv2_conv3x3_ln_gate_pre(d, x, w_packed, bias, pre, ld_pre, ln_weight, ln_bias, nullptr, nullptr, nullptr, res, y, stream);
   PRV2_REQUIRE(d->fmt == 0, "conv2d: pre-split (X2) operands are only taken by the 256-column 3x3 kernels (fmt %d, %d->%d k%d)", d->fmt, d->cin, d->cout, d->kh);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.mul = mul; p.res = res; p.res2 = res2; p.y = y;
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps;
   p.gate_w = gate_w; p.gate_bias = gate_bias;
+  p.pre = pre; p.ld_pre = ld_pre;
   if (tail1) {
     p.tail1 = tail1; p.tail2 = tail2; p.tH = tail_h; p.tW = tail_w;
     p.tsy = ac_scale(tail_h, d->h); p.tsx = ac_scale(tail_w, d->w);
@@ -515,6 +536,8 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
                  d->cin, d->cout, d->h, d->w, d->prec);
     PRV2_REQUIRE(!tail1 || (conv3x3_halo16_usable(p, d->prec) && p.vec_epi), "conv2d_tail: layer not covered by the 16x16x32 halo kernels (%d->%d, %dx%d, prec %d)",
                  d->cin, d->cout, d->h, d->w, d->prec);
+    PRV2_REQUIRE(!pre || conv3x3_halo16_usable(p, d->prec), "conv2d_pre: layer not covered by the 16x16x32 halo kernels (%d->%d, %dx%d, prec %d)",
+                 d->cin, d->cout, d->h, d->w, d->prec);
     if (strip && conv3x3_halo16_usable(p, d->prec)) {  // bf16 modes: tiles and strip are one launch
       PRV2_REQUIRE(d->part == 0, "conv2d: part=%d is only meaningful when the strip is a launch of its own (f32 mode)", d->part);
       p.rx0 = p.W - rem;
@@ -535,8 +558,8 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
     p.M = (long long)d->n * p.OH * rem;
     p.tiles_m = (int)cdiv(p.M, BM);
   } else
-  if (gate_w || ups || tail1) {
-    PRV2_REQUIRE(false, "%s: layer not covered by the halo kernels (%d->%d k%d, %dx%d)", ups ? "conv2d_ups" : (tail1 ? "conv2d_tail" : "conv3x3_ln_gate"), d->cin, d->cout, d->kh, d->h, d->w);
+  if (gate_w || ups || tail1 || pre) {
+    PRV2_REQUIRE(false, "%s: layer not covered by the halo kernels (%d->%d k%d, %dx%d)", ups ? "conv2d_ups" : (tail1 ? "conv2d_tail" : (pre ? "conv2d_pre" : "conv3x3_ln_gate")), d->cin, d->cout, d->kh, d->h, d->w);
   } else
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;

@@ -26,6 +26,8 @@ from .ops import ACT_GELU, ACT_RELU, ACT_SIGMOID, Feat
 import os
 
 FOLD_OUT_CONV = os.environ.get("PRV2_FOLD_OUT_CONV", "1") != "0"  # A/B and test switch (BiDirectionalFusion._pack)
+# A/B and test switch: which consumers take their coarse half from the per-frame tap tables (prepare_frame)
+TAPS_PARTS = tuple(os.environ.get("PRV2_TAPS_PARTS", "gate256,gate_narrow,enc1").split(","))
 
 
 def as_feat1(t: torch.Tensor) -> Feat:
@@ -93,10 +95,11 @@ class _EncDec(StateDictModule):
         return P
 
     def _encode_decode(self, P, pairs, sizes, pred1: Feat, pred2: Feat, update_base: Optional[torch.Tensor], out=None,
-                       cat1_bufs=None):
+                       cat1_bufs=None, enc1_taps=None):
         """pairs[l] = (fill_fn(dst_cat: Feat) writing the level-l [c, f] concat), sizes[l] = (h, w);
         levels high -> low resolution (fusion_model.py:91-118).  ``cat1_bufs`` = already allocated (and
-        possibly partly filled) level concat buffers."""
+        possibly partly filled) level concat buffers.  ``enc1_taps[l]`` = (ops.CoarseTaps, the level's ops.RoiSource, fine feature) for
+        levels whose first encoder conv takes the coarse half of cat([c, f]) from the per-frame tap table (no concat buffer), or None."""
         B, dev = pred1.n, pred1.device
         L_ = len(self.temp_chl)
         nd = len(self.dec_in)
@@ -120,12 +123,21 @@ class _EncDec(StateDictModule):
         for l in range(L_):
             h, w = sizes[l]
             tc = self.temp_chl[l]
-            cat1 = cat1_bufs[l] if cat1_bufs is not None else Feat.alloc(B, h, w, self.in_chl[l], dev)
-            pairs[l](cat1)
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
             cat2 = alloc_with_pred_tail(B, h, w, tc, dev)
-            if not conv_ln_gelu(cat1, conv, lnw, lnb, cat2.slice(0, tc), tail_c0=tc):
+            if enc1_taps is not None and enc1_taps[l] is not None:
+                taps, roi, fine = enc1_taps[l]
+                pre = taps.gather(roi.boxes, roi.scale, h, w)  # conv3x3(c; W[:, :c_l]) of the tiles, from the frame's table
+                fused_ln = tc <= 128 or tc == 256
+                ops.conv2d_pre(fine, P[f"{self.ENC1}.{l}.fine"], pre, cat2.slice(0, tc) if fused_ln else None, act=ACT_GELU if fused_ln else ops.ACT_NONE,
+                               ln=(lnw, lnb) if fused_ln else None, pre_cin=roi.c)
+                assert fused_ln  # (wider levels are not taken: BiDirectionalFusion.forward asks conv2d_pre_supported(ln=True))
                 place_preds(pred1, pred2, cat2, tc)
+            else:
+                cat1 = cat1_bufs[l] if cat1_bufs is not None else Feat.alloc(B, h, w, self.in_chl[l], dev)
+                pairs[l](cat1)
+                if not conv_ln_gelu(cat1, conv, lnw, lnb, cat2.slice(0, tc), tail_c0=tc):
+                    place_preds(pred1, pred2, cat2, tc)
             conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
             j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
             if 0 <= j < nd:
@@ -230,7 +242,7 @@ class BiDirectionalFusion(_EncDec):
                 u["f3g"] = ops.pack_gate(w3.to(self.device))
                 w0 = self._sd[b + "fusion_conv.0.weight"]
                 F_ = w3.shape[0]
-                if F_ == self.FEATURES and w0.shape[1] == 2 * F_:
+                if w0.shape[1] == 2 * F_:
                     # fusion_conv.0 over cat([out, c_feat]) (:70-73) = conv3x3(out; W[:, :F]) + conv3x3(c_feat; W[:, F:]); the second
                     # term is linear in the per-frame pyramid level and is computed once per frame at coarse resolution
                     # (prepare_frame / ops.CoarseTaps): ``f0a`` = the fine half (with the bias), ``tapw`` = the coarse half as the
@@ -244,12 +256,6 @@ class BiDirectionalFusion(_EncDec):
                         u2=unit(b + "GateresConfUnit2."))
 
         P["refine"] = {r: block(f"{s}refinenet{r}.") for r in range(1, 6)}
-        # per level: the coarse-half GEMM of the block's GatedConvUnits in ONE 1x1 conv (unit 2 first; refinenet5 runs unit 2 only, :125-129)
-        P["taps"] = {}
-        for r in range(1, 6):
-            us = [P["refine"][r]["u2"]] + ([P["refine"][r]["u1"]] if r < 5 else [])
-            if all("tapw" in u for u in us):
-                P["taps"][r] = ops.pack_conv(torch.cat([u["tapw"] for u in us], 0), None, device=self.device, prec=self.prec)
         P["out1"] = self._conv(s + "output_conv1")
         if self.prec != ops.PREC_F32 and FOLD_OUT_CONV:
             # refinenet1.out_conv (1x1) -> bilinear x2 -> output_conv1 (3x3) is ONE 3x3 conv on the upsampled gate output: a 1x1
@@ -266,27 +272,50 @@ class BiDirectionalFusion(_EncDec):
         P["out2_fusion"] = block(s + "output_conv2_fusion.")
         P["out3_w"] = self._dev(s + "output_conv3.0.weight")
         P["out3_b"] = self._dev(s + "output_conv3.0.bias")
+        # Per pyramid level: every conv that reads cat([., c_feat[l]]) with no activation in front -- the level's GatedConvUnits
+        # (refinenet{l}: unit 2, and unit 1 where the block has two inputs, :125-129; level 0: output_conv2_fusion's unit 2) and
+        # fusion_layers_1[l] -- hands the coarse half of its weights to ONE 1x1 GEMM per level and frame (prepare_frame).
+        # P["taps"][l] = (packed [sum 9 * cout, c_l] weights, [(consumer name, cout), ...])
+        P["taps"] = {}
+        if self.prec != ops.PREC_F32:
+            for l in range(6):
+                blk = P["refine"][l] if l >= 1 else P["out2_fusion"]
+                cons = [("u2", blk["u2"])] + ([("u1", blk["u1"])] if 1 <= l < 5 else [])
+                rows = [(n, u["tapw"]) for n, u in cons if "tapw" in u and u["tapw"].shape[1] == self.coarse_chl[l] and
+                        ("gate256" if u["tapw"].shape[0] == 9 * 256 else "gate_narrow") in TAPS_PARTS]
+                cc = self.coarse_chl[l]
+                w1 = self._sd[f"{self.ENC1}.{l}.single_conv.0.weight"]
+                if w1.shape[1] > cc and w1.shape[0] % 4 == 0 and "enc1" in TAPS_PARTS:
+                    # fusion_layers_1[l] over cat([c, f]) (:424-426): coarse half FIRST
+                    P[f"{self.ENC1}.{l}.fine"] = ops.pack_conv(w1[:, cc:], None, device=self.device, prec=self.prec)
+                    rows.append(("enc1", ops.coarse_tap_weight(w1[:, :cc])))
+                if rows:
+                    P["taps"][l] = (ops.pack_conv(torch.cat([t for _, t in rows], 0), None, device=self.device, prec=self.prec),
+                                    [(n, t.shape[0] // 9) for n, t in rows])
         self._packed = P
 
     # -- once per frame ------------------------------------------------------------------------
     def prepare_frame(self, c_feat: List[Feat], knot_b):
-        """Per-frame part of the fusion network: the coarse half of every GatedConvUnit's ``fusion_conv.0`` (the pyramid level through
-        the conv's coarse weights: one 1x1 GEMM per level at COARSE resolution + its knot table, ops.CoarseTaps) -- the reference
-        convolves the x``split`` zoom of the same map once per tile.  c_feat: the 6 pyramid levels high -> low (as ``forward`` takes
-        their ROIs); knot_b = (tile height / frame height, tile width / frame width).  Attached to the maps (``Feat.aux``): ``forward``
-        finds it through its ``ops.RoiSource``s.  A no-op when the arithmetic mode / widths have no fused gate kernel."""
+        """Per-frame part of the fusion network: the coarse half of every conv that reads cat([., c_feat[l]]) -- the GatedConvUnits'
+        ``fusion_conv.0`` and ``fusion_layers_1[l]`` -- as the pyramid level through the convs' coarse weights (ONE 1x1 GEMM per level at
+        COARSE resolution) + the knot table of each consumer (ops.CoarseTaps); the reference convolves the x``split`` zoom of the same
+        map once per tile.  c_feat: the 6 pyramid levels high -> low (as ``forward`` takes their ROIs); knot_b = (tile height / frame
+        height, tile width / frame width).  Attached to the maps (``Feat.aux``): ``forward`` finds it through its ``ops.RoiSource``s.
+        A no-op in the f32 mode (which keeps the reference's order of operations)."""
         P = self._packed
         if P is None or not ops.COARSE_TAPS or not P.get("taps") or max(knot_b) > 0.5 or min(knot_b) <= 0:
             return
-        F_ = self.FEATURES
         kb = (float(knot_b[0]), float(knot_b[1]))
-        for r, tw in P["taps"].items():
-            f = c_feat[r]
-            if f.c != F_ or f.n != 1 or (f.aux is not None and f.aux.get("kb") == kb):
+        for l, (tw, cons) in P["taps"].items():
+            f = c_feat[l]
+            if f.c != self.coarse_chl[l] or f.n != 1 or (f.aux is not None and f.aux.get("kb") == kb):
                 continue
-            g = ops.conv2d(f, tw, algo=0.0)  # [1, H, W, units * 9 * F]
-            names = ["u2"] + (["u1"] if r < 5 else [])
-            f.aux = dict(kb=kb, g=g, taps={n: ops.CoarseTaps(g.slice(i * 9 * F_, 9 * F_), F_, kb) for i, n in enumerate(names)})
+            g = ops.conv2d(f, tw, algo=0.0)  # [1, H, W, sum 9 * cout]
+            taps, o = {}, 0
+            for n, co in cons:
+                taps[n] = ops.CoarseTaps(g.slice(o, 9 * co), co, kb)
+                o += 9 * co
+            f.aux = dict(kb=kb, g=g, taps=taps)
 
     @staticmethod
     def frame_tensors(c_feat: List[Feat]):
@@ -303,7 +332,7 @@ class BiDirectionalFusion(_EncDec):
     def _gated_unit_taps(u, x: Feat, taps: "ops.CoarseTaps", coarse: "ops.RoiSource", F_: int, res: Optional[Feat] = None) -> Feat:
         """GatedConvUnit.forward with the coarse half of ``fusion_conv.0`` taken from the per-frame tap table: the 3x3 conv runs over
         ``out`` only (K = F instead of 2F), ``c_feat`` is never gathered."""
-        out = Feat(torch.empty((x.n, x.h, x.w, F_), device=x.device, dtype=torch.float32), x2=True)  # the gate kernel's operand format
+        out = Feat(torch.empty((x.n, x.h, x.w, F_), device=x.device, dtype=torch.float32), x2=F_ == 256)  # (256: the gate kernel's operand format)
         ops.conv2d(x, u["conv"], out, relu_in=True, res=x)                                          # conv(relu(x)) + x
         pre = taps.gather(coarse.boxes, coarse.scale, x.h, x.w)                                      # conv3x3(c_feat; W[:, F:]) per tile
         return ops.conv3x3_ln_gate(out, u["f0a"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res, pre=pre,
@@ -328,14 +357,17 @@ class BiDirectionalFusion(_EncDec):
         ref = xs[-1]
         units = [blk["u2"]] + ([blk["u1"]] if len(xs) == 2 else [])
         aux = coarse.feat.aux if isinstance(coarse, ops.RoiSource) else None
-        if (aux is not None and ops.COARSE_TAPS and ops.X2_FORMAT and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and F_ == self.FEATURES
-                and (coarse.h, coarse.w) == (ref.h, ref.w) and upscale
-                and all("f0a" in u and ops.conv3x3_ln_gate_supported(ref, u["f0a"]) and ops._c256(ref, u["conv"]) and u["conv"].cout == 256 for u in units)):
+        if (aux is not None and ops.COARSE_TAPS and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and (coarse.h, coarse.w) == (ref.h, ref.w)
+                and all(n in aux["taps"] for n in (["u2"] + (["u1"] if len(xs) == 2 else [])))
+                and all("f0a" in u and ops.conv3x3_ln_gate_supported(ref, u["f0a"]) for u in units)
+                and (F_ != 256 or (ops.X2_FORMAT and all(ops._c256(ref, u["conv"]) and u["conv"].cout == 256 for u in units)))):
             # the coarse half of both units comes from the per-frame tap tables (prepare_frame): no concat buffer, no ROI gather
             out = xs[0]
             if len(xs) == 2:
                 out = self._gated_unit_taps(blk["u1"], xs[1], aux["taps"]["u1"], coarse, F_, res=xs[0])
             out = self._gated_unit_taps(blk["u2"], out, aux["taps"]["u2"], coarse, F_)
+            if not upscale:
+                return ops.conv2d(out, blk["out_conv"], dest)
             y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])
             if defer_upsample is not None and ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample):
                 return y
@@ -404,9 +436,19 @@ class BiDirectionalFusion(_EncDec):
                     raise RuntimeError("coarse / refiner pyramids differ at a middle level only: the reference "
                                        "cannot run this shape either (torch.cat fails)")
         B, dev = c_feat[0].n, c_feat[0].device
-        # level concat buffers [coarse | c2f feature]; the c2f outputs are written straight into them
-        cat1 = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l], dev) for l in range(6)]
-        dests = [cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]
+        # fusion_layers_1[l] over cat([c, f]) (:424-426).  Levels whose coarse half comes from the per-frame tap table (prepare_frame)
+        # convolve the c2f feature alone; the others get a concat buffer [coarse | c2f feature] the c2f outputs are written straight into.
+        enc1_taps = [None] * 6
+        for l in range(6):
+            c = c_feat[l]
+            aux = c.feat.aux if isinstance(c, ops.RoiSource) else None
+            fine_c = self.in_chl[l] - c.c
+            if (aux is not None and "enc1" in aux["taps"] and ops.COARSE_TAPS and f"{self.ENC1}.{l}.fine" in P and (c.h, c.w) == tuple(f_sizes[l])
+                    and P[f"{self.ENC1}.{l}.fine"].cin == fine_c and ops.conv2d_pre_supported(*f_sizes[l], P[f"{self.ENC1}.{l}.fine"], ln=True)):
+                enc1_taps[l] = (aux["taps"]["enc1"], c)
+        cat1 = [None if enc1_taps[l] is not None else Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l], dev) for l in range(6)]
+        dests = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l] - c_feat[l].c, dev) if cat1[l] is None else
+                 cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]
         out_depth = self._c2f(P, list(f_feat[1:]), c_feat, dests)
         if self.trace is not None:
             self.trace["c2f_depth"], self.trace["c2f_last"] = out_depth.clone(), dests[0].to_nchw()
@@ -417,6 +459,6 @@ class BiDirectionalFusion(_EncDec):
             return fn
 
         return self._encode_decode(P, [fill(l) for l in range(6)], list(f_sizes), as_feat1(pred1), as_feat1(out_depth),
-                                   update_base, out=out, cat1_bufs=cat1)
+                                   update_base, out=out, cat1_bufs=cat1, enc1_taps=[None if t is None else (t[0], t[1], dests[l]) for l, t in enumerate(enc1_taps)])
 
     __call__ = forward

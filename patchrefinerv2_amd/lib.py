@@ -83,6 +83,8 @@ SIGNATURES = {
     "prv2_pack_gate_weight": (_I, [_P, _P, _I, _I, _P]),
     "prv2_conv3x3_ln_gate": (_I, [_P] * 12),
     "prv2_conv3x3_ln_gate_pre": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "prv2_conv2d_pre_supported": (_I, [C.POINTER(ConvDesc)]),
+    "prv2_conv2d_pre": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "prv2_coarse_tap_knots": (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
     "prv2_coarse_tap_gather": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _F, _I, _I, _P, _I, _P]),
     "prv2_conv_border_bias": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -323,11 +323,21 @@ class _PatchModel(StateDictModule):
         counts, who owns which tile) follows from (cai_mode, process_num, patch_split_num) alone."""
         dev = image_hr.device
         n_all = sum(len(p["raw"]) for p in passes)
-        plan_t = torch.tensor([t for p in passes for t in p["raw"]] + [t for p in passes for t in p["proc"]],
-                              dtype=torch.int32).view(2 * n_all, 2).to(dev, non_blocking=True)
+        # staged through a pinned buffer (one per plan size, reused once the previous frame's copy out of it has completed): the
+        # H2D copy is then really asynchronous -- a pageable source would block the host against the worker streams
+        pins = self.__dict__.setdefault("_plan_pins", {})
+        ent = pins.get((n_all, str(dev)))
+        if ent is None:
+            ent = pins[(n_all, str(dev))] = dict(buf=torch.empty((2 * n_all, 2), dtype=torch.int32).pin_memory(), done=None)
+        if ent["done"] is not None:
+            ent["done"].synchronize()
+        ent["buf"].copy_(torch.tensor([t for p in passes for t in p["raw"]] + [t for p in passes for t in p["proc"]], dtype=torch.int32).view(2 * n_all, 2))
+        plan_t = ent["buf"].to(dev, non_blocking=True)
+        ent["done"] = torch.cuda.Event()
+        ent["done"].record(torch.cuda.current_stream(dev))
         plan_t = self._sync_plan_tensor(plan_t)
         plan = dict(kinds=[p["kind"] for p in passes], counts=[len(p["raw"]) for p in passes], n_all=n_all)
-        depth, coarse_prediction = self._device_frame_sharded(image_lr, image_hr, plan_t, plan, tile_cfg, shard, gather_dst)
+        depth, coarse_prediction = self._device_frame_sharded(image_lr, image_hr, plan_t, plan, tile_cfg, shard, gather_dst, process_num)
         if depth is None:  # gather-to-one: this rank's part of the frame is done
             return None, dict(rgb=image_lr, depth_pred=None, depth_gt=depth_gt, coarse_prediction=coarse_prediction)
         if not return_device:
@@ -408,7 +418,7 @@ class _PatchModel(StateDictModule):
         cache[key] = groups
         return groups
 
-    def _device_frame_sharded(self, image_lr, image_hr, plan_t, plan, tile_cfg, shard, gather_dst):
+    def _device_frame_sharded(self, image_lr, image_hr, plan_t, plan, tile_cfg, shard, gather_dst, process_num=4):
         """A frame on rank ``shard[0]`` of ``shard[1]``: coarse forward (every rank; next frame's beside the tiles when
         announced), this rank's tiles group by group (``shard_layout``), the group's prediction stacks exchanged ASYNCHRONOUSLY
         (RCCL gather to ``gather_dst`` / all-gather on the collective's own stream) while the next group computes, and on the
@@ -429,15 +439,25 @@ class _PatchModel(StateDictModule):
             coarse_feats = coarse_prediction = coarse_depth = None
         image_chw = image_hr[0].contiguous().float()
         raw_all, proc_all = plan_t[:n_all], plan_t[n_all:]
-        bs = max(1, int(getattr(self, "max_batch", None) or 4))
+        bs = max(1, int(getattr(self, "max_batch", None) or process_num))  # (as the unsharded path: _device_frame)
         n_streams = max(1, int(getattr(self, "n_streams", None) or 1))
         main = torch.cuda.current_stream(dev)
         streams = [main] if n_streams == 1 else self._streams(dev, n_streams)
+
+        def layout_dev(g):
+            """this rank's tile indices and the group's permutation as device tensors, made once per layout (the layout is cached:
+            no per-frame blocking H2D copies)"""
+            ent = g.setdefault("_dev", {}).get((rank, str(dev)))
+            if ent is None:
+                ent = g["_dev"][(rank, str(dev))] = (torch.tensor([g["base"] + i for i in g["mine"][rank]], dtype=torch.int64, device=dev),
+                                                     torch.tensor(g["perm"], dtype=torch.int64, device=dev))
+            return ent
+
         # per group: the (padded) stack this rank sends and its tiles' coordinates, allocated before the worker streams start
         stacks, coords = [], []
         for g in groups:
             stacks.append(torch.zeros((g["per"], 1, ph, pw), device=dev))
-            idx = torch.tensor([g["base"] + i for i in g["mine"][rank]], dtype=torch.int64, device=dev)
+            idx = layout_dev(g)[0]
             t = raw_all.index_select(0, idx)
             coords.append((t, self._boxes_dev(t, tile_cfg) if self.needs_coarse else None))
         if n_streams > 1:
@@ -469,7 +489,7 @@ class _PatchModel(StateDictModule):
 
         def blend(gi, allp):
             g = groups[gi]
-            perm = torch.tensor(g["perm"], dtype=torch.int64, device=dev)
+            perm = layout_dev(g)[1]
             preds = allp.view(world * g["per"], ph, pw).index_select(0, perm)
             o = 0
             for pi in g["passes"]:
@@ -486,24 +506,33 @@ class _PatchModel(StateDictModule):
                     ram.update(pr, blend_mask((rh, rw), self.blend_border, 1e-3, dev), tdev, rh, rw)
 
         pending = None  # (group index, exchange handle) whose stacks are on their way
+        unwaited = []   # handles of exchanges this rank has not waited for (sending-only ranks): EVERY one is waited for before returning
         for gi in range(len(groups)):
             used = launch(gi)
             if gi == 0:
                 self._prefetch_coarse(getattr(self, "_next_lr", None), main, tile_cfg)
-            if pending is not None and receiver:   # blend the previous group on the main stream while this one computes
-                allp = pending[1]()
-                receiver = allp is not None        # (None on a receiving rank: the tests' recording pass of the shard emulation)
-                if receiver:
-                    blend(pending[0], allp)
+            if pending is not None:
+                if receiver:                       # blend the previous group on the main stream while this one computes
+                    allp = pending[1]()
+                    receiver = allp is not None    # (None on a receiving rank: the tests' recording pass of the shard emulation)
+                    if receiver:
+                        blend(pending[0], allp)
+                else:
+                    unwaited.append(pending[1])
             for st in used:
                 if st is not main:
                     main.wait_stream(st)
             pending = (gi, self._exchange_begin(stacks[gi], shard, gather_dst, gi))
         if pending is not None:
-            allp = pending[1]()
-            receiver = receiver and allp is not None
             if receiver:
-                blend(pending[0], allp)
+                allp = pending[1]()
+                receiver = allp is not None
+                if receiver:
+                    blend(pending[0], allp)
+            else:
+                unwaited.append(pending[1])
+        for h in unwaited:  # the send buffers (``stacks``) must outlive their collectives: the main stream waits for each of them
+            h()
         if receiver and "random" in plan["kinds"] and not any(plan["kinds"][i] == "random" for g in groups for i in g["passes"]):
             ram.resize(tile_cfg["image_raw_shape"])  # an r-mode whose N // process_num is 0: the resize still happens
         if not receiver:
@@ -753,12 +782,14 @@ class _PatchModel(StateDictModule):
         from . import weights as W_
         spec = self.spec()
         sd, applied = W_.remap_state_dict(sd, spec)
+        diag = W_.diagnose_state_dict(spec, sd)  # BEFORE loading: load_state_dict raises on the first shape mismatch
+        if diag["shape_mismatch"]:
+            raise RuntimeError("load_dict: checkpoint tensors whose shape differs from the model's -- " + W_.format_diagnosis(diag))
         res = self.load_state_dict(sd, strict=False)
-        diag = W_.diagnose_state_dict(spec, sd)
         self.last_load_report = dict(diag, remapped=applied)
         if applied:
             warnings.warn("load_dict: renamed checkpoint keys -- " + ", ".join(f"{k}: {v}" for k, v in applied.items()))
-        if res["missing_keys"] or res["unexpected_keys"] or diag["shape_mismatch"]:
+        if res["missing_keys"] or res["unexpected_keys"]:
             warnings.warn("load_dict: " + W_.format_diagnosis(diag))
         return res
 
@@ -1003,43 +1034,6 @@ class PatchRefiner(_PatchModel):
         base = depth_roi.buf.view(depth_roi.n, 1, depth_roi.h, depth_roi.w)
         return self.refiner_fusion_model(c_feat=rois[-n:][::-1], f_feat=r_feats[-n:][::-1], pred1=base,
                                          pred2=fine["metric_depth"], update_base=base, out=out)
-
-
-@MODELS.register_module()
-class PatchRefinerSemi(StateDictModule):
-    """estimator/models/patchrefiner_semi.py:46-210, inference side only: the teacher / pseudo-label / edge-loss machinery
-    is training; at test time ``forward`` hands everything to the student (:208-210) -- note that it
-    forwards ``cai_mode`` but neither ``tile_cfg`` nor ``process_num``, so the student runs with its configured tiling.
-    The teacher is not built (never used for inference)."""
-
-    def __init__(self, model_cfg_student, teacher_pretrain=None, model_cfg_teacher=None, **_training_only):
-        super().__init__()
-        self.student_model = build_model(model_cfg_student)
-        self._children = dict(student_model=self.student_model)
-        self.device, self.prec = self.student_model.device, self.student_model.prec
-
-    def _pack(self):
-        pass
-
-    def __getattr__(self, name):  # resizer, tile_cfg, patch_process_shape, min/max_depth ... are the student's (:163)
-        if name in ("student_model", "_children", "_spec", "_sd"):
-            raise AttributeError(name)
-        return getattr(self.student_model, name)
-
-    def load_dict(self, sd):
-        if "student_model.coarse_branch.core.core.pretrained.model.cls_token" in sd:  # old checkpoints: teacher + student (:113-115)
-            return self.load_state_dict({k: v for k, v in sd.items() if k.startswith("student_model.")}, strict=True)
-        return self.student_model.load_state_dict(sd, strict=False)
-
-    def get_save_dict(self):
-        return self.student_model.get_save_dict()
-
-    def forward(self, mode=None, image_lr=None, image_hr=None, depth_gt=None, cai_mode="m1", **kw):
-        if mode == "train":
-            raise NotImplementedError("only inference is built (training is out of scope, SURVEY.md 2 #12-14)")
-        return self.student_model(mode=mode, image_lr=image_lr, image_hr=image_hr, depth_gt=depth_gt, cai_mode=cai_mode)
-
-    __call__ = forward
 
 
 @MODELS.register_module()

@@ -726,6 +726,39 @@ def upsample_bilinear(x: Feat, oh: int, ow: int, out: Optional[Feat] = None) -> 
     return out
 
 
+def _pre_desc(x: Feat, cw: ConvW, out_ld: int, act: int, res_ld: int, ln_eps: float):
+    return L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=x.ld, ldy=out_ld,
+                      x_bstride=0, y_bstride=0, relu_in=0, act=act, convt_k=cw.convt_k, ld_mul=0, ld_res=res_ld, ld_res2=0, prec=cw.prec,
+                      force_generic=0, ln_eps=ln_eps, part=0, same_pad=int(cw.same_pad), fmt=0)
+
+
+def conv2d_pre_supported(h: int, w: int, cw: ConvW, ln: bool) -> bool:
+    """can ``conv2d_pre`` add a pre-epilogue addend to this 3x3 conv on h x w images (a property of the layer)?"""
+    if DISPATCH == "torch" or (ln and cw.cout > 128 and cw.cout != 256):
+        return False
+    d = L.ConvDesc(n=1, h=h, w=w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=roundup(cw.cin, 4),
+                   ldy=roundup(cw.cout, 4), x_bstride=0, y_bstride=0, relu_in=0, act=ACT_NONE, convt_k=cw.convt_k, ld_mul=0, ld_res=0, ld_res2=0,
+                   prec=cw.prec, force_generic=0, ln_eps=1e-6, part=0, same_pad=int(cw.same_pad), fmt=0)
+    return bool(L.load().prv2_conv2d_pre_supported(C.byref(d)))
+
+
+def conv2d_pre(x: Feat, cw: ConvW, pre: Feat, out: Optional[Feat] = None, *, act: int = ACT_NONE, res: Optional[Feat] = None, ln=None,
+               ln_eps: float = 1e-6, pre_cin: int = 0) -> Feat:
+    """y = act([LN](conv3x3(x) + pre + bias)) (+ res) (include/prv2.h::prv2_conv2d_pre): ``pre`` [n, h, w, cout] is the coarse half of the
+    reference's conv over cat([coarse_roi, x]) from ``CoarseTaps.gather``, standing for ``pre_cin`` further input channels"""
+    assert x.c == cw.cin and (pre.n, pre.h, pre.w, pre.c) == (x.n, x.h, x.w, cw.cout) and not pre.x2
+    if out is None:
+        out = Feat.alloc(x.n, x.h, x.w, cw.cout, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and not out.x2
+    d = _pre_desc(x, cw, out.ld, act, res.ld if res is not None else 0, ln_eps)
+    flops = 2.0 * x.n * x.h * x.w * cw.cout * cw.cin * 9
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
+                    lambda: L.check(L.load().prv2_conv2d_pre(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), pre.ptr, pre.ld, _ptr(ln[0]) if ln is not None else None,
+                                                             _ptr(ln[1]) if ln is not None else None, _ptr(res), out.ptr, _stream()), "conv2d_pre"),
+                    shape=f"{cw.cin}(+{pre_cin} coarse)->{cw.cout} k3s1 {x.n}x{x.h}x{x.w}", algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9)
+    return out
+
+
 COARSE_TAPS = os.environ.get("PRV2_COARSE_TAPS", "1") != "0"  # A/B and test switch: coarse half of the cat([fine, coarse_roi]) convs once per frame
 
 

@@ -648,7 +648,6 @@ REMAP_RULES = (
     ("timm FeatureListNet flattening (blocks_N -> blocks.N)", r"(^|\.)blocks_(\d+)(\.|$)", r"\1blocks.\2\3"),
     ("timm unflattened stem (stem.N -> stem_N)", r"(^|\.)stem\.(\d+)\.", r"\1stem_\2."),
     ("timm unflattened stages (stages.N -> stages_N)", r"(^|\.)stages\.(\d+)\.", r"\1stages_\2."),
-    ("timm BEiT fused-qkv naming (attn.qkv.bias split kept by timm as q_bias / v_bias)", r"\.attn\.qkv_bias$", ".attn.q_bias"),
 )
 IGNORABLE = (r"\.num_batches_tracked$", r"\.relative_position_index$", r"\.attn\.k_bias$")  # bookkeeping / derived buffers
 

@@ -130,3 +130,38 @@ def test_boxes_on_device_equal_host_boxes():
         want = torch.from_numpy(h._boxes(tiles, tc))
         got = h._boxes_dev(torch.tensor(tiles, dtype=torch.int32), tc)
         assert torch.equal(got, want)
+
+
+def _run_bench(args, env_extra=None, drop=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + tuple(drop)}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_n_launches_itself():
+    """``python bench.py --gpus 2`` started the way the driver starts ``--gpus 1`` (no launcher, no WORLD_SIZE) must run TWO ranks
+    (docs/user_infer.md:124-129: the reference's launcher contract) -- the parent spawns torch.distributed.run as a child before any GPU
+    call and relays rank 0's line; gloo + a stub model here (no GPU in this container)"""
+    r, line = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--stub-model", "--no-roofline", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["steps"] == 3, r.stdout
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """a launcher that started another number of ranks than ``--gpus`` says: refuse loudly in every case (also WORLD_SIZE=1 vs --gpus 2)"""
+    for ws, gpus in (("1", "2"), ("2", "1")):
+        r, line = _run_bench(["--gpus", gpus, "--backend", "gloo", "--stub-model"], env_extra=dict(WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0"))
+        assert r.returncode != 0 and line is None and "WORLD_SIZE" in r.stderr, (r.stdout, r.stderr[-500:])
+
+
+def test_bench_child_failure_is_reported():
+    """a rank that fails makes the self-launching parent exit non-zero"""
+    r, line = _run_bench(["--gpus", "2", "--backend", "gloo", "--stub-model", "--workload", "no_such_workload", "--steps", "-1"],
+                         env_extra=dict(PRV2_BENCH_STUB_FAIL="1"))
+    assert r.returncode != 0, (r.stdout, r.stderr[-500:])

@@ -10,7 +10,7 @@ BiDirectionalFusion, bf16x3 arithmetic -- against the fp32 oracle on the same sy
   * one tile of ``v1_zoe_4k_r32`` (the README's pr_u4k.py: BEiT-L on every tile + full-width FusionUnet).
 
 The synthetic heads are re-scaled (oracle.cases.widen_depth_range) so that the coarse depth spans an order of magnitude and the
-offsets are metres.  Numbers of the last GPU run: profiles/r03_parity_numbers.txt (printed with -s).
+offsets are metres.  Numbers of the last GPU run: profiles/r04_parity_numbers.txt (printed with -s).
 """
 import random
 
@@ -158,6 +158,33 @@ def test_headline_whole_4k_m1_frame_vs_oracle():
     off = rel_l2(got - torch.nn.functional.interpolate(log["coarse_prediction"].cpu(), (1536, 2048), mode="bilinear"),
                  ref - torch.nn.functional.interpolate(rlog["coarse_prediction"], (1536, 2048), mode="bilinear"))
     print(f"{name} whole 4K m1 frame bf16x3 vs oracle: AbsRel {ar:.3e} max|d| {mx:.3e} (depth {float(ref.min()):.2f}..{float(ref.max()):.2f}); "
+          f"coarse AbsRel {ar_c:.3e}; (frame - upsampled coarse) relative L2 {off:.3e}")
+    assert ar < ABSREL_TOL and ar_c < ABSREL_TOL, (ar, mx)
+    assert off <= REL_L2_TOL, off
+
+
+def test_headline_whole_4k_r32_frame_vs_oracle():
+    """(e) the metric's own configuration: one WHOLE 4K frame in cai-mode **r32** -- 81 tiles: the grid pass, the three half-offset
+    passes, 32 random tiles (nearest-upsampled 540 x 960 predictions, raw-resolution resize of the running average / count maps,
+    ``+1e-3`` mask; patchrefinerplus.py:499-520, baseline_pretrain.py:149-231, utils.py:38-43) -- through the product's frame driver
+    at the bench's batching against the oracle's frame driver on the same ``random`` draws; ~2.5 min of host time for the oracle"""
+    name = "v2_zoe_4k_r32"
+    model, ora, w = _pair(name, max_batch=41, n_streams=3)
+    hr = rand_image(11, 1, *w["raw"])
+    tc = dict(image_raw_shape=w["raw"], patch_split_num=w["split"])
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    random.seed(621)
+    ref, rlog = ora(mode="infer", cai_mode="r32", process_num=4, tile_cfg=tc, image_lr=ora.resizer(hr), image_hr=hr)
+    hr_d = hr.to(DEV)
+    random.seed(621)
+    got, log = model(mode="infer", cai_mode="r32", process_num=4, tile_cfg=tc, image_lr=model.resizer(hr_d), image_hr=hr_d)
+    assert sum(len(p["raw"]) for p in model.last_plan) == 81
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 1, 2160, 3840)
+    ar, mx = absrel(got, ref)
+    ar_c, _ = absrel(log["coarse_prediction"], rlog["coarse_prediction"])
+    up = lambda c: torch.nn.functional.interpolate(c, (2160, 3840), mode="bilinear")  # noqa: E731
+    off = rel_l2(got - up(log["coarse_prediction"].cpu()), ref - up(rlog["coarse_prediction"]))
+    print(f"{name} whole 4K r32 frame (81 tiles) bf16x3 vs oracle: AbsRel {ar:.3e} max|d| {mx:.3e} (depth {float(ref.min()):.2f}..{float(ref.max()):.2f}); "
           f"coarse AbsRel {ar_c:.3e}; (frame - upsampled coarse) relative L2 {off:.3e}")
     assert ar < ABSREL_TOL and ar_c < ABSREL_TOL, (ar, mx)
     assert off <= REL_L2_TOL, off

@@ -1029,3 +1029,29 @@ def test_gated_unit_with_coarse_taps_vs_fp32_reference(P, case, prec):
     y2 = P.conv3x3_ln_gate(cat, cw_f, ln, gw, gb.to(DEV), act=P.ACT_RELU, mul=out2, res=res)
     close(y2.to_nchw(), ref, 4e-5, "concat-order GatedConvUnit vs fp32 reference")
     close(y.to_nchw(), y2.to_nchw().cpu(), 2e-5, "restructured vs concat-order unit")
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40, 32, 32, True), (2, 24, 32, 256, 64, True), (1, 17, 29, 256, 128, True), (2, 24, 32, 256, 256, True),
+                                  (1, 19, 75, 96, 40, False), (2, 30, 70, 64, 130 + 2, False)])
+def test_conv2d_pre_addend_in_front_of_the_epilogue(P, case):
+    """prv2_conv2d_pre: y = act([LN](conv3x3(x) + pre + bias)) (+ res) on every kernel family that takes it (16x16x32 halo kernels at
+    32 / 64 / 128 columns incl. ragged tiles and the remainder strip, the 256-column kernel) == the same conv over the concatenated
+    input in fp32 -- fusion_layers_1[l](cat([c, f])) with the coarse half as the addend (bi_directional_fusion_model.py:424-426)"""
+    n, h, w, cin, cout, ln = case
+    PR = P.L.PREC_NAMES["bf16x3"]
+    x_t, pre_t = rnd(1, n, cin, h, w), rnd(2, n, cout, h, w)
+    wt, bias = rnd(3, cout, cin, 3, 3) / np.sqrt(9 * cin), rnd(4, cout) * 0.1
+    lnw, lnb = torch.rand(cout, generator=torch.Generator().manual_seed(5)) + 0.5, rnd(6, cout) * 0.1
+    res_t = None if ln else rnd(7, n, cout, h, w)
+    v = F.conv2d(x_t, wt, bias, padding=1) + pre_t
+    if ln:
+        mu = v.mean(1, keepdim=True)
+        v = (v - mu) / torch.sqrt(((v - mu) ** 2).mean(1, keepdim=True) + 1e-6) * lnw[None, :, None, None] + lnb[None, :, None, None]
+    ref = F.gelu(v) + (res_t if res_t is not None else 0)
+    cw = P.pack_conv(wt.to(DEV), bias.to(DEV), pad=1, prec=PR)
+    assert P.conv2d_pre_supported(h, w, cw, ln)
+    y = P.conv2d_pre(P.Feat.from_nchw(x_t.to(DEV)), cw, P.Feat.from_nchw(pre_t.to(DEV)), act=P.ACT_GELU, ln=(lnw.to(DEV), lnb.to(DEV)) if ln else None,
+                     res=P.Feat.from_nchw(res_t.to(DEV)) if res_t is not None else None)
+    close(y.to_nchw(), ref, 3e-5, f"conv2d_pre {case} on {P.L.load().prv2_last_kernel().decode()}")
+    if y.ld != cout:  # pad channels behind cout stay zero
+        assert float(y.buf[..., cout:].abs().max()) == 0.0

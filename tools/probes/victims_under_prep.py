@@ -1,0 +1,74 @@
+"""Which kernel family gives different bits when the per-frame coarse-tap preparation (a 4608-column 1x1 GEMM + the knot-table kernel,
+256 VGPRs) runs beside it on another stream?   python tools/probes/victims_under_prep.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from patchrefinerv2_amd import ops as P, lib as L
+PR = L.PREC_NAMES["bf16x3"]
+dev = "cuda"
+torch.manual_seed(0)
+
+
+def conv_layer(n, h, w, cin, cout, k=3, **kw):
+    x = P.Feat.alloc(n, h, w, cin, dev); x.buf.normal_()
+    if x.ld != cin:
+        x.buf[..., cin:] = 0
+    cw = P.pack_conv(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5, torch.randn(cout, device=dev), prec=PR)
+    ln = ((torch.rand(cout, device=dev) + 0.5), torch.randn(cout, device=dev) * 0.1) if kw.pop("ln", False) else None
+    return lambda: P.conv2d(x, cw, ln=ln, **kw).buf, f"conv {cin}->{cout} k{k} {n}x{h}x{w} {'ln' if ln else ''} {kw}"
+
+
+victims = [
+    conv_layer(20, 384, 512, 128, 32, act=P.ACT_RELU),
+    conv_layer(20, 384, 512, 98, 32, act=P.ACT_GELU),
+    conv_layer(20, 384, 512, 34, 32, act=P.ACT_GELU, ln=True),
+    conv_layer(20, 192, 256, 512, 64, act=P.ACT_GELU, ln=True),
+    conv_layer(20, 192, 256, 194, 64, act=P.ACT_GELU),
+    conv_layer(20, 384, 512, 98, 98, act=P.ACT_GELU),
+    conv_layer(20, 192, 256, 194, 194, act=P.ACT_GELU),
+    conv_layer(20, 192, 256, 256, 256, relu_in=True),
+    conv_layer(20, 96, 128, 512, 256, act=P.ACT_GELU, ln=True),
+    conv_layer(20, 192, 256, 32, 256),
+    conv_layer(20, 192, 256, 256, 256, k=1),
+    conv_layer(20, 384, 512, 32, 32, k=1),
+    conv_layer(20, 48, 64, 642, 642, act=P.ACT_GELU),
+    conv_layer(20, 24, 32, 770, 770, act=P.ACT_GELU),
+    conv_layer(20, 12, 16, 960, 256),
+]
+xd = P.Feat.alloc(20, 192, 256, 64, dev); xd.buf.normal_()
+wdw = torch.randn(9, 64, device=dev)
+victims.append((lambda: P.dwconv2d(xd, wdw, None, 3, 1, relu=True).buf, "dwconv 3x3 64ch"))
+xu = P.Feat.alloc(20, 96, 128, 256, dev); xu.buf.normal_()
+victims.append((lambda: P.upsample_bilinear(xu, 192, 256).buf, "upsample x2 256ch"))
+xc = P.Feat.alloc(20, 384, 512, 32, dev); xc.buf.normal_()
+wc1 = torch.randn(1, 32, 3, 3, device=dev)
+victims.append((lambda: P.conv2d_cout1(xc, wc1, None, 3), "conv_cout1 3x3"))
+
+F_ = 256
+coarse = P.Feat(torch.randn(1, 192, 256, F_, device=dev))
+cw_t = P.pack_conv(torch.randn(18 * F_, F_, device=dev) / 16, None, prec=PR)
+
+
+def frame_prep():
+    G = P.conv2d(coarse, cw_t)
+    return G, [P.CoarseTaps(G.slice(i * 9 * F_, 9 * F_), F_, (0.25, 0.25)) for i in range(2)]
+
+
+torch.cuda.synchronize()
+ref = [fn().clone() for fn, _ in victims]
+torch.cuda.synchronize()
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+bad = [0] * len(victims)
+for it in range(5):
+    for i, (fn, name) in enumerate(victims):
+        with torch.cuda.stream(s2):
+            keep = [frame_prep() for _ in range(2)]
+        with torch.cuda.stream(s1):
+            y = fn()
+        torch.cuda.synchronize()
+        if not torch.equal(y, ref[i]):
+            bad[i] += 1
+            d = y.view(torch.int32) != ref[i].view(torch.int32)
+            print(f"iter {it} {name}: {int(d.sum())} words differ", flush=True)
+for (fn, name), b in zip(victims, bad):
+    print(f"{b}/5  {name}")
