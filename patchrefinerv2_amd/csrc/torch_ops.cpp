@@ -11,6 +11,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/prv2.h"
@@ -37,11 +38,12 @@ void dev_f32(const Tensor& t, const char* name) {
 }
 
 // NHWC view [n, h, w, c] with unit channel stride, pixel stride ld and dense rows / images on top of it
-int64_t nhwc_ld(const Tensor& t, const char* name) {
+int64_t nhwc_ld(const Tensor& t, const char* name, bool free_batch_stride = false) {
   dev_f32(t, name);
   TORCH_CHECK(t.dim() == 4, "prv2: ", name, " must be NHWC [n, h, w, c]");
   const int64_t ld = t.stride(2);
-  TORCH_CHECK(t.stride(3) == 1 && ld >= t.size(3) && t.stride(1) == t.size(2) * ld && (t.size(0) == 1 || t.stride(0) == t.size(1) * t.size(2) * ld),
+  TORCH_CHECK(t.stride(3) == 1 && ld >= t.size(3) && t.stride(1) == t.size(2) * ld &&
+                  (t.size(0) == 1 || free_batch_stride || t.stride(0) == t.size(1) * t.size(2) * ld),
               "prv2: ", name, " must be an NHWC tensor or a channel slice of one (strides ", t.strides(), ")");
   return ld;
 }
@@ -88,7 +90,8 @@ Tensor pack_conv_weight(const Tensor& w, const optional<Tensor>& bn_scale, int64
 Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
               int64_t pad, int64_t act, bool relu_in, const optional<Tensor>& ln_weight, const optional<Tensor>& ln_bias,
               const optional<Tensor>& gamma, const optional<Tensor>& mul, const optional<Tensor>& res, const optional<Tensor>& res2,
-              int64_t convt_k, int64_t prec, double ln_eps, bool same_pad, const optional<Tensor>& out) {
+              int64_t convt_k, int64_t prec, double ln_eps, bool same_pad, const optional<Tensor>& out, int64_t fmt, bool force_generic,
+              int64_t part) {
   Tensor x = x_in;
   if (x.is_cuda() && x.dim() == 4 && x.scalar_type() == at::kFloat && (x.stride(2) % 4 != 0 || (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15))) {
     // the kernels read 16-byte groups: a dense tensor whose channel count is not a multiple of 4 (34, 66, 98 ... channels) is
@@ -97,7 +100,7 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
     padded.copy_(x);
     x = padded;
   }
-  const int64_t ldx = nhwc_ld(x, "x");
+  const int64_t ldx = nhwc_ld(x, "x", true);  // (an image stride of its own: token maps read as NHWC images, DPT head)
   dev_f32(w_packed, "w_packed");
   if (convt_k) TORCH_CHECK(kh == convt_k && kw == convt_k && pad == 0, "prv2::conv2d: convt_k needs kh == kw == convt_k and pad 0");
   const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
@@ -114,6 +117,8 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
   d.n = (int)n; d.h = (int)h; d.w = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.kh = (int)kh; d.kw = (int)kw;
   d.stride = (int)(convt_k ? convt_k : stride); d.pad = (int)pad; d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out");
   d.relu_in = relu_in; d.act = (int)act; d.convt_k = (int)convt_k; d.prec = (int)prec; d.ln_eps = (float)ln_eps; d.same_pad = same_pad;
+  d.fmt = (int)fmt; d.force_generic = force_generic; d.part = (int)part;
+  if (x.size(0) > 1 && x.stride(0) != h * w * ldx) d.x_bstride = x.stride(0);
   auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
     if (!t.has_value()) return nullptr;
     ld = (int32_t)nhwc_ld(*t, name);
@@ -178,7 +183,8 @@ Tensor pack_gate_weight(const Tensor& w) {
 
 Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, const Tensor& ln_weight, const Tensor& ln_bias,
                        const optional<Tensor>& gate_w_packed, const optional<Tensor>& gate_bias, const optional<Tensor>& mul,
-                       const optional<Tensor>& res, int64_t act, bool relu_in, int64_t prec, double ln_eps, const optional<Tensor>& out) {
+                       const optional<Tensor>& res, int64_t act, bool relu_in, int64_t prec, double ln_eps, const optional<Tensor>& out,
+                       const optional<Tensor>& pre, int64_t fmt) {
   const int64_t ldx = nhwc_ld(x, "x");
   dev_f32(w_packed, "w_packed");
   const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = ln_weight.numel();
@@ -188,7 +194,8 @@ Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<T
   prv2_conv_desc d = {};
   d.n = (int)n; d.h = (int)h; d.w = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.kh = 3; d.kw = 3; d.stride = 1; d.pad = 1;
   d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out"); d.relu_in = relu_in; d.act = (int)act; d.prec = (int)prec; d.ln_eps = (float)ln_eps;
-  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256 / 128 / 32, cin % 32 == 0, bf16 modes)");
+  d.fmt = (int)fmt;
+  TORCH_CHECK(prv2_conv3x3_ln_gate_supported(&d), "prv2::conv3x3_ln_gate: shape not covered (3x3 s1 p1, cout 256 with width >= 16 or 128 / 32 with width >= 24 and height >= 4, cin % 32 == 0, bf16 modes)");
   auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
     if (!t.has_value()) return nullptr;
     ld = (int32_t)nhwc_ld(*t, name);
@@ -201,11 +208,230 @@ Tensor conv3x3_ln_gate(const Tensor& x, const Tensor& w_packed, const optional<T
     dev_f32(*gate_w_packed, "gate_w_packed");
     TORCH_CHECK(gate_w_packed->numel() * 4 == prv2_gate_weight_bytes((int)cout), "prv2::conv3x3_ln_gate: gate_w_packed is not a pack_gate_weight image");
   }
+  int32_t ld_pre = 0;
+  const float* pp = aux(pre, "pre", ld_pre);
   Launch L(x);
-  ok(prv2_conv3x3_ln_gate(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), opt_ptr(ln_weight, "ln_weight", cout),
-                          opt_ptr(ln_bias, "ln_bias", cout), gate_w_packed.has_value() ? gate_w_packed->data_ptr() : nullptr,
-                          opt_ptr(gate_bias, "gate_bias", cout), pm, pr, y.data_ptr<float>(), L.stream), "conv3x3_ln_gate");
+  ok(prv2_conv3x3_ln_gate_pre(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), pp, ld_pre, opt_ptr(ln_weight, "ln_weight", cout),
+                              opt_ptr(ln_bias, "ln_bias", cout), gate_w_packed.has_value() ? gate_w_packed->data_ptr() : nullptr,
+                              opt_ptr(gate_bias, "gate_bias", cout), pm, pr, y.data_ptr<float>(), L.stream), "conv3x3_ln_gate");
   return y;
+}
+
+// shared by conv3x3_tail / conv3x3_pre: the descriptor of a 3x3 s1 p1 conv over x -> y
+prv2_conv_desc desc3x3(const Tensor& x, const Tensor& y, int64_t cout, int64_t act, int64_t prec, double ln_eps) {
+  prv2_conv_desc d = {};
+  d.n = (int)x.size(0); d.h = (int)x.size(1); d.w = (int)x.size(2); d.cin = (int)x.size(3); d.cout = (int)cout; d.kh = 3; d.kw = 3; d.stride = 1; d.pad = 1;
+  d.ldx = (int)nhwc_ld(x, "x"); d.ldy = (int)nhwc_ld(y, "out"); d.act = (int)act; d.prec = (int)prec; d.ln_eps = (float)ln_eps;
+  return d;
+}
+
+// include/prv2.h::prv2_conv2d_tail: the conv that fills a fusion level's features also writes the [pred1 | pred2 | 0 | 0] tail behind them
+// (fusion_model.py:91-118).  out: the [n, h, w, cout] slice of a buffer with at least 4 more channels per pixel.
+void conv3x3_tail(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t act, const optional<Tensor>& ln_weight,
+                  const optional<Tensor>& ln_bias, const optional<Tensor>& res, const Tensor& p1, const Tensor& p2, int64_t prec, double ln_eps, Tensor out) {
+  dev_f32(w_packed, "w_packed"); dev_f32(p1, "p1"); dev_f32(p2, "p2");
+  TORCH_CHECK(p1.is_contiguous() && p2.is_contiguous() && p1.sizes() == p2.sizes() && p1.size(0) == x.size(0), "prv2::conv3x3_tail: p1 / p2 are dense [n, ph, pw] maps");
+  prv2_conv_desc d = desc3x3(x, out, cout, act, prec, ln_eps);
+  const float* pr = nullptr;
+  if (res.has_value()) { d.ld_res = (int32_t)nhwc_ld(*res, "res"); pr = res->data_ptr<float>(); }
+  TORCH_CHECK(prv2_conv2d_tail_supported(&d), "prv2::conv3x3_tail: layer not covered");
+  Launch L(x);
+  ok(prv2_conv2d_tail(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), opt_ptr(ln_weight, "ln_weight", cout), opt_ptr(ln_bias, "ln_bias", cout),
+                      pr, p1.data_ptr<float>(), p2.data_ptr<float>(), (int)p1.size(-2), (int)p1.size(-1), out.data_ptr<float>(), L.stream), "conv3x3_tail");
+}
+
+// include/prv2.h::prv2_conv2d_pre: y = act([LN](conv3x3(x) + pre + bias)) (+ res) -- fusion_layers_1[l](cat([c, f])) over f with the coarse
+// half of the conv (coarse_tap_gather) as the addend (bi_directional_fusion_model.py:424-426)
+Tensor conv3x3_pre(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, const Tensor& pre, int64_t cout, int64_t act,
+                   const optional<Tensor>& ln_weight, const optional<Tensor>& ln_bias, const optional<Tensor>& res, int64_t prec, double ln_eps,
+                   const optional<Tensor>& out) {
+  dev_f32(w_packed, "w_packed");
+  Tensor y = out_or_alloc(out, x, x.size(0), x.size(1), x.size(2), cout, "conv3x3_pre");
+  prv2_conv_desc d = desc3x3(x, y, cout, act, prec, ln_eps);
+  TORCH_CHECK(pre.sizes() == y.sizes(), "prv2::conv3x3_pre: pre must have the output's shape");
+  const float* pr = nullptr;
+  if (res.has_value()) { d.ld_res = (int32_t)nhwc_ld(*res, "res"); pr = res->data_ptr<float>(); }
+  Launch L(x);
+  ok(prv2_conv2d_pre(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), pre.data_ptr<float>(), (int)nhwc_ld(pre, "pre"),
+                     opt_ptr(ln_weight, "ln_weight", cout), opt_ptr(ln_bias, "ln_bias", cout), pr, y.data_ptr<float>(), L.stream), "conv3x3_pre");
+  return y;
+}
+
+// the per-frame coarse half of the cat([fine, coarse_roi]) convs (include/prv2.h::prv2_coarse_tap_knots / prv2_coarse_tap_gather)
+Tensor coarse_tap_knots(const Tensor& g, int64_t cout, double knot_bh, double knot_bw) {
+  const int64_t ldg = nhwc_ld(g, "g");
+  TORCH_CHECK(g.size(0) == 1 && g.size(3) == 9 * cout, "prv2::coarse_tap_knots: g is [1, h, w, 9 * cout] (tap-major)");
+  Tensor v = at::empty({1, 3 * g.size(1), 3 * g.size(2), cout}, g.options());
+  Launch L(g);
+  ok(prv2_coarse_tap_knots(g.data_ptr<float>(), (int)g.size(1), (int)g.size(2), (int)cout, (int)ldg, (float)knot_bh, (float)knot_bw, v.data_ptr<float>(), (int)cout,
+                           L.stream), "coarse_tap_knots");
+  return v;
+}
+Tensor coarse_tap_gather(const Tensor& v, const Tensor& g, double knot_bh, double knot_bw, const Tensor& boxes, double spatial_scale, int64_t oh, int64_t ow,
+                         const optional<Tensor>& out) {
+  const int64_t ldv = nhwc_ld(v, "v"), ldg = nhwc_ld(g, "g"), cout = v.size(3);
+  dev_f32(boxes, "boxes");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && boxes.is_contiguous() && g.size(3) == 9 * cout && v.size(1) == 3 * g.size(1) && v.size(2) == 3 * g.size(2),
+              "prv2::coarse_tap_gather: v [1, 3h, 3w, cout], g [1, h, w, 9 cout], boxes [k, 4]");
+  Tensor y = out_or_alloc(out, v, boxes.size(0), oh, ow, cout, "coarse_tap_gather");
+  Launch L(v);
+  ok(prv2_coarse_tap_gather(v.data_ptr<float>(), g.data_ptr<float>(), (int)g.size(1), (int)g.size(2), (int)cout, (int)ldv, (int)ldg, (float)knot_bh, (float)knot_bw,
+                            boxes.data_ptr<float>(), (int)boxes.size(0), (float)spatial_scale, (int)oh, (int)ow, y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream),
+     "coarse_tap_gather");
+  return y;
+}
+
+// single-output-channel convs (final_conv 3x3 + clamp(update_base + offset, 0), output heads): include/prv2.h::prv2_conv2d_cout1
+Tensor conv_cout1(const Tensor& x, const Tensor& weight, const optional<Tensor>& bias, int64_t k, int64_t act, double scale, const optional<Tensor>& res,
+                  bool clamp0, const optional<Tensor>& out) {
+  const int64_t ldx = nhwc_ld(x, "x");
+  dev_f32(weight, "weight");
+  Tensor y = out.has_value() ? *out : at::empty({x.size(0), 1, x.size(1), x.size(2)}, x.options());
+  TORCH_CHECK(y.is_contiguous() && y.numel() == x.size(0) * x.size(1) * x.size(2), "prv2::conv_cout1: out must be a dense [n, 1, h, w] map");
+  Launch L(x);
+  ok(prv2_conv2d_cout1(x.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)ldx, weight.data_ptr<float>(), (int)k,
+                       opt_ptr(bias, "bias", 1), (int)act, (float)scale, res.has_value() ? res->data_ptr<float>() : nullptr, clamp0, y.data_ptr<float>(), L.stream),
+     "conv_cout1");
+  return y;
+}
+
+// depthwise k x k of the refiner encoders (include/prv2.h::prv2_dwconv2d_ex); weights tap-major [k*k, c]
+Tensor dwconv2d(const Tensor& x, const Tensor& w_tapmajor, const optional<Tensor>& bias, int64_t k, int64_t stride, int64_t act, bool same_pad) {
+  const int64_t ldx = nhwc_ld(x, "x"), c = x.size(3);
+  dev_f32(w_tapmajor, "weight");
+  const int64_t oh = same_pad ? (x.size(1) + stride - 1) / stride : (x.size(1) + 2 * (k / 2) - k) / stride + 1;
+  const int64_t ow = same_pad ? (x.size(2) + stride - 1) / stride : (x.size(2) + 2 * (k / 2) - k) / stride + 1;
+  Tensor y = alloc_nhwc(x, x.size(0), oh, ow, c);
+  Launch L(x);
+  ok(prv2_dwconv2d_ex(x.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2), (int)c, (int)ldx, w_tapmajor.data_ptr<float>(), opt_ptr(bias, "bias", c),
+                      (int)k, (int)stride, (int)act, same_pad, y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream), "dwconv2d");
+  return y;
+}
+
+// SqueezeExcite pieces (include/prv2.h::prv2_global_avgpool / prv2_se_gate / prv2_channel_scale)
+Tensor global_avgpool(const Tensor& x) {
+  const int64_t ldx = nhwc_ld(x, "x"), n = x.size(0), hw = x.size(1) * x.size(2), c = x.size(3);
+  Tensor out = at::empty({n, c}, x.options());
+  Tensor ws = at::empty({std::max<int64_t>(prv2_global_avgpool_workspace_floats((int)n, hw, (int)c), 1)}, x.options());
+  Launch L(x);
+  ok(prv2_global_avgpool(x.data_ptr<float>(), (int)n, hw, (int)c, (int)ldx, out.data_ptr<float>(), ws.data_ptr<float>(), L.stream), "global_avgpool");
+  return out;
+}
+Tensor se_gate(const Tensor& mean, const Tensor& w1, const optional<Tensor>& b1, const Tensor& w2t, const optional<Tensor>& b2) {
+  dev_f32(mean, "mean"); dev_f32(w1, "w1"); dev_f32(w2t, "w2t");
+  const int64_t n = mean.size(0), c = mean.size(1), cse = w1.size(0);
+  TORCH_CHECK(mean.is_contiguous() && w1.is_contiguous() && w2t.is_contiguous() && w1.size(1) == c && w2t.size(0) == cse && w2t.size(1) == c, "prv2::se_gate: shapes");
+  Tensor g = at::empty({n, c}, mean.options()), ws = at::empty({n, cse}, mean.options());
+  Launch L(mean);
+  ok(prv2_se_gate(mean.data_ptr<float>(), (int)n, (int)c, w1.data_ptr<float>(), opt_ptr(b1, "b1", cse), (int)cse, w2t.data_ptr<float>(), opt_ptr(b2, "b2", c),
+                  g.data_ptr<float>(), ws.data_ptr<float>(), L.stream), "se_gate");
+  return g;
+}
+void channel_scale_(Tensor x, const Tensor& s) {
+  const int64_t ldx = nhwc_ld(x, "x");
+  dev_f32(s, "s");
+  TORCH_CHECK(s.is_contiguous() && s.size(0) == x.size(0) && s.size(1) == x.size(3), "prv2::channel_scale_: s is [n, c]");
+  Launch L(x);
+  ok(prv2_channel_scale(x.data_ptr<float>(), (int)x.size(0), x.size(1) * x.size(2), (int)x.size(3), (int)ldx, s.data_ptr<float>(), L.stream), "channel_scale_");
+}
+
+// ViT token path (include/prv2.h: patchify, assemble_tokens, split-swizzled operands of the large linears)
+Tensor patchify(const Tensor& img, int64_t p, int64_t ldo) {
+  const int64_t ldi = nhwc_ld(img, "img"), gh = img.size(1) / p, gw = img.size(2) / p;
+  Tensor rows = at::empty({img.size(0) * gh * gw, ldo}, img.options());
+  Launch L(img);
+  ok(prv2_patchify(img.data_ptr<float>(), (int)img.size(0), (int)gh, (int)gw, (int)p, (int)ldi, rows.data_ptr<float>(), (int)ldo, L.stream), "patchify");
+  return rows;
+}
+Tensor assemble_tokens(const Tensor& emb, const Tensor& cls, const Tensor& pos, int64_t b, int64_t np_, int64_t dim) {
+  dev_f32(emb, "emb"); dev_f32(cls, "cls"); dev_f32(pos, "pos");
+  Tensor tok = at::empty({b, np_ + 1, dim}, emb.options());
+  Launch L(emb);
+  ok(prv2_assemble_tokens(emb.data_ptr<float>(), cls.data_ptr<float>(), pos.data_ptr<float>(), (int)b, (int)np_, (int)dim, tok.data_ptr<float>(), L.stream), "assemble_tokens");
+  return tok;
+}
+Tensor split_ss(const Tensor& x) {
+  dev_f32(x, "x");
+  TORCH_CHECK(x.dim() == 2 && x.stride(1) == 1, "prv2::split_ss: x is [rows, c] with unit column stride");
+  Tensor y = at::empty({x.size(0), x.size(1)}, x.options());
+  Launch L(x);
+  ok(prv2_split_ss(x.data_ptr<float>(), x.size(0), (int)x.size(1), (int)x.stride(0), y.data_ptr(), L.stream), "split_ss");
+  return y;
+}
+void layernorm_ss(const Tensor& x, const Tensor& weight, const Tensor& bias, double eps, Tensor y_ss) {
+  dev_f32(x, "x"); dev_f32(y_ss, "y_ss");
+  TORCH_CHECK(x.dim() == 2 && x.stride(1) == 1 && y_ss.is_contiguous() && y_ss.numel() == x.numel(), "prv2::layernorm_ss: x [rows, c] (unit column stride), y_ss dense");
+  const int64_t c = x.size(1);
+  Launch L(x);
+  ok(prv2_layernorm_ss(x.data_ptr<float>(), x.size(0), (int)c, (int)x.stride(0), opt_ptr(weight, "weight", c), opt_ptr(bias, "bias", c), (float)eps, y_ss.data_ptr(),
+                       L.stream), "layernorm_ss");
+}
+Tensor gemm_ss(const Tensor& a_ss, const Tensor& w_packed, int64_t cout, const optional<Tensor>& bias, const optional<Tensor>& gamma, const optional<Tensor>& res,
+               int64_t act, bool out_ss, const optional<Tensor>& out) {
+  dev_f32(a_ss, "a_ss"); dev_f32(w_packed, "w_packed");
+  TORCH_CHECK(a_ss.dim() == 2 && a_ss.is_contiguous(), "prv2::gemm_ss: a_ss is a dense [rows, k] container");
+  const int64_t m = a_ss.size(0), k = a_ss.size(1);
+  Tensor y = out.has_value() ? *out : at::empty({m, cout}, a_ss.options());
+  TORCH_CHECK(y.dim() == 2 && y.size(0) == m && y.size(1) == cout && y.stride(1) == 1, "prv2::gemm_ss: out is [rows, cout]");
+  const float* pr = nullptr;
+  int ld_res = 0;
+  if (res.has_value()) { dev_f32(*res, "res"); TORCH_CHECK(res->dim() == 2 && res->stride(1) == 1, "prv2::gemm_ss: res rows"); pr = res->data_ptr<float>(); ld_res = (int)res->stride(0); }
+  Launch L(a_ss);
+  ok(prv2_gemm_ss(a_ss.data_ptr(), m, (int)k, w_packed.data_ptr(), (int)cout, opt_ptr(bias, "bias", cout), opt_ptr(gamma, "gamma", cout), pr, ld_res, (int)act,
+                  out_ss ? nullptr : y.data_ptr<float>(), (int)y.stride(0), out_ss ? y.data_ptr() : nullptr, L.stream), "gemm_ss");
+  return y;
+}
+Tensor attention_ss(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, const optional<Tensor>& bias) {
+  dev_f32(qkv, "qkv");
+  TORCH_CHECK(qkv.is_contiguous() && qkv.numel() == b * ntok * 3 * heads * 64, "prv2::attention_ss: qkv must be contiguous [b * ntok, 3 * heads * 64]");
+  if (bias.has_value()) { dev_f32(*bias, "bias"); TORCH_CHECK(bias->is_contiguous() && bias->dim() == 3, "prv2::attention_ss: bias [heads, ntok, ld]"); }
+  Tensor out = at::empty({b * ntok, heads * 64}, qkv.options());
+  const int64_t wsb = prv2_attention_workspace_bytes((int)b, (int)ntok, (int)heads, PRV2_PREC_BF16X3);
+  Tensor ws = at::empty({wsb > 0 ? wsb : 1}, qkv.options().dtype(at::kByte));
+  Launch L(qkv);
+  ok(prv2_attention_ss(qkv.data_ptr<float>(), (int)b, (int)ntok, (int)heads, 64, bias.has_value() ? bias->data_ptr<float>() : nullptr,
+                       bias.has_value() ? (int)bias->size(2) : 0, out.data_ptr(), wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream), "attention_ss");
+  return out;
+}
+
+// input stage and small placement kernels
+Tensor bicubic_resize(const Tensor& img_hwc, int64_t oh, int64_t ow) {
+  TORCH_CHECK(img_hwc.is_cuda() && (img_hwc.scalar_type() == at::kByte || img_hwc.scalar_type() == at::kFloat) && img_hwc.dim() == 3 && img_hwc.size(2) == 3 &&
+                  img_hwc.is_contiguous(), "prv2::bicubic_resize: a contiguous [h, w, 3] uint8 or float32 GPU image");
+  Tensor out = at::empty({3, oh, ow}, img_hwc.options().dtype(at::kFloat));
+  Launch L(img_hwc);
+  ok(prv2_bicubic_resize(img_hwc.data_ptr(), img_hwc.scalar_type() == at::kByte, (int)img_hwc.size(0), (int)img_hwc.size(1), out.data_ptr<float>(), (int)oh, (int)ow,
+                         L.stream), "bicubic_resize");
+  return out;
+}
+void depth_pair_fill(const Tensor& p1, const Tensor& p2, Tensor tail) {
+  // tail: the [n, oh, ow, 4] channel slice (c0 .. c0 + 3) of the concat buffer that receives (p1, p2, 0, 0)
+  dev_f32(p1, "p1"); dev_f32(p2, "p2");
+  TORCH_CHECK(p1.is_contiguous() && p2.is_contiguous() && p1.sizes() == p2.sizes() && tail.size(3) == 4 && tail.size(0) == p1.size(0), "prv2::depth_pair_fill: shapes");
+  Launch L(tail);
+  ok(prv2_depth_pair_fill(p1.data_ptr<float>(), p2.data_ptr<float>(), (int)p1.size(0), (int)p1.size(-2), (int)p1.size(-1), (int)tail.size(1), (int)tail.size(2),
+                          tail.data_ptr<float>(), (int)nhwc_ld(tail, "tail"), L.stream), "depth_pair_fill");
+}
+void conv_border_bias_(Tensor y, const Tensor& tap_bias) {
+  dev_f32(tap_bias, "tap_bias");
+  TORCH_CHECK(tap_bias.is_contiguous() && tap_bias.size(0) == 9 && tap_bias.size(1) == y.size(3), "prv2::conv_border_bias_: tap_bias is [9, c]");
+  Launch L(y);
+  ok(prv2_conv_border_bias(y.data_ptr<float>(), (int)y.size(0), (int)y.size(1), (int)y.size(2), (int)y.size(3), (int)nhwc_ld(y, "y"), tap_bias.data_ptr<float>(), L.stream),
+     "conv_border_bias_");
+}
+Tensor add_nhwc(const Tensor& a, const Tensor& b, const optional<Tensor>& out) {
+  TORCH_CHECK(a.sizes() == b.sizes(), "prv2::add_nhwc: shapes differ");
+  Tensor y = out_or_alloc(out, a, a.size(0), a.size(1), a.size(2), a.size(3), "add_nhwc");
+  Launch L(a);
+  ok(prv2_add(a.data_ptr<float>(), (int)nhwc_ld(a, "a"), b.data_ptr<float>(), (int)nhwc_ld(b, "b"), a.size(0) * a.size(1) * a.size(2), (int)a.size(3), y.data_ptr<float>(),
+              (int)nhwc_ld(y, "out"), L.stream), "add_nhwc");
+  return y;
+}
+void zero_pad_channels_(Tensor buf, int64_t c) {
+  dev_f32(buf, "buf");
+  TORCH_CHECK(buf.dim() == 4 && buf.is_contiguous() && c <= buf.size(3), "prv2::zero_pad_channels_: buf is a dense NHWC buffer [n, h, w, ld], c <= ld");
+  Launch L(buf);
+  ok(prv2_zero_pad_channels(buf.data_ptr<float>(), buf.size(0) * buf.size(1) * buf.size(2), (int)c, (int)buf.size(3), L.stream), "zero_pad_channels_");
 }
 
 // nn.LayerNorm over the last dimension of [rows, c] (tokens) or of an NHWC map (the reference's channels-first LayerNorm)
@@ -290,15 +516,16 @@ std::vector<Tensor> roi_gather_pyramid(at::TensorList feats, const Tensor& boxes
 }
 
 // one level of the above with explicit scale / output size: torchvision.ops.roi_align(feat.repeat(K), boxes, (oh, ow), scale, aligned=True)
-Tensor roi_align(const Tensor& feat, const Tensor& boxes, double spatial_scale, int64_t oh, int64_t ow, const optional<Tensor>& out) {
+Tensor roi_align(const Tensor& feat, const Tensor& boxes, double spatial_scale, int64_t oh, int64_t ow, const optional<Tensor>& out, bool x2) {
   dev_f32(boxes, "boxes");
   TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && boxes.is_contiguous(), "prv2::roi_align: boxes must be contiguous [k, 4]");
   const int64_t ld = nhwc_ld(feat, "feat");
   TORCH_CHECK(feat.size(0) == 1, "prv2::roi_align: one feature map (batch 1)");
   Tensor y = out_or_alloc(out, feat, boxes.size(0), oh, ow, feat.size(3), "roi_align");
   Launch L(feat);
-  ok(prv2_roi_align(feat.data_ptr<float>(), (int)feat.size(1), (int)feat.size(2), (int)feat.size(3), (int)ld, boxes.data_ptr<float>(), (int)boxes.size(0),
-                    (float)spatial_scale, (int)oh, (int)ow, y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream), "roi_align");
+  ok((x2 ? prv2_roi_align_x2 : prv2_roi_align)(feat.data_ptr<float>(), (int)feat.size(1), (int)feat.size(2), (int)feat.size(3), (int)ld, boxes.data_ptr<float>(),
+                                                (int)boxes.size(0), (float)spatial_scale, (int)oh, (int)ow, y.data_ptr<float>(), (int)nhwc_ld(y, "out"), L.stream),
+     "roi_align");
   return y;
 }
 
@@ -392,14 +619,38 @@ TORCH_LIBRARY(prv2, m) {
   m.def("pack_conv_weight(Tensor weight, Tensor? bn_scale=None, int convt_k=0, int prec=0) -> Tensor");
   m.def("conv2d(Tensor x, Tensor w_packed, Tensor? bias, int cout, int kh, int kw, int stride=1, int pad=0, int act=0, bool relu_in=False, "
         "Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? gamma=None, Tensor? mul=None, Tensor? res=None, Tensor? res2=None, int convt_k=0, "
-        "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None) -> Tensor");
+        "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None, int fmt=0, bool force_generic=False, int part=0) -> Tensor");
   m.def("conv3x3_ups(Tensor? x, Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, Tensor? ln_weight=None, "
         "Tensor? ln_bias=None, Tensor? res=None, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
   m.def("pack_gate_weight(Tensor weight) -> Tensor");
   m.def("conv3x3_ln_gate(Tensor x, Tensor w_packed, Tensor? bias, Tensor ln_weight, Tensor ln_bias, Tensor? gate_w_packed=None, Tensor? gate_bias=None, "
-        "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
+        "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None, Tensor? pre=None, "
+        "int fmt=0) -> Tensor");
+  m.def("conv3x3_tail(Tensor x, Tensor w_packed, Tensor? bias, int cout, int act, Tensor? ln_weight, Tensor? ln_bias, Tensor? res, Tensor p1, Tensor p2, "
+        "int prec, float ln_eps, Tensor(a!) out) -> ()");
+  m.def("conv3x3_pre(Tensor x, Tensor w_packed, Tensor? bias, Tensor pre, int cout, int act=0, Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? res=None, "
+        "int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
+  m.def("coarse_tap_knots(Tensor g, int cout, float knot_bh, float knot_bw) -> Tensor");
+  m.def("coarse_tap_gather(Tensor v, Tensor g, float knot_bh, float knot_bw, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None) -> Tensor");
+  m.def("conv_cout1(Tensor x, Tensor weight, Tensor? bias, int k, int act=0, float scale=1.0, Tensor? res=None, bool clamp0=False, Tensor(a!)? out=None) -> Tensor");
+  m.def("dwconv2d(Tensor x, Tensor w_tapmajor, Tensor? bias, int k, int stride, int act=0, bool same_pad=False) -> Tensor");
+  m.def("global_avgpool(Tensor x) -> Tensor");
+  m.def("se_gate(Tensor mean, Tensor w1, Tensor? b1, Tensor w2t, Tensor? b2) -> Tensor");
+  m.def("channel_scale_(Tensor(a!) x, Tensor s) -> ()");
+  m.def("patchify(Tensor img, int p, int ldo) -> Tensor");
+  m.def("assemble_tokens(Tensor emb, Tensor cls, Tensor pos, int b, int np, int dim) -> Tensor");
+  m.def("split_ss(Tensor x) -> Tensor");
+  m.def("layernorm_ss(Tensor x, Tensor weight, Tensor bias, float eps, Tensor(a!) y_ss) -> ()");
+  m.def("gemm_ss(Tensor a_ss, Tensor w_packed, int cout, Tensor? bias=None, Tensor? gamma=None, Tensor? res=None, int act=0, bool out_ss=False, "
+        "Tensor(a!)? out=None) -> Tensor");
+  m.def("attention_ss(Tensor qkv, int b, int ntok, int heads, Tensor? bias=None) -> Tensor");
+  m.def("bicubic_resize(Tensor img_hwc, int oh, int ow) -> Tensor");
+  m.def("depth_pair_fill(Tensor p1, Tensor p2, Tensor(a!) tail) -> ()");
+  m.def("conv_border_bias_(Tensor(a!) y, Tensor tap_bias) -> ()");
+  m.def("add_nhwc(Tensor a, Tensor b, Tensor(a!)? out=None) -> Tensor");
+  m.def("zero_pad_channels_(Tensor(a!) buf, int c) -> ()");
   m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0, Tensor(a!)? out=None) -> Tensor");
-  m.def("roi_align(Tensor feat, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None) -> Tensor");
+  m.def("roi_align(Tensor feat, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None, bool x2=False) -> Tensor");
   m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0, Tensor? bias=None) -> Tensor");
   m.def("crop_resize_bilinear(Tensor img_chw, Tensor tiles, int ch, int cw, int oh, int ow, float[]? mean=None, float[]? std=None, "
         "Tensor(a!)? out=None) -> Tensor");
@@ -422,6 +673,26 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("conv3x3_ups", &conv3x3_ups);
   m.impl("pack_gate_weight", &pack_gate_weight);
   m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
+  m.impl("conv3x3_tail", &conv3x3_tail);
+  m.impl("conv3x3_pre", &conv3x3_pre);
+  m.impl("coarse_tap_knots", &coarse_tap_knots);
+  m.impl("coarse_tap_gather", &coarse_tap_gather);
+  m.impl("conv_cout1", &conv_cout1);
+  m.impl("dwconv2d", &dwconv2d);
+  m.impl("global_avgpool", &global_avgpool);
+  m.impl("se_gate", &se_gate);
+  m.impl("channel_scale_", &channel_scale_);
+  m.impl("patchify", &patchify);
+  m.impl("assemble_tokens", &assemble_tokens);
+  m.impl("split_ss", &split_ss);
+  m.impl("layernorm_ss", &layernorm_ss);
+  m.impl("gemm_ss", &gemm_ss);
+  m.impl("attention_ss", &attention_ss);
+  m.impl("bicubic_resize", &bicubic_resize);
+  m.impl("depth_pair_fill", &depth_pair_fill);
+  m.impl("conv_border_bias_", &conv_border_bias_);
+  m.impl("add_nhwc", &add_nhwc);
+  m.impl("zero_pad_channels_", &zero_pad_channels_);
   m.impl("layernorm", &layernorm);
   m.impl("attention_fwd", &attention_fwd);
   m.impl("crop_resize_bilinear", &crop_resize_bilinear);

@@ -306,7 +306,13 @@ class _TokenMap(Feat):
     def __init__(self, tok: Feat, gh: int, gw: int, d: int):
         self.buf = tok.buf
         self.n, self.h, self.w, self.c, self.c0 = tok.n, gh, gw, d, 0
+        self.x2, self.aux = False, None
         self._off = d  # skip the cls token of image 0; x_bstride = N*D skips the others
+
+    def view(self):
+        """the strided tensor [B, gh, gw, D] the torch.ops.prv2 route takes (image stride N * D, first row skipped)"""
+        ntok = self.buf.shape[1]
+        return torch.as_strided(self.buf, (self.n, self.h, self.w, self.c), (ntok * self.c, self.w * self.c, self.c, 1), self.buf.storage_offset() + self._off)
 
     @property
     def ld(self):

@@ -48,7 +48,7 @@ def place(src, dst: Feat):
 
 def _fused_tail(c0: int) -> bool:
     """can [.. c0 channels | pred1 | pred2 | pad | pad] be closed by ops.depth_pair_fill?"""
-    return c0 % 4 == 0 and ops.DIRECT_PLACEMENT and ops.DISPATCH != "torch"
+    return c0 % 4 == 0 and ops.DIRECT_PLACEMENT
 
 
 def alloc_with_pred_tail(B, h, w, c0, dev) -> Feat:
@@ -357,7 +357,7 @@ class BiDirectionalFusion(_EncDec):
         ref = xs[-1]
         units = [blk["u2"]] + ([blk["u1"]] if len(xs) == 2 else [])
         aux = coarse.feat.aux if isinstance(coarse, ops.RoiSource) else None
-        if (aux is not None and ops.COARSE_TAPS and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and (coarse.h, coarse.w) == (ref.h, ref.w)
+        if (aux is not None and ops.COARSE_TAPS and self.prec != ops.PREC_F32 and (coarse.h, coarse.w) == (ref.h, ref.w)
                 and all(n in aux["taps"] for n in (["u2"] + (["u1"] if len(xs) == 2 else [])))
                 and all("f0a" in u and ops.conv3x3_ln_gate_supported(ref, u["f0a"]) for u in units)
                 and (F_ != 256 or (ops.X2_FORMAT and all(ops._c256(ref, u["conv"]) and u["conv"].cout == 256 for u in units)))):
@@ -376,7 +376,7 @@ class BiDirectionalFusion(_EncDec):
         # The concat [out | coarse ROI] is read by the fused gate kernel only (as its conv input and, first half, as ``mul``): when
         # every writer can produce it -- the ROI gather and the 256-column conv of GatedConvUnit.conv -- it is kept in the kernel's
         # own pre-split operand format (ops.Feat.x2; include/prv2.h PRV2_FMT_*): the halo loader then only copies.  Same results.
-        cat.x2 = bool(ops.X2_FORMAT and ops.DISPATCH != "torch" and self.prec != ops.PREC_F32 and F_ % 8 == 0 and
+        cat.x2 = bool(ops.X2_FORMAT and self.prec != ops.PREC_F32 and F_ % 8 == 0 and
                       isinstance(coarse, ops.RoiSource) and ops.DIRECT_PLACEMENT and (coarse.h, coarse.w) == (ref.h, ref.w) and
                       all("f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]) and ops._c256(ref, u["conv"]) and u["conv"].cout == 256
                           for u in units))

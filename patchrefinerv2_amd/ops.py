@@ -6,10 +6,9 @@ mechanism that makes every ``torch.cat`` of the reference free: producers write 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
-
-import os
 
 import torch
 
@@ -21,11 +20,12 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# How the host mirror reaches the kernels: "ctypes" = straight through the C ABI (lib.py), "torch" = through the PyTorch
-# custom ops torch.ops.prv2.* (csrc/torch_ops.cpp) for every operator that surface covers (conv2d / linear, layernorm,
-# attention, crop+resize, ROI gather, upsample, blend, ZoeDepth head ops); the rest stays on ctypes.  Same kernels, same
-# results bit for bit (tests/test_hip_models.py::test_models_through_torch_custom_ops).
-DISPATCH = "ctypes"
+# How the host mirror reaches the kernels: "torch" = through the PyTorch-ROCm custom ops torch.ops.prv2.* (csrc/torch_ops.cpp ->
+# libprv2_torch.so: at::Tensor in / out on torch's current stream), "ctypes" = straight through the C ABI (lib.py).  Every entry
+# point a frame uses exists on both routes; same kernels, same results bit for bit (tests/test_hip_models.py::
+# test_models_through_torch_custom_ops).  PRV2_DISPATCH selects the default (INTEGRATION.md has the measured per-frame difference).
+DISPATCH = os.environ.get("PRV2_DISPATCH", "torch")
+assert DISPATCH in ("ctypes", "torch"), DISPATCH
 
 
 def _tops():
@@ -144,7 +144,10 @@ class Feat:
         # pad channels are read by the conv loader (x zero weights): they must be finite -- zero just those
         buf = torch.empty((n, h, w, ld), device=device, dtype=torch.float32)
         if ld != c:
-            L.check(L.load().prv2_zero_pad_channels(buf.data_ptr(), n * h * w, c, ld, _stream()), "zero_pad_channels")
+            if DISPATCH == "torch":
+                _tops().zero_pad_channels_(buf, c)
+            else:
+                L.check(L.load().prv2_zero_pad_channels(buf.data_ptr(), n * h * w, c, ld, _stream()), "zero_pad_channels")
         return Feat(buf, c)
 
     @property
@@ -168,6 +171,10 @@ class Feat:
         assert not self.x2, "a pre-split (X2) buffer is not an fp32 tensor"
         return self.buf[..., self.c0:self.c0 + self.c]
 
+    def raw(self) -> torch.Tensor:
+        """the same strided tensor whatever the format (an X2 buffer is a float32 CONTAINER: the operator is told by its ``fmt``)"""
+        return self.buf[..., self.c0:self.c0 + self.c]
+
     def batch(self, b0: int, b1: int) -> "Feat":
         return Feat(self.buf[b0:b1], self.c, self.c0, self.x2)
 
@@ -185,6 +192,8 @@ class Feat:
 
     def to_nchw(self) -> torch.Tensor:
         """Debug / boundary helper: dense NCHW copy (through the HIP layout kernel)."""
+        if DISPATCH == "torch":
+            return _tops().nhwc_to_nchw(self.view())
         out = torch.empty((self.n, self.c, self.h, self.w), device=self.device, dtype=torch.float32)
         L.check(L.load().prv2_nhwc_to_nchw(self.ptr, self.n, self.c, self.h, self.w, self.ld, out.data_ptr(),
                                            _stream()), "nhwc_to_nchw")
@@ -195,6 +204,9 @@ class Feat:
         _require_dev(x)
         x = x.contiguous()
         n, c, h, w = x.shape
+        if DISPATCH == "torch" and pad_to == 4:
+            y = _tops().nchw_to_nhwc(x)
+            return Feat(y if y.is_contiguous() else y._base, c)
         f = Feat.alloc(n, h, w, c, x.device, pad_to)
         L.check(L.load().prv2_nchw_to_nhwc(x.data_ptr(), n, c, h, w, f.ptr, f.ld, _stream()), "nchw_to_nhwc")
         return f
@@ -231,11 +243,14 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride:
         cout, cin, kh, kw = w.shape
     if pad is None:
         pad = kh // 2 if not convt_k else 0
-    nbytes = lib.prv2_packed_weight_bytes(cout, cin, kh, kw, convt_k, prec)
-    packed = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
     sc = bn_scale.detach().to(device=device, dtype=torch.float32).contiguous() if bn_scale is not None else None
-    L.check(lib.prv2_pack_conv_weight(w.data_ptr(), _ptr(sc), packed.data_ptr(), cout, cin, kh, kw, convt_k, prec,
-                                      _stream()), "pack_conv_weight")
+    if DISPATCH == "torch":
+        packed = _tops().pack_conv_weight(w, sc, convt_k, prec)
+    else:
+        nbytes = lib.prv2_packed_weight_bytes(cout, cin, kh, kw, convt_k, prec)
+        packed = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        L.check(lib.prv2_pack_conv_weight(w.data_ptr(), _ptr(sc), packed.data_ptr(), cout, cin, kh, kw, convt_k, prec,
+                                          _stream()), "pack_conv_weight")
     b = bias.detach().to(device=device, dtype=torch.float32).contiguous() if bias is not None else None
     return ConvW(packed, b, cout, cin, kh, kw, convt_k if convt_k else stride, pad, convt_k, prec, same_pad)
 
@@ -289,14 +304,14 @@ def conv2d(x: Feat, cw: ConvW, out: Optional[Feat] = None, *, relu_in: bool = Fa
     m_rows = x.n * (x.h * x.w if cw.convt_k else oh * ow)
     halo = (cw.kh == 3 and cw.kw == 3 and cw.stride == 1 and (cw.pad == 1 or cw.same_pad) and not cw.convt_k and x.w >= 24 and x.h >= 4
             and not force_generic)  # only for the f32-mode strip split below; kernel names come from prv2_last_kernel()
-    via_torch = DISPATCH == "torch" and type(x) is Feat and not x_bstride and not force_generic and not out.x2
+    via_torch = DISPATCH == "torch"
 
     def call():
-        if via_torch and d.part == 0:
+        if via_torch:
             v = lambda f: None if f is None else f.view()  # noqa: E731
             _tops().conv2d(x.view(), cw.w, cw.bias, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, act, relu_in,
                            ln[0] if ln is not None else None, ln[1] if ln is not None else None, gamma, v(mul), v(res), v(res2),
-                           cw.convt_k, cw.prec, ln_eps, cw.same_pad, out.view())
+                           cw.convt_k, cw.prec, ln_eps, cw.same_pad, out.raw(), d.fmt, force_generic, d.part)
             return
         L.check(L.load().prv2_conv2d(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
                                      _ptr(ln[1]) if ln is not None else None, _ptr(gamma), _ptr(mul), _ptr(res), _ptr(res2),
@@ -339,7 +354,7 @@ class UpsOnly:
 def conv2d_ups_supported(x, u: Feat, cw: ConvW) -> bool:
     """can ``conv2d_ups`` fuse the upsample of ``u`` (the first u.c input channels) into this 3x3 conv's loader?  A property of the
     layer (channels, per-image size, arithmetic mode) -- never of the batch."""
-    if not UPS_FUSION or DISPATCH == "torch" or type(x) not in (Feat, UpsOnly) or type(u) is not Feat or x.n != u.n or (x.h, x.w) == (u.h, u.w):
+    if not UPS_FUSION or type(x) not in (Feat, UpsOnly) or type(u) is not Feat or x.n != u.n or (x.h, x.w) == (u.h, u.w):
         return False
     d, us = _ups_desc(x, u, cw, roundup(cw.cout, 4), ACT_NONE, 0, 1e-6)
     return bool(L.load().prv2_conv2d_ups_supported(C.byref(d), C.byref(us)))
@@ -359,6 +374,10 @@ def conv2d_ups(x: Feat, u: Feat, cw: ConvW, out: Optional[Feat] = None, *, act: 
     d, us = _ups_desc(x, u, cw, out.ld, act, res.ld if res is not None else 0, ln_eps)
 
     def call():
+        if DISPATCH == "torch":
+            _tops().conv3x3_ups(None if type(x) is UpsOnly else x.view(), u.view(), cw.w, cw.bias, cw.cout, x.h, x.w, act, ln[0] if ln is not None else None,
+                                ln[1] if ln is not None else None, res.view() if res is not None else None, cw.prec, ln_eps, out.view())
+            return
         L.check(L.load().prv2_conv2d_ups(C.byref(d), x.ptr, C.byref(us), cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
                                          _ptr(ln[1]) if ln is not None else None, _ptr(res), out.ptr, _stream()), "conv2d_ups")
 
@@ -378,7 +397,7 @@ def _tail_desc(x: Feat, cw: ConvW, out: Feat, act: int, res_ld: int, ln_eps: flo
 
 def conv2d_tail_supported(x: Feat, cw: ConvW, out: Feat) -> bool:
     """can ``conv2d_tail`` close the [.. | pred1 | pred2 | 0 | 0] row behind this conv's output slice?  (a property of the layer)"""
-    if not TAIL_FUSION or not DIRECT_PLACEMENT or DISPATCH == "torch" or type(x) is not Feat or out.ld != out.c0 + cw.cout + 4 or (out.c0 + cw.cout) % 4:
+    if not TAIL_FUSION or not DIRECT_PLACEMENT or type(x) is not Feat or out.ld != out.c0 + cw.cout + 4 or (out.c0 + cw.cout) % 4:
         return False
     d = _tail_desc(x, cw, out, ACT_NONE, 0, 1e-6)
     return bool(L.load().prv2_conv2d_tail_supported(C.byref(d)))
@@ -393,6 +412,10 @@ def conv2d_tail(x: Feat, cw: ConvW, out: Feat, p1: Feat, p2: Feat, *, act: int =
     d = _tail_desc(x, cw, out, act, 0, ln_eps)
 
     def call():
+        if DISPATCH == "torch":
+            _tops().conv3x3_tail(x.view(), cw.w, cw.bias, cw.cout, act, ln[0] if ln is not None else None, ln[1] if ln is not None else None, None,
+                                 p1.buf.view(p1.n, p1.h, p1.w), p2.buf.view(p2.n, p2.h, p2.w), cw.prec, ln_eps, out.view())
+            return
         L.check(L.load().prv2_conv2d_tail(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]) if ln is not None else None,
                                           _ptr(ln[1]) if ln is not None else None, None, p1.ptr, p2.ptr, p1.h, p1.w, out.ptr, _stream()), "conv2d_tail")
 
@@ -451,24 +474,20 @@ def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate
     flops = 2.0 * x.n * x.h * x.w * cw.cout * (cw.cin * 9 + (cw.cout if gate_w is not None else 0))
     if pre is not None:
         assert (pre.n, pre.h, pre.w, pre.c) == (out.n, out.h, out.w, out.c) and not pre.x2
-        PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
-                        lambda: L.check(L.load().prv2_conv3x3_ln_gate_pre(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), pre.ptr, pre.ld, _ptr(ln[0]),
-                                                                          _ptr(ln[1]), _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), out.ptr, _stream()),
-                                        "conv3x3_ln_gate_pre"),
-                        shape=f"{cw.cin}(+{pre_cin} coarse)->{cw.cout}{'->' + str(cw.cout) + ' gate' if gate_w is not None else ''} k3s1 {x.n}x{x.h}x{x.w}",
-                        algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9)
-        return out
-    if DISPATCH == "torch" and type(x) is Feat and not d.fmt:
-        v = lambda f: None if f is None else f.view()  # noqa: E731
-        PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
-                        lambda: _tops().conv3x3_ln_gate(x.view(), cw.w, cw.bias, ln[0], ln[1], gate_w, gate_bias, v(mul), v(res), act, relu_in, cw.prec,
-                                                        ln_eps, out.view()))
-        return out
-    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
-                    lambda: L.check(L.load().prv2_conv3x3_ln_gate(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(ln[0]), _ptr(ln[1]),
-                                                                  _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), out.ptr, _stream()),
-                                    "conv3x3_ln_gate"),
-                    shape=f"{cw.cin}->{cw.cout}{'->' + str(cw.cout) + ' gate' if gate_w is not None else ''} k3s1 {x.n}x{x.h}x{x.w}")
+
+    def call():
+        if DISPATCH == "torch":
+            r = lambda f: None if f is None else f.raw()  # noqa: E731
+            _tops().conv3x3_ln_gate(x.raw(), cw.w, cw.bias, ln[0], ln[1], gate_w, gate_bias, r(mul), r(res), act, relu_in, cw.prec, ln_eps, out.view(),
+                                    r(pre), d.fmt)
+            return
+        L.check(L.load().prv2_conv3x3_ln_gate_pre(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(pre), pre.ld if pre is not None else 0, _ptr(ln[0]),
+                                                  _ptr(ln[1]), _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), out.ptr, _stream()), "conv3x3_ln_gate")
+
+    coarse = f"(+{pre_cin} coarse)" if pre is not None else ""
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops, call,
+                    shape=f"{cw.cin}{coarse}->{cw.cout}{'->' + str(cw.cout) + ' gate' if gate_w is not None else ''} k3s1 {x.n}x{x.h}x{x.w}",
+                    algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9 if pre is not None else None)
     return out
 
 
@@ -493,10 +512,14 @@ def conv2d_cout1(x: Feat, weight: torch.Tensor, bias: Optional[torch.Tensor], k:
     """Single-output-channel conv -> dense [n, 1, h, w] tensor (NCHW == NHWC for one channel)."""
     y = out if out is not None else torch.empty((x.n, 1, x.h, x.w), device=x.device, dtype=torch.float32)
     assert y.is_contiguous() and y.numel() == x.n * x.h * x.w
-    PROFILER.launch("conv_cout1_kernel", 2.0 * x.n * x.h * x.w * x.c * k * k,
-                    lambda: L.check(L.load().prv2_conv2d_cout1(x.ptr, x.n, x.h, x.w, x.c, x.ld, weight.data_ptr(), k,
-                                                               _ptr(bias), act, scale, _ptr(res), int(clamp0),
-                                                               y.data_ptr(), _stream()), "conv2d_cout1"))
+    def call():
+        if DISPATCH == "torch":
+            _tops().conv_cout1(x.view(), weight, bias, k, act, scale, res, clamp0, y)
+            return
+        L.check(L.load().prv2_conv2d_cout1(x.ptr, x.n, x.h, x.w, x.c, x.ld, weight.data_ptr(), k, _ptr(bias), act, scale, _ptr(res), int(clamp0),
+                                           y.data_ptr(), _stream()), "conv2d_cout1")
+
+    PROFILER.launch("conv_cout1_kernel", 2.0 * x.n * x.h * x.w * x.c * k * k, call)
     return y
 
 
@@ -509,6 +532,12 @@ def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k:
     else:
         oh = (x.h + 2 * (k // 2) - k) // stride + 1
         ow = (x.w + 2 * (k // 2) - k) // stride + 1
+    if DISPATCH == "torch":
+        box = []
+        PROFILER.launch("dwconv_kernel", 2.0 * x.n * oh * ow * x.c * k * k,
+                        lambda: box.append(_tops().dwconv2d(x.view(), w_tapmajor, bias, k, stride, act, same_pad)))
+        y = box[0]
+        return Feat(y if y.is_contiguous() else y._base, x.c)
     out = Feat.alloc(x.n, oh, ow, x.c, x.device)
     PROFILER.launch("dwconv_kernel", 2.0 * x.n * oh * ow * x.c * k * k,
                     lambda: L.check(L.load().prv2_dwconv2d_ex(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(),
@@ -520,6 +549,10 @@ def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k:
 def global_avgpool(x: Feat) -> torch.Tensor:
     """[n, c] mean over the pixels (the squeeze of timm's SqueezeExcite: x.mean((2, 3)))"""
     assert x.c % 4 == 0
+    if DISPATCH == "torch":
+        box = []
+        PROFILER.launch_aux("global_avgpool", 4.0 * x.n * x.h * x.w * x.c, lambda: box.append(_tops().global_avgpool(x.view())), f"{x.c}ch {x.n}x{x.h}x{x.w}")
+        return box[0]
     out = torch.empty((x.n, x.c), device=x.device, dtype=torch.float32)
     ws = torch.empty(L.load().prv2_global_avgpool_workspace_floats(x.n, x.h * x.w, x.c), device=x.device, dtype=torch.float32)
     PROFILER.launch_aux("global_avgpool", 4.0 * x.n * x.h * x.w * x.c,
@@ -535,6 +568,10 @@ def se_gate(mean: torch.Tensor, w1: torch.Tensor, b1, w2t: torch.Tensor, b2) -> 
     n, c = mean.shape
     cse = w1.shape[0]
     assert w1.shape == (cse, c) and w2t.shape == (cse, c) and w1.is_contiguous() and w2t.is_contiguous()
+    if DISPATCH == "torch":
+        box = []
+        PROFILER.launch_aux("se_gate", 4.0 * (n * c + 2 * c * cse), lambda: box.append(_tops().se_gate(mean, w1, b1, w2t, b2)), f"{c}->{cse}->{c} x{n}")
+        return box[0]
     g = torch.empty((n, c), device=mean.device, dtype=torch.float32)
     ws = torch.empty((n, cse), device=mean.device, dtype=torch.float32)
     PROFILER.launch_aux("se_gate", 4.0 * (n * c + 2 * c * cse),
@@ -548,15 +585,17 @@ def channel_scale_(x: Feat, s: torch.Tensor) -> Feat:
     """x *= s[n, c] in place (the excite of SqueezeExcite)"""
     assert s.shape == (x.n, x.c) and s.is_contiguous() and x.c % 4 == 0
     PROFILER.launch_aux("channel_scale", 8.0 * x.n * x.h * x.w * x.c,
-                        lambda: L.check(L.load().prv2_channel_scale(x.ptr, x.n, x.h * x.w, x.c, x.ld, s.data_ptr(), _stream()),
-                                        "channel_scale"), f"{x.c}ch {x.n}x{x.h}x{x.w}")
+                        (lambda: _tops().channel_scale_(x.view(), s)) if DISPATCH == "torch" else
+                        (lambda: L.check(L.load().prv2_channel_scale(x.ptr, x.n, x.h * x.w, x.c, x.ld, s.data_ptr(), _stream()), "channel_scale")),
+                        f"{x.c}ch {x.n}x{x.h}x{x.w}")
     return x
 
 
 def layernorm_rows(x: torch.Tensor, rows: int, c: int, ldx: int, weight, bias, eps: float, act: int, y: torch.Tensor,
                    ldy: int, x_off: int = 0, y_off: int = 0):
-    if DISPATCH == "torch" and not x_off and not y_off:
-        _tops().layernorm(torch.as_strided(x, (rows, c), (ldx, 1)), weight, bias, eps, act, torch.as_strided(y, (rows, c), (ldy, 1)))
+    if DISPATCH == "torch":
+        _tops().layernorm(torch.as_strided(x, (rows, c), (ldx, 1), x.storage_offset() + x_off), weight, bias, eps, act,
+                          torch.as_strided(y, (rows, c), (ldy, 1), y.storage_offset() + y_off))
         return
     L.check(L.load().prv2_layernorm(x.data_ptr() + 4 * x_off, rows, c, ldx, weight.data_ptr(), bias.data_ptr(), eps,
                                     act, y.data_ptr() + 4 * y_off, ldy, _stream()), "layernorm")
@@ -592,12 +631,16 @@ SS_MIN_ROWS = 512   # token rows from which the ViT blocks run on the pre-split 
 def split_ss(x2d: torch.Tensor) -> torch.Tensor:
     M, K = x2d.shape
     _require_dev(x2d)
+    if DISPATCH == "torch":
+        return _tops().split_ss(x2d)
     out = torch.empty((M, K), device=x2d.device, dtype=torch.float32)
     L.check(L.load().prv2_split_ss(x2d.data_ptr(), M, K, x2d.stride(0), out.data_ptr(), _stream()), "split_ss")
     return out
 
 
 def layernorm_ss(x: torch.Tensor, rows: int, c: int, ldx: int, weight, bias, eps: float, y_ss: torch.Tensor):
+    if DISPATCH == "torch":
+        return _tops().layernorm_ss(torch.as_strided(x, (rows, c), (ldx, 1)), weight, bias, eps, y_ss)
     L.check(L.load().prv2_layernorm_ss(x.data_ptr(), rows, c, ldx, weight.data_ptr(), bias.data_ptr(), eps, y_ss.data_ptr(),
                                        _stream()), "layernorm_ss")
 
@@ -612,6 +655,9 @@ def gemm_ss(a_ss: torch.Tensor, cw: ConvW, out: Optional[torch.Tensor] = None, *
     lib = L.load()
 
     def call():
+        if DISPATCH == "torch":
+            _tops().gemm_ss(a_ss, cw.w, cw.cout, cw.bias, gamma, res, act, out_ss, out)
+            return
         L.check(lib.prv2_gemm_ss(a_ss.data_ptr(), M, K, cw.w.data_ptr(), cw.cout, _ptr(cw.bias), _ptr(gamma), _ptr(res),
                                  res.stride(0) if res is not None else 0, act, None if out_ss else out.data_ptr(), out.stride(0),
                                  out.data_ptr() if out_ss else None, _stream()), "gemm_ss")
@@ -621,12 +667,16 @@ def gemm_ss(a_ss: torch.Tensor, cw: ConvW, out: Optional[torch.Tensor] = None, *
 
 def patchify(img: Feat, p: int, ldo: int) -> torch.Tensor:
     gh, gw = img.h // p, img.w // p
+    if DISPATCH == "torch":
+        return _tops().patchify(img.view(), p, ldo)
     rows = torch.empty((img.n * gh * gw, ldo), device=img.device, dtype=torch.float32)
     L.check(L.load().prv2_patchify(img.ptr, img.n, gh, gw, p, img.ld, rows.data_ptr(), ldo, _stream()), "patchify")
     return rows
 
 
 def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: int, np_: int, dim: int) -> torch.Tensor:
+    if DISPATCH == "torch":
+        return _tops().assemble_tokens(emb, cls, pos, b, np_, dim)
     tok = torch.empty((b, np_ + 1, dim), device=emb.device, dtype=torch.float32)
     L.check(L.load().prv2_assemble_tokens(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), b, np_, dim, tok.data_ptr(),
                                           _stream()), "assemble_tokens")
@@ -644,10 +694,10 @@ def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC
     if bias is not None:
         _require_dev(bias)
         assert bias.is_contiguous() and bias.shape[0] == heads and bias.shape[1] == ntok
-    if DISPATCH == "torch" and not out_ss:
+    if DISPATCH == "torch":
         res = []
         PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel", 4.0 * b * heads * ntok * ntok * 64,
-                        lambda: res.append(_tops().attention_fwd(qkv, b, ntok, heads, prec, bias)))
+                        lambda: res.append(_tops().attention_ss(qkv, b, ntok, heads, bias) if out_ss else _tops().attention_fwd(qkv, b, ntok, heads, prec, bias)))
         return res[0]
     if out_ss:
         assert prec == L.PREC_BF16X3
@@ -687,6 +737,8 @@ def bicubic_resize(img_hwc: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
         raise ValueError("bicubic_resize needs a uint8 or float32 image on the GPU (no CPU fallback exists)")
     assert img_hwc.dim() == 3 and img_hwc.shape[2] == 3
     img_hwc = img_hwc.contiguous()
+    if DISPATCH == "torch":
+        return _tops().bicubic_resize(img_hwc, oh, ow)
     out = torch.empty((3, oh, ow), device=img_hwc.device, dtype=torch.float32)
     L.check(L.load().prv2_bicubic_resize(img_hwc.data_ptr(), int(img_hwc.dtype == torch.uint8), img_hwc.shape[0], img_hwc.shape[1],
                                          out.data_ptr(), oh, ow, _stream()), "bicubic_resize")
@@ -698,10 +750,10 @@ def roi_align(feat: Feat, boxes: torch.Tensor, spatial_scale: float, oh: int, ow
     k = boxes.shape[0]
     if out is None:
         out = Feat.alloc(k, oh, ow, feat.c, feat.device)
-    if DISPATCH == "torch" and not out.x2:
+    if DISPATCH == "torch":
         PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
-                            lambda: _tops().roi_align(feat.view(), boxes.contiguous(), float(spatial_scale), oh, ow, out.view()),
-                            f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}")
+                            lambda: _tops().roi_align(feat.view(), boxes.contiguous(), float(spatial_scale), oh, ow, out.raw(), out.x2),
+                            f"{feat.c}ch {feat.h}x{feat.w}->{k}x{oh}x{ow}{' x2' if out.x2 else ''}")
         return out
     fn = L.load().prv2_roi_align_x2 if out.x2 else L.load().prv2_roi_align  # (x2: the pre-split format of the gate kernel's input)
     PROFILER.launch_aux("roi_align", 4.0 * feat.c * (feat.h * feat.w + k * oh * ow),
@@ -734,7 +786,7 @@ def _pre_desc(x: Feat, cw: ConvW, out_ld: int, act: int, res_ld: int, ln_eps: fl
 
 def conv2d_pre_supported(h: int, w: int, cw: ConvW, ln: bool) -> bool:
     """can ``conv2d_pre`` add a pre-epilogue addend to this 3x3 conv on h x w images (a property of the layer)?"""
-    if DISPATCH == "torch" or (ln and cw.cout > 128 and cw.cout != 256):
+    if ln and cw.cout > 128 and cw.cout != 256:
         return False
     d = L.ConvDesc(n=1, h=h, w=w, cin=cw.cin, cout=cw.cout, kh=cw.kh, kw=cw.kw, stride=cw.stride, pad=cw.pad, ldx=roundup(cw.cin, 4),
                    ldy=roundup(cw.cout, 4), x_bstride=0, y_bstride=0, relu_in=0, act=ACT_NONE, convt_k=cw.convt_k, ld_mul=0, ld_res=0, ld_res2=0,
@@ -752,9 +804,15 @@ def conv2d_pre(x: Feat, cw: ConvW, pre: Feat, out: Optional[Feat] = None, *, act
     assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and not out.x2
     d = _pre_desc(x, cw, out.ld, act, res.ld if res is not None else 0, ln_eps)
     flops = 2.0 * x.n * x.h * x.w * cw.cout * cw.cin * 9
-    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops,
-                    lambda: L.check(L.load().prv2_conv2d_pre(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), pre.ptr, pre.ld, _ptr(ln[0]) if ln is not None else None,
-                                                             _ptr(ln[1]) if ln is not None else None, _ptr(res), out.ptr, _stream()), "conv2d_pre"),
+    def call():
+        if DISPATCH == "torch":
+            _tops().conv3x3_pre(x.view(), cw.w, cw.bias, pre.view(), cw.cout, act, ln[0] if ln is not None else None, ln[1] if ln is not None else None,
+                                res.view() if res is not None else None, cw.prec, ln_eps, out.view())
+            return
+        L.check(L.load().prv2_conv2d_pre(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), pre.ptr, pre.ld, _ptr(ln[0]) if ln is not None else None,
+                                         _ptr(ln[1]) if ln is not None else None, _ptr(res), out.ptr, _stream()), "conv2d_pre")
+
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops, call,
                     shape=f"{cw.cin}(+{pre_cin} coarse)->{cw.cout} k3s1 {x.n}x{x.h}x{x.w}", algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9)
     return out
 
@@ -770,6 +828,12 @@ class CoarseTaps:
     def __init__(self, g: Feat, cout: int, kb):
         assert g.n == 1 and g.c == 9 * cout and 0 < kb[0] <= 0.5 and 0 < kb[1] <= 0.5
         self.g, self.cout, self.kb = g, cout, (float(kb[0]), float(kb[1]))
+        if DISPATCH == "torch":
+            box = []
+            PROFILER.launch_aux("coarse_tap_knots", 4.0 * g.h * g.w * 18 * cout, lambda: box.append(_tops().coarse_tap_knots(g.view(), cout, self.kb[0], self.kb[1])),
+                                f"{cout}ch {g.h}x{g.w}")
+            self.v = Feat(box[0])
+            return
         self.v = Feat(torch.empty((1, 3 * g.h, 3 * g.w, cout), device=g.device, dtype=torch.float32))
         PROFILER.launch_aux("coarse_tap_knots", 4.0 * g.h * g.w * 18 * cout,
                             lambda: L.check(L.load().prv2_coarse_tap_knots(g.ptr, g.h, g.w, cout, g.ld, self.kb[0], self.kb[1], self.v.ptr, self.v.ld,
@@ -784,6 +848,11 @@ class CoarseTaps:
             out = Feat(torch.empty((k, oh, ow, self.cout), device=self.g.device, dtype=torch.float32))
         assert (out.n, out.h, out.w, out.c) == (k, oh, ow, self.cout) and not out.x2
         g, v = self.g, self.v
+        if DISPATCH == "torch":
+            PROFILER.launch_aux("coarse_tap_gather", 4.0 * self.cout * (9 * g.h * g.w + k * oh * ow),
+                                lambda: _tops().coarse_tap_gather(v.view(), g.view(), self.kb[0], self.kb[1], boxes.contiguous(), float(spatial_scale), oh, ow, out.view()),
+                                f"{self.cout}ch {g.h}x{g.w}->{k}x{oh}x{ow}")
+            return out
         PROFILER.launch_aux("coarse_tap_gather", 4.0 * self.cout * (9 * g.h * g.w + k * oh * ow),
                             lambda: L.check(L.load().prv2_coarse_tap_gather(v.ptr, g.ptr, g.h, g.w, self.cout, v.ld, g.ld, self.kb[0], self.kb[1],
                                                                             boxes.data_ptr(), k, spatial_scale, oh, ow, out.ptr, out.ld, _stream()),
@@ -831,6 +900,8 @@ class RoiSource:
 def conv_border_bias(y: Feat, tap_bias: torch.Tensor):
     """y -= the folded bias of the 3x3 taps that the zero padding hides at the image border (include/prv2.h::prv2_conv_border_bias)"""
     assert tap_bias.shape == (9, y.c) and tap_bias.is_contiguous()
+    if DISPATCH == "torch":
+        return PROFILER.launch_aux("conv_border_bias", 8.0 * y.n * 2 * (y.h + y.w) * y.c, lambda: _tops().conv_border_bias_(y.view(), tap_bias), f"{y.c}ch {y.n}x{y.h}x{y.w}")
     PROFILER.launch_aux("conv_border_bias", 8.0 * y.n * 2 * (y.h + y.w) * y.c,
                         lambda: L.check(L.load().prv2_conv_border_bias(y.ptr, y.n, y.h, y.w, y.c, y.ld, tap_bias.data_ptr(), _stream()),
                                         "conv_border_bias"), f"{y.c}ch {y.n}x{y.h}x{y.w}")
@@ -840,6 +911,10 @@ def depth_pair_fill(p1: Feat, p2: Feat, buf: Feat, c0: int):
     """channels c0, c0 + 1 of ``buf`` <- (p1, p2) resized to the buffer's size, channels c0 + 2, c0 + 3 (the pad) <- 0"""
     assert p1.c == 1 and p2.c == 1 and p1.ld == 1 and p2.ld == 1 and (p1.n, p1.h, p1.w) == (p2.n, p2.h, p2.w) == (buf.n, p1.h, p1.w)
     assert buf.ld == buf.c0 + c0 + 4 and (buf.c0 + c0) % 4 == 0, (buf.ld, buf.c0, c0)
+    if DISPATCH == "torch":
+        return PROFILER.launch_aux("depth_pair_fill", 16.0 * buf.n * buf.h * buf.w,
+                                   lambda: _tops().depth_pair_fill(p1.buf.view(p1.n, p1.h, p1.w), p2.buf.view(p2.n, p2.h, p2.w), buf.buf[..., buf.c0 + c0:buf.c0 + c0 + 4]),
+                                   f"{buf.n}x{p1.h}x{p1.w}->{buf.h}x{buf.w}")
     PROFILER.launch_aux("depth_pair_fill", 16.0 * buf.n * buf.h * buf.w,
                         lambda: L.check(L.load().prv2_depth_pair_fill(p1.ptr, p2.ptr, p1.n, p1.h, p1.w, buf.h, buf.w, buf.ptr + 4 * c0, buf.ld,
                                                                       _stream()), "depth_pair_fill"), f"{buf.n}x{p1.h}x{p1.w}->{buf.h}x{buf.w}")
@@ -875,14 +950,18 @@ def add(a: Feat, b: Feat, out: Optional[Feat] = None) -> Feat:
     assert (a.n, a.h, a.w, a.c) == (b.n, b.h, b.w, b.c)
     if out is None:
         out = Feat.alloc(a.n, a.h, a.w, a.c, a.device)
+    if DISPATCH == "torch":
+        _tops().add_nhwc(a.view(), b.view(), out.view())
+        return out
     L.check(L.load().prv2_add(a.ptr, a.ld, b.ptr, b.ld, a.n * a.h * a.w, a.c, out.ptr, out.ld, _stream()), "add")
     return out
 
 
 def zoe_attractor(attr: Feat, bins: Feat, alpha: float = 300.0) -> Feat:
     assert (attr.n, attr.h, attr.w) == (bins.n, bins.h, bins.w)
-    if DISPATCH == "torch" and bins.c % 4 == 0:
-        return Feat(_tops().zoe_attractor(attr.view(), bins.view(), alpha))
+    if DISPATCH == "torch":
+        y = _tops().zoe_attractor(attr.view(), bins.view(), alpha)
+        return Feat(y if y.is_contiguous() else y._base, bins.c)
     out = Feat.alloc(bins.n, bins.h, bins.w, bins.c, bins.device)
     L.check(L.load().prv2_zoe_attractor(attr.ptr, attr.ld, attr.c, bins.ptr, bins.ld, bins.c, alpha,
                                         bins.n * bins.h * bins.w, out.ptr, out.ld, _stream()), "zoe_attractor")

@@ -21,7 +21,11 @@ from .lib import (ABI_VERSION, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SI
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprv2_torch.so")
 OPS = ("abi_version", "pack_conv_weight", "conv2d", "conv3x3_ups", "pack_gate_weight", "conv3x3_ln_gate", "layernorm", "attention_fwd", "crop_resize_bilinear", "roi_gather_pyramid", "roi_align",
        "upsample_bilinear_ac", "blend_init", "blend_update", "blend_resize", "zoe_attractor", "zoe_bins_head", "nchw_to_nhwc",
-       "nhwc_to_nchw")
+       "nhwc_to_nchw",
+       # round 4: every remaining entry point a frame uses (the host mirror's default route can be torch.ops: ops.DISPATCH)
+       "conv3x3_tail", "conv3x3_pre", "coarse_tap_knots", "coarse_tap_gather", "conv_cout1", "dwconv2d", "global_avgpool", "se_gate", "channel_scale_",
+       "patchify", "assemble_tokens", "split_ss", "layernorm_ss", "gemm_ss", "attention_ss", "bicubic_resize", "depth_pair_fill", "conv_border_bias_",
+       "add_nhwc", "zero_pad_channels_")
 _loaded = False
 
 

@@ -476,33 +476,35 @@ def test_compute_metrics_device_on_the_gpu_vs_reference_golden(P, golden):
 
 
 def test_models_through_torch_custom_ops(P):
-    """ops.DISPATCH = 'torch': the host mirror reaches the kernels through the PyTorch custom ops torch.ops.prv2.* (conv2d / linear,
-    layernorm, attention, crop+resize, ROI gather, upsample, blend, ZoeDepth head ops) instead of ctypes -- whole frames of V1, V2
-    and V2 over the ZoeDepth/BEiT coarse branch are bit-identical on both routes"""
+    """The host mirror reaches the kernels on two routes -- the PyTorch custom ops torch.ops.prv2.* (ops.DISPATCH = 'torch', the
+    default) and ctypes straight on the C ABI -- for EVERY entry point a frame uses (convs with all epilogues, X2 formats, coarse taps,
+    gathers, ViT pieces, blend): whole frames of V1, V2 and V2 over the ZoeDepth/BEiT coarse branch are bit-identical on both routes"""
     from oracle.cases import E2E_V2B, e2e_v2b_sd
     from patchrefinerv2_amd import ops, torch_ops
     from patchrefinerv2_amd.registry import build_model
     torch_ops.load()
+    default = ops.DISPATCH
+
+    def both(m, c, mode):
+        out = {}
+        try:
+            for route in ("ctypes", "torch"):
+                ops.DISPATCH = route
+                out[route] = _run(m, c, mode)
+        finally:
+            ops.DISPATCH = default
+        return out["ctypes"], out["torch"]
+
     cases = [("PatchRefiner", E2E_V1, e2e_v1_sd(), "r8"), ("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4")]
     for kind, c, sd, mode in cases:
         for prec in ("f32", "bf16x3"):
             m = _build(kind, c, sd, prec=prec, n_streams=2, max_batch=3)
-            a, la = _run(m, c, mode)
-            try:
-                ops.DISPATCH = "torch"
-                b, lb = _run(m, c, mode)
-            finally:
-                ops.DISPATCH = "ctypes"
+            (a, la), (b, lb) = both(m, c, mode)
             assert torch.equal(a, b) and torch.equal(la["coarse_prediction"], lb["coarse_prediction"]), (kind, prec)
     c = E2E_V2B
     m = build_model(dict(type="PatchRefinerPlus", config={**c["ref_config"], "prec": "bf16x3"}))
     m.load_state_dict(e2e_v2b_sd(), strict=True)
-    a, _ = _run(m, c, "m1")
-    try:
-        ops.DISPATCH = "torch"
-        b, _ = _run(m, c, "m1")
-    finally:
-        ops.DISPATCH = "ctypes"
+    (a, _), (b, _) = both(m, c, "m1")
     assert torch.equal(a, b)
 
 

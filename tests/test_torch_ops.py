@@ -233,3 +233,20 @@ def test_conv3x3_ups_equals_interpolate_then_conv(T):
     assert float((got2.permute(0, 3, 1, 2).cpu() - want2).abs().max()) < 3e-5 * max(1.0, float(want2.abs().max()))
     with pytest.raises(RuntimeError):
         ops.conv3x3_ups(None, u, ops.pack_conv_weight(wt[:32, :cu].contiguous().to(DEV), None, 0, mod.PREC_BF16X3), None, 32, H, W, prec=mod.PREC_BF16X3)  # cout <= 64
+
+
+@gpu
+def test_every_op_test_passes_on_the_other_route():
+    """The host wrappers reach EVERY kernel on two routes: torch.ops.prv2.* (ops.DISPATCH = 'torch', the default) and ctypes straight
+    on the C ABI (PRV2_DISPATCH=ctypes).  The whole per-op parity file (tests/test_hip_ops.py: convs with every epilogue, X2 formats,
+    gate kernels, coarse taps, gathers, blend, ViT pieces) is run once more on the route that is NOT the default, in a child process
+    (the switch is read at import)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    from patchrefinerv2_amd import ops
+    env = dict(os.environ, PRV2_DISPATCH="ctypes" if ops.DISPATCH == "torch" else "torch")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_ops.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], env=env,
+                       capture_output=True, text=True, timeout=1800, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
