@@ -118,7 +118,9 @@ Tensor conv2d(const Tensor& x_in, const Tensor& w_packed, const optional<Tensor>
   d.stride = (int)(convt_k ? convt_k : stride); d.pad = (int)pad; d.ldx = (int)ldx; d.ldy = (int)nhwc_ld(y, "out");
   d.relu_in = relu_in; d.act = (int)act; d.convt_k = (int)convt_k; d.prec = (int)prec; d.ln_eps = (float)ln_eps; d.same_pad = same_pad;
   d.fmt = (int)fmt; d.force_generic = force_generic; d.part = (int)part;
-  if (x.size(0) > 1 && x.stride(0) != h * w * ldx) d.x_bstride = x.stride(0);
+  // (also for one image: which kernel runs a layer depends on the layer's layout, never on the batch -- a token map read through an
+  // image stride takes the same kernel for one tile as for forty)
+  if (x.stride(0) != h * w * ldx) d.x_bstride = x.stride(0);
   auto aux = [&](const optional<Tensor>& t, const char* name, int32_t& ld) -> const float* {
     if (!t.has_value()) return nullptr;
     ld = (int32_t)nhwc_ld(*t, name);
