@@ -104,10 +104,20 @@ class OperatingPoint(threading.Thread):
         self.period, self.samples, self._stop_ev = period, [], threading.Event()
         self.power_f = self.clk_f = None
         import glob
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"), key=lambda q: int(q.split("/card")[1].split("/")[0]))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
-        if index < len(cards):
-            h = cards[index]
+        self.where = None
+        try:  # the sysfs node of THIS torch device (the box may expose more cards than the process sees): by PCI address
+            pr = torch.cuda.get_device_properties(index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cands = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        except Exception:  # noqa: BLE001  (older torch: no PCI fields)
+            bdf, cands = None, []
+        if not cands:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"), key=lambda q: int(q.split("/card")[1].split("/")[0]))
+            cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+            cands = cards[index:index + 1]
+        if cands:
+            h = cands[0]
+            self.where = bdf or h
             self.power_f = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
             self.clk_f = os.path.join(h, "freq1_input") if os.path.exists(os.path.join(h, "freq1_input")) else None
 
@@ -131,7 +141,7 @@ class OperatingPoint(threading.Thread):
         ck = [c / 1e9 for _, c in self.samples if c is not None]
         mean = lambda v: (sum(v) / len(v)) if v else None  # noqa: E731
         return dict(clock_ghz=mean(ck), clock_ghz_min=min(ck) if ck else None, power_w=mean(pw), power_w_max=max(pw) if pw else None,
-                    samples=len(self.samples), source="sysfs hwmon (freq1_input, power1_average)" if (pw or ck) else None)
+                    samples=len(self.samples), source=f"sysfs hwmon of {self.where} (freq1_input = shader clock, power1_average)" if (pw or ck) else None)
 
 
 def cpu_baseline(name, sd, frame_seed):

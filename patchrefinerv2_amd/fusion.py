@@ -94,6 +94,69 @@ class _EncDec(StateDictModule):
         P["final_w"] = self._dev("final_conv.weight")
         return P
 
+    def _pack_enc1_taps(self, P, coarse_chl, extra=None):
+        """``ENC1[l]`` over cat([c, f]) (fusion_model.py:91-95, bi_directional_fusion_model.py:424-426; coarse half FIRST): the fine
+        half as a conv of its own and the coarse half as 1x1 GEMM weights of the nine tap maps (ops.CoarseTaps / prepare_frame).
+        ``extra[l]``: further consumers of the level's coarse map [(name, tap weights)] that share the level's GEMM.
+        P["taps"][l] = (packed [sum 9 * cout, c_l] weights, [(consumer name, cout), ...]).  bf16 modes only."""
+        P["taps"] = {}
+        if self.prec == ops.PREC_F32:
+            return
+        for l in range(len(self.temp_chl)):
+            rows = list(extra[l]) if extra is not None else []
+            cc = coarse_chl[l]
+            w1 = self._sd[f"{self.ENC1}.{l}.single_conv.0.weight"]
+            if w1.shape[1] > cc and w1.shape[0] % 4 == 0 and "enc1" in TAPS_PARTS:
+                P[f"{self.ENC1}.{l}.fine"] = ops.pack_conv(w1[:, cc:], None, device=self.device, prec=self.prec)
+                rows.append(("enc1", ops.coarse_tap_weight(w1[:, :cc])))
+            if rows:
+                P["taps"][l] = (ops.pack_conv(torch.cat([t for _, t in rows], 0), None, device=self.device, prec=self.prec),
+                                [(n, t.shape[0] // 9) for n, t in rows])
+
+    def _enc1_taps_of(self, P, c_feat, f_sizes):
+        """per level: (ops.CoarseTaps, the level's ops.RoiSource) when ENC1[l] takes its coarse half from the frame's tap table, else None"""
+        out = [None] * len(self.temp_chl)
+        for l, c in enumerate(c_feat):
+            aux = c.feat.aux if isinstance(c, ops.RoiSource) else None
+            key = f"{self.ENC1}.{l}.fine"
+            if (aux is not None and "enc1" in aux["taps"] and ops.COARSE_TAPS and key in P and (c.h, c.w) == tuple(f_sizes[l])
+                    and P[key].cin == self.in_chl[l] - c.c and ops.conv2d_pre_supported(*f_sizes[l], P[key], ln=True)):
+                out[l] = (aux["taps"]["enc1"], c)
+        return out
+
+    # -- once per frame ------------------------------------------------------------------------
+    def prepare_frame(self, c_feat: List[Feat], knot_b):
+        """Per-frame part of the fusion network: the coarse half of every conv that reads cat([., c_feat[l]]) -- the GatedConvUnits'
+        ``fusion_conv.0`` and ``fusion_layers_1[l]`` -- as the pyramid level through the convs' coarse weights (ONE 1x1 GEMM per level at
+        COARSE resolution) + the knot table of each consumer (ops.CoarseTaps); the reference convolves the x``split`` zoom of the same
+        map once per tile.  c_feat: the 6 pyramid levels high -> low (as ``forward`` takes their ROIs); knot_b = (tile height / frame
+        height, tile width / frame width).  Attached to the maps (``Feat.aux``): ``forward`` finds it through its ``ops.RoiSource``s.
+        A no-op in the f32 mode (which keeps the reference's order of operations)."""
+        P = self._packed
+        if P is None or not ops.COARSE_TAPS or not P.get("taps") or max(knot_b) > 0.5 or min(knot_b) <= 0:
+            return
+        kb = (float(knot_b[0]), float(knot_b[1]))
+        for l, (tw, cons) in P["taps"].items():
+            f = c_feat[l]
+            if f.c != tw.cin or f.n != 1 or (f.aux is not None and f.aux.get("kb") == kb):
+                continue
+            g = ops.conv2d(f, tw, algo=0.0)  # [1, H, W, sum 9 * cout]
+            taps, o = {}, 0
+            for n, co in cons:
+                taps[n] = ops.CoarseTaps(g.slice(o, 9 * co), co, kb)
+                o += 9 * co
+            f.aux = dict(kb=kb, g=g, taps=taps)
+
+    @staticmethod
+    def frame_tensors(c_feat: List[Feat]):
+        """the device tensors ``prepare_frame`` attached (for stream bookkeeping by the caller)"""
+        out = []
+        for f in c_feat:
+            if f.aux is not None:
+                out.append(f.aux["g"].buf)
+                out.extend(t.v.buf for t in f.aux["taps"].values())
+        return out
+
     def _encode_decode(self, P, pairs, sizes, pred1: Feat, pred2: Feat, update_base: Optional[torch.Tensor], out=None,
                        cat1_bufs=None, enc1_taps=None):
         """pairs[l] = (fill_fn(dst_cat: Feat) writing the level-l [c, f] concat), sizes[l] = (h, w);
@@ -174,6 +237,7 @@ class FusionUnet(_EncDec):
     ENC1, ENC2, DEC = "encoder_layers_1", "encoder_layers_2", "decoder_layers"
 
     def __init__(self, input_chl=(64, 512, 512), temp_chl=(32, 256, 256), dec_chl=(256, 32), device="cuda", prec="f32"):
+        """(the reference's constructor: input_chl[l] = coarse + fine channels of level l; the split is read off the first call's inputs)"""
         super().__init__()
         self.device = torch.device(device)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
@@ -185,11 +249,21 @@ class FusionUnet(_EncDec):
     def _pack(self):
         if len(self._sd) == len(self._spec):
             self._packed = self._pack_encdec()
+            self._packed["taps"] = {}
+
+    def prepare_frame(self, c_feat: List[Feat], knot_b):
+        """_EncDec.prepare_frame; the coarse / fine split of ``input_chl`` is only known from the maps themselves (the reference's
+        constructor takes the sums): the coarse-half weights are packed at the first frame"""
+        P = self._packed
+        if P is not None and not P["taps"] and self.prec != ops.PREC_F32 and ops.COARSE_TAPS and len(c_feat) == len(self.temp_chl):
+            self._pack_enc1_taps(P, [f.c for f in c_feat])
+        super().prepare_frame(c_feat, knot_b)
 
     def forward(self, c_feat: List[Feat], f_feat: List[Feat], pred1: torch.Tensor, pred2: torch.Tensor,
                 update_base: Optional[torch.Tensor] = None, out=None) -> torch.Tensor:
         """c_feat / f_feat: high -> low resolution; pred1/pred2/update_base dense [B,1,H,W]."""
-        if self._packed is None:
+        P = self._packed
+        if P is None:
             raise RuntimeError("FusionUnet: weights not loaded")
 
         def fill(l):
@@ -199,8 +273,11 @@ class FusionUnet(_EncDec):
             return fn
 
         sizes = [(f.h, f.w) for f in f_feat]
-        return self._encode_decode(self._packed, [fill(l) for l in range(len(c_feat))], sizes, as_feat1(pred1),
-                                   as_feat1(pred2), update_base, out=out)
+        # levels whose first encoder conv takes the coarse half of cat([c, f]) from the frame's tap table convolve f alone
+        taps = [None if t is None or not isinstance(f_feat[l], Feat) or (f_feat[l].h, f_feat[l].w) != sizes[l] else (t[0], t[1], f_feat[l])
+                for l, t in enumerate(self._enc1_taps_of(P, c_feat, sizes))]
+        return self._encode_decode(P, [fill(l) for l in range(len(c_feat))], sizes, as_feat1(pred1),
+                                   as_feat1(pred2), update_base, out=out, enc1_taps=taps)
 
     __call__ = forward
 
@@ -275,57 +352,14 @@ class BiDirectionalFusion(_EncDec):
         # Per pyramid level: every conv that reads cat([., c_feat[l]]) with no activation in front -- the level's GatedConvUnits
         # (refinenet{l}: unit 2, and unit 1 where the block has two inputs, :125-129; level 0: output_conv2_fusion's unit 2) and
         # fusion_layers_1[l] -- hands the coarse half of its weights to ONE 1x1 GEMM per level and frame (prepare_frame).
-        # P["taps"][l] = (packed [sum 9 * cout, c_l] weights, [(consumer name, cout), ...])
-        P["taps"] = {}
-        if self.prec != ops.PREC_F32:
-            for l in range(6):
-                blk = P["refine"][l] if l >= 1 else P["out2_fusion"]
-                cons = [("u2", blk["u2"])] + ([("u1", blk["u1"])] if 1 <= l < 5 else [])
-                rows = [(n, u["tapw"]) for n, u in cons if "tapw" in u and u["tapw"].shape[1] == self.coarse_chl[l] and
-                        ("gate256" if u["tapw"].shape[0] == 9 * 256 else "gate_narrow") in TAPS_PARTS]
-                cc = self.coarse_chl[l]
-                w1 = self._sd[f"{self.ENC1}.{l}.single_conv.0.weight"]
-                if w1.shape[1] > cc and w1.shape[0] % 4 == 0 and "enc1" in TAPS_PARTS:
-                    # fusion_layers_1[l] over cat([c, f]) (:424-426): coarse half FIRST
-                    P[f"{self.ENC1}.{l}.fine"] = ops.pack_conv(w1[:, cc:], None, device=self.device, prec=self.prec)
-                    rows.append(("enc1", ops.coarse_tap_weight(w1[:, :cc])))
-                if rows:
-                    P["taps"][l] = (ops.pack_conv(torch.cat([t for _, t in rows], 0), None, device=self.device, prec=self.prec),
-                                    [(n, t.shape[0] // 9) for n, t in rows])
+        extra = []
+        for l in range(6):
+            blk = P["refine"][l] if l >= 1 else P["out2_fusion"]
+            cons = [("u2", blk["u2"])] + ([("u1", blk["u1"])] if 1 <= l < 5 else [])
+            extra.append([(n, u["tapw"]) for n, u in cons if "tapw" in u and u["tapw"].shape[1] == self.coarse_chl[l] and
+                          ("gate256" if u["tapw"].shape[0] == 9 * 256 else "gate_narrow") in TAPS_PARTS])
+        self._pack_enc1_taps(P, self.coarse_chl, extra)
         self._packed = P
-
-    # -- once per frame ------------------------------------------------------------------------
-    def prepare_frame(self, c_feat: List[Feat], knot_b):
-        """Per-frame part of the fusion network: the coarse half of every conv that reads cat([., c_feat[l]]) -- the GatedConvUnits'
-        ``fusion_conv.0`` and ``fusion_layers_1[l]`` -- as the pyramid level through the convs' coarse weights (ONE 1x1 GEMM per level at
-        COARSE resolution) + the knot table of each consumer (ops.CoarseTaps); the reference convolves the x``split`` zoom of the same
-        map once per tile.  c_feat: the 6 pyramid levels high -> low (as ``forward`` takes their ROIs); knot_b = (tile height / frame
-        height, tile width / frame width).  Attached to the maps (``Feat.aux``): ``forward`` finds it through its ``ops.RoiSource``s.
-        A no-op in the f32 mode (which keeps the reference's order of operations)."""
-        P = self._packed
-        if P is None or not ops.COARSE_TAPS or not P.get("taps") or max(knot_b) > 0.5 or min(knot_b) <= 0:
-            return
-        kb = (float(knot_b[0]), float(knot_b[1]))
-        for l, (tw, cons) in P["taps"].items():
-            f = c_feat[l]
-            if f.c != self.coarse_chl[l] or f.n != 1 or (f.aux is not None and f.aux.get("kb") == kb):
-                continue
-            g = ops.conv2d(f, tw, algo=0.0)  # [1, H, W, sum 9 * cout]
-            taps, o = {}, 0
-            for n, co in cons:
-                taps[n] = ops.CoarseTaps(g.slice(o, 9 * co), co, kb)
-                o += 9 * co
-            f.aux = dict(kb=kb, g=g, taps=taps)
-
-    @staticmethod
-    def frame_tensors(c_feat: List[Feat]):
-        """the device tensors ``prepare_frame`` attached (for stream bookkeeping by the caller)"""
-        out = []
-        for f in c_feat:
-            if f.aux is not None:
-                out.append(f.aux["g"].buf)
-                out.extend(t.v.buf for t in f.aux["taps"].values())
-        return out
 
     # -- coarse2fine ---------------------------------------------------------------------------
     @staticmethod
@@ -438,14 +472,7 @@ class BiDirectionalFusion(_EncDec):
         B, dev = c_feat[0].n, c_feat[0].device
         # fusion_layers_1[l] over cat([c, f]) (:424-426).  Levels whose coarse half comes from the per-frame tap table (prepare_frame)
         # convolve the c2f feature alone; the others get a concat buffer [coarse | c2f feature] the c2f outputs are written straight into.
-        enc1_taps = [None] * 6
-        for l in range(6):
-            c = c_feat[l]
-            aux = c.feat.aux if isinstance(c, ops.RoiSource) else None
-            fine_c = self.in_chl[l] - c.c
-            if (aux is not None and "enc1" in aux["taps"] and ops.COARSE_TAPS and f"{self.ENC1}.{l}.fine" in P and (c.h, c.w) == tuple(f_sizes[l])
-                    and P[f"{self.ENC1}.{l}.fine"].cin == fine_c and ops.conv2d_pre_supported(*f_sizes[l], P[f"{self.ENC1}.{l}.fine"], ln=True)):
-                enc1_taps[l] = (aux["taps"]["enc1"], c)
+        enc1_taps = self._enc1_taps_of(P, c_feat, f_sizes)
         cat1 = [None if enc1_taps[l] is not None else Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l], dev) for l in range(6)]
         dests = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l] - c_feat[l].c, dev) if cat1[l] is None else
                  cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]

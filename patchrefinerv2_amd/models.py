@@ -716,9 +716,16 @@ class _PatchModel(StateDictModule):
 
     # -- coarse forward of the NEXT frame beside this frame's tile batches (forward(next_image_lr=...)) -----------------------
     def _prepare_frame(self, coarse_feats, tile_cfg):
-        """per-frame work of the per-patch networks that depends on the coarse pyramid only (PatchRefinerPlus: the coarse half of
-        the fusion convs, fusion.BiDirectionalFusion.prepare_frame) -> the device tensors it created"""
-        return []
+        """per-frame work of the per-patch networks that depends on the coarse pyramid only: the coarse half of the fusion convs that
+        read cat([., coarse_roi]) (fusion._EncDec.prepare_frame: FusionUnet's encoder_layers_1, BiDirectionalFusion's fusion_layers_1
+        and GatedConvUnits) -> the device tensors it created"""
+        fm = getattr(self, "refiner_fusion_model", None)
+        if fm is None or not hasattr(fm, "prepare_frame"):
+            return []
+        (rh, rw), (H, W) = tile_cfg["patch_raw_shape"], tile_cfg["image_raw_shape"]
+        c_feat = coarse_feats[-self.fusion_feat_level:][::-1]
+        fm.prepare_frame(c_feat, (rh / H, rw / W))
+        return fm.frame_tensors(c_feat)
 
     def _coarse_of(self, image_lr, tile_cfg=None):
         """this frame's coarse pyramid: the one prefetched by the previous call if it was made for this very tensor OBJECT,
@@ -1061,15 +1068,6 @@ class PatchRefinerPlus(_PatchModel):
 
     def _pack(self):
         pass
-
-    def _prepare_frame(self, coarse_feats, tile_cfg):
-        fm = self.refiner_fusion_model
-        if not hasattr(fm, "prepare_frame"):
-            return []
-        (rh, rw), (H, W) = tile_cfg["patch_raw_shape"], tile_cfg["image_raw_shape"]
-        c_feat = coarse_feats[-self.fusion_feat_level:][::-1]
-        fm.prepare_frame(c_feat, (rh / H, rw / W))
-        return fm.frame_tensors(c_feat)
 
     def infer_forward(self, crops: Feat, rois: List[Feat], depth_roi: Feat, out=None):
         """patchrefinerplus.py:330-365: encoder on [norm(rgb), coarse depth roi] then BiDirectionalFusion."""
