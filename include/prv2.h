@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 12
+#define PRV2_ABI_VERSION 13
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -235,6 +235,13 @@ int prv2_attention(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int
  * bias of the MiDaS BEiT blocks (torch.hub MiDaS midas/backbones/beit.py attention_forward; called by
  * external/zoedepth/models/base_models/midas.py:267).  bias: [heads][ntok][ld_bias] fp32, ld_bias >= roundup(ntok, 64),
  * a multiple of 4, rows 16-byte aligned (pad keys are never read past ntok's 64-key tile and are masked).  bias == NULL: no bias. */
+/* The bias of a (model, resolution) is a constant: prv2_pack_attention_bias re-orders its rows once into the image the bf16x3 kernel
+ * reads with coalesced loads (per head, block of 32 queries and tile of 64 keys: the values in accumulator order, pre-multiplied by
+ * log2 e -- the product the kernel otherwise forms per tile; same bits).  Passed to prv2_attention_bias / prv2_attention_ss as
+ * ``bias`` with ld_bias == PRV2_ATTENTION_BIAS_IMAGE (bf16 modes). */
+#define PRV2_ATTENTION_BIAS_IMAGE (-1)
+int64_t prv2_attention_bias_image_bytes(int32_t heads, int32_t ntok);
+int prv2_pack_attention_bias(const float* bias, int32_t heads, int32_t ntok, int32_t ld_bias, float* image, void* stream);
 int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias,
                         float* out, int32_t prec, void* workspace, int64_t workspace_bytes, void* stream);
 /* ------------------------------------------------------------------------------------------

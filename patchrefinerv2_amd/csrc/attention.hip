@@ -182,7 +182,7 @@ extern "C" int prv2_attention_ss(const float* qkv, int32_t b, int32_t ntok, int3
   PRV2_REQUIRE(qkv && out_ss, "attention_ss: null pointer");
   PRV2_REQUIRE(b > 0 && ntok > 0 && heads > 0 && hd == 64, "attention: head_dim must be 64 (got %d)", hd);
   PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_ss) & 15) == 0, "attention_ss: 16-byte alignment");
-  PRV2_REQUIRE(!bias || (ld_bias >= prv2::roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+  PRV2_REQUIRE(!bias || ld_bias == PRV2_ATTENTION_BIAS_IMAGE || (ld_bias >= prv2::roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
                "attention: bias rows must be 16-byte aligned and padded to a multiple of 64 keys (ld_bias %d, ntok %d)", ld_bias, ntok);
   int rc = launch_attention_bf16x3(qkv, b, ntok, heads, bias, ld_bias, nullptr, out_ss, workspace, workspace_bytes, (hipStream_t)stream);
   if (rc) return rc;
@@ -194,8 +194,9 @@ extern "C" int prv2_attention_bias(const float* qkv, int32_t b, int32_t ntok, in
                                    int32_t ld_bias, float* out, int32_t prec, void* workspace, int64_t workspace_bytes,
                                    void* stream) {
   PRV2_REQUIRE(qkv && out, "attention: null pointer");
-  PRV2_REQUIRE(!bias || (ld_bias >= prv2::roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
-               "attention: bias rows must be 16-byte aligned and padded to a multiple of 64 keys (ld_bias %d, ntok %d)", ld_bias, ntok);
+  PRV2_REQUIRE(!bias || (ld_bias == PRV2_ATTENTION_BIAS_IMAGE && prec != PRV2_PREC_F32) ||
+                   (ld_bias >= prv2::roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+               "attention: bias rows must be 16-byte aligned and padded to a multiple of 64 keys (ld_bias %d, ntok %d); the packed image is for the bf16 modes", ld_bias, ntok);
   PRV2_REQUIRE(b > 0 && ntok > 0 && heads > 0 && hd == 64, "attention: head_dim must be 64 (got %d)", hd);
   PRV2_REQUIRE(prec >= PRV2_PREC_F32 && prec <= PRV2_PREC_BF16, "attention: unknown precision mode %d", prec);
   PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attention: qkv must be 16-byte aligned");
@@ -299,7 +300,10 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const 
 
 // (launch bounds: THREE workgroups per CU -- the kernel needed 169 (with bias 202) registers, one more than three waves per SIMD
 //  allow; asking for 168 costs nothing and a third independent wave per SIMD fills the softmax / staging gaps of the other two)
-template <bool HAS_BIAS>
+// BIAS: 0 none, 1 rows [heads][N][ldb] (every lane walks its own query's row: 64 cache lines per load instruction), 2 the
+// prv2_pack_attention_bias image -- the same values pre-multiplied by log2 e in the order the S^T accumulators want them, so that a
+// key tile's bias is eight coalesced 1 KB loads per wave, requested BEFORE the S^T MFMAs (BEiT: 0.17 -> see profiles/r04_*)
+template <int BIAS>
 __global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
                                                                   const __bf16* __restrict__ Ks,
                                                                   const __bf16* __restrict__ VtH,
@@ -378,6 +382,14 @@ __global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* 
     // garbage (a ninth / seventh of the launch's matrix work)
     if (!wave_active) return;
 
+    f32x4 btile[BIAS == 2 ? 8 : 1];
+    if constexpr (BIAS == 2) {
+      // image: [head][query block of 32][key tile of 64][i = 4 t + g][lane][4]; ldb = key tiles per row of blocks
+      const int q32 = qt * (AT_BQ / 32) + wave, q32n = ((N + AT_BQ - 1) / AT_BQ) * (AT_BQ / 32);
+      const f32x4* bt = reinterpret_cast<const f32x4*>(bias) + ((((long long)head * q32n + q32) * ldb + (k0 >> 6)) * 8) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) btile[i] = bt[i * 64];
+    }
     // S^T tiles: rows = keys (t*32 + row), cols = this wave's 32 queries
     f32x16 st[2];
 #pragma unroll
@@ -391,7 +403,7 @@ __global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* 
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kr + 128);
         st[t] = mfma3(kh, kl, qh[ks], ql[ks], st[t]);
       }
-    if (HAS_BIAS) {
+    if constexpr (BIAS == 1) {
       // + bias[head][this lane's query][key]: register e = 4g + i is key 8g + 4half + i -> one 16-byte load per g
       const float* br = bias + ((long long)head * N + (q_row < N ? q_row : 0)) * ldb + k0 + 4 * half;
 #pragma unroll
@@ -399,6 +411,15 @@ __global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 bv = *reinterpret_cast<const f32x4*>(br + t * 32 + 8 * g) * 1.4426950408889634f;  // (base-2 domain)
+          st[t][4 * g] += bv.x; st[t][4 * g + 1] += bv.y; st[t][4 * g + 2] += bv.z; st[t][4 * g + 3] += bv.w;
+        }
+    }
+    if constexpr (BIAS == 2) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = btile[4 * t + g];
           st[t][4 * g] += bv.x; st[t][4 * g + 1] += bv.y; st[t][4 * g + 2] += bv.z; st[t][4 * g + 3] += bv.w;
         }
     }
@@ -516,6 +537,53 @@ __global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* 
 
 }  // namespace prv2
 
+namespace prv2 {
+// bias rows [heads][N][ldb] -> the image attention_bf16x3_kernel<2> reads: thread = one f32x4 of it
+__global__ void __launch_bounds__(256) pack_attention_bias_kernel(const float* __restrict__ bias, int heads, int N, int ldb, float* __restrict__ dst,
+                                                                  int q32n, int ktn) {
+  const long long total = (long long)heads * q32n * ktn * 8 * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63), i = (int)((idx >> 6) & 7);
+    long long rest = idx >> 9;
+    const int kt = (int)(rest % ktn);
+    rest /= ktn;
+    const int q32 = (int)(rest % q32n), head = (int)(rest / q32n);
+    const int r32 = lane & 31, half = lane >> 5, t = i >> 2, g = i & 3;
+    const int q = q32 * 32 + r32, key = kt * 64 + t * 32 + 8 * g + 4 * half;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < N) {
+      const float* src = bias + ((long long)head * N + q) * ldb + key;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (key + e < N) v[e] = src[e] * 1.4426950408889634f;  // (the kernel's base-2 domain: the product it used to form per tile)
+    }
+    reinterpret_cast<f32x4*>(dst)[idx] = v;
+  }
+}
+}  // namespace prv2
+
+static void bias_image_dims(int ntok, int& q32n, int& ktn) {
+  q32n = (int)prv2::cdiv(ntok, prv2::AT_BQ) * (prv2::AT_BQ / 32);
+  ktn = (int)prv2::cdiv(ntok, prv2::AT_BK);
+}
+
+extern "C" int64_t prv2_attention_bias_image_bytes(int32_t heads, int32_t ntok) {
+  int q32n, ktn;
+  bias_image_dims(ntok, q32n, ktn);
+  return (int64_t)heads * q32n * ktn * 8 * 64 * 16;
+}
+
+extern "C" int prv2_pack_attention_bias(const float* bias, int32_t heads, int32_t ntok, int32_t ld_bias, float* image, void* stream) {
+  PRV2_REQUIRE(bias && image && heads > 0 && ntok > 0 && ld_bias >= ntok && (reinterpret_cast<uintptr_t>(image) & 15) == 0, "pack_attention_bias: bad arguments");
+  int q32n, ktn;
+  bias_image_dims(ntok, q32n, ktn);
+  const long long total = (long long)heads * q32n * ktn * 8 * 64;
+  hipLaunchKernelGGL(prv2::pack_attention_bias_kernel, dim3(prv2::flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, bias, (int)heads, (int)ntok, (int)ld_bias,
+                     image, q32n, ktn);
+  PRV2_LAUNCH_CHECK("pack_attention_bias");
+  return 0;
+}
+
 extern "C" int64_t prv2_attention_workspace_bytes(int32_t b, int32_t ntok, int32_t heads, int32_t prec) {
   if (prec == PRV2_PREC_F32) return 0;
   const int64_t npad = prv2::roundup(ntok, 64);
@@ -538,7 +606,11 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
   dim3 g2((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
   char* oss = reinterpret_cast<char*>(out_ss);
-  if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<true>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
-  else hipLaunchKernelGGL(attention_bf16x3_kernel<false>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
+  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {  // the prv2_pack_attention_bias image: ldb carries the key tiles per block row
+    int q32n, ktn;
+    bias_image_dims(ntok, q32n, ktn);
+    hipLaunchKernelGGL(attention_bf16x3_kernel<2>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ktn, out, oss);
+  } else if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<1>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_bf16x3_kernel<0>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
   return 0;
 }

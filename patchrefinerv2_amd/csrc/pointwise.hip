@@ -460,12 +460,66 @@ __global__ void __launch_bounds__(256) zoe_attractor_kernel(const float* __restr
   }
 }
 
-// one thread per pixel: log-binomial logits over the bins, softmax at temperature t, expectation of the centres
+// one thread per pixel: log-binomial logits over the bins, softmax at temperature t, expectation of the centres.
+// The per-bin Stirling term depends on (k, K) only: computed once per block into LDS (same float operations as before).  The
+// pixel's K bin centres are read through an LDS tile filled with coalesced row loads (a thread walking its own 256-byte row made
+// every load instruction touch 64 cache lines: 5.2 ms per 41 x 384 x 512 launch, 16 ms per frame of the V1 ZoeDepth workload).
+template <int KMAX>
 __global__ void __launch_bounds__(256) zoe_logbinom_depth_kernel(const float* __restrict__ pt, int ld_pt,
                                                                  const float* __restrict__ centers, int ld_c, int K,
                                                                  float min_temp, float max_temp, int64_t rows,
                                                                  float* __restrict__ depth) {
+  constexpr int PITCH = KMAX + 1;  // (odd pitch: the 64 lanes of a wave read 64 different banks)
+  __shared__ float ctile[256 * PITCH];
+  __shared__ float lbs[KMAX];
   const float p_eps = 1e-4f, eps = 1e-4f, sb = 1e-7f;  // ConditionalLogBinomial.p_eps, LogBinomial eps, log_binom eps
+  const float n = (float)(K - 1) + sb;
+  const float nlogn = n * logf(n);
+  if ((int)threadIdx.x < K) {
+    const float kk = (float)threadIdx.x + sb;
+    lbs[threadIdx.x] = nlogn - kk * logf(kk) - (n - kk) * logf(n - kk + sb);
+  }
+  for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < rows; r0 += (int64_t)gridDim.x * 256) {
+    __syncthreads();  // (lbs written / the previous tile consumed)
+    for (int idx = threadIdx.x; idx < 256 * K; idx += 256) {  // coalesced: consecutive threads walk consecutive bins of a row
+      const int rl = idx / K, k = idx - rl * K;
+      const int64_t r = r0 + rl;
+      ctile[rl * PITCH + k] = r < rows ? centers[r * ld_c + k] : 0.f;
+    }
+    __syncthreads();
+    const int64_t r = r0 + threadIdx.x;
+    if (r >= rows) continue;
+    const float* q = pt + r * ld_pt;
+    float p0 = q[0] + p_eps, p1 = q[1] + p_eps, t0 = q[2] + p_eps, t1 = q[3] + p_eps;
+    float p = p0 / (p0 + p1);
+    float t = (max_temp - min_temp) * (t0 / (t0 + t1)) + min_temp;
+    float omp = fminf(fmaxf(1.0f - p, eps), 1.0f);
+    p = fminf(fmaxf(p, eps), 1.0f);
+    const float lp = logf(p), lomp = logf(omp);
+    const float* c = ctile + threadIdx.x * PITCH;
+    // pass 1: max logit; pass 2: softmax-weighted sum
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      float y = (lbs[k] + (float)k * lp + (float)(K - 1 - k) * lomp) / t;
+      mx = fmaxf(mx, y);
+    }
+    float den = 0.f, num = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float y = (lbs[k] + (float)k * lp + (float)(K - 1 - k) * lomp) / t;
+      float e = expf(y - mx);
+      den += e;
+      num += e * c[k];
+    }
+    depth[r] = num / den;
+  }
+}
+
+// any number of bins (no LDS tile): one thread per pixel
+__global__ void __launch_bounds__(256) zoe_logbinom_depth_generic_kernel(const float* __restrict__ pt, int ld_pt,
+                                                                         const float* __restrict__ centers, int ld_c, int K,
+                                                                         float min_temp, float max_temp, int64_t rows,
+                                                                         float* __restrict__ depth) {
+  const float p_eps = 1e-4f, eps = 1e-4f, sb = 1e-7f;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
     const float* q = pt + r * ld_pt;
     float p0 = q[0] + p_eps, p1 = q[1] + p_eps, t0 = q[2] + p_eps, t1 = q[3] + p_eps;
@@ -477,7 +531,6 @@ __global__ void __launch_bounds__(256) zoe_logbinom_depth_kernel(const float* __
     const float n = (float)(K - 1) + sb;
     const float nlogn = n * logf(n);
     const float* c = centers + r * ld_c;
-    // pass 1: max logit; pass 2: softmax-weighted sum
     float mx = -INFINITY;
     for (int k = 0; k < K; ++k) {
       float kk = (float)k + sb;
@@ -708,8 +761,12 @@ extern "C" int prv2_zoe_logbinom_depth(const float* pt, int32_t ld_pt, const flo
                                        float min_temp, float max_temp, int64_t rows, float* depth, void* stream) {
   PRV2_REQUIRE(pt && centers && depth && rows > 0 && n_bins > 1 && ld_pt >= 4 && ld_c >= n_bins,
                "zoe_logbinom_depth: bad arguments");
-  hipLaunchKernelGGL(zoe_logbinom_depth_kernel, dim3(flat_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, pt, ld_pt,
-                     centers, ld_c, n_bins, min_temp, max_temp, rows, depth);
+  if (n_bins <= 64)
+    hipLaunchKernelGGL(zoe_logbinom_depth_kernel<64>, dim3(flat_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, pt, ld_pt, centers, ld_c, n_bins, min_temp,
+                       max_temp, rows, depth);
+  else
+    hipLaunchKernelGGL(zoe_logbinom_depth_generic_kernel, dim3(flat_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, pt, ld_pt, centers, ld_c, n_bins,
+                       min_temp, max_temp, rows, depth);
   PRV2_LAUNCH_CHECK("zoe_logbinom_depth");
   return 0;
 }

@@ -383,16 +383,20 @@ Tensor gemm_ss(const Tensor& a_ss, const Tensor& w_packed, int64_t cout, const o
                   out_ss ? nullptr : y.data_ptr<float>(), (int)y.stride(0), out_ss ? y.data_ptr() : nullptr, L.stream), "gemm_ss");
   return y;
 }
-Tensor attention_ss(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, const optional<Tensor>& bias) {
+Tensor attention_ss(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, const optional<Tensor>& bias, bool bias_image) {
   dev_f32(qkv, "qkv");
   TORCH_CHECK(qkv.is_contiguous() && qkv.numel() == b * ntok * 3 * heads * 64, "prv2::attention_ss: qkv must be contiguous [b * ntok, 3 * heads * 64]");
-  if (bias.has_value()) { dev_f32(*bias, "bias"); TORCH_CHECK(bias->is_contiguous() && bias->dim() == 3, "prv2::attention_ss: bias [heads, ntok, ld]"); }
+  if (bias.has_value()) {
+    dev_f32(*bias, "bias");
+    TORCH_CHECK(bias->is_contiguous() && (bias_image ? bias->numel() * 4 == prv2_attention_bias_image_bytes((int)heads, (int)ntok) : bias->dim() == 3),
+                "prv2::attention_ss: bias is [heads, ntok, ld] or a pack_attention_bias image");
+  }
   Tensor out = at::empty({b * ntok, heads * 64}, qkv.options());
   const int64_t wsb = prv2_attention_workspace_bytes((int)b, (int)ntok, (int)heads, PRV2_PREC_BF16X3);
   Tensor ws = at::empty({wsb > 0 ? wsb : 1}, qkv.options().dtype(at::kByte));
   Launch L(qkv);
   ok(prv2_attention_ss(qkv.data_ptr<float>(), (int)b, (int)ntok, (int)heads, 64, bias.has_value() ? bias->data_ptr<float>() : nullptr,
-                       bias.has_value() ? (int)bias->size(2) : 0, out.data_ptr(), wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream), "attention_ss");
+                       bias.has_value() ? (bias_image ? PRV2_ATTENTION_BIAS_IMAGE : (int)bias->size(2)) : 0, out.data_ptr(), wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream), "attention_ss");
   return out;
 }
 
@@ -461,9 +465,22 @@ Tensor layernorm(const Tensor& x, const Tensor& weight, const Tensor& bias, doub
 }
 
 // softmax((q * scale) k^T) v, head_dim 64; qkv rows [3][heads][64] as nn.Linear(dim, 3 * dim) leaves them (attention.py:49-62)
-Tensor attention_fwd(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, int64_t prec, const optional<Tensor>& bias) {
+// the score bias of a (model, resolution) re-ordered once for the bf16x3 kernel (include/prv2.h::prv2_pack_attention_bias)
+Tensor pack_attention_bias(const Tensor& bias, int64_t ntok) {
+  dev_f32(bias, "bias");
+  TORCH_CHECK(bias.is_contiguous() && bias.dim() == 3 && bias.size(1) == ntok, "prv2::pack_attention_bias: bias is contiguous [heads, ntok, ld]");
+  Tensor img = at::empty({prv2_attention_bias_image_bytes((int)bias.size(0), (int)ntok) / 4}, bias.options());
+  Launch L(bias);
+  ok(prv2_pack_attention_bias(bias.data_ptr<float>(), (int)bias.size(0), (int)ntok, (int)bias.size(2), img.data_ptr<float>(), L.stream), "pack_attention_bias");
+  return img;
+}
+
+Tensor attention_fwd(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, int64_t prec, const optional<Tensor>& bias, bool bias_image) {
   dev_f32(qkv, "qkv");
-  if (bias.has_value()) {  // additive score bias [heads, ntok, ld >= roundup(ntok, 64)] shared by the batch (BEiT relative position bias)
+  if (bias.has_value() && bias_image) {
+    dev_f32(*bias, "bias");
+    TORCH_CHECK(bias->numel() * 4 == prv2_attention_bias_image_bytes((int)heads, (int)ntok), "prv2::attention_fwd: bias is not a pack_attention_bias image of (heads, ntok)");
+  } else if (bias.has_value()) {  // additive score bias [heads, ntok, ld >= roundup(ntok, 64)] shared by the batch (BEiT relative position bias)
     dev_f32(*bias, "bias");
     TORCH_CHECK(bias->is_contiguous() && bias->dim() == 3 && bias->size(0) == heads && bias->size(1) == ntok && bias->size(2) >= (ntok + 63) / 64 * 64,
                 "prv2::attention_fwd: bias must be contiguous [heads, ntok, ld] with ld >= ntok rounded up to 64");
@@ -474,7 +491,8 @@ Tensor attention_fwd(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, 
   Tensor ws = at::empty({wsb > 0 ? wsb : 1}, qkv.options().dtype(at::kByte));
   Launch L(qkv);
   ok(prv2_attention_bias(qkv.data_ptr<float>(), (int)b, (int)ntok, (int)heads, 64, bias.has_value() ? bias->data_ptr<float>() : nullptr,
-                         bias.has_value() ? (int)bias->size(2) : 0, out.data_ptr<float>(), (int)prec, wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream),
+                         bias.has_value() ? (bias_image ? PRV2_ATTENTION_BIAS_IMAGE : (int)bias->size(2)) : 0, out.data_ptr<float>(), (int)prec,
+                         wsb > 0 ? ws.data_ptr() : nullptr, wsb, L.stream),
      "attention_fwd");
   return out;
 }
@@ -645,7 +663,7 @@ TORCH_LIBRARY(prv2, m) {
   m.def("layernorm_ss(Tensor x, Tensor weight, Tensor bias, float eps, Tensor(a!) y_ss) -> ()");
   m.def("gemm_ss(Tensor a_ss, Tensor w_packed, int cout, Tensor? bias=None, Tensor? gamma=None, Tensor? res=None, int act=0, bool out_ss=False, "
         "Tensor(a!)? out=None) -> Tensor");
-  m.def("attention_ss(Tensor qkv, int b, int ntok, int heads, Tensor? bias=None) -> Tensor");
+  m.def("attention_ss(Tensor qkv, int b, int ntok, int heads, Tensor? bias=None, bool bias_image=False) -> Tensor");
   m.def("bicubic_resize(Tensor img_hwc, int oh, int ow) -> Tensor");
   m.def("depth_pair_fill(Tensor p1, Tensor p2, Tensor(a!) tail) -> ()");
   m.def("conv_border_bias_(Tensor(a!) y, Tensor tap_bias) -> ()");
@@ -653,7 +671,8 @@ TORCH_LIBRARY(prv2, m) {
   m.def("zero_pad_channels_(Tensor(a!) buf, int c) -> ()");
   m.def("layernorm(Tensor x, Tensor weight, Tensor bias, float eps=1e-06, int act=0, Tensor(a!)? out=None) -> Tensor");
   m.def("roi_align(Tensor feat, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None, bool x2=False) -> Tensor");
-  m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0, Tensor? bias=None) -> Tensor");
+  m.def("attention_fwd(Tensor qkv, int b, int ntok, int heads, int prec=0, Tensor? bias=None, bool bias_image=False) -> Tensor");
+  m.def("pack_attention_bias(Tensor bias, int ntok) -> Tensor");
   m.def("crop_resize_bilinear(Tensor img_chw, Tensor tiles, int ch, int cw, int oh, int ow, float[]? mean=None, float[]? std=None, "
         "Tensor(a!)? out=None) -> Tensor");
   m.def("roi_gather_pyramid(Tensor[] feats, Tensor boxes, int ph) -> Tensor[]");
@@ -697,6 +716,7 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("zero_pad_channels_", &zero_pad_channels_);
   m.impl("layernorm", &layernorm);
   m.impl("attention_fwd", &attention_fwd);
+  m.impl("pack_attention_bias", &pack_attention_bias);
   m.impl("crop_resize_bilinear", &crop_resize_bilinear);
   m.impl("roi_gather_pyramid", &roi_gather_pyramid);
   m.impl("roi_align", &roi_align);

@@ -17,7 +17,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
 FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(C.Structure):
@@ -63,6 +63,8 @@ SIGNATURES = {
     "prv2_patchify": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "prv2_assemble_tokens": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "prv2_attention": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _L, _P]),
+    "prv2_attention_bias_image_bytes": (_L, [_I, _I]),
+    "prv2_pack_attention_bias": (_I, [_P, _I, _I, _I, _P, _P]),
     "prv2_attention_bias": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _L, _P]),
     "prv2_split_ss": (_I, [_P, _L, _I, _I, _P, _P]),
     "prv2_layernorm_ss": (_I, [_P, _L, _I, _I, _P, _P, _F, _P, _P]),

@@ -127,7 +127,9 @@ class MidasBeitCore(StateDictModule):
                 full = torch.cat([new, table[oh * ow:]])
                 bias = torch.zeros((c["heads"], n, ld), dtype=torch.float32)
                 bias[:, :, :n] = full[idx].view(n, n, -1).permute(2, 0, 1)
-                out.append(bias.to(self.device))
+                bias = bias.to(self.device)
+                # bf16 modes: the rows re-ordered once for the attention kernel's coalesced loads (ops.pack_attention_bias)
+                out.append(ops.pack_attention_bias(bias, n) if (self.prec != ops.PREC_F32 and ops.ATT_BIAS_IMAGE) else bias)
             self._bias_cache[key] = out
         return self._bias_cache[key]
 

@@ -683,33 +683,62 @@ def assemble_tokens(emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: 
     return tok
 
 
-def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32, bias: Optional[torch.Tensor] = None,
+class AttnBiasImage:
+    """a [heads, ntok, ld] score bias re-ordered once for the bf16x3 attention kernel (include/prv2.h::prv2_pack_attention_bias)"""
+
+    def __init__(self, image: torch.Tensor, heads: int, ntok: int):
+        self.image, self.heads, self.ntok = image, heads, ntok
+
+
+ATT_BIAS_IMAGE = os.environ.get("PRV2_ATT_BIAS_IMAGE", "1") != "0"  # A/B and test switch
+
+
+def pack_attention_bias(bias: torch.Tensor, ntok: int):
+    """bias rows [heads, ntok, ld] -> AttnBiasImage (bf16 modes; same values, the kernel's per-tile log2 e product pre-formed)"""
+    _require_dev(bias)
+    assert bias.is_contiguous() and bias.dim() == 3 and bias.shape[1] == ntok
+    heads = bias.shape[0]
+    if DISPATCH == "torch":
+        return AttnBiasImage(_tops().pack_attention_bias(bias, ntok), heads, ntok)
+    lib = L.load()
+    img = torch.empty(lib.prv2_attention_bias_image_bytes(heads, ntok) // 4, device=bias.device, dtype=torch.float32)
+    L.check(lib.prv2_pack_attention_bias(bias.data_ptr(), heads, ntok, bias.shape[2], img.data_ptr(), _stream()), "pack_attention_bias")
+    return AttnBiasImage(img, heads, ntok)
+
+
+def attention(qkv: torch.Tensor, b: int, ntok: int, heads: int, prec: int = PREC_F32, bias=None,
               out_ss: bool = False) -> torch.Tensor:
-    """``bias``: optional [heads, ntok, ld >= roundup(ntok, 64)] additive score bias shared by the batch (BEiT);
-    ``out_ss``: write the output split-swizzled (the operand format of gemm_ss; bf16x3 only)"""
+    """``bias``: optional [heads, ntok, ld >= roundup(ntok, 64)] additive score bias shared by the batch (BEiT), or its
+    ``AttnBiasImage`` (bf16 modes); ``out_ss``: write the output split-swizzled (the operand format of gemm_ss; bf16x3 only)"""
     out = torch.empty((b * ntok, heads * 64), device=qkv.device, dtype=torch.float32)
     lib = L.load()
     nbytes = lib.prv2_attention_workspace_bytes(b, ntok, heads, prec)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device) if nbytes else None
-    if bias is not None:
+    image = isinstance(bias, AttnBiasImage)
+    if image:
+        assert prec != PREC_F32 and (bias.heads, bias.ntok) == (heads, ntok)
+        bias_t, ld_bias = bias.image, -1
+    elif bias is not None:
         _require_dev(bias)
         assert bias.is_contiguous() and bias.shape[0] == heads and bias.shape[1] == ntok
+        bias_t, ld_bias = bias, bias.shape[2]
+    else:
+        bias_t, ld_bias = None, 0
     if DISPATCH == "torch":
         res = []
         PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel", 4.0 * b * heads * ntok * ntok * 64,
-                        lambda: res.append(_tops().attention_ss(qkv, b, ntok, heads, bias) if out_ss else _tops().attention_fwd(qkv, b, ntok, heads, prec, bias)))
+                        lambda: res.append(_tops().attention_ss(qkv, b, ntok, heads, bias_t, image) if out_ss else
+                                           _tops().attention_fwd(qkv, b, ntok, heads, prec, bias_t, image)))
         return res[0]
     if out_ss:
         assert prec == L.PREC_BF16X3
         PROFILER.launch("attention_bf16x3_kernel", 4.0 * b * heads * ntok * ntok * 64,
-                        lambda: L.check(lib.prv2_attention_ss(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias),
-                                                              bias.shape[2] if bias is not None else 0, out.data_ptr(), _ptr(ws),
+                        lambda: L.check(lib.prv2_attention_ss(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias_t), ld_bias, out.data_ptr(), _ptr(ws),
                                                               nbytes, _stream()), "attention_ss"))
         return out
     PROFILER.launch("attention_f32_kernel" if prec == PREC_F32 else "attention_bf16x3_kernel",
                     4.0 * b * heads * ntok * ntok * 64,
-                    lambda: L.check(lib.prv2_attention_bias(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias),
-                                                            bias.shape[2] if bias is not None else 0, out.data_ptr(), prec,
+                    lambda: L.check(lib.prv2_attention_bias(qkv.data_ptr(), b, ntok, heads, 64, _ptr(bias_t), ld_bias, out.data_ptr(), prec,
                                                             _ptr(ws), nbytes, _stream()), "attention"))
     return out
 

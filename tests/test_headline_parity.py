@@ -49,6 +49,11 @@ def _pair(name, prec="bf16x3", **model_kw):
     sd = widen_depth_range(W.synth_state_dict(state_spec(name), seed=0))
     model = build_model(model_config(name, prec=prec, **model_kw))
     model.load_state_dict(sd, strict=True)
+    if not w.get("zoe"):  # DepthAnythingV2 coarse branch (type='DA2': sigmoid * max_depth head, no bins to widen; the offsets are scaled)
+        kw = dict(patch_process_shape=w["pps"], image_raw_shape=w["raw"], patch_split_num=w["split"])
+        ccfg = W.dav2_cfg({**w["coarse"], "max_depth": 80.0})
+        assert w["kind"] == "PatchRefinerPlus"
+        return model, o_tiling.OraclePatchRefinerPlus(sd, ccfg, **kw), w
     zc = W.zoedepth_cfg(w["zoe"])
     kw = dict(patch_process_shape=w["pps"], image_raw_shape=w["raw"], patch_split_num=w["split"],
               resizer="zoe" if w.get("zoe_type") == "ZoeDepth" else "da")
@@ -125,6 +130,23 @@ def test_headline_v2_zoe_tile_vs_fp32_oracle():
     assert hi / lo >= 8.0 and float(c.max()) / float(c.min()) >= 10.0, (lo, hi)    # the bins are exercised
     assert float(want["trace"]["offset"].abs().mean()) > 0.1                        # the offsets are not noise-level
     assert tuple(got["pred"].shape) == tuple(want["pred"].shape) == (1, 1, 384, 512)
+    assert ar_c < ABSREL_TOL and ar < ABSREL_TOL, (ar_c, ar)
+    assert all(v <= REL_L2_TOL for v in r.values()), r
+
+
+def test_v2_dav2l_r64_tile_vs_fp32_oracle():
+    """(a') ONE full-width tile of ``v2_dav2l_4k_r64`` -- the workload of BASELINE configs [3] / [4]: DepthAnythingV2 ViT-L coarse
+    branch at 448 x 448 (24 blocks, 1025 tokens), MobileNetV4-S refiner, BiDirectionalFusion with coarse_chl[0] = 128 (the 128-channel
+    gate kernel at full resolution, the coarse-tap tables of every level) -- bf16x3 vs the fp32 oracle with the offset / intermediate
+    assertions of the headline tile"""
+    name = "v2_dav2l_4k_r64"
+    model, ora, w = _pair(name)
+    assert tuple(w["pps"]) == (448, 448) and w["fusion"]["coarse_chl"][0] == 128
+    hr = rand_image(5, 1, *w["raw"])
+    got, want = _one_tile(model, ora, hr, (405, 1200), dict(image_raw_shape=w["raw"], patch_split_num=w["split"]))
+    ar_c, ar, r = _report(f"{name} one tile bf16x3", got, want, ["c2f_depth", "c2f_last", "dec_last", "offset"])
+    assert tuple(got["pred"].shape) == tuple(want["pred"].shape) == (1, 1, 448, 448)
+    assert float(want["trace"]["offset"].abs().mean()) > 0.01
     assert ar_c < ABSREL_TOL and ar < ABSREL_TOL, (ar_c, ar)
     assert all(v <= REL_L2_TOL for v in r.values()), r
 

@@ -1055,3 +1055,28 @@ def test_conv2d_pre_addend_in_front_of_the_epilogue(P, case):
     close(y.to_nchw(), ref, 3e-5, f"conv2d_pre {case} on {P.L.load().prv2_last_kernel().decode()}")
     if y.ld != cout:  # pad channels behind cout stay zero
         assert float(y.buf[..., cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 769, 4), (1, 197, 3), (3, 130, 2)])
+def test_attention_score_bias_rows_and_packed_image(P, shape):
+    """softmax(q k^T / 8 + bias[head]) v (BEiT relative position bias; midas_beit.py / beit.py:_get_rel_pos_bias) in the bf16x3 kernel:
+    the bias as rows [heads, N, ld] and as the prv2_pack_attention_bias image (coalesced loads, log2 e pre-multiplied) give the SAME
+    bits -- fp32 and split-swizzled outputs alike -- and agree with the fp32 reference"""
+    b, n, heads = shape
+    g = torch.Generator().manual_seed(21)
+    qkv = torch.randn(b * n, 3 * heads * 64, generator=g)
+    ld = (n + 63) // 64 * 64
+    bias = torch.zeros(heads, n, ld)
+    bias[:, :, :n] = torch.randn(heads, n, n, generator=g) * 2.0
+    q, k, v = qkv.view(b, n, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125 + bias[None, :, :, :n], -1) @ v).permute(0, 2, 1, 3).reshape(b * n, heads * 64)
+    qd, bd = qkv.to(DEV), bias.to(DEV)
+    img = P.pack_attention_bias(bd, n)
+    a_rows = P.attention(qd, b, n, heads, P.L.PREC_BF16X3, bias=bd)
+    a_img = P.attention(qd, b, n, heads, P.L.PREC_BF16X3, bias=img)
+    assert torch.equal(a_rows, a_img)
+    assert torch.equal(P.attention(qd, b, n, heads, P.L.PREC_BF16X3, bias=bd, out_ss=True), P.attention(qd, b, n, heads, P.L.PREC_BF16X3, bias=img, out_ss=True))
+    close(a_img, ref, 2e-5, "attention + bias image")
+    close(P.attention(qd, b, n, heads, P.L.PREC_F32, bias=bd), ref, 2e-6, "attention + bias rows, f32")
+    with pytest.raises((RuntimeError, AssertionError)):
+        P.attention(qd, b, n, heads, P.L.PREC_F32, bias=img)   # the image is for the bf16 modes
