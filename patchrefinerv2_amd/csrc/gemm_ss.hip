@@ -46,7 +46,11 @@ struct GemmSSParams {
 
 // NS = LDS stages.  2: slab k + 1 in flight while slab k multiplies (what the LDS allows for 256 x 256 tiles and for two 128 x 128
 // workgroups per CU).  4 (clamped issue, counted waits): the 64 x 64 tiles of grids with at most one workgroup per CU.
-template <int WM, int WN, int RI, int RJ, bool OUT_SS, int ACT, int NS = 2>
+// DEFER (NS == 2): the MFMAs of a slab's LAST row block are issued behind the next slab's barrier, DMA issue and first fragment
+// reads -- their operands are registers by then -- so that the matrix pipe has work while the waves of the workgroup re-converge
+// (both waves of a SIMD arrive at the barrier together: without it the pipe idles for the barrier skew + 8 DMA issues + the LDS
+// latency of the first fragments, ~15 % of a slab).  Every accumulator still receives its slabs in order: same bits.
+template <int WM, int WN, int RI, int RJ, bool OUT_SS, int ACT, int NS = 2, bool DEFER = false>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2) gemm_ss_kernel(const GemmSSParams p) {
   constexpr int NW = WM * WN, TM = WM * RI * 16, TN = WN * RJ * 16;
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
@@ -146,7 +150,53 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
     }
   };
 
-  if constexpr (NS == 2) {
+  if constexpr (NS == 2 && DEFER) {
+    bf16x8 dbh[RJ], dbl[RJ], dah, dal;  // operands of the deferred row block (RI - 1) of the previous slab
+    auto mma_last = [&]() {
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[RI - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dal, dbh[j], acc[RI - 1][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[RI - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dah, dbl[j], acc[RI - 1][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[RI - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dah, dbh[j], acc[RI - 1][j], 0, 0, 0);
+    };
+    issue(0, 0);
+    for (int k = 0; k < p.kslabs; ++k) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (k + 1 < p.kslabs) issue((k + 1) & 1, k + 1);
+      const char* const sb = smem + (k & 1) * STAGE;
+      bf16x8 bh[RJ], bl[RJ], ah[2], al[2];
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_off_hi + j * 2048);
+        bl[j] = *reinterpret_cast<const bf16x8*>(sb + b_off_lo + j * 2048);
+      }
+      ah[0] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi);
+      al[0] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo);
+      if (k > 0) mma_last();  // (registers only: runs while the fragments above travel)
+#pragma unroll
+      for (int i = 0; i < RI - 1; ++i) {
+        ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi + (i + 1) * 2048);
+        al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo + (i + 1) * 2048);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+      }
+      dah = ah[(RI - 1) & 1];
+      dal = al[(RI - 1) & 1];
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) {
+        dbh[j] = bh[j];
+        dbl[j] = bl[j];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the deferred operands are in registers before anyone may overwrite the stage)
+    }
+    mma_last();
+    asm volatile("s_barrier" ::: "memory");
+  } else if constexpr (NS == 2) {
     issue(0, 0);
     for (int k = 0; k < p.kslabs; ++k) {
       // my DMAs of slab k have landed; behind the barrier everyone's have, and everyone is done reading the other stage
@@ -345,6 +395,16 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
     p.tiles_m = (int)cdiv(m, 256);
     p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
     const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
+    const char* const dfe = getenv("PRV2_GSS_DEFER");  // A/B switch; OFF by default: same time within noise (profiles/r04_experiments.txt)
+    if (dfe ? atoi(dfe) != 0 : false) {
+      if (y_ss) {
+        if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, true, PRV2_ACT_GELU, 2, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, true, PRV2_ACT_NONE, 2, true>), grid, dim3(512), 0, s, p);
+      } else {
+        if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, false, PRV2_ACT_GELU, 2, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, false, PRV2_ACT_NONE, 2, true>), grid, dim3(512), 0, s, p);
+      }
+    } else
     PRV2_GSS(2, 4, 8, 4, 512, 2);
     set_kernel("gemm_ss_kernel", 256, PRV2_PREC_BF16X3);
   } else {

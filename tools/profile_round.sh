@@ -2,7 +2,7 @@
 # Run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): regenerates the profiles/ evidence of the default
 # bench workload into gpurun_out/profiles/ (copy what should be judged into profiles/ afterwards).
 set -u
-TAG=${1:-r03}; PREC=${2:-bf16x3}
+TAG=${1:-r04}; PREC=${2:-bf16x3}
 R=$(pwd); O=$R/gpurun_out/profiles; mkdir -p $O
 WL=$(python3 -c "from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD as w; print(w)")
 export TMPDIR=/tmp
@@ -18,6 +18,11 @@ python3 bench.py --workload v1_zoe_4k_r32 --layer-report $O/${TAG}_${PREC}_layer
 # the bench's cpu_baseline extrapolation against a fully timed oracle frame (m1, 16 tiles)
 python3 tools/cpu_baseline_validate.py > $O/${TAG}_cpu_baseline_validation.json 2>> $O/bench.err
 python3 tools/shard_model.py > $O/${TAG}_shard_model.json 2>> $O/bench.err
+# the power-limited frame's operating range: all-zero frames (upper end) beside the default random frames
+python3 bench.py --data zeros --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/${TAG}_${PREC}_bench_${WL}_zeros.json 2>> $O/bench.err
+# same-box A/B of the round's frame-level changes
+for T in 1 0 1 0; do PRV2_COARSE_TAPS=$T python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_COARSE_TAPS=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_coarse_taps_ab.txt
+for D in torch ctypes torch ctypes; do PRV2_DISPATCH=$D python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_DISPATCH=$D', round(d['ms_per_step'],2), 'ms')"; done > $O/${TAG}_dispatch_ab.txt
 # kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-roofline > /tmp/kt.log 2>&1
