@@ -833,7 +833,7 @@ extern "C" int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x,
   // (tools/probes/gate_clock.sh, profiles/r03_power_wall.txt)
 #ifdef PRV2_EXPERIMENTS
   static const int use_w4 = getenv("PRV2_W4") ? atoi(getenv("PRV2_W4")) : 0;
-  if (gate_w_packed && gp.x_x2 && x3 && use_w4 && (!mul || gp.mul_x2) && !pre) {
+  if (gate_w_packed && gp.x_x2 && x3 && use_w4 && (!mul || gp.mul_x2)) {
     hipLaunchKernelGGL((conv3x3_w4_gate_kernel<PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(256), 0, s, gp);
     set_kernel("conv3x3_w4_gate_kernel", 256, d->prec);
     PRV2_LAUNCH_CHECK("conv3x3_ln_gate");

@@ -249,6 +249,18 @@ __global__ void __launch_bounds__(256, 2) conv3x3_w4_gate_kernel(const GateConvP
   // ---- epilogue, wave-local: bias, LayerNorm over the 256 channels of a pixel (4 lanes x 64), ReLU, bf16 split -------------------
   // lane's channels of accumulator j: ch0(j) + e,  ch0(j) = 32 (j >> 1) + 8 g + 4 (j & 1)
   auto ch0 = [&](int j) { return 32 * (j >> 1) + 8 * g + 4 * (j & 1); };
+  if (gp.pre) {  // block-uniform: the conv's coarse half (prv2_conv3x3_ln_gate_pre; coarse_taps.hip) joins in front of the LayerNorm
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int oy = y0 + 2 * wave + f, ox = x0 + m16;
+      const float* pp = gp.pre + ((long long)n_img * p.H * p.W + min(oy, p.H - 1) * p.W + min(ox, p.W - 1)) * gp.ld_pre;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        acc[f][j] += *reinterpret_cast<const f32x4*>(pp + ch0(j));
+        if ((j & 3) == 3) asm volatile("" ::: "memory");  // (four loads in flight, not sixteen: registers)
+      }
+    }
+  }
   if (p.bias) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {

@@ -9,17 +9,20 @@ for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VA
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pg_$i -- python3 $R/tools/probes/gate_conv_bench.py 14 192 256 512 > /tmp/pg_$i.log 2>&1 || tail -3 /tmp/pg_$i.log
+  # round 4: the unit as the frame runs it -- K = 256 gate kernel on the X2 ``out`` + the gathered coarse half (tap_gather_kernel)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pg_t$i -- python3 $R/tools/probes/gate_taps_bench.py 14 192 256 > /tmp/pg_t$i.log 2>&1 || tail -3 /tmp/pg_t$i.log
 done
 python3 - <<'PY'
 import csv, glob, collections
 tot=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(lambda: collections.defaultdict(int)); dur=collections.defaultdict(list)
-for f in glob.glob('/tmp/pg_*/**/*counter_collection.csv', recursive=True):
+for f in glob.glob('/tmp/pg_*/**/*counter_collection.csv', recursive=True):  # (pg_N: the 512-channel concat form; pg_tN: the round-4 form)
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0].replace('void ','').replace('prv2::','')
-        if not any(t in k for t in ('c256', 'halo16', 'gemm16', 'layernorm')): continue
+        if not any(t in k for t in ('c256', 'halo16', 'gemm16', 'layernorm', 'tap_')): continue
         tot[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
         dur[k].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
-print("14 x 192 x 256 pixels, 512 -> 256 3x3 (+ LayerNorm + ReLU + 256 -> 256 gate + sigmoid * mul + res), bf16x3; per launch")
+print("14 x 192 x 256 pixels, bf16x3; per launch.  conv3x3_c256_gate_kernel = the 512 -> 256 concat form (3x3 + LayerNorm + ReLU + 256 -> 256 gate + sigmoid * mul + res);\n"
+      "conv3x3_c256_gate_x2_kernel = the round-4 form: K = 256 on the pre-split ``out`` + the coarse half as a pre-LayerNorm addend (tap_gather_kernel)")
 for k in sorted(tot, key=lambda k: -sum(dur[k]) / len(dur[k])):
     c={x: tot[k][x]/n[k][x] for x in tot[k]}
     d=sum(dur[k])/len(dur[k])/1e3
