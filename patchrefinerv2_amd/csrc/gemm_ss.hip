@@ -200,7 +200,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
     issue(0, 0);
     for (int k = 0; k < p.kslabs; ++k) {
       // my DMAs of slab k have landed; behind the barrier everyone's have, and everyone is done reading the other stage
+#ifdef PRV2_GSS_NOBAR  // timing ablation (results wrong): no workgroup barrier in the K loop
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #ifdef PRV2_GSS_NODMA  // timing ablation (results wrong; profiles/r03_experiments.txt): only the first two slabs are ever fetched
       if (k + 1 < p.kslabs && k < 1) issue((k + 1) & 1, k + 1);
 #else
@@ -226,6 +230,17 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // nothing may land on the epilogue strips
   }
 
+#ifdef PRV2_GSS_NOEPI  // timing ablation (results wrong): the K loop alone -- one store per lane keeps the accumulators alive
+  {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) sum += acc[i][j];
+    if (sum[0] == 12345.678f) p.y[threadIdx.x] = sum[1] + sum[2] + sum[3];
+    return;
+  }
+#endif
   // ---- epilogue: one 16-row block at a time through a wave-private LDS strip -> whole 256-byte row segments ----------
   float* const strip = reinterpret_cast<float*>(smem + wave * STRIP_BYTES);
   const long long wrow0 = row0 + wm * RI * 16;
