@@ -22,6 +22,8 @@
 // term -- but only inside a frame with two tile streams and a third stream busy; never in isolation, and independent of every
 // s_waitcnt / s_nop added around the loads and the store (tools/probes/taps_stage_checksums.py, profiles/r04_experiments.txt).
 // Scalar v_fma_f32 code is bit-stable under the same load; the kernels are HBM-bound, the flag costs nothing measurable.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace prv2 {
@@ -132,7 +134,7 @@ __device__ __forceinline__ void roi_axis(float v, int n, int& lo, int& hi, float
 
 // B[k, i, j, ch] = U(ys(i), xs(j)) - (taps hidden by the zero padding at the tile border).  Thread = (column j, 4 channels) x R
 // output rows; the x-interpolated knot rows of the previous output row are kept (consecutive rows share one knot row).
-template <int R>
+template <int R, bool NT = false>
 __global__ void __launch_bounds__(256) tap_gather_kernel(const float* __restrict__ V, const float* __restrict__ G, int H, int W, int C, int ldv,
                                                          int ldg, float kbh, float kbw, const float* __restrict__ boxes, float scale, int oh,
                                                          int ow, float* __restrict__ out, int ldo) {
@@ -205,7 +207,13 @@ __global__ void __launch_bounds__(256) tap_gather_kernel(const float* __restrict
           }
         }
     }
-    *reinterpret_cast<float4*>(out + (((int64_t)k * oh + py) * ow + px) * ldo + ch) = acc;
+    float4* dst = reinterpret_cast<float4*>(out + (((int64_t)k * oh + py) * ow + px) * ldo + ch);
+    if constexpr (NT) {
+      typedef float f32x4n __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f32x4n{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4n*>(dst));
+    } else {
+      *dst = acc;
+    }
   }
 }
 
@@ -238,11 +246,15 @@ extern "C" int prv2_coarse_tap_gather(const float* v, const float* g, int32_t h,
                "coarse_tap_gather: c %% 4 == 0, ldg >= 9 c, 16-byte aligned rows (c=%d ldg=%d ldv=%d ldo=%d)", c, ldg, ldv, ldo);
   PRV2_REQUIRE(knot_bh > 0.f && knot_bh <= 0.5f && knot_bw > 0.f && knot_bw <= 0.5f,
                "coarse_tap_gather: the knot offsets must be in (0, 1/2] (got %g, %g)", (double)knot_bh, (double)knot_bw);
-  constexpr int R = 4;
-  PRV2_REQUIRE(cdiv(oh, R) <= 65535 && k <= 65535, "coarse_tap_gather: grid too large");
+  static const int variant = getenv("PRV2_TAPG") ? atoi(getenv("PRV2_TAPG")) : 0;  // A/B switch: bit 0 = 8 rows per thread, bit 1 = nontemporal stores
+  const int R = (variant & 1) && oh >= 32 ? 8 : 4;
+  PRV2_REQUIRE(cdiv(oh, 4) <= 65535 && k <= 65535, "coarse_tap_gather: grid too large");
   const dim3 grid((unsigned)cdiv((int64_t)ow * (c / 4), 256), (unsigned)cdiv(oh, R), (unsigned)k);
-  hipLaunchKernelGGL(tap_gather_kernel<R>, grid, dim3(256), 0, (hipStream_t)stream, v, g, h, w, c, ldv, ldg, knot_bh, knot_bw, boxes, spatial_scale,
-                     oh, ow, out, ldo);
+#define PRV2_TG(R_, NT_) hipLaunchKernelGGL((tap_gather_kernel<R_, NT_>), grid, dim3(256), 0, (hipStream_t)stream, v, g, h, w, c, ldv, ldg, knot_bh, knot_bw, boxes, \
+                                            spatial_scale, oh, ow, out, ldo)
+  if (R == 8) { if (variant & 2) PRV2_TG(8, true); else PRV2_TG(8, false); }
+  else { if (variant & 2) PRV2_TG(4, true); else PRV2_TG(4, false); }
+#undef PRV2_TG
   PRV2_LAUNCH_CHECK("coarse_tap_gather");
   return 0;
 }

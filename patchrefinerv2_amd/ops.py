@@ -115,6 +115,14 @@ def roundup(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+def _feat_of(y: torch.Tensor, c: int) -> "Feat":
+    """the ``Feat`` of an NHWC tensor a torch.ops.prv2 operator allocated: dense, or -- channel counts that are not a multiple of 4 -- the
+    first c channels of a buffer whose pixel stride is padded (csrc/torch_ops.cpp::alloc_nhwc)"""
+    n, h, w, _ = y.shape
+    ld = y.stride(2)
+    return Feat(y if ld == y.shape[3] else torch.as_strided(y, (n, h, w, ld), (h * w * ld, w * ld, ld, 1)), c)
+
+
 class Feat:
     """NHWC fp32 activation [n, h, w, c] living in ``buf`` ([n, h, w, ld]) at channel offset c0."""
 
@@ -206,7 +214,7 @@ class Feat:
         n, c, h, w = x.shape
         if DISPATCH == "torch" and pad_to == 4:
             y = _tops().nchw_to_nhwc(x)
-            return Feat(y if y.is_contiguous() else y._base, c)
+            return _feat_of(y, c)
         f = Feat.alloc(n, h, w, c, x.device, pad_to)
         L.check(L.load().prv2_nchw_to_nhwc(x.data_ptr(), n, c, h, w, f.ptr, f.ld, _stream()), "nchw_to_nhwc")
         return f
@@ -537,7 +545,7 @@ def dwconv2d(x: Feat, w_tapmajor: torch.Tensor, bias: Optional[torch.Tensor], k:
         PROFILER.launch("dwconv_kernel", 2.0 * x.n * oh * ow * x.c * k * k,
                         lambda: box.append(_tops().dwconv2d(x.view(), w_tapmajor, bias, k, stride, act, same_pad)))
         y = box[0]
-        return Feat(y if y.is_contiguous() else y._base, x.c)
+        return _feat_of(y, x.c)
     out = Feat.alloc(x.n, oh, ow, x.c, x.device)
     PROFILER.launch("dwconv_kernel", 2.0 * x.n * oh * ow * x.c * k * k,
                     lambda: L.check(L.load().prv2_dwconv2d_ex(x.ptr, x.n, x.h, x.w, x.c, x.ld, w_tapmajor.data_ptr(),
@@ -990,7 +998,7 @@ def zoe_attractor(attr: Feat, bins: Feat, alpha: float = 300.0) -> Feat:
     assert (attr.n, attr.h, attr.w) == (bins.n, bins.h, bins.w)
     if DISPATCH == "torch":
         y = _tops().zoe_attractor(attr.view(), bins.view(), alpha)
-        return Feat(y if y.is_contiguous() else y._base, bins.c)
+        return _feat_of(y, bins.c)
     out = Feat.alloc(bins.n, bins.h, bins.w, bins.c, bins.device)
     L.check(L.load().prv2_zoe_attractor(attr.ptr, attr.ld, attr.c, bins.ptr, bins.ld, bins.c, alpha,
                                         bins.n * bins.h * bins.w, out.ptr, out.ld, _stream()), "zoe_attractor")
