@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 13
+#define PRV2_ABI_VERSION 14
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -126,6 +126,22 @@ typedef struct prv2_ups_src {
 int prv2_conv2d_ups_supported(const prv2_conv_desc* d, const prv2_ups_src* u);
 int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src* u, const void* w_packed, const float* bias,
                     const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution of a bilinear(align_corners=True) UPSAMPLE (factor >= 2) of u, computed at u's resolution
+ * (csrc/upconv.hip) -- the layers prv2_conv2d_ups interpolates inside its loader, with 2.3x fewer matrix operations:
+ *   C2FModule output_conv1      bi_directional_fusion_model.py:139-142,201   conv3x3(interpolate(path_1, scale 2, align_corners=True))
+ *   UpSample.forward_hardcode   fusion_model.py:15-24                        the interpolate(x1) part of DoubleConv.0(cat[x1, x2, pred1, pred2])
+ * The conv is linear and its input an interpolation of u, so  conv3x3(up(u); W)(p) = sum_tap [p + d_tap inside] Bil(G_tap; s(p + d_tap))
+ * with G_tap = W[:, :, tap] . u at LOW resolution (MFMA) and the 36 corner terms per output gathered on the VALU.
+ *     y[n, h, w, 0 .. cout) = act(conv3x3(interpolate(u, (h, w), 'bilinear', align_corners=True)) + bias)
+ * w_packed: prv2_pack_conv_weight(cout, cin = u->channels, 3, 3) -- for a conv over a concat, the weight columns of the upsampled
+ * part; act NONE + bias NULL gives the partial sum that prv2_conv2d_pre takes as its addend for the rest of the concat.
+ * Same split products and fp32 accumulation as the other bf16 kernels; the taps / corners are summed in another order than
+ * upsample -> conv (fp32-grade, not bit-identical).  Contract (prv2_upconv3x3_supported != 0): bf16 modes, u->channels % 32 == 0,
+ * h >= 2 u->h - 1 and w >= 2 u->w - 1 (source step <= 1/2 pixel), 16-byte aligned NHWC rows. */
+int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec);
+int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, int32_t n, int32_t h, int32_t w, int32_t cout,
+                   int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream);
 
 /* prv2_conv2d (3x3 / stride 1 / pad 1, bias, [LayerNorm,] activation, [+ res]) that ALSO writes the two depth maps every fusion
  * level appends to its features behind its own output channels: y[pixel][cout .. cout + 3] = (p1, p2, 0, 0), p1 / p2 dense

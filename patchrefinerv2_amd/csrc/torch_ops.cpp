@@ -171,6 +171,26 @@ Tensor conv3x3_ups(const optional<Tensor>& x_in, const Tensor& u, const Tensor& 
   return y;
 }
 
+// include/prv2.h::prv2_upconv3x3: act(conv3x3(interpolate(u, (oh, ow), bilinear, align_corners=True)) + bias) computed at u's resolution
+// (tap GEMMs on the low-resolution grid + a gather): output_conv1 (bi_directional_fusion_model.py:139-142,201), the x1 part of
+// UpSample.forward_hardcode's first conv (fusion_model.py:15-24)
+Tensor upconv3x3(const Tensor& u, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t oh, int64_t ow, int64_t act, int64_t prec,
+                 const optional<Tensor>& out) {
+  const int64_t ldu = nhwc_ld(u, "u");
+  const int64_t n = u.size(0), cu = u.size(3);
+  dev_f32(w_packed, "w_packed");
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_packed_weight_bytes((int)cout, (int)cu, 3, 3, 0, (int)prec), "prv2::upconv3x3: w_packed does not match (cout, u channels, prec)");
+  Tensor y = out_or_alloc(out, u, n, oh, ow, cout, "upconv3x3");
+  prv2_ups_src us = {};
+  us.x = u.data_ptr<float>(); us.h = (int)u.size(1); us.w = (int)u.size(2); us.ld = (int)ldu; us.channels = (int)cu; us.bstride = 0;
+  TORCH_CHECK(prv2_upconv3x3_supported(&us, (int)n, (int)oh, (int)ow, (int)cout, (int)prec),
+              "prv2::upconv3x3: layer not covered (bf16 modes, u channels % 32 == 0, output at least 2h-1 x 2w-1 of u)");
+  Launch L(u);
+  ok(prv2_upconv3x3(&us, w_packed.data_ptr(), opt_ptr(bias, "bias", cout), (int)n, (int)oh, (int)ow, (int)cout, (int)act, (int)prec, y.data_ptr<float>(),
+                    (int)nhwc_ld(y, "out"), 0, L.stream), "upconv3x3");
+  return y;
+}
+
 // include/prv2.h::prv2_pack_gate_weight / prv2_conv3x3_ln_gate: the GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80)
 Tensor pack_gate_weight(const Tensor& w) {
   dev_f32(w, "weight");
@@ -642,6 +662,7 @@ TORCH_LIBRARY(prv2, m) {
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None, int fmt=0, bool force_generic=False, int part=0) -> Tensor");
   m.def("conv3x3_ups(Tensor? x, Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, Tensor? ln_weight=None, "
         "Tensor? ln_bias=None, Tensor? res=None, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
+  m.def("upconv3x3(Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None) -> Tensor");
   m.def("pack_gate_weight(Tensor weight) -> Tensor");
   m.def("conv3x3_ln_gate(Tensor x, Tensor w_packed, Tensor? bias, Tensor ln_weight, Tensor ln_bias, Tensor? gate_w_packed=None, Tensor? gate_bias=None, "
         "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None, Tensor? pre=None, "
@@ -692,6 +713,7 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("pack_conv_weight", &pack_conv_weight);
   m.impl("conv2d", &conv2d);
   m.impl("conv3x3_ups", &conv3x3_ups);
+  m.impl("upconv3x3", &upconv3x3);
   m.impl("pack_gate_weight", &pack_gate_weight);
   m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
   m.impl("conv3x3_tail", &conv3x3_tail);

@@ -368,6 +368,44 @@ def conv2d_ups_supported(x, u: Feat, cw: ConvW) -> bool:
     return bool(L.load().prv2_conv2d_ups_supported(C.byref(d), C.byref(us)))
 
 
+UPCONV = os.environ.get("PRV2_UPCONV", "1") != "0"  # A/B and test switch: 3x3 convs of an upsampled tensor computed at the low resolution
+
+
+def upconv3x3_supported(u: Feat, h: int, w: int, cw: ConvW) -> bool:
+    """can ``upconv3x3`` take conv3x3(bilinear_align_corners(u -> h x w); cw)?  A property of the layer (channels, per-image sizes, mode)."""
+    if not UPCONV or type(u) is not Feat or (cw.kh, cw.kw, cw.stride, cw.pad, cw.convt_k) != (3, 3, 1, 1, 0) or cw.cin != u.c or cw.same_pad:
+        return False
+    us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
+    return bool(L.load().prv2_upconv3x3_supported(C.byref(us), u.n, h, w, cw.cout, cw.prec))
+
+
+def upconv3x3(u: Feat, h: int, w: int, cw: ConvW, out: Optional[Feat] = None, *, act: int = ACT_NONE, bias: bool = True) -> Feat:
+    """act(conv3x3(bilinear_align_corners(u -> h x w); cw) + bias) computed at u's resolution (include/prv2.h::prv2_upconv3x3): nine tap
+    GEMMs on the low-resolution grid, then the four interpolation corners of every tap gathered per output pixel -- 2.3x fewer matrix
+    operations than ``conv2d_ups``.  fp32-grade, not bit-identical to it (summation order).  ``bias=False``: the raw sum (the addend
+    ``conv2d_pre`` takes when ``u`` is only a part of the conv's concat input)."""
+    assert cw.cin == u.c
+    if out is None:
+        out = Feat.alloc(u.n, h, w, cw.cout, u.device)
+    assert (out.n, out.h, out.w, out.c) == (u.n, h, w, cw.cout)
+    b = cw.bias if bias else None
+
+    def call():
+        if DISPATCH == "torch":
+            _tops().upconv3x3(u.view(), cw.w, b, cw.cout, h, w, act, cw.prec, out.view())
+            return
+        us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
+        L.check(L.load().prv2_upconv3x3(C.byref(us), cw.w.data_ptr(), _ptr(b), u.n, h, w, cw.cout, act, cw.prec, out.ptr, out.ld, 0, _stream()), "upconv3x3")
+
+    # executed: the tap GEMMs over every tile's 192-pixel source footprint (16 x 28 output tiles, 32-channel passes); algo: the reference
+    # graph's nine taps at the OUTPUT resolution
+    tiles = -(-h // 16) * -(-w // 28)
+    shape = f"{cw.cin}->{cw.cout} k3s1 {u.n}x{h}x{w} (lowres {u.c}ch {u.h}x{u.w})"
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), 2.0 * u.n * tiles * 192 * 9 * cw.cin * roundup(cw.cout, 32), call, shape=shape,
+                    algo=2.0 * u.n * h * w * cw.cout * cw.cin * 9)
+    return out
+
+
 def conv2d_ups(x: Feat, u: Feat, cw: ConvW, out: Optional[Feat] = None, *, act: int = ACT_NONE, res: Optional[Feat] = None, ln=None,
                ln_eps: float = 1e-6) -> Feat:
     """3x3 conv over the VIRTUAL concat [bilinear_align_corners(u -> x.h x x.w) | x[..., u.c:]]: channels [0, u.c) are interpolated

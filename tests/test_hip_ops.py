@@ -805,6 +805,76 @@ def test_conv2d_ups_equals_upsample_then_conv(P, case, prec):
     close(got.to_nchw(), want, 3e-5 if prec == "bf16x3" else 2e-2, "conv2d_ups vs torch")
 
 
+UPCONV_CASES = [
+    # n, (h, w) of u, (H, W) of the output, cin, cout, act, bias
+    (2, (24, 32), (48, 64), 64, 128, "none", True),       # output_conv1-like: whole tiles, four passes
+    (1, (13, 21), (26, 42), 32, 98, "gelu", False),       # ragged tiles in both directions, cout = 96 + 2 (partial quad), one slab
+    (2, (10, 20), (20, 40), 96, 40, "none", False),       # raw partial sum (the addend of conv2d_pre), two passes, second one partial
+    (1, (9, 12), (17, 23), 64, 32, "relu", True),         # H = 2 h - 1: the largest source step the contract admits
+    (1, (6, 8), (24, 32), 32, 64, "none", True),          # x4: source step 1/4
+    (3, (4, 4), (8, 8), 256, 290, "gelu", True),          # tiny images (the low pyramid levels): pass groups spread over workgroups, 8 slabs
+]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", UPCONV_CASES)
+def test_upconv3x3_vs_fp64_upsample_then_conv(P, case, prec):
+    """prv2_upconv3x3 (csrc/upconv.hip: conv3x3 of a bilinear(align_corners=True) upsample as nine tap GEMMs at the LOW resolution + a
+    four-corner gather per tap) against float64 F.interpolate -> F.conv2d (bi_directional_fusion_model.py:139-142,201,
+    fusion_model.py:15-24), and within the same tolerance of prv2_conv2d_ups, the kernel that interpolates inside its loader"""
+    n, (h, w), (H, W), cin, cout, act, bias = case
+    PR = P.L.PREC_NAMES[prec]
+    u_t = rnd(1, n, cin, h, w)
+    w_t = rnd(2, cout, cin, 3, 3) / np.sqrt(9 * cin)
+    b_t = rnd(3, cout) if bias else None
+    cw = P.pack_conv(w_t.to(DEV), b_t.to(DEV) if bias else None, pad=1, prec=PR)
+    u = P.Feat.from_nchw(u_t.to(DEV))
+    assert P.upconv3x3_supported(u, H, W, cw)
+    A = dict(none=P.ACT_NONE, gelu=P.ACT_GELU, relu=P.ACT_RELU)[act]
+    out = P.Feat.alloc_raw(n, H, W, P.roundup(cout, 4) + 4, DEV)   # (a slice of a wider buffer: nothing behind cout may be touched)
+    out.buf.fill_(-7.0)
+    got = P.upconv3x3(u, H, W, cw, out=out.slice(0, cout), act=A)
+    assert "upconv3x3" in P.L.load().prv2_last_kernel().decode()
+    assert bool((out.buf[..., cout:] == -7.0).all()), "channels behind cout were written"
+    up = torch.nn.functional.interpolate(u_t.double(), (H, W), mode="bilinear", align_corners=True)
+    ref = torch.nn.functional.conv2d(up, w_t.double(), b_t.double() if bias else None, padding=1)
+    ref = dict(none=lambda v: v, gelu=torch.nn.functional.gelu, relu=torch.relu)[act](ref).float()
+    tol = 2e-5 if prec == "bf16x3" else 6e-3
+    close(got.to_nchw(), ref, tol, f"upconv3x3 {case} {prec}")
+    if cout > 64 and W >= 24 and H >= 4:  # the loader-interpolating kernel takes this layer too: the two must agree
+        other = P.conv2d_ups(P.UpsOnly(u, H, W), u, cw, act=A)
+        close(got.to_nchw(), other.to_nchw().cpu(), tol, f"upconv3x3 vs conv2d_ups {case} {prec}")
+
+
+def test_upconv3x3_border_taps_and_batch_independence(P):
+    """taps that fall outside the OUTPUT image contribute nothing (zero padding of the conv, not of the source): constant input and
+    all-ones weights give 9 / 6 / 4 x cin in the interior / on edges / in corners; an image's result does not depend on its batch"""
+    PR = P.L.PREC_NAMES["bf16x3"]
+    cin, cout = 32, 32
+    cw = P.pack_conv(torch.ones(cout, cin, 3, 3, device=DEV), None, pad=1, prec=PR)
+    u = P.Feat.from_nchw(torch.ones(1, cin, 20, 24, device=DEV))
+    y = P.upconv3x3(u, 40, 48, cw).to_nchw().cpu()
+    exp = torch.nn.functional.conv2d(torch.ones(1, 1, 40, 48), torch.ones(1, 1, 3, 3), padding=1) * cin
+    close(y, exp.expand(1, cout, 40, 48), 1e-6, "border taps")
+    cw2 = P.pack_conv((rnd(1, 64, 64, 3, 3) / 24).to(DEV), rnd(2, 64).to(DEV), pad=1, prec=PR)
+    ub = rnd(3, 3, 64, 11, 17).to(DEV)
+    full = P.upconv3x3(P.Feat.from_nchw(ub), 22, 34, cw2).to_nchw()
+    one = P.upconv3x3(P.Feat.from_nchw(ub[1:2].contiguous()), 22, 34, cw2).to_nchw()
+    assert torch.equal(full[1:2], one)
+
+
+def test_upconv3x3_rejects_what_it_does_not_cover(P):
+    PR = P.L.PREC_NAMES["bf16x3"]
+    u = P.Feat.from_nchw(rnd(1, 1, 64, 12, 16).to(DEV))
+    ok = P.pack_conv(rnd(2, 98, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
+    assert P.upconv3x3_supported(u, 24, 32, ok) and P.upconv3x3_supported(u, 23, 31, ok)
+    assert not P.upconv3x3_supported(u, 22, 32, ok)                                                                   # source step > 1/2
+    assert not P.upconv3x3_supported(u, 24, 32, P.pack_conv(rnd(2, 98, 64, 3, 3).to(DEV), None, pad=1, prec=P.L.PREC_NAMES["f32"]))
+    assert not P.upconv3x3_supported(P.Feat.from_nchw(rnd(1, 1, 48, 12, 16).to(DEV)), 24, 32, P.pack_conv(rnd(2, 98, 48, 3, 3).to(DEV), None, pad=1, prec=PR))
+    with pytest.raises(RuntimeError):
+        P.upconv3x3(u, 16, 32, ok)
+
+
 def test_conv2d_ups_rejects_what_it_does_not_cover(P):
     PR = P.L.PREC_NAMES["bf16x3"]
     u = P.Feat.from_nchw(rnd(1, 1, 64, 12, 16).to(DEV))
