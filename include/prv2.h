@@ -133,15 +133,16 @@ int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src*
  *   UpSample.forward_hardcode   fusion_model.py:15-24                        the interpolate(x1) part of DoubleConv.0(cat[x1, x2, pred1, pred2])
  * The conv is linear and its input an interpolation of u, so  conv3x3(up(u); W)(p) = sum_tap [p + d_tap inside] Bil(G_tap; s(p + d_tap))
  * with G_tap = W[:, :, tap] . u at LOW resolution (MFMA) and the 36 corner terms per output gathered on the VALU.
- *     y[n, h, w, 0 .. cout) = act(conv3x3(interpolate(u, (h, w), 'bilinear', align_corners=True)) + bias)
- * w_packed: prv2_pack_conv_weight(cout, cin = u->channels, 3, 3) -- for a conv over a concat, the weight columns of the upsampled
- * part; act NONE + bias NULL gives the partial sum that prv2_conv2d_pre takes as its addend for the rest of the concat.
+ *     y[n, h, w, 0 .. cout) = act(conv3x3(interpolate(u, (h, w), 'bilinear', align_corners=True)) + bias + add)
+ * w_packed: prv2_pack_conv_weight(cout, cin = u->channels, 3, 3) -- for a conv over a concat [up(u) | rest], the weight columns of
+ * the upsampled part; ``add`` (NHWC [n, h, w, ld_add >= cout], or NULL) is then prv2_conv2d of ``rest`` with the other columns,
+ * activation NONE -- it may be y itself (every output element is read by the thread that writes it).
  * Same split products and fp32 accumulation as the other bf16 kernels; the taps / corners are summed in another order than
  * upsample -> conv (fp32-grade, not bit-identical).  Contract (prv2_upconv3x3_supported != 0): bf16 modes, u->channels % 32 == 0,
  * h >= 2 u->h - 1 and w >= 2 u->w - 1 (source step <= 1/2 pixel), 16-byte aligned NHWC rows. */
 int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec);
-int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, int32_t n, int32_t h, int32_t w, int32_t cout,
-                   int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream);
+int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, const float* add, int32_t ld_add, int32_t n, int32_t h,
+                   int32_t w, int32_t cout, int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream);
 
 /* prv2_conv2d (3x3 / stride 1 / pad 1, bias, [LayerNorm,] activation, [+ res]) that ALSO writes the two depth maps every fusion
  * level appends to its features behind its own output channels: y[pixel][cout .. cout + 3] = (p1, p2, 0, 0), p1 / p2 dense

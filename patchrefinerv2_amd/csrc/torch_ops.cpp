@@ -175,7 +175,7 @@ Tensor conv3x3_ups(const optional<Tensor>& x_in, const Tensor& u, const Tensor& 
 // (tap GEMMs on the low-resolution grid + a gather): output_conv1 (bi_directional_fusion_model.py:139-142,201), the x1 part of
 // UpSample.forward_hardcode's first conv (fusion_model.py:15-24)
 Tensor upconv3x3(const Tensor& u, const Tensor& w_packed, const optional<Tensor>& bias, int64_t cout, int64_t oh, int64_t ow, int64_t act, int64_t prec,
-                 const optional<Tensor>& out) {
+                 const optional<Tensor>& out, const optional<Tensor>& add) {
   const int64_t ldu = nhwc_ld(u, "u");
   const int64_t n = u.size(0), cu = u.size(3);
   dev_f32(w_packed, "w_packed");
@@ -185,9 +185,16 @@ Tensor upconv3x3(const Tensor& u, const Tensor& w_packed, const optional<Tensor>
   us.x = u.data_ptr<float>(); us.h = (int)u.size(1); us.w = (int)u.size(2); us.ld = (int)ldu; us.channels = (int)cu; us.bstride = 0;
   TORCH_CHECK(prv2_upconv3x3_supported(&us, (int)n, (int)oh, (int)ow, (int)cout, (int)prec),
               "prv2::upconv3x3: layer not covered (bf16 modes, u channels % 32 == 0, output at least 2h-1 x 2w-1 of u)");
+  const float* pa = nullptr;
+  int ld_add = 0;
+  if (add.has_value()) {
+    TORCH_CHECK(add->sizes() == y.sizes(), "prv2::upconv3x3: add must have the output's shape");
+    pa = add->data_ptr<float>();
+    ld_add = (int)nhwc_ld(*add, "add");
+  }
   Launch L(u);
-  ok(prv2_upconv3x3(&us, w_packed.data_ptr(), opt_ptr(bias, "bias", cout), (int)n, (int)oh, (int)ow, (int)cout, (int)act, (int)prec, y.data_ptr<float>(),
-                    (int)nhwc_ld(y, "out"), 0, L.stream), "upconv3x3");
+  ok(prv2_upconv3x3(&us, w_packed.data_ptr(), opt_ptr(bias, "bias", cout), pa, ld_add, (int)n, (int)oh, (int)ow, (int)cout, (int)act, (int)prec,
+                    y.data_ptr<float>(), (int)nhwc_ld(y, "out"), 0, L.stream), "upconv3x3");
   return y;
 }
 
@@ -662,7 +669,7 @@ TORCH_LIBRARY(prv2, m) {
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None, int fmt=0, bool force_generic=False, int part=0) -> Tensor");
   m.def("conv3x3_ups(Tensor? x, Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, Tensor? ln_weight=None, "
         "Tensor? ln_bias=None, Tensor? res=None, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
-  m.def("upconv3x3(Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None) -> Tensor");
+  m.def("upconv3x3(Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None, Tensor? add=None) -> Tensor");
   m.def("pack_gate_weight(Tensor weight) -> Tensor");
   m.def("conv3x3_ln_gate(Tensor x, Tensor w_packed, Tensor? bias, Tensor ln_weight, Tensor ln_bias, Tensor? gate_w_packed=None, Tensor? gate_bias=None, "
         "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None, Tensor? pre=None, "

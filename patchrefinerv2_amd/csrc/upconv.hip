@@ -64,6 +64,8 @@ struct UpconvParams {
   long long xu_bstride;
   const void* w;    // packed [cout rows][9 taps][C] image
   const float* bias;
+  const float* add;  // pre-activation addend [n, H, W, ld_add >= Cout] (may alias y: every thread reads what it writes), or null
+  int ld_add;
   int act;
   float* y;
   int H, W, ldy, Cout;
@@ -294,6 +296,9 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
     const int ch0 = pass * CP + 4 * quad;
     const int nvalid = min(max(p.Cout - ch0, 0), 4);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 av[SEG];
+#pragma unroll
+    for (int xi = 0; xi < SEG; ++xi) av[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -317,6 +322,22 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (e < nvalid) bv[e] = p.bias[ch0 + e];
+        }
+        if (p.add) {  // the rest of the conv's concat input, convolved by the direct kernel: requested here, added in the output stage
+          const int oy_ = y0 + prow_t;
+#pragma unroll
+          for (int xi = 0; xi < SEG; ++xi) {
+            const int ox = x0 + SEG * seg + xi;
+            if (oy_ < p.H && ox < p.W) {
+              const float* src = p.add + (long long)n_img * p.H * p.W * p.ld_add + ((long long)oy_ * p.W + ox) * p.ld_add + ch0;
+              if (nvalid == 4) av[xi] = *reinterpret_cast<const f32x4*>(src);
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (e < nvalid) av[xi][e] = src[e];
+              }
+            }
+          }
         }
       }
       const int yy = y0 + prow_t + ky - 1;
@@ -400,7 +421,7 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
         if (oy < p.H && ox < p.W && nvalid > 0) {
           f32x4 ov;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = act_apply_bf(o[xi][e] + bv[e], decltype(act_c)::value);
+          for (int e = 0; e < 4; ++e) ov[e] = act_apply_bf(o[xi][e] + bv[e] + av[xi][e], decltype(act_c)::value);
           float* dst = p.y + img_y + ((long long)oy * p.W + ox) * p.ldy + ch0;
           if (nvalid == 4) {
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
@@ -431,17 +452,18 @@ extern "C" int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_
   return upconv_shape_ok(u, n, h, w, cout, prec) ? 1 : 0;
 }
 
-extern "C" int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, int32_t n, int32_t h, int32_t w, int32_t cout,
-                              int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream) {
+extern "C" int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, const float* add, int32_t ld_add, int32_t n, int32_t h,
+                              int32_t w, int32_t cout, int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream) {
   PRV2_REQUIRE(upconv_shape_ok(u, n, h, w, cout, prec),
                "upconv3x3: layer not covered (bf16 modes, channels %% 32 == 0, output at least 2 h - 1 x 2 w - 1 of the source)");
   PRV2_REQUIRE(w_packed && y && al16u(u->x) && al16u(w_packed) && al16u(y) && ldy % 4 == 0 && ldy >= cout && u->bstride % 4 == 0 && y_bstride % 4 == 0,
                "upconv3x3: 16-byte aligned NHWC rows (ldy=%d)", ldy);
   PRV2_REQUIRE((long long)h * w * ldy < (1LL << 31), "upconv3x3: image too large");
+  PRV2_REQUIRE(!add || (ld_add >= cout && ld_add % 4 == 0 && al16u(add)), "upconv3x3: addend rows must be 16-byte aligned (ld_add=%d)", ld_add);
   UpconvParams p = {};
   p.xu = u->x; p.uH = u->h; p.uW = u->w; p.ldxu = u->ld; p.C = u->channels;
   p.xu_bstride = u->bstride ? u->bstride : (long long)u->h * u->w * u->ld;
-  p.w = w_packed; p.bias = bias; p.act = act;
+  p.w = w_packed; p.bias = bias; p.act = act; p.add = add; p.ld_add = ld_add;
   p.y = y; p.H = h; p.W = w; p.ldy = ldy; p.Cout = cout;
   p.y_bstride = y_bstride ? y_bstride : (long long)h * w * ldy;
   p.usy = ac_scale(u->h, h); p.usx = ac_scale(u->w, w);

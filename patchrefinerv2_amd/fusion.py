@@ -27,6 +27,7 @@ import os
 
 FOLD_OUT_CONV = os.environ.get("PRV2_FOLD_OUT_CONV", "1") != "0"  # A/B and test switch (BiDirectionalFusion._pack)
 # A/B and test switch: which consumers take their coarse half from the per-frame tap tables (prepare_frame)
+UPCONV_MIN_C = int(os.environ.get("PRV2_UPCONV_MIN_C", "128"))  # decoder stages with at least this many interpolated input channels split (see _pack_encdec)
 TAPS_PARTS = tuple(os.environ.get("PRV2_TAPS_PARTS", "gate256,gate_narrow,enc1").split(","))
 
 
@@ -88,9 +89,17 @@ class _EncDec(StateDictModule):
             for e in (self.ENC1, self.ENC2):
                 P[f"{e}.{l}"] = (self._conv(f"{e}.{l}.single_conv.0"), self._dev(f"{e}.{l}.single_conv.1.weight"),
                                  self._dev(f"{e}.{l}.single_conv.1.bias"))
-        for j in range(len(self.dec_in)):
+        for j, (c1, c2, _) in enumerate(self.dec_in):
             P[f"{self.DEC}.{j}"] = (self._conv(f"{self.DEC}.{j}.conv.double_conv.0"),
                                     self._conv(f"{self.DEC}.{j}.conv.double_conv.2"))
+            # UpSample.forward_hardcode (fusion_model.py:15-24): double_conv.0 over cat([interpolate(x1), x2, pred1, pred2]) is linear in
+            # its input, so it splits by weight columns: the interpolated x1 part runs as tap GEMMs at x1's resolution (ops.upconv3x3),
+            # the rest as an ordinary conv whose raw output is that kernel's pre-activation addend.  Worth it from 128 upsampled
+            # channels on (tools/probes/upconv_time.py: 64 -> 98 loses to the gather's fixed cost per output channel).
+            w0 = self._sd[f"{self.DEC}.{j}.conv.double_conv.0.weight"]
+            if self.prec != ops.PREC_F32 and ops.UPCONV and c1 >= UPCONV_MIN_C and c1 % 32 == 0 and w0.shape[1] == c1 + c2 + 2:
+                P[f"{self.DEC}.{j}.split"] = (ops.pack_conv(w0[:, :c1], None, device=self.device, prec=self.prec),
+                                              ops.pack_conv(w0[:, c1:], None, device=self.device, prec=self.prec))
         P["final_w"] = self._dev("final_conv.weight")
         return P
 
@@ -218,7 +227,12 @@ class _EncDec(StateDictModule):
             if not dec_tail_done[j]:
                 place_preds(pred1, pred2, buf, c1 + c2)
             c0w, c2w = P[f"{self.DEC}.{j}"]
-            if isinstance(feat, Feat) and ops.conv2d_ups_supported(buf, feat, c0w):
+            split = P.get(f"{self.DEC}.{j}.split")
+            if split is not None and isinstance(feat, Feat) and ops.upconv3x3_supported(feat, buf.h, buf.w, split[0]):
+                # conv over [x2 | pred1 | pred2] with the weights' other columns (raw), then the interpolated x1 part on top + GELU
+                t = ops.conv2d(buf.slice(c1, buf.c - c1), split[1])
+                ops.upconv3x3(feat, buf.h, buf.w, split[0], out=t, act=ACT_GELU, add=t, bias=False)
+            elif isinstance(feat, Feat) and ops.conv2d_ups_supported(buf, feat, c0w):
                 # bilinear(x1 -> size of x2) is formed inside the conv's tile loader (fusion_model.py:16-18): the upsampled x1 is
                 # never written; channels [0, c1) of ``buf`` stay unused
                 t = ops.conv2d_ups(buf, feat, c0w, act=ACT_GELU)
@@ -403,7 +417,8 @@ class BiDirectionalFusion(_EncDec):
             if not upscale:
                 return ops.conv2d(out, blk["out_conv"], dest)
             y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])
-            if defer_upsample is not None and ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample):
+            if defer_upsample is not None and (ops.upconv3x3_supported(y, size[0], size[1], defer_upsample) or
+                                               ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample)):
                 return y
             return ops.upsample_bilinear(y, size[0], size[1], out=dest)
         cat = Feat.alloc(ref.n, ref.h, ref.w, 2 * F_, ref.device)
@@ -421,8 +436,9 @@ class BiDirectionalFusion(_EncDec):
         out = self._gated_unit(blk["u2"], out, cat, F_)
         if upscale:
             y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])  # (skip: folded into the consumer's weights, _pack)
-            if defer_upsample is not None and ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample):
-                return y  # the consumer (a 3x3 conv) interpolates while it stages its tiles: ops.conv2d_ups
+            if defer_upsample is not None and (ops.upconv3x3_supported(y, size[0], size[1], defer_upsample) or
+                                               ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample)):
+                return y  # the consumer (a 3x3 conv) works from the low-resolution tensor: ops.upconv3x3 / ops.conv2d_ups
             return ops.upsample_bilinear(y, size[0], size[1], out=dest)
         return ops.conv2d(out, blk["out_conv"], dest)
 
@@ -440,7 +456,11 @@ class BiDirectionalFusion(_EncDec):
         w1 = P["out1_folded"] if folded else P["out1"]
         size1 = (rn[0].h * 2, rn[0].w * 2)
         path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=size1, skip_out_conv=folded, defer_upsample=w1)
-        if (path1.h, path1.w) != size1:  # not upsampled yet: output_conv1 samples it bilinearly inside its loader (:139-142, :201)
+        if (path1.h, path1.w) != size1 and ops.upconv3x3_supported(path1, size1[0], size1[1], w1):
+            # not upsampled yet, and never: output_conv1(interpolate(path_1)) (:139-142, :201) as nine tap GEMMs at path_1's resolution
+            # and a four-corner gather per tap (csrc/upconv.hip): 2.3x fewer matrix operations than the conv over the upsampled map
+            out = ops.upconv3x3(path1, size1[0], size1[1], w1)
+        elif (path1.h, path1.w) != size1:  # output_conv1 samples path_1 bilinearly inside its loader
             out = ops.conv2d_ups(ops.UpsOnly(path1, *size1), path1, w1)
         else:
             out = ops.conv2d(path1, w1)

@@ -86,7 +86,7 @@ SIGNATURES = {
     "prv2_conv3x3_ln_gate": (_I, [_P] * 12),
     "prv2_conv3x3_ln_gate_pre": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prv2_upconv3x3_supported": (_I, [C.POINTER(UpsSrc), _I, _I, _I, _I, _I]),
-    "prv2_upconv3x3": (_I, [C.POINTER(UpsSrc), _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _L, _P]),
+    "prv2_upconv3x3": (_I, [C.POINTER(UpsSrc), _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _L, _P]),
     "prv2_conv2d_pre_supported": (_I, [C.POINTER(ConvDesc)]),
     "prv2_conv2d_pre": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "prv2_coarse_tap_knots": (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),

@@ -379,11 +379,11 @@ def upconv3x3_supported(u: Feat, h: int, w: int, cw: ConvW) -> bool:
     return bool(L.load().prv2_upconv3x3_supported(C.byref(us), u.n, h, w, cw.cout, cw.prec))
 
 
-def upconv3x3(u: Feat, h: int, w: int, cw: ConvW, out: Optional[Feat] = None, *, act: int = ACT_NONE, bias: bool = True) -> Feat:
+def upconv3x3(u: Feat, h: int, w: int, cw: ConvW, out: Optional[Feat] = None, *, act: int = ACT_NONE, bias: bool = True, add: Optional[Feat] = None) -> Feat:
     """act(conv3x3(bilinear_align_corners(u -> h x w); cw) + bias) computed at u's resolution (include/prv2.h::prv2_upconv3x3): nine tap
     GEMMs on the low-resolution grid, then the four interpolation corners of every tap gathered per output pixel -- 2.3x fewer matrix
-    operations than ``conv2d_ups``.  fp32-grade, not bit-identical to it (summation order).  ``bias=False``: the raw sum (the addend
-    ``conv2d_pre`` takes when ``u`` is only a part of the conv's concat input)."""
+    operations than ``conv2d_ups``.  fp32-grade, not bit-identical to it (summation order).  ``add`` [n, h, w, cout]: a pre-activation
+    addend -- the direct conv over the REST of a concat input [up(u) | rest] with the other weight columns (it may be ``out`` itself)."""
     assert cw.cin == u.c
     if out is None:
         out = Feat.alloc(u.n, h, w, cw.cout, u.device)
@@ -392,10 +392,11 @@ def upconv3x3(u: Feat, h: int, w: int, cw: ConvW, out: Optional[Feat] = None, *,
 
     def call():
         if DISPATCH == "torch":
-            _tops().upconv3x3(u.view(), cw.w, b, cw.cout, h, w, act, cw.prec, out.view())
+            _tops().upconv3x3(u.view(), cw.w, b, cw.cout, h, w, act, cw.prec, out.view(), add.view() if add is not None else None)
             return
         us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
-        L.check(L.load().prv2_upconv3x3(C.byref(us), cw.w.data_ptr(), _ptr(b), u.n, h, w, cw.cout, act, cw.prec, out.ptr, out.ld, 0, _stream()), "upconv3x3")
+        L.check(L.load().prv2_upconv3x3(C.byref(us), cw.w.data_ptr(), _ptr(b), _ptr(add), add.ld if add is not None else 0, u.n, h, w, cw.cout, act, cw.prec,
+                                        out.ptr, out.ld, 0, _stream()), "upconv3x3")
 
     # executed: the tap GEMMs over every tile's 192-pixel source footprint (16 x 28 output tiles, 32-channel passes); algo: the reference
     # graph's nine taps at the OUTPUT resolution

@@ -846,6 +846,31 @@ def test_upconv3x3_vs_fp64_upsample_then_conv(P, case, prec):
         close(got.to_nchw(), other.to_nchw().cpu(), tol, f"upconv3x3 vs conv2d_ups {case} {prec}")
 
 
+@pytest.mark.parametrize("case", [(2, (12, 16), 128, 64, 194), (1, (13, 20), 256, 32, 290), (1, (6, 12), 512, 128, 642)])
+def test_upconv3x3_addend_splits_a_concat_conv(P, case):
+    """UpSample.forward_hardcode's first conv (fusion_model.py:15-24) over cat([interpolate(x1), x2, pred1, pred2]) split by weight
+    columns: prv2_conv2d over [x2 | p1 | p2] (raw) as the pre-activation addend of prv2_upconv3x3 over x1 -- IN PLACE (add == out) --
+    against the fused-loader kernel on the whole concat and against float64"""
+    n, (h, w), c1, c2, cout = case
+    H, W, cin = 2 * h, 2 * w, c1 + c2 + 2
+    PR = P.L.PREC_NAMES["bf16x3"]
+    x1_t, rest_t, w_t = rnd(1, n, c1, h, w), rnd(2, n, cin - c1, H, W), rnd(3, cout, cin, 3, 3) / np.sqrt(9 * cin)
+    x1 = P.Feat.from_nchw(x1_t.to(DEV))
+    buf = P.Feat.alloc(n, H, W, cin, DEV)
+    buf.buf[..., :c1] = float("nan")   # never read on either route
+    buf.buf[..., c1:cin] = rest_t.to(DEV).permute(0, 2, 3, 1)
+    whole = P.pack_conv(w_t.to(DEV), None, pad=1, prec=PR)
+    up_w, rest_w = P.pack_conv(w_t[:, :c1].to(DEV), None, pad=1, prec=PR), P.pack_conv(w_t[:, c1:].to(DEV), None, pad=1, prec=PR)
+    ref_k = P.conv2d_ups(buf, x1, whole, act=P.ACT_GELU).to_nchw().cpu()
+    t = P.conv2d(buf.slice(c1, cin - c1), rest_w)
+    got = P.upconv3x3(x1, H, W, up_w, out=t, act=P.ACT_GELU, add=t, bias=False)
+    assert got.buf.data_ptr() == t.buf.data_ptr()
+    up = torch.nn.functional.interpolate(x1_t.double(), (H, W), mode="bilinear", align_corners=True)
+    ref = torch.nn.functional.gelu(torch.nn.functional.conv2d(torch.cat([up, rest_t.double()], 1), w_t.double(), None, padding=1)).float()
+    close(got.to_nchw(), ref, 2e-5, f"split concat conv {case} vs float64")
+    close(got.to_nchw(), ref_k, 2e-5, f"split concat conv {case} vs conv2d_ups")
+
+
 def test_upconv3x3_border_taps_and_batch_independence(P):
     """taps that fall outside the OUTPUT image contribute nothing (zero padding of the conv, not of the source): constant input and
     all-ones weights give 9 / 6 / 4 x cin in the interior / on edges / in corners; an image's result does not depend on its batch"""
