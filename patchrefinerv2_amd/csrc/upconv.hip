@@ -248,11 +248,6 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
       if (cc == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const bool more = cc + 1 < cslabs;  // block-uniform
-      if (more) {
-        dma_w(pass, cc + 1, st ^ 1);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) load_a_async(cc + 1, it);
-      }
       const char* const sb = smem + st * S1_OFF;
       bf16x8 ah[3], al[3], bh[2], bl[2];
 #pragma unroll
@@ -272,6 +267,13 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) mma(acc[a][j], ah[a], al[a], bh[j & 1], bl[j & 1]);
         __builtin_amdgcn_sched_barrier(0);
+        if (j == 0 && more) {  // the next slab's requests go out BEHIND the first MFMA block: the fragment reads above are what the matrix
+                               // pipe waits for after the barrier (both waves of a SIMD arrive together), not these
+          dma_w(pass, cc + 1, st ^ 1);
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) load_a_async(cc + 1, it);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (j == 5 && more) {  // the next slab's footprint rows have had ~2/3 of a slab to arrive
 #pragma unroll
           for (int it = 0; it < NIT; ++it) store_a(st ^ 1, it);

@@ -27,7 +27,7 @@ import os
 
 FOLD_OUT_CONV = os.environ.get("PRV2_FOLD_OUT_CONV", "1") != "0"  # A/B and test switch (BiDirectionalFusion._pack)
 # A/B and test switch: which consumers take their coarse half from the per-frame tap tables (prepare_frame)
-UPCONV_MIN_C = int(os.environ.get("PRV2_UPCONV_MIN_C", "128"))  # decoder stages with at least this many interpolated input channels split (see _pack_encdec)
+UPCONV_MIN_C = int(os.environ.get("PRV2_UPCONV_MIN_C", "256"))  # decoder stages with at least this many interpolated input channels split (see _pack_encdec)
 TAPS_PARTS = tuple(os.environ.get("PRV2_TAPS_PARTS", "gate256,gate_narrow,enc1").split(","))
 
 
@@ -94,8 +94,8 @@ class _EncDec(StateDictModule):
                                     self._conv(f"{self.DEC}.{j}.conv.double_conv.2"))
             # UpSample.forward_hardcode (fusion_model.py:15-24): double_conv.0 over cat([interpolate(x1), x2, pred1, pred2]) is linear in
             # its input, so it splits by weight columns: the interpolated x1 part runs as tap GEMMs at x1's resolution (ops.upconv3x3),
-            # the rest as an ordinary conv whose raw output is that kernel's pre-activation addend.  Worth it from 128 upsampled
-            # channels on (tools/probes/upconv_time.py: 64 -> 98 loses to the gather's fixed cost per output channel).
+            # the rest as an ordinary conv whose raw output is that kernel's pre-activation addend.  Worth it from 256 upsampled
+            # channels on (layer report: 128 of 194 breaks even, 64 of 98 loses to the gather's fixed cost per output channel).
             w0 = self._sd[f"{self.DEC}.{j}.conv.double_conv.0.weight"]
             if self.prec != ops.PREC_F32 and ops.UPCONV and c1 >= UPCONV_MIN_C and c1 % 32 == 0 and w0.shape[1] == c1 + c2 + 2:
                 P[f"{self.DEC}.{j}.split"] = (ops.pack_conv(w0[:, :c1], None, device=self.device, prec=self.prec),
