@@ -395,7 +395,8 @@ def main():
             executed_gflop_per_launch=d["flops"] / d["launches"] / 1e9,
             # FLOP accounting: ``frame_algorithmic_tflop`` = the REFERENCE graph's 2*MAC per frame (what the PyTorch model
             # spends on conv / linear / attention matmuls); ``executed_tflop`` = what the kernels here multiply -- less, because the coarse
-            # half of every cat([fine, coarse_roi]) conv is computed once per frame at coarse resolution (csrc/coarse_taps.hip) and the
+            # half of every cat([fine, coarse_roi]) conv is computed once per frame at coarse resolution (csrc/coarse_taps.hip), the
+            # 3x3 convs of bilinearly upsampled tensors run as tap GEMMs at the source resolution (csrc/upconv.hip) and the
             # refinenet1 out_conv is folded into output_conv1's weights.  Per-kernel ``achieved`` / ``frac`` are EXECUTED FLOPs / time
             # (a kernel's frac can never exceed 1); ``whole_frame_frac`` is the algorithmic FLOPs / the timed step.
             frame_algorithmic_tflop=sum(x["algo"] for x in summ.values()) / 1e12,

@@ -22,6 +22,9 @@ python3 tools/shard_model.py > $O/${TAG}_shard_model.json 2>> $O/bench.err
 python3 bench.py --data zeros --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/${TAG}_${PREC}_bench_${WL}_zeros.json 2>> $O/bench.err
 # same-box A/B of the round's frame-level changes
 for T in 1 0 1 0; do PRV2_COARSE_TAPS=$T python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_COARSE_TAPS=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_coarse_taps_ab.txt
+for T in 1 0 1 0; do PRV2_UPCONV=$T python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v2_zoe_4k_r32 PRV2_UPCONV=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_upconv_ab.txt
+for T in 1 0 1 0; do PRV2_UPCONV=$T python3 bench.py --workload v1_zoe_4k_r32 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v1_zoe_4k_r32 PRV2_UPCONV=$T', round(d['ms_per_step'],2), 'ms')"; done >> $O/${TAG}_upconv_ab.txt
+python3 tools/probes/upconv_time.py 41 2>/dev/null | grep upconv >> $O/${TAG}_upconv_ab.txt
 for D in torch ctypes torch ctypes; do PRV2_DISPATCH=$D python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_DISPATCH=$D', round(d['ms_per_step'],2), 'ms')"; done > $O/${TAG}_dispatch_ab.txt
 # kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
 cd /tmp
