@@ -210,11 +210,13 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
   const int b_off_hi = A_BYTES + (nslot * 9 * 16 + m16) * 128 + ((g ^ key) << 4);
   const int b_off_lo = A_BYTES + (nslot * 9 * 16 + m16) * 128 + (((4 + g) ^ key) << 4);
   auto mma = [&](f32x4& c, const bf16x8& xh, const bf16x8& xl, const bf16x8& wh, const bf16x8& wl) {
+    // weights as the A operand: D = [16 channels x 16 footprint pixels], lane (pixel m16, g) holds channels 4g .. 4g + 3 of its pixel --
+    // one 16-byte LDS write per accumulator into the G tile, in the float4-per-channel-quad layout the gather reads
     if constexpr (PREC == PRV2_PREC_BF16X3) {
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
     }
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
   };
 
   const int cslabs = p.C / BK;
@@ -307,11 +309,9 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
       for (int j = 0; j < 9; ++j) {
         const int b = nslot * 9 + j, tp = b >> 1;
         if (tp / 3 == ky) {  // wave-uniform
-          const int col = (tp - 3 * ky) * CP + (b & 1) * 16 + m16g;
+          const int col = (tp - 3 * ky) * CP + (b & 1) * 16 + 4 * gg;
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) csm[((run0 + a) * 16 + 4 * gg + e) * CLD + col] = acc[a][j][e];
+          for (int a = 0; a < 3; ++a) *reinterpret_cast<f32x4*>(&csm[((run0 + a) * 16 + m16g) * CLD + col]) = acc[a][j];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -355,12 +355,20 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
       // "defined" them -- and did (v_mov of registers whose data had not landed).  Here the compiler's own counted waits stand in front
       // of the uses.
       typedef const __attribute__((address_space(3))) f32x4* lds_f32x4;
-      auto issue = [&](int c, int kx, f32x4& v0, f32x4& v1) {
-        const unsigned off = (unsigned)((c * CLD + kx * CP) * 4);  // (scalar)
+      auto issue3 = [&](int c, f32x4 (&v0)[3], f32x4 (&v1)[3]) {  // source column c of the round's three taps (tap = a constant offset)
+        const unsigned off = (unsigned)(c * CLD * 4);  // (scalar)
         unsigned a0 = g0 + off, a1 = g1 + off;
         asm volatile("" : "+v"(a0), "+v"(a1));
-        v0 = *(lds_f32x4)(size_t)a0;
-        v1 = *(lds_f32x4)(size_t)a1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#ifdef UPC_ABL_NOREAD  // (timing ablation: the walk without its LDS reads)
+          v0[k] = f32x4{(float)a0, 0.f, 0.f, 0.f};
+          v1[k] = f32x4{(float)a1, 0.f, 0.f, 0.f};
+#else
+          v0[k] = *(lds_f32x4)(size_t)(a0 + k * CP * 4);
+          v1[k] = *(lds_f32x4)(size_t)(a1 + k * CP * 4);
+#endif
+        }
       };
 #ifndef UPC_ABL_NOWALK
       // The three taps of the kernel row walk the SAME source columns (tap kx reaches table entry i at its pixel i - kx), so they walk
@@ -369,17 +377,14 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
       int c = __builtin_amdgcn_readlane(vci, 0);
       {
         f32x4 a0[3], a1[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) issue(c, k, a0[k], a1[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) issue(c + 1, k, q0[k], q1[k]);
+        issue3(c, a0, a1);
+        issue3(c + 1, q0, q1);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           lc[k] = fma4(wy0, a0[k], wy1 * a1[k]);
           ln[k] = fma4(wy0, q0[k], wy1 * q1[k]);
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) issue(c + 2, k, q0[k], q1[k]);  // one column ahead of the walk
+        issue3(c + 2, q0, q1);  // one column ahead of the walk
       }
 #pragma unroll
       for (int i = 0; i < SEG + 2; ++i) {
@@ -391,8 +396,7 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
             lc[k] = ln[k];
             ln[k] = fma4(wy0, q0[k], wy1 * q1[k]);
           }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) issue(c + 2, k, q0[k], q1[k]);
+          issue3(c + 2, q0, q1);
         }
         const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vw0, i)), w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vw1, i));
 #pragma unroll
@@ -420,10 +424,12 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
 #pragma unroll
       for (int xi = 0; xi < SEG; ++xi) {
         const int ox = x0 + SEG * seg + xi;
-        if (oy < p.H && ox < p.W && nvalid > 0) {
-          f32x4 ov;
+        // (the arithmetic stays OUTSIDE the exec-masked branch: hipcc's packed-fp32 code under exec masks gave intermittently wrong
+        //  values in tap_gather_kernel, profiles/r04_experiments.txt #1 -- only the store is predicated)
+        f32x4 ov;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = act_apply_bf(o[xi][e] + bv[e] + av[xi][e], decltype(act_c)::value);
+        for (int e = 0; e < 4; ++e) ov[e] = act_apply_bf(o[xi][e] + bv[e] + av[xi][e], decltype(act_c)::value);
+        if (oy < p.H && ox < p.W && nvalid > 0) {
           float* dst = p.y + img_y + ((long long)oy * p.W + ox) * p.ldy + ch0;
           if (nvalid == 4) {
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
