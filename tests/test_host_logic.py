@@ -279,3 +279,54 @@ def test_split_arithmetic_study_orders_the_schemes():
     assert err["bf16x3"] < 1e-5 < err["f16"] and err["bf16"] > 1e-3
     assert err["f16+f6x2"] < 4 * err["bf16x3"] and err["f16+f6x2"] * 15 < err["f16"]
     assert err["f16+f6x2"] <= err["f16+f8x2"] < err["f16+f4x2"]
+
+
+def test_upconv_algebra_conv_of_upsample_equals_gathered_tap_gemms():
+    """The identity csrc/upconv.hip computes (prv2_upconv3x3), in float64 on the CPU with the kernel's own index arithmetic:
+        conv3x3(interpolate(u, (H, W), 'bilinear', align_corners=True); W)(p) = sum_tap [p + d_tap inside the image] Bil(G_tap; s(p + d_tap)),
+        G_tap = W[:, :, tap] . u  (a 1x1 GEMM at u's resolution)
+    -- the channel contraction commutes with the interpolation; the zero padding of the conv applies to the OUTPUT grid (a tap outside
+    the image contributes nothing), not to the source.  bi_directional_fusion_model.py:139-142,201; fusion_model.py:15-24.  Also the two
+    bounds the kernel's tile shape relies on for a source step <= 1/2 pixel: consecutive output pixels advance the source column by at
+    most one, and a 16 x 28 output tile with its one-pixel tap ring touches at most 11 x 17 source pixels."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+
+    def ac_tap(dst, scale, n_in):  # common.h::ac_tap in float32, as the kernels evaluate it
+        src = np.float32(scale) * np.float32(dst)
+        i0 = min(int(src), n_in - 1)
+        i1 = i0 + (1 if i0 < n_in - 1 else 0)
+        w1 = float(np.float32(src) - np.float32(i0))
+        return i0, i1, 1.0 - w1, w1
+
+    for (h, w, H, W, cin, cout) in [(5, 7, 10, 14, 3, 4), (6, 5, 11, 9, 2, 3), (4, 4, 16, 13, 2, 2)]:
+        u = torch.randn(1, cin, h, w, generator=g, dtype=torch.float64)
+        wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
+        ref = F.conv2d(F.interpolate(u, (H, W), mode="bilinear", align_corners=True), wt, padding=1)[0]
+        sy = np.float32((h - 1) / (H - 1)) if H > 1 else np.float32(0)
+        sx = np.float32((w - 1) / (W - 1)) if W > 1 else np.float32(0)
+        G = torch.einsum("oikl,ihw->klohw", wt, u[0])  # [ky, kx, cout, h, w]: the nine tap GEMMs
+        got = torch.zeros(cout, H, W, dtype=torch.float64)
+        for y in range(H):
+            for x in range(W):
+                for ky in range(3):
+                    for kx in range(3):
+                        yy, xx = y + ky - 1, x + kx - 1
+                        if not (0 <= yy < H and 0 <= xx < W):
+                            continue  # the conv's zero padding: this tap sees nothing
+                        r0, r1, wy0, wy1 = ac_tap(yy, sy, h)
+                        c0, c1, wx0, wx1 = ac_tap(xx, sx, w)
+                        t = G[ky, kx]
+                        got[:, y, x] += wy0 * (wx0 * t[:, r0, c0] + wx1 * t[:, r0, c1]) + wy1 * (wx0 * t[:, r1, c0] + wx1 * t[:, r1, c1])
+        # float32 source coordinates against torch's float64 ones: ~1e-7 relative, the same difference the HIP upsample kernel has
+        assert float((got - ref).abs().max()) < 5e-6 * max(1.0, float(ref.abs().max())), (h, w, H, W)
+    # footprint bounds of a 16 x 28 tile (csrc/upconv.hip: LR = 11, LC = 17) for every tile origin of a x2 upsample and of the 2n - 1 corner case
+    for (n_in, n_out) in [(192, 384), (256, 512), (9, 17), (24, 48), (100, 199)]:
+        s = np.float32((n_in - 1) / (n_out - 1))
+        i0 = [ac_tap(min(max(d, 0), n_out - 1), s, n_in)[0] for d in range(-1, n_out + 1)]
+        assert all(0 <= b - a <= 1 for a, b in zip(i0, i0[1:]))
+        for span, bound in ((16, 11), (28, 17)):
+            for o in range(0, n_out, span):
+                lo, hi = i0[o], i0[min(o + span + 1, len(i0) - 1)]   # taps o - 1 .. o + span
+                assert hi - lo + 2 <= bound, (n_in, n_out, span, o, lo, hi)
