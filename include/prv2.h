@@ -127,7 +127,7 @@ int prv2_conv2d_ups_supported(const prv2_conv_desc* d, const prv2_ups_src* u);
 int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src* u, const void* w_packed, const float* bias,
                     const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream);
 
-/* 3x3 / stride 1 / pad 1 convolution of a bilinear(align_corners=True) UPSAMPLE (factor >= 2) of u, computed at u's resolution
+/* 3x3 / stride 1 / pad 1 convolution of a bilinear(align_corners=True) UPSAMPLE (factor >= 5/3) of u, computed at u's resolution
  * (csrc/upconv.hip) -- the layers prv2_conv2d_ups interpolates inside its loader, with 2.3x fewer matrix operations:
  *   C2FModule output_conv1      bi_directional_fusion_model.py:139-142,201   conv3x3(interpolate(path_1, scale 2, align_corners=True))
  *   UpSample.forward_hardcode   fusion_model.py:15-24                        the interpolate(x1) part of DoubleConv.0(cat[x1, x2, pred1, pred2])
@@ -139,7 +139,8 @@ int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src*
  * activation NONE -- it may be y itself (every output element is read by the thread that writes it).
  * Same split products and fp32 accumulation as the other bf16 kernels; the taps / corners are summed in another order than
  * upsample -> conv (fp32-grade, not bit-identical).  Contract (prv2_upconv3x3_supported != 0): bf16 modes, u->channels % 32 == 0,
- * h >= 2 u->h - 1 and w >= 2 u->w - 1 (source step <= 1/2 pixel), 16-byte aligned NHWC rows. */
+ * source step (u->h - 1) / (h - 1) and (u->w - 1) / (w - 1) <= 0.6 pixel (16 x 28 output tiles up to 1/2 -- the x2 upsamples --,
+ * 14 x 24 up to 3/5: DepthAnything's 256 -> 448 head resolution), 16-byte aligned NHWC rows. */
 int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec);
 int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, const float* add, int32_t ld_add, int32_t n, int32_t h,
                    int32_t w, int32_t cout, int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream);

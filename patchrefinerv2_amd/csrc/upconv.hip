@@ -36,11 +36,11 @@
 namespace prv2 {
 
 namespace upc {
-constexpr int TH = 16, TW = 28;
+constexpr int TH0 = 16, TW0 = 28;            // output tile for a source step <= 1/2 pixel (x2 upsamples)
+constexpr int TH1 = 14, TW1 = 24;            // ... for a step in (1/2, 3/5]: the same 11 x 17 footprint bound (15 rows x 0.6 = 9, 25 columns x 0.6 = 15)
 constexpr int LR = 11, LC = 17;              // source footprint of a tile (rows x columns), see the head of the file
 constexpr int RUNS = 12, MPX = RUNS * 16;    // 192 >= LR * LC = 187: three runs per wave (with 16 x 32 tiles, 224 footprint pixels and 4 / 3
                                              // runs per wave the kernel needed ~270 registers: accumulators in scratch inside the slab loop)
-constexpr int SEG = TW / 4;                  // output pixels per thread in the gather
 constexpr int CP = 32;                       // output channels per pass: 18 column blocks of 16 (9 taps x 2)
 constexpr int AROW = 144;                    // bytes per footprint pixel in LDS: [32 bf16 hi | 32 bf16 lo | 16 B pad] (16 rows x 16 B hit 64 distinct banks)
 constexpr int A_BYTES = MPX * AROW;          // 27 648
@@ -52,7 +52,7 @@ constexpr int C_BYTES = MPX * CLD * 4;       // 76 800
 // gather: the NEXT pass's first slab lands there while this pass is gathered (a pass therefore starts on stage 1)
 constexpr int S1_OFF = C_BYTES;
 constexpr int TAB_OFF = S1_OFF + STAGE;      // 141 312
-constexpr int NTAB = TW + 2;                 // output columns x0 - 1 .. x0 + 28
+constexpr int NTAB = TW0 + 2;                // output columns x0 - 1 .. x0 + TW (the wider tile's count)
 constexpr int SMEM_BYTES = TAB_OFF + NTAB * 16;
 constexpr int NDMA = 5;                      // weight pieces per wave and slab (36 over 8 waves: 5 or 4)
 static_assert(LR * LC <= MPX && STAGE <= C_BYTES && SMEM_BYTES <= 160 * 1024, "LDS layout");
@@ -84,9 +84,10 @@ __device__ __forceinline__ f32x4 fma4(float s, const f32x4 a, const f32x4 c) {
   return r;
 }
 
-template <int PREC>
+template <int PREC, int TH, int TW>
 __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
   using namespace upc;
+  constexpr int SEG = TW / 4;  // output pixels per thread in the gather
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
   float* const csm = reinterpret_cast<float*>(smem);
   f32x4* const tab = reinterpret_cast<f32x4*>(smem + TAB_OFF);
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
 #pragma unroll
           for (int xi = 0; xi < SEG; ++xi) {
             const int ox = x0 + SEG * seg + xi;
-            if (oy_ < p.H && ox < p.W) {
+            if ((TH >= 16 || prow_t < TH) && oy_ < p.H && ox < p.W) {
               const float* src = p.add + (long long)n_img * p.H * p.W * p.ld_add + ((long long)oy_ * p.W + ox) * p.ld_add + ch0;
               if (nvalid == 4) av[xi] = *reinterpret_cast<const f32x4*>(src);
               else {
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
         f32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ov[e] = act_apply_bf(o[xi][e] + bv[e] + av[xi][e], decltype(act_c)::value);
-        if (oy < p.H && ox < p.W && nvalid > 0) {
+        if ((TH >= 16 || prow_t < TH) && oy < p.H && ox < p.W && nvalid > 0) {
           float* dst = p.y + img_y + ((long long)oy * p.W + ox) * p.ldy + ch0;
           if (nvalid == 4) {
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
@@ -452,8 +453,8 @@ static inline bool al16u(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 
 static bool upconv_shape_ok(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec) {
   return u && u->x && n > 0 && h >= 2 && w >= 2 && cout > 0 && (prec == PRV2_PREC_BF16X3 || prec == PRV2_PREC_BF16) && u->channels >= 32 &&
-         u->channels % 32 == 0 && u->ld % 4 == 0 && u->ld >= u->channels && u->h >= 1 && u->w >= 1 && ac_scale(u->h, h) <= 0.5f &&
-         ac_scale(u->w, w) <= 0.5f && (long long)u->h * u->w * u->ld < (1LL << 29) && (long long)roundup(cout, 128) * 9 * u->channels < (1LL << 29);
+         u->channels % 32 == 0 && u->ld % 4 == 0 && u->ld >= u->channels && u->h >= 1 && u->w >= 1 && ac_scale(u->h, h) <= 0.6f &&
+         ac_scale(u->w, w) <= 0.6f && (long long)u->h * u->w * u->ld < (1LL << 29) && (long long)roundup(cout, 128) * 9 * u->channels < (1LL << 29);
 }
 
 extern "C" int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec) {
@@ -463,7 +464,7 @@ extern "C" int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_
 extern "C" int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, const float* add, int32_t ld_add, int32_t n, int32_t h,
                               int32_t w, int32_t cout, int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream) {
   PRV2_REQUIRE(upconv_shape_ok(u, n, h, w, cout, prec),
-               "upconv3x3: layer not covered (bf16 modes, channels %% 32 == 0, output at least 2 h - 1 x 2 w - 1 of the source)");
+               "upconv3x3: layer not covered (bf16 modes, channels %% 32 == 0, source step (h_in - 1) / (h_out - 1) <= 0.6 in both directions)");
   PRV2_REQUIRE(w_packed && y && al16u(u->x) && al16u(w_packed) && al16u(y) && ldy % 4 == 0 && ldy >= cout && u->bstride % 4 == 0 && y_bstride % 4 == 0,
                "upconv3x3: 16-byte aligned NHWC rows (ldy=%d)", ldy);
   PRV2_REQUIRE((long long)h * w * ldy < (1LL << 31), "upconv3x3: image too large");
@@ -475,7 +476,11 @@ extern "C" int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const
   p.y = y; p.H = h; p.W = w; p.ldy = ldy; p.Cout = cout;
   p.y_bstride = y_bstride ? y_bstride : (long long)h * w * ldy;
   p.usy = ac_scale(u->h, h); p.usx = ac_scale(u->w, w);
-  p.tiles_x = (int)cdiv(w, upc::TW); p.tiles_y = (int)cdiv(h, upc::TH);
+  // tile shape by the source step: the footprint bound (11 x 17 source pixels) holds for 16 x 28 outputs up to 1/2 pixel per output pixel
+  // (x2 upsamples) and for 14 x 24 outputs up to 3/5 (DepthAnything's 256 -> 448 head resolution under a V1 fusion decoder)
+  const bool wide = p.usy <= 0.5f && p.usx <= 0.5f;
+  const int th = wide ? upc::TH0 : upc::TH1, tw = wide ? upc::TW0 : upc::TW1;
+  p.tiles_x = (int)cdiv(w, tw); p.tiles_y = (int)cdiv(h, th);
   p.npass = (int)cdiv(cout, upc::CP);
   const long long tiles = (long long)n * p.tiles_x * p.tiles_y;
   // few tiles (the low pyramid levels): the passes of a tile are spread over workgroups until the chip has two rounds of them
@@ -484,8 +489,14 @@ extern "C" int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const
   groups = groups < 1 ? 1 : (groups > p.npass ? p.npass : groups);
   p.pass_groups = (int)groups;
   const dim3 grid((unsigned)(tiles * groups));
-  if (prec == PRV2_PREC_BF16X3) hipLaunchKernelGGL((upconv3x3_kernel<PRV2_PREC_BF16X3>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((upconv3x3_kernel<PRV2_PREC_BF16>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == PRV2_PREC_BF16X3) {
+    if (wide) hipLaunchKernelGGL((upconv3x3_kernel<PRV2_PREC_BF16X3, upc::TH0, upc::TW0>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((upconv3x3_kernel<PRV2_PREC_BF16X3, upc::TH1, upc::TW1>), grid, dim3(512), 0, s, p);
+  } else {
+    if (wide) hipLaunchKernelGGL((upconv3x3_kernel<PRV2_PREC_BF16, upc::TH0, upc::TW0>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((upconv3x3_kernel<PRV2_PREC_BF16, upc::TH1, upc::TW1>), grid, dim3(512), 0, s, p);
+  }
   set_kernel("upconv3x3_kernel", 32, prec);
   PRV2_LAUNCH_CHECK("upconv3x3");
   return 0;

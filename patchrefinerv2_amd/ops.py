@@ -400,7 +400,8 @@ def upconv3x3(u: Feat, h: int, w: int, cw: ConvW, out: Optional[Feat] = None, *,
 
     # executed: the tap GEMMs over every tile's 192-pixel source footprint (16 x 28 output tiles, 32-channel passes); algo: the reference
     # graph's nine taps at the OUTPUT resolution
-    tiles = -(-h // 16) * -(-w // 28)
+    wide = (u.h - 1) * 2 <= (h - 1) and (u.w - 1) * 2 <= (w - 1)  # (csrc/upconv.hip: 16 x 28 output tiles up to a source step of 1/2, else 14 x 24)
+    tiles = -(-h // 16) * -(-w // 28) if wide else -(-h // 14) * -(-w // 24)
     shape = f"{cw.cin}->{cw.cout} k3s1 {u.n}x{h}x{w} (lowres {u.c}ch {u.h}x{u.w})"
     PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), 2.0 * u.n * tiles * 192 * 9 * cw.cin * roundup(cw.cout, 32), call, shape=shape,
                     algo=2.0 * u.n * h * w * cw.cout * cw.cin * 9)

@@ -813,6 +813,8 @@ UPCONV_CASES = [
     (1, (9, 12), (17, 23), 64, 32, "relu", True),         # H = 2 h - 1: the largest source step the contract admits
     (1, (6, 8), (24, 32), 32, 64, "none", True),          # x4: source step 1/4
     (3, (4, 4), (8, 8), 256, 290, "gelu", True),          # tiny images (the low pyramid levels): pass groups spread over workgroups, 8 slabs
+    (2, (16, 16), (28, 28), 64, 130, "gelu", False),      # x1.75 (DepthAnything's 256 -> 448): source step 0.556 -> the 14 x 24 tile shape
+    (1, (11, 19), (19, 31), 32, 32, "none", True),        # source step 0.556 / 0.6: the contract's upper end, ragged 14 x 24 tiles
 ]
 
 
@@ -893,7 +895,7 @@ def test_upconv3x3_rejects_what_it_does_not_cover(P):
     u = P.Feat.from_nchw(rnd(1, 1, 64, 12, 16).to(DEV))
     ok = P.pack_conv(rnd(2, 98, 64, 3, 3).to(DEV), None, pad=1, prec=PR)
     assert P.upconv3x3_supported(u, 24, 32, ok) and P.upconv3x3_supported(u, 23, 31, ok)
-    assert not P.upconv3x3_supported(u, 22, 32, ok)                                                                   # source step > 1/2
+    assert P.upconv3x3_supported(u, 20, 32, ok) and not P.upconv3x3_supported(u, 19, 32, ok)                           # source step 11/19 <= 0.6 < 11/18
     assert not P.upconv3x3_supported(u, 24, 32, P.pack_conv(rnd(2, 98, 64, 3, 3).to(DEV), None, pad=1, prec=P.L.PREC_NAMES["f32"]))
     assert not P.upconv3x3_supported(P.Feat.from_nchw(rnd(1, 1, 48, 12, 16).to(DEV)), 24, 32, P.pack_conv(rnd(2, 98, 48, 3, 3).to(DEV), None, pad=1, prec=PR))
     with pytest.raises(RuntimeError):

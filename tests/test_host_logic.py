@@ -322,11 +322,12 @@ def test_upconv_algebra_conv_of_upsample_equals_gathered_tap_gemms():
         # float32 source coordinates against torch's float64 ones: ~1e-7 relative, the same difference the HIP upsample kernel has
         assert float((got - ref).abs().max()) < 5e-6 * max(1.0, float(ref.abs().max())), (h, w, H, W)
     # footprint bounds of a 16 x 28 tile (csrc/upconv.hip: LR = 11, LC = 17) for every tile origin of a x2 upsample and of the 2n - 1 corner case
-    for (n_in, n_out) in [(192, 384), (256, 512), (9, 17), (24, 48), (100, 199)]:
+    # ... and of a 14 x 24 tile for a source step up to 3/5 (DepthAnything's 256 -> 448)
+    for (n_in, n_out) in [(192, 384), (256, 512), (9, 17), (24, 48), (100, 199), (256, 448), (16, 28), (4, 6)]:
         s = np.float32((n_in - 1) / (n_out - 1))
         i0 = [ac_tap(min(max(d, 0), n_out - 1), s, n_in)[0] for d in range(-1, n_out + 1)]
         assert all(0 <= b - a <= 1 for a, b in zip(i0, i0[1:]))
-        for span, bound in ((16, 11), (28, 17)):
+        for span, bound in (((16, 11), (28, 17)) if s <= 0.5 else ((14, 11), (24, 17))):
             for o in range(0, n_out, span):
                 lo, hi = i0[o], i0[min(o + span + 1, len(i0) - 1)]   # taps o - 1 .. o + span
                 assert hi - lo + 2 <= bound, (n_in, n_out, span, o, lo, hi)
