@@ -140,6 +140,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
         ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi + (i + 1) * 2048);
         al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo + (i + 1) * 2048);
       }
+#ifndef PRV2_GSS_NOSCHED
+      // (fences: without them hipcc sinks the two reads above to just in front of their first use -- `ds_read; s_waitcnt lgkmcnt(1); v_mfma`
+      //  on the value just requested: an LDS round trip of idle matrix pipe per row block, ~1 k of a slab's 1.5 k MFMA cycles per wave)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       // smallest terms first (as gemm16_kernel): lo*hi, hi*lo, hi*hi; consecutive MFMAs never share an accumulator
 #pragma unroll
       for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
@@ -147,6 +152,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
       for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+#ifndef PRV2_GSS_NOSCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   };
 
