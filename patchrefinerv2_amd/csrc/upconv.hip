@@ -1,4 +1,4 @@
-// 3x3 convolution of a bilinear(align_corners=True) x2 UPSAMPLE, computed at the LOW resolution:
+// 3x3 convolution of a bilinear(align_corners=True) UPSAMPLE (x2; up to a source step of 3/5 pixel), computed at the LOW resolution:
 //
 //   C2FModule output_conv1       bi_directional_fusion_model.py:139-142,201   conv3x3(interpolate(path_1, scale 2, align_corners=True))
 //   UpSample.forward_hardcode    fusion_model.py:15-24                        the x1 part of DoubleConv.0(cat[interpolate(x1), x2, pred1, pred2])
@@ -7,27 +7,32 @@
 // interpolation:
 //     conv3x3(up(u); W)(p) = sum_tap [p + d_tap inside the image] Bil(G_tap; s(p + d_tap)),     G_tap = W[:, :, tap] . u   (a 1x1 GEMM)
 // with s() = PyTorch's align_corners source position and Bil = its two-by-two interpolation.  The nine G_tap live on the LOW-resolution
-// grid: the MFMA work is 9 * cin * cout MACs per low-resolution pixel of a tile's footprint -- 224 footprint pixels for 512 outputs,
-// 2.29x fewer matrix operations than the direct conv over the upsampled image (conv3x3_m16.hip UPS), which these power-limited layers
+// grid: the MFMA work is 9 * cin * cout MACs per low-resolution pixel of a tile's footprint -- 192 footprint rows for 448 outputs,
+// 2.3x fewer matrix operations than the direct conv over the upsampled image (conv3x3_m16.hip UPS), which these power-limited layers
 // turn into time.  What is added is VALU / LDS work: 36 FMAs per output element (four corners x nine taps), organised below so that a
 // thread reads each G value it needs once.
 //
-// Workgroup = one 16 x 32 tile of output pixels (8 waves).  Its source footprint is at most 11 x 19 low-resolution pixels (scale <=
-// 1/2: 17 rows span <= 10 source rows + 1, 33 columns <= 18 + 1), linearised and padded to 224 = 14 MFMA row runs.
-// A PASS produces 32 output channels for all nine taps: GEMM [224 x cin] x [cin x 288] (18 column blocks = 9 taps x 2), so that the
-// output accumulators of a pass (8 pixels x 4 channels per thread) never coexist with more than one pass of MFMA accumulators -- the
-// register file (256 per wave at 8 waves) is what shapes this: 3-tap passes over all channels would need 192 + 128 accumulators.
+// Workgroup = one 16 x 28 tile of output pixels (8 waves; 14 x 24 for a source step in (1/2, 3/5]).  Its source footprint is at most
+// 11 x 17 low-resolution pixels (17 rows x 1/2 span <= 9 source rows + 2, 29 columns <= 15 + 2), linearised and padded to 192 = 12 MFMA
+// row runs.  A PASS produces 32 output channels for all nine taps: GEMM [192 x cin] x [cin x 288] (18 column blocks = 9 taps x 2; 8 waves
+// = 4 row slots of 3 runs x 2 column slots of 9 blocks = 108 accumulator registers), so that the output accumulators of a pass (7 pixels
+// x 4 channels per thread) never coexist with more than one pass of MFMA accumulators.  The register file (256 per wave at 8 waves)
+// shapes all of this: 3-tap passes over all channels would need 192 + 128 accumulators, and the first shape tried (16 x 32 tiles, 224
+// rows, 4 / 3 runs per wave) needed ~270 registers -- accumulators spilled inside the slab loop and the kernel lost to the direct one.
 //   main loop, per 32 input channels: the footprint slab is loaded as fp32, split to bf16 hi / lo and staged once (A fragments are read
 //   ONCE per slab: they do not depend on the tap), the slab's 288 x 128 B of packed weights arrive by LDS-DMA (36 pieces of 8 rows);
-//   two stages, one barrier per slab, 108 / 81 MFMAs per wave between barriers (waves take 4, 4, 3, 3 runs x 9 column blocks; the
-//   two waves of a SIMD take 4 + 3 runs).
-//   gather, per kernel row ky: the three taps' G tiles (224 x 96 floats) go through LDS; thread = (output row, 8-pixel segment, channel
-//   quad) walks its segment once per tap: the row interpolation of a source column is formed when the walk first needs it
-//   (wave-uniform walk: every lane of a wave has the same segment), so each G value is read once and each output costs 2 FMAs per tap
-//   and channel on top.
+//   two stages, one barrier per slab, 81 MFMAs per wave between barriers; weights are the MFMA's A operand, so that an accumulator holds
+//   four consecutive CHANNELS of one footprint pixel: one 16-byte write into the G tile, in the layout the gather reads.
+//   gather, per kernel row ky: the three taps' G tiles (192 x 96 floats) go through LDS; thread = (output row, 7-pixel segment, channel
+//   quad).  The three taps of a kernel row walk the SAME source columns (tap kx reaches column-table entry i at its pixel i - kx), so
+//   they walk together: one wave-uniform step per table entry (every lane of a wave has the same segment), the row interpolation of a
+//   source column formed when the walk first needs it, one column prefetched: each G value is read once and each output costs 2 FMAs
+//   per tap and channel on top.
+//   LDS [G tile | stage 1 | column table]: stage 0 aliases the G tile; stage 1 is never touched by the gather, so the NEXT pass's first
+//   slab lands there while this pass is gathered.
 // Weights: the ordinary packed 3x3 image of prv2_pack_conv_weight (row = cout, tap-major 128-byte slabs), read slab by slab.
 // Arithmetic: same split products (lo*hi, hi*lo, hi*hi) and fp32 accumulation as the other bf16x3 kernels; the sum over taps and
-// corners is ordered differently from upsample -> conv (not bit-identical: tests compare against the fp32 reference of the pair).
+// corners is ordered differently from upsample -> conv (not bit-identical: tests compare against the float64 reference of the pair).
 #include <cstdlib>
 #include <type_traits>
 
