@@ -183,6 +183,44 @@ def test_bidir_fusion_x2_format_is_bit_identical(P):
     assert torch.equal(a, b)
 
 
+def test_bidir_fusion_upconv_route_matches_the_loader_route(P, golden):
+    """BiDirectionalFusion in bf16x3 with the 3x3 convs of upsampled tensors on csrc/upconv.hip (output_conv1 and every decoder stage
+    with >= 256 interpolated channels, split by weight columns) against the same network with PRV2_UPCONV off (the fused-upsample
+    loader kernel) and against the reference's golden output: same tolerance on both routes"""
+    from patchrefinerv2_amd import ops
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    c = TINY_BIDIR
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"],
+                                                c["dec_chl"]), seed=c["seed"])
+    i = c["make_inputs"]("same")
+    sizes = [(t.shape[-2], t.shape[-1]) for t in i["f_feat"]]
+    outs, calls = {}, {}
+    real = ops.upconv3x3
+    for on in (True, False):
+        ops.UPCONV = on
+        n = []
+
+        def spy(*a, **k):
+            n.append(1)
+            return real(*a, **k)
+        ops.upconv3x3 = spy
+        try:
+            m = BiDirectionalFusion(coarse2fine_type="coarse-gated", coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                                    fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec="bf16x3")
+            m.load_state_dict(sd)   # (the decoder's weight split is decided when the weights are packed)
+            f = lambda ts: [P.Feat.from_nchw(t.to(DEV)) for t in ts]  # noqa: E731
+            ff = f(i["f_feat"])
+            outs[on] = m(f(i["c_feat"]), [None] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV), f_sizes=sizes).clone()
+        finally:
+            ops.UPCONV = True
+            ops.upconv3x3 = real
+        calls[on] = len(n)
+    assert calls[True] >= 3 and calls[False] == 0, calls   # output_conv1 + the 770- and 642-channel decoder stages (+ 322)
+    close(outs[True], golden("bidir_fusion")["same"], 3e-5, "upconv route vs golden")
+    close(outs[False], golden("bidir_fusion")["same"], 3e-5, "loader route vs golden")
+    close(outs[True], outs[False].cpu(), 3e-5, "upconv route vs loader route")
+
+
 def test_lightweight_refiner(P):
     from patchrefinerv2_amd.refiner import LightWeightRefiner
     sd = W.synth_state_dict(W.mnv4_spec("refiner_encoder.", in_chans=4), seed=9)
