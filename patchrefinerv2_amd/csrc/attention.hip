@@ -303,8 +303,13 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const 
 // BIAS: 0 none, 1 rows [heads][N][ldb] (every lane walks its own query's row: 64 cache lines per load instruction), 2 the
 // prv2_pack_attention_bias image -- the same values pre-multiplied by log2 e in the order the S^T accumulators want them, so that a
 // key tile's bias is eight coalesced 1 KB loads per wave, requested BEFORE the S^T MFMAs (BEiT: 0.17 -> see profiles/r04_*)
+// (the bias-image variant needs 198 registers: under the three-workgroup cap of 168 it spilled 12 of them and reloaded them from scratch
+//  inside the key-tile loop -- two workgroups per CU without scratch: BEiT-L attention 0.675 -> 0.630 ms per 41 x 769-token launch, same bits)
+#ifndef ATT_WG_BIAS
+#define ATT_WG_BIAS 2
+#endif
 template <int BIAS>
-__global__ void __launch_bounds__(256, 3) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
+__global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
                                                                   const __bf16* __restrict__ Ks,
                                                                   const __bf16* __restrict__ VtH,
                                                                   const __bf16* __restrict__ VtL, int N, int Npad,
