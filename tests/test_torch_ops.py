@@ -236,6 +236,39 @@ def test_conv3x3_ups_equals_interpolate_then_conv(T):
 
 
 @gpu
+def test_upconv3x3_and_the_split_concat_conv(T):
+    """torch.ops.prv2.upconv3x3 exactly as INTEGRATION.md section B writes it: output_conv1(interpolate(path_1)) at path_1's resolution
+    (bi_directional_fusion_model.py:139-142,201), and UpSample.forward_hardcode's first conv (fusion_model.py:15-24) split by weight
+    columns -- conv2d over [x2 | pred1 | pred2] (raw) as the in-place addend of upconv3x3 over x1 -- against F.interpolate + F.conv2d in fp64"""
+    import torch.nn.functional as F
+    ops, mod = T
+    n, h, w, cu, c2, cout = 2, 13, 20, 64, 32, 98
+    H, W = 2 * h, 2 * w
+    u = randn(1, n, h, w, cu).to(DEV)
+    up = F.interpolate(u.permute(0, 3, 1, 2).cpu().double(), (H, W), mode="bilinear", align_corners=True)
+    # (a) every input channel interpolated, bias, no activation
+    w1, b1 = randn(2, 128, cu, 3, 3) / (9 * cu) ** 0.5, randn(3, 128)
+    got = ops.upconv3x3(u, ops.pack_conv_weight(w1.to(DEV), None, 0, mod.PREC_BF16X3), b1.to(DEV), 128, H, W, act=mod.ACT_NONE, prec=mod.PREC_BF16X3)
+    want = F.conv2d(up, w1.double(), b1.double(), padding=1).float()
+    assert float((got.permute(0, 3, 1, 2).cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    # (b) the concat conv, split
+    rest = randn(4, n, H, W, c2 + 2).to(DEV)
+    w0 = randn(5, cout, cu + c2 + 2, 3, 3) / (9 * (cu + c2 + 2)) ** 0.5
+    cat_buf = torch.full((n, H, W, cu + c2 + 2 + 2), float("nan"), device=DEV)   # [never-written up(x1) slot | x2 | pred1 | pred2 | pad]
+    cat_buf[..., cu:cu + c2 + 2] = rest
+    cat_buf[..., cu + c2 + 2:] = 0.0
+    wa = ops.pack_conv_weight(w0[:, :cu].contiguous().to(DEV), None, 0, mod.PREC_BF16X3)
+    wb = ops.pack_conv_weight(w0[:, cu:].contiguous().to(DEV), None, 0, mod.PREC_BF16X3)
+    t = ops.conv2d(cat_buf[..., cu:cu + c2 + 2], wb, None, cout, 3, 3, pad=1, prec=mod.PREC_BF16X3)
+    y = ops.upconv3x3(u, wa, None, cout, H, W, act=mod.ACT_GELU, prec=mod.PREC_BF16X3, out=t, add=t)
+    assert y.data_ptr() == t.data_ptr()
+    want = F.gelu(F.conv2d(torch.cat([up, rest.permute(0, 3, 1, 2).cpu().double()], 1), w0.double(), None, padding=1)).float()
+    assert float((y.permute(0, 3, 1, 2).cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    with pytest.raises(RuntimeError):
+        ops.upconv3x3(u, wa, None, cout, h + 3, W, prec=mod.PREC_BF16X3)   # source step 12/15 > 3/5
+
+
+@gpu
 def test_every_op_test_passes_on_the_other_route():
     """The host wrappers reach EVERY kernel on two routes: torch.ops.prv2.* (ops.DISPATCH = 'torch', the default) and ctypes straight
     on the C ABI (PRV2_DISPATCH=ctypes).  The whole per-op parity file (tests/test_hip_ops.py: convs with every epilogue, X2 formats,
