@@ -321,8 +321,11 @@ __global__ void __launch_bounds__(256) conv1x1_small_kernel(const IgemmParams p,
 }
 
 static bool conv1x1_small_supported(const IgemmParams& p) {
-  return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 && p.Cin <= 64 && p.Cout <= 64 &&
-         p.Cout >= 8 && !p.ln_w && p.x_bstride == (long long)p.H * p.W * p.ldx &&
+  // ... and the handful-of-outputs 1x1s behind a wider input (ZoeDepth's 80 -> 4 head conv on every V1 tile: 2.4 ms per 41 x 384 x 512 on
+  // the generic MFMA kernel -- a 128-column tile for 4 columns -- against 0.7 ms of HBM traffic): one thread per pixel, 8 output slots
+  const bool few_outputs = p.Cout < 8 && p.Cin_pad * 8 <= 64 * 64;
+  return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.convt_k == 0 && ((p.Cin <= 64 && p.Cout <= 64 && p.Cout >= 8) || few_outputs) &&
+         !p.ln_w && p.x_bstride == (long long)p.H * p.W * p.ldx &&
          p.y_bstride == (long long)p.OH * p.OW * p.ldy && (long long)p.OH * p.OW >= 4096;  // per image: the choice (fp32 VALU vs MFMA) must not depend on the batch
 }
 

@@ -49,6 +49,7 @@ CONV_CASES = [
     (1, 56, 56, 512, 256, 3, 1, dict(bias=True)),
     (2, 21, 45, 98, 32, 3, 1, dict(bias=True, act="gelu")),   # cout <= 32: 8x1 wave grid variant
     (1, 40, 64, 34, 20, 3, 1, dict(res=True)),
+    (2, 64, 64, 80, 4, 1, 1, dict(bias=True)),               # ZoeDepth's 80 -> 4 head conv: the few-outputs form of conv1x1_small_kernel
 ]
 
 
