@@ -30,3 +30,22 @@ for n, h, w, cin in ((14, 192, 256, 512), (14, 96, 128, 512), (14, 192, 256, 256
     rel = (sw - sw[:, :1, :1]) / 1000.0  # every wave's stamps relative to wave 0's kernel start
     for i in (4, 5, 6, 7, 8):
         print(f"    stamp {i} ({NAMES[i - 1]} done) per wave, median kcycles since start: " + " ".join(f"{rel[:, wv, i].median():.1f}" for wv in range(8)), flush=True)
+
+# the round-4 form of the unit: K = 256 on the pre-split (X2) ``out`` + the coarse half as a pre-LayerNorm addend (stamp 3 = C tile + addend in LDS)
+for n, h, w in ((14, 192, 256),):
+    F_ = 256
+    out = P.Feat(torch.randn(n, h, w, F_, device="cuda"), x2=True)   # (bytes of random floats read as bf16 pairs: timing only)
+    pre = P.Feat(torch.randn(n, h, w, F_, device="cuda"))
+    res = P.Feat(torch.randn(n, h, w, F_, device="cuda"))
+    y = P.Feat.alloc(n, h, w, F_, "cuda")
+    cwa = P.pack_conv(torch.randn(F_, F_, 3, 3, device="cuda") / (3 * F_ ** 0.5), torch.randn(F_, device="cuda"), pad=1, prec=PR)
+    for _ in range(3):
+        P.conv3x3_ln_gate(out, cwa, ln, gw, gb, y, act=P.ACT_RELU, mul=out, res=res, pre=pre, pre_cin=F_)
+    torch.cuda.synchronize()
+    nblk = n * (h // 8) * (w // 16)
+    sw = stamps[: nblk * 80].view(nblk, 8, 10).cpu().double()
+    s0 = sw[:, 0]
+    d = (s0[:, 1:] - s0[:, :-1]) / 1000.0
+    tot = (s0[:, 9] - s0[:, 0]) / 1000.0
+    print(f"{n}x{h}x{w} 256(+pre, X2)->256->256: {nblk} workgroups, median {tot.median():.1f} kcycles per workgroup: " +
+          "  ".join(f"{nm} {d[:, i].median():.2f}" for i, nm in enumerate(NAMES)), flush=True)

@@ -7,4 +7,4 @@ cd "$(dirname "$0")/../../patchrefinerv2_amd/csrc"
 objs=$(ls *.o | grep -v conv3x3_gate.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libprv2_hip_stamps.so $objs /tmp/conv3x3_gate_st.o
 cd ../..
-PRV2_LIB_OVERRIDE=/tmp/libprv2_hip_stamps.so python tools/probes/gate_phase_stamps.py
+PRV2_DISPATCH=ctypes PRV2_LIB_OVERRIDE=/tmp/libprv2_hip_stamps.so python tools/probes/gate_phase_stamps.py  # (ctypes route: the torch-op library links the in-tree build)
