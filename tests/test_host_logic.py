@@ -331,3 +331,23 @@ def test_upconv_algebra_conv_of_upsample_equals_gathered_tap_gemms():
             for o in range(0, n_out, span):
                 lo, hi = i0[o], i0[min(o + span + 1, len(i0) - 1)]   # taps o - 1 .. o + span
                 assert hi - lo + 2 <= bound, (n_in, n_out, span, o, lo, hi)
+
+
+def test_composite_5x5_of_the_two_linear_convs_behind_the_upsample():
+    """Groundwork for DESIGN.md section 9 item 0a (tools/studies/composite5x5_study.py): output_conv2[0] o output_conv1 o interpolate
+    (bi_directional_fusion_model.py:139-146,201-203) == ONE 5x5 conv of the upsampled map + a nine-valued bias map - a fix on the one-pixel
+    border ring, exactly (float64), for the real channel ratio too (fewer MACs: 25 cin c2 against 9 cin c1 + 9 c1 c2)"""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("c5", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "studies", "composite5x5_study.py"))
+    c5 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(c5)
+    g = torch.Generator().manual_seed(3)
+    for (cin, c1, c2, h, w) in [(8, 6, 4, 9, 11), (16, 8, 2, 5, 6)]:
+        u = torch.randn(1, cin, h, w, generator=g, dtype=torch.float64)
+        w1, b1 = torch.randn(c1, cin, 3, 3, generator=g, dtype=torch.float64) / 8, torch.randn(c1, generator=g, dtype=torch.float64)
+        w2, b2 = torch.randn(c2, c1, 3, 3, generator=g, dtype=torch.float64) / 7, torch.randn(c2, generator=g, dtype=torch.float64)
+        r = c5.composite(u, w1, b1, w2, b2, (2 * h, 2 * w))
+        assert r["err"] < 1e-12 * max(1.0, r["scale"]), r
+        assert r["ring_pixels"] == 2 * (2 * h + 2 * w) - 4 and r["bias_vectors"] == 9 and r["err_without_ring_fix"] > 1e-3, r
+    assert 25 * 256 * 32 < 9 * 256 * 128 + 9 * 128 * 32   # the real layer pair: 204.8 k against 331.8 k MACs per output pixel
