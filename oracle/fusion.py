@@ -71,20 +71,24 @@ def fusion_unet(sd, p, c_feat, f_feat, pred1, pred2, update_base=None):
                           c_feat, f_feat, pred1, pred2, update_base)
 
 
-def gated_conv_unit(sd, p, x, c_feat):
+def gated_conv_unit(sd, p, x, c_feat, fusion=True, gate=True):
+    """GatedConvUnit.forward (:56-82): ``fusion=False`` ('self-agg') stops after the residual conv; ``gate=False`` ('coarse-fusion')
+    returns the fusion_conv output itself instead of gating ``out`` with its sigmoid (:76-80)."""
     out = F.conv2d(F.relu(x), sd[p + "conv.weight"], sd[p + "conv.bias"], padding=1) + x
+    if not fusion:
+        return out
     fused = torch.cat([out, c_feat], dim=1)
     fused = F.conv2d(fused, sd[p + "fusion_conv.0.weight"], sd[p + "fusion_conv.0.bias"], padding=1)
     fused = F.relu(ln_cf(fused, sd[p + "fusion_conv.1.weight"], sd[p + "fusion_conv.1.bias"]))
     fused = F.conv2d(fused, sd[p + "fusion_conv.3.weight"], None)
-    return out * torch.sigmoid(fused)
+    return out * torch.sigmoid(fused) if gate else fused
 
 
-def gated_fusion_block(sd, p, xs, coarse_feat, size=None, upscale=True):
+def gated_fusion_block(sd, p, xs, coarse_feat, size=None, upscale=True, fusion=True, gate=True):
     out = xs[0]
     if len(xs) == 2:
-        out = out + gated_conv_unit(sd, p + "GateresConfUnit1.", xs[1], coarse_feat)
-    out = gated_conv_unit(sd, p + "GateresConfUnit2.", out, coarse_feat)
+        out = out + gated_conv_unit(sd, p + "GateresConfUnit1.", xs[1], coarse_feat, fusion, gate)
+    out = gated_conv_unit(sd, p + "GateresConfUnit2.", out, coarse_feat, fusion, gate)
     if upscale:
         if size is None:
             size = (out.shape[-2] * 2, out.shape[-1] * 2)
@@ -92,30 +96,34 @@ def gated_fusion_block(sd, p, xs, coarse_feat, size=None, upscale=True):
     return F.conv2d(out, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
 
 
-def c2f_module(sd, p, fine, coarse):
+C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self-agg": (False, False)}  # :355-372 -> (fusion, gate)
+
+
+def c2f_module(sd, p, fine, coarse, fusion=True, gate=True):
     """C2FModule.forward (bi_directional_fusion_model.py:184-208); fine & coarse high -> low."""
     s = p + "scratch."
+    kw = dict(fusion=fusion, gate=gate)
     rn = [F.conv2d(fine[i], sd[f"{s}layer{i + 1}_rn.weight"], None, padding=1) for i in range(5)]
-    path5 = gated_fusion_block(sd, s + "refinenet5.", [rn[4]], coarse[5], size=rn[3].shape[2:])
-    path4 = gated_fusion_block(sd, s + "refinenet4.", [path5, rn[3]], coarse[4], size=rn[2].shape[2:])
-    path3 = gated_fusion_block(sd, s + "refinenet3.", [path4, rn[2]], coarse[3], size=rn[1].shape[2:])
-    path2 = gated_fusion_block(sd, s + "refinenet2.", [path3, rn[1]], coarse[2], size=rn[0].shape[2:])
-    path1 = gated_fusion_block(sd, s + "refinenet1.", [path2, rn[0]], coarse[1])
+    path5 = gated_fusion_block(sd, s + "refinenet5.", [rn[4]], coarse[5], size=rn[3].shape[2:], **kw)
+    path4 = gated_fusion_block(sd, s + "refinenet4.", [path5, rn[3]], coarse[4], size=rn[2].shape[2:], **kw)
+    path3 = gated_fusion_block(sd, s + "refinenet3.", [path4, rn[2]], coarse[3], size=rn[1].shape[2:], **kw)
+    path2 = gated_fusion_block(sd, s + "refinenet2.", [path3, rn[1]], coarse[2], size=rn[0].shape[2:], **kw)
+    path1 = gated_fusion_block(sd, s + "refinenet1.", [path2, rn[0]], coarse[1], **kw)
     out = F.conv2d(path1, sd[s + "output_conv1.weight"], sd[s + "output_conv1.bias"], padding=1)
     last = F.relu(F.conv2d(out, sd[s + "output_conv2.0.weight"], sd[s + "output_conv2.0.bias"], padding=1))
-    last = gated_fusion_block(sd, s + "output_conv2_fusion.", [last], coarse[0], upscale=False)
+    last = gated_fusion_block(sd, s + "output_conv2_fusion.", [last], coarse[0], upscale=False, **kw)
     out = F.conv2d(last, sd[s + "output_conv3.0.weight"], sd[s + "output_conv3.0.bias"])
     return [rn[4], path5, path4, path3, path2, last], out
 
 
-def bidirectional_fusion(sd, p, c_feat, f_feat, pred1, pred2, update_base=None):
-    """BiDirectionalFusion.forward, coarse2fine_type='coarse-gated', glb_att=False
+def bidirectional_fusion(sd, p, c_feat, f_feat, pred1, pred2, update_base=None, coarse2fine_type="coarse-gated"):
+    """BiDirectionalFusion.forward, coarse2fine_type in C2F_TYPES, glb_att=False
     (bi_directional_fusion_model.py:379-446).  c_feat: 6 maps high -> low; f_feat: 6 maps
     high -> low (index 0 = the 2x-upsampled copy that is dropped at :408)."""
     c_feat = list(c_feat)
     if c_feat[-1].shape[-2:] != f_feat[-1].shape[-2:]:
         c_feat = [bilinear_ac(c, f.shape[-2:]) for c, f in zip(c_feat, f_feat)]
-    f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat)
+    f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat, *C2F_TYPES[coarse2fine_type])
     f_feat, pred2 = f_feat[::-1], out_depth
     if TRACE is not None:
         TRACE["c2f_depth"], TRACE["c2f_last"] = out_depth, f_feat[0]

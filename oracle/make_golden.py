@@ -154,24 +154,28 @@ def g_bidir():
     print("[bidir_fusion]")
     bm = refharness.ref_module("estimator.models.blocks.bi_directional_fusion_model")
     c = TINY_BIDIR
-    spec = W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"])
-    sd = W.synth_state_dict(spec, seed=c["seed"])
-    m = bm.BiDirectionalFusion(coarse2fine=True, coarse2fine_type="coarse-gated", coarse_chl=list(c["coarse_chl"]),
-                               fine_chl=list(c["fine_chl"]), fine_chl_after_coarse2fine=list(c["fine_chl_after"]),
-                               temp_chl=list(c["temp_chl"]), dec_chl=list(c["dec_chl"])).eval()
-    missing = m.load_state_dict(sd, strict=True)
-    print("  strict load ok:", missing)
-    res = {}
-    for tag in ("same", "resized"):
-        inp = c["make_inputs"](tag)
-        ref = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]],
-                pred1=inp["pred1"], pred2=inp["pred2"], update_base=inp["pred1"])
-        ora = o_fusion.bidirectional_fusion(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"],
-                                            update_base=inp["pred1"])
-        print(f"  {tag}: out range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
-        assert maxdiff(ref, ora) < 2e-4
-        res[tag] = ref
-    save("bidir_fusion", **res)
+    # 'coarse-gated' = every released V2 config; 'coarse-fusion' / 'self-agg' = the C2FModule ablations (:355-372)
+    for c2f_type, name in (("coarse-gated", "bidir_fusion"), ("coarse-fusion", "bidir_fusion_coarse_fusion"),
+                           ("self-agg", "bidir_fusion_self_agg")):
+        spec = W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"],
+                                   coarse2fine_type=c2f_type)
+        sd = W.synth_state_dict(spec, seed=c["seed"])
+        m = bm.BiDirectionalFusion(coarse2fine=True, coarse2fine_type=c2f_type, coarse_chl=list(c["coarse_chl"]),
+                                   fine_chl=list(c["fine_chl"]), fine_chl_after_coarse2fine=list(c["fine_chl_after"]),
+                                   temp_chl=list(c["temp_chl"]), dec_chl=list(c["dec_chl"])).eval()
+        missing = m.load_state_dict(sd, strict=True)
+        print(f"  {c2f_type}: strict load ok:", missing)
+        res = {}
+        for tag in ("same", "resized"):
+            inp = c["make_inputs"](tag)
+            ref = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]],
+                    pred1=inp["pred1"], pred2=inp["pred2"], update_base=inp["pred1"])
+            ora = o_fusion.bidirectional_fusion(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"],
+                                                update_base=inp["pred1"], coarse2fine_type=c2f_type)
+            print(f"  {c2f_type}/{tag}: out range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
+            assert maxdiff(ref, ora) < 2e-4
+            res[tag] = ref
+        save(name, **res)
 
 
 def g_tiling():

@@ -2,7 +2,7 @@
 
 Host-side mirrors of
   FusionUnet           estimator/models/blocks/fusion_model.py:53-122
-  BiDirectionalFusion  estimator/models/blocks/bi_directional_fusion_model.py:290-446 ('coarse-gated')
+  BiDirectionalFusion  estimator/models/blocks/bi_directional_fusion_model.py:290-446 ('coarse-gated' | 'coarse-fusion' | 'self-agg')
   C2FModule / GatedFusionBlock / GatedConvUnit   ...bi_directional_fusion_model.py:26-208
 with the reference constructor arguments and state-dict names.
 
@@ -305,16 +305,22 @@ class BiDirectionalFusion(_EncDec):
                  fine_chl_after_coarse2fine=(32, 256, 256, 256, 256, 256), temp_chl=(32, 64, 64, 128, 256, 512),
                  dec_chl=(512, 256, 128, 64, 32), glb_att=False, device="cuda", prec="f32", **_unused):
         super().__init__()
-        if not coarse2fine or coarse2fine_type != "coarse-gated" or glb_att:
-            raise NotImplementedError("only coarse2fine_type='coarse-gated', glb_att=False is on the hot path "
-                                      "(every V2 config in configs/patchrefinerv2_*)")
+        if not coarse2fine or coarse2fine_type not in W.C2F_TYPES or glb_att:
+            raise NotImplementedError("coarse2fine_type in ('coarse-gated', 'coarse-fusion', 'self-agg') with glb_att=False is built: "
+                                      "'coarse-gated' is every released V2 config, the other two are the C2FModule ablations "
+                                      "(bi_directional_fusion_model.py:355-372); 'only-gate' (C2FNOENCModule) is not")
+        # (fusion, gate) of every GatedConvUnit (:149-176): 'coarse-fusion' hands on the fusion_conv output itself (:79-80),
+        # 'self-agg' has no fusion_conv and never looks at the coarse pyramid inside the c2f module
+        self.coarse2fine_type = coarse2fine_type
+        self.c2f_fusion, self.c2f_gate = W.C2F_TYPES[coarse2fine_type]
         self.device = torch.device(device)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
         self.encoder_name = encoder_name
         self.glb_att = False
         self.coarse_chl, self.fine_chl = list(coarse_chl), list(fine_chl)
         self._init_encdec([c + f for c, f in zip(coarse_chl, fine_chl_after_coarse2fine)], temp_chl, dec_chl)
-        self._spec = W.bidir_fusion_spec("", coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl)
+        self._spec = W.bidir_fusion_spec("", coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
+                                         coarse2fine_type=coarse2fine_type)
         self._packed = None
 
     def _pack(self):
@@ -325,11 +331,13 @@ class BiDirectionalFusion(_EncDec):
         P["rn"] = [self._conv(f"{s}layer{i + 1}_rn") for i in range(5)]
 
         def unit(b):
+            if not self.c2f_fusion:
+                return dict(conv=self._conv(b + "conv"))
             u = dict(conv=self._conv(b + "conv"), f0=self._conv(b + "fusion_conv.0"),
                      lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
                      f3=self._conv(b + "fusion_conv.3"))
             w3 = self._sd[b + "fusion_conv.3.weight"]
-            if self.prec != ops.PREC_F32 and w3.shape[0] == w3.shape[1] and w3.shape[0] in ops.GATE_CHANNELS:  # fused tail kernel (ops.conv3x3_ln_gate)
+            if self.c2f_gate and self.prec != ops.PREC_F32 and w3.shape[0] == w3.shape[1] and w3.shape[0] in ops.GATE_CHANNELS:  # fused tail kernel (ops.conv3x3_ln_gate)
                 u["f3g"] = ops.pack_gate(w3.to(self.device))
                 w0 = self._sd[b + "fusion_conv.0.weight"]
                 F_ = w3.shape[0]
@@ -387,10 +395,19 @@ class BiDirectionalFusion(_EncDec):
                                    pre_cin=F_)
 
     @staticmethod
-    def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None) -> Feat:
+    def _plain_unit(u, x: Feat, res: Optional[Feat] = None) -> Feat:
+        """GatedConvUnit(fusion=False).forward ('self-agg', :65-70): conv(relu(x)) + x, plus the block's ``xs[0]`` (:127) when given."""
+        return ops.conv2d(x, u["conv"], relu_in=True, res=x if res is None else ops.add(x, res))
+
+    @staticmethod
+    def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None, gate: bool = True) -> Feat:
         """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
-        half already holds the coarse feature; the lower half receives ``out``."""
+        half already holds the coarse feature; the lower half receives ``out``.  ``gate=False`` ('coarse-fusion', :79-80): the
+        fusion_conv output is the unit's output."""
         out = ops.conv2d(x, u["conv"], cat.slice(0, F_), relu_in=True, res=x)            # conv(relu(x)) + x
+        if not gate:
+            fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))   # conv -> LN -> ReLU (:47-50)
+            return ops.conv2d(fused, u["f3"], res=res)                                   # the 1x1 (:51) (+ xs[0], :127)
         if "f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]):                  # the whole fusion_conv + gate in one kernel
             return ops.conv3x3_ln_gate(cat, u["f0"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res)
         fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
@@ -421,6 +438,12 @@ class BiDirectionalFusion(_EncDec):
                                                ops.conv2d_ups_supported(ops.UpsOnly(y, size[0], size[1]), y, defer_upsample)):
                 return y
             return ops.upsample_bilinear(y, size[0], size[1], out=dest)
+        if not self.c2f_fusion:  # 'self-agg': the coarse pyramid is not read here
+            out = xs[0]
+            if len(xs) == 2:
+                out = self._plain_unit(blk["u1"], xs[1], res=xs[0])
+            out = self._plain_unit(blk["u2"], out)
+            return self._block_tail(blk, out, size, upscale, dest, skip_out_conv, defer_upsample)
         cat = Feat.alloc(ref.n, ref.h, ref.w, 2 * F_, ref.device)
         # The concat [out | coarse ROI] is read by the fused gate kernel only (as its conv input and, first half, as ``mul``): when
         # every writer can produce it -- the ROI gather and the 256-column conv of GatedConvUnit.conv -- it is kept in the kernel's
@@ -432,8 +455,13 @@ class BiDirectionalFusion(_EncDec):
         place(coarse, cat.slice(F_, F_))
         out = xs[0]
         if len(xs) == 2:
-            out = self._gated_unit(blk["u1"], xs[1], cat, F_, res=xs[0])
-        out = self._gated_unit(blk["u2"], out, cat, F_)
+            out = self._gated_unit(blk["u1"], xs[1], cat, F_, res=xs[0], gate=self.c2f_gate)
+        out = self._gated_unit(blk["u2"], out, cat, F_, gate=self.c2f_gate)
+        return self._block_tail(blk, out, size, upscale, dest, skip_out_conv, defer_upsample)
+
+    @staticmethod
+    def _block_tail(blk, out: Feat, size, upscale, dest, skip_out_conv, defer_upsample) -> Feat:
+        """The end of GatedFusionBlock.forward (:131-144): interpolate + out_conv, as out_conv + interpolate."""
         if upscale:
             y = out if skip_out_conv else ops.conv2d(out, blk["out_conv"])  # (skip: folded into the consumer's weights, _pack)
             if defer_upsample is not None and (ops.upconv3x3_supported(y, size[0], size[1], defer_upsample) or

@@ -302,9 +302,11 @@ def fusion_unet_spec(prefix: str, input_chl, temp_chl, dec_chl) -> Spec:
     return s
 
 
-def _gated_unit_spec(s: Spec, b: str, F_: int):
+def _gated_unit_spec(s: Spec, b: str, F_: int, fusion: bool = True):
     s[b + "conv.weight"] = (F_, F_, 3, 3)
     s[b + "conv.bias"] = (F_,)
+    if not fusion:  # 'self-agg': GatedConvUnit(fusion=False) has no fusion_conv (bi_directional_fusion_model.py:45-51)
+        return
     s[b + "fusion_conv.0.weight"] = (F_, 2 * F_, 3, 3)
     s[b + "fusion_conv.0.bias"] = (F_,)
     s[b + "fusion_conv.1.weight"] = (F_,)
@@ -312,16 +314,21 @@ def _gated_unit_spec(s: Spec, b: str, F_: int):
     s[b + "fusion_conv.3.weight"] = (F_, F_, 1, 1)
 
 
-def _gated_block_spec(s: Spec, b: str, F_: int):
+def _gated_block_spec(s: Spec, b: str, F_: int, fusion: bool = True):
     s[b + "out_conv.weight"] = (F_, F_, 1, 1)
     s[b + "out_conv.bias"] = (F_,)
-    _gated_unit_spec(s, b + "GateresConfUnit1.", F_)
-    _gated_unit_spec(s, b + "GateresConfUnit2.", F_)
+    _gated_unit_spec(s, b + "GateresConfUnit1.", F_, fusion)
+    _gated_unit_spec(s, b + "GateresConfUnit2.", F_, fusion)
+
+
+C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self-agg": (False, False)}  # -> (fusion, gate)
 
 
 def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
-                      features: int = 256) -> Spec:
-    """BiDirectionalFusion(coarse2fine_type='coarse-gated') parameter table."""
+                      features: int = 256, coarse2fine_type: str = "coarse-gated") -> Spec:
+    """BiDirectionalFusion parameter table for the C2FModule types (bi_directional_fusion_model.py:355-372): 'coarse-gated' and
+    'coarse-fusion' hold the same parameters, 'self-agg' drops every fusion_conv."""
+    fusion = C2F_TYPES[coarse2fine_type][0]
     s: Spec = OrderedDict()
     for l, (cc, fc, tc) in enumerate(zip(coarse_chl, fine_chl_after_coarse2fine, temp_chl)):
         s[f"{prefix}fusion_layers_1.{l}.single_conv.0.weight"] = (tc, cc + fc, 3, 3)
@@ -343,13 +350,13 @@ def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2f
     for i in range(5):
         s[f"{c}layer{i + 1}_rn.weight"] = (features, fine_chl[i], 3, 3)
     for r in range(1, 6):
-        _gated_block_spec(s, f"{c}refinenet{r}.", features)
+        _gated_block_spec(s, f"{c}refinenet{r}.", features, fusion)
     h2 = coarse_chl[0]
     s[c + "output_conv1.weight"] = (features // 2, features, 3, 3)
     s[c + "output_conv1.bias"] = (features // 2,)
     s[c + "output_conv2.0.weight"] = (h2, features // 2, 3, 3)
     s[c + "output_conv2.0.bias"] = (h2,)
-    _gated_block_spec(s, c + "output_conv2_fusion.", h2)
+    _gated_block_spec(s, c + "output_conv2_fusion.", h2, fusion)
     s[c + "output_conv3.0.weight"] = (1, h2, 1, 1)
     s[c + "output_conv3.0.bias"] = (1,)
     return s

@@ -140,6 +140,28 @@ def test_bidir_fusion(P, golden):
         close(out, g[tag], 3e-5, tag)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("c2f_type,name", [("coarse-fusion", "bidir_fusion_coarse_fusion"), ("self-agg", "bidir_fusion_self_agg")])
+def test_bidir_fusion_c2f_ablation_types(P, golden, c2f_type, name, prec):
+    """coarse2fine_type 'coarse-fusion' (the fusion_conv output replaces the gated product) and 'self-agg' (no fusion_conv, the coarse
+    pyramid only enters at fusion_layers_1) against the reference's outputs (tests/golden, oracle/make_golden.py g_bidir)"""
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    c = TINY_BIDIR
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"],
+                                                coarse2fine_type=c2f_type), seed=c["seed"])
+    m = BiDirectionalFusion(coarse2fine_type=c2f_type, coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                            fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec=prec)
+    m.load_state_dict(sd)
+    g = golden(name)
+    for tag in ("same", "resized"):
+        i = c["make_inputs"](tag)
+        f = lambda ts: [P.Feat.from_nchw(t.to(DEV)) for t in ts]  # noqa: E731
+        ff = f(i["f_feat"])
+        out = m(f(i["c_feat"]), [None] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV),
+                f_sizes=[(t.shape[-2], t.shape[-1]) for t in i["f_feat"]])
+        close(out, g[tag], 3e-5, f"{c2f_type}/{prec}/{tag}")
+
+
 def test_bidir_fusion_x2_format_is_bit_identical(P):
     """BiDirectionalFusion with the GatedConvUnits' concat buffers in the pre-split X2 operand format (default when the coarse
     pyramid arrives as ROI sources at the refiner's sizes) == the same network on fp32 buffers (PRV2_X2=0), bit for bit"""

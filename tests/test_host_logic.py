@@ -176,7 +176,7 @@ def test_output_stage_matches_reference():
         M.get_boundaries(gt.squeeze().numpy(), dilation=3)
 
 
-REFERENCE_CONFIG_FLOOR = 48  # raised as components land; see the printed table (the 19 PatchRefinerSemi configs are a training wrapper: SURVEY.md 2 #14, out of scope)
+REFERENCE_CONFIG_FLOOR = 50  # raised as components land; see the printed table (the 19 PatchRefinerSemi configs are a training wrapper: SURVEY.md 2 #14, out of scope)
 
 
 def test_reference_model_configs_build_through_the_registry():
@@ -351,3 +351,18 @@ def test_composite_5x5_of_the_two_linear_convs_behind_the_upsample():
         assert r["err"] < 1e-12 * max(1.0, r["scale"]), r
         assert r["ring_pixels"] == 2 * (2 * h + 2 * w) - 4 and r["bias_vectors"] == 9 and r["err_without_ring_fix"] > 1e-3, r
     assert 25 * 256 * 32 < 9 * 256 * 128 + 9 * 128 * 32   # the real layer pair: 204.8 k against 331.8 k MACs per output pixel
+
+
+def test_bidir_fusion_c2f_types_spec_and_refusal():
+    """The parameter tables of the three C2FModule types built here (bi_directional_fusion_model.py:355-372) and the loud refusal of
+    the fourth ('only-gate', C2FNOENCModule)"""
+    from patchrefinerv2_amd import weights as W
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    a = (list((32, 256, 256, 256, 256, 256)), [32, 32, 64, 96, 960], [32, 256, 256, 256, 256, 256], [32, 64, 64, 128, 256, 512],
+         [512, 256, 128, 64, 32])
+    gated = W.bidir_fusion_spec("", *a)
+    assert gated == W.bidir_fusion_spec("", *a, coarse2fine_type="coarse-fusion")
+    plain = W.bidir_fusion_spec("", *a, coarse2fine_type="self-agg")
+    assert {k for k in gated if k not in plain} == {k for k in gated if ".fusion_conv." in k} and len(plain) == len(gated) - 12 * 5
+    with pytest.raises(NotImplementedError, match="only-gate"):
+        BiDirectionalFusion(coarse2fine_type="only-gate", device="cpu")
