@@ -68,6 +68,19 @@ TINY_BIDIR = dict(coarse_chl=[32, 256, 256, 256, 256, 256], fine_chl=[32, 32, 64
                   dec_chl=[512, 256, 128, 64, 32], seed=31, make_inputs=_bd_inputs)
 
 
+# BiDirectionalFusion(coarse2fine=False) -- the "base" ablations (configs/patchrefinerv2_zoedepth_ablation/plus_*_u4k_base_coarse.py): the
+# refiner pyramid enters fusion_layers_1 directly; level 0 is the x2 bilinear copy of level 1 (lightweight_refiner.py:314-316), pred2 zeros
+def _bd_noc2f_inputs(tag):
+    import torch.nn.functional as F
+    i = _bd_inputs(tag)
+    f = i["f_feat"]
+    f[0] = F.interpolate(f[1], scale_factor=2, mode="bilinear", align_corners=True)
+    return i
+
+
+TINY_BIDIR_NOC2F = dict(TINY_BIDIR, fine_chl_after=[32, 32, 32, 64, 96, 960], make_inputs=_bd_noc2f_inputs)
+
+
 # -- end-to-end V1: PatchRefiner(DA2 tiny x2 + FusionUnet), 216x384 frame, 2x2 -------------------
 _E2E_DA2 = dict(encoder="vits", features=32, out_channels=[16, 32, 64, 64],
                 vit=dict(dim=128, depth=4, heads=2, taps=[0, 1, 2, 3], img_size=70))

@@ -116,16 +116,17 @@ def c2f_module(sd, p, fine, coarse, fusion=True, gate=True):
     return [rn[4], path5, path4, path3, path2, last], out
 
 
-def bidirectional_fusion(sd, p, c_feat, f_feat, pred1, pred2, update_base=None, coarse2fine_type="coarse-gated"):
+def bidirectional_fusion(sd, p, c_feat, f_feat, pred1, pred2, update_base=None, coarse2fine_type="coarse-gated", coarse2fine=True):
     """BiDirectionalFusion.forward, coarse2fine_type in C2F_TYPES, glb_att=False
     (bi_directional_fusion_model.py:379-446).  c_feat: 6 maps high -> low; f_feat: 6 maps
     high -> low (index 0 = the 2x-upsampled copy that is dropped at :408)."""
     c_feat = list(c_feat)
     if c_feat[-1].shape[-2:] != f_feat[-1].shape[-2:]:
         c_feat = [bilinear_ac(c, f.shape[-2:]) for c, f in zip(c_feat, f_feat)]
-    f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat, *C2F_TYPES[coarse2fine_type])
-    f_feat, pred2 = f_feat[::-1], out_depth
-    if TRACE is not None:
-        TRACE["c2f_depth"], TRACE["c2f_last"] = out_depth, f_feat[0]
+    if coarse2fine:  # (:407-414; without it all six refiner maps and the caller's pred2 go on)
+        f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat, *C2F_TYPES[coarse2fine_type])
+        f_feat, pred2 = f_feat[::-1], out_depth
+        if TRACE is not None:
+            TRACE["c2f_depth"], TRACE["c2f_last"] = out_depth, f_feat[0]
     return _encode_decode(sd, p, "fusion_layers_1", "fusion_layers_2", "f2r_agg",
                           c_feat, f_feat, pred1, pred2, update_base)

@@ -26,7 +26,7 @@ refharness.install()
 
 from oracle import dav2 as o_dav2, fusion as o_fusion, mnv4 as o_mnv4, ops as o_ops, tiling as o_tiling  # noqa: E402
 from oracle import zoe as o_zoe  # noqa: E402
-from oracle.cases import (TINY_DAV2, TINY_FUSION_UNET, TINY_BIDIR, E2E_V1, E2E_V2, E2E_V2Z, rand_image, tiny_dav2_sd,  # noqa: E402
+from oracle.cases import (TINY_DAV2, TINY_FUSION_UNET, TINY_BIDIR, TINY_BIDIR_NOC2F, E2E_V1, E2E_V2, E2E_V2Z, rand_image, tiny_dav2_sd,  # noqa: E402
                           e2e_v1_sd, e2e_v2_sd, e2e_v2z_sd)
 from patchrefinerv2_amd import weights as W  # noqa: E402
 
@@ -176,6 +176,25 @@ def g_bidir():
             assert maxdiff(ref, ora) < 2e-4
             res[tag] = ref
         save(name, **res)
+    # coarse2fine=False: no c2f module, six refiner maps (level 0 = the x2 copy of level 1) and the caller's pred2 (zeros)
+    c = TINY_BIDIR_NOC2F
+    spec = W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"], coarse2fine=False)
+    sd = W.synth_state_dict(spec, seed=c["seed"])
+    m = bm.BiDirectionalFusion(coarse2fine=False, coarse2fine_type="coarse-gated", coarse_chl=list(c["coarse_chl"]),
+                               fine_chl=list(c["fine_chl"]), fine_chl_after_coarse2fine=list(c["fine_chl_after"]),
+                               temp_chl=list(c["temp_chl"]), dec_chl=list(c["dec_chl"])).eval()
+    print("  coarse2fine=False: strict load ok:", m.load_state_dict(sd, strict=True))
+    res = {}
+    for tag in ("same", "resized"):
+        inp = c["make_inputs"](tag)
+        ref = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]],
+                pred1=inp["pred1"], pred2=inp["pred2"], update_base=inp["pred1"])
+        ora = o_fusion.bidirectional_fusion(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"],
+                                            update_base=inp["pred1"], coarse2fine=False)
+        print(f"  coarse2fine=False/{tag}: out range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
+        assert maxdiff(ref, ora) < 2e-4
+        res[tag] = ref
+    save("bidir_fusion_no_c2f", **res)
 
 
 def g_tiling():

@@ -127,13 +127,14 @@ def mnv4_features(sd, p, x):
     return feats
 
 
-def lightweight_refiner(sd, p, crop_image, coarse_depth):
+def lightweight_refiner(sd, p, crop_image, coarse_depth, coarse_condition=True):
     """Returns the reference's ``refiner_features[::-1]`` (low -> high resolution, the 2x-upsampled copy of map 0
-    LAST) and out_depth = 0 (lightweight_refiner.py:285-322)."""
+    LAST) and out_depth = 0 (lightweight_refiner.py:285-322).  ``coarse_condition=False`` (:298-299): the encoder sees the image only
+    (a 3-channel stem: no stem surgery at patchrefinerplus.py:144)."""
     mean = torch.tensor(MEAN, dtype=crop_image.dtype).view(-1, 1, 1)
     std = torch.tensor(STD, dtype=crop_image.dtype).view(-1, 1, 1)
     x = (crop_image - mean) / std
-    feats = mnv4_features(sd, p + "refiner_encoder.", torch.cat([x, coarse_depth], dim=1))
+    feats = mnv4_features(sd, p + "refiner_encoder.", torch.cat([x, coarse_depth], dim=1) if coarse_condition else x)
     hi = feats[0]
     up = bilinear_ac(hi, (hi.shape[-2] * 2, hi.shape[-1] * 2))  # scale_factor=2 (lightweight_refiner.py:316)
     feats = [up] + feats

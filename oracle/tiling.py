@@ -288,8 +288,10 @@ class OraclePatchRefinerPlus(OracleRefiner):
     """V2: DA2 coarse + LightWeightRefiner(MNv4-S) + BiDirectionalFusion
     (configs/patchrefinerv2_dav2/plus_mobile_u4k_base_coarse_e2e_c2f_pretrain.py)."""
 
-    def __init__(self, sd, coarse_cfg, coarse_fn=None, convnext_arch=None, effnet_arch=None, **kw):
+    def __init__(self, sd, coarse_cfg, coarse_fn=None, convnext_arch=None, effnet_arch=None, fusion_kw=None, coarse_condition=True, **kw):
         super().__init__(sd, **kw)
+        self.coarse_condition = coarse_condition  # LightWeightRefiner(coarse_condition=...) (MNv4 encoder only)
+        self.fusion_kw = fusion_kw or {}    # coarse2fine / coarse2fine_type of the ablation configs (fusion.bidirectional_fusion)
         self.coarse_cfg = coarse_cfg
         self.coarse_fn = coarse_fn
         self.convnext_arch = convnext_arch  # set: the v2_convx_u4k.py variant (ConvNeXt refiner encoder)
@@ -309,10 +311,10 @@ class OraclePatchRefinerPlus(OracleRefiner):
                                                                      post["coarse_depth_roi"], self.convnext_arch)
         else:
             r_feats, r_depth = mnv4.lightweight_refiner(self.sd, "refiner_fine_branch.", imgs_crop,
-                                                        post["coarse_depth_roi"])
+                                                        post["coarse_depth_roi"], self.coarse_condition)
         return fusion.bidirectional_fusion(self.sd, "refiner_fusion_model.", post["coarse_feats_roi"][::-1],
                                            r_feats[::-1], post["coarse_depth_roi"], r_depth,
-                                           update_base=post["coarse_depth_roi"])
+                                           update_base=post["coarse_depth_roi"], **self.fusion_kw)
 
 
 class OracleBaselinePretrain(OracleRefiner):

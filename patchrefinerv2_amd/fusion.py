@@ -305,10 +305,14 @@ class BiDirectionalFusion(_EncDec):
                  fine_chl_after_coarse2fine=(32, 256, 256, 256, 256, 256), temp_chl=(32, 64, 64, 128, 256, 512),
                  dec_chl=(512, 256, 128, 64, 32), glb_att=False, device="cuda", prec="f32", **_unused):
         super().__init__()
-        if not coarse2fine or coarse2fine_type not in W.C2F_TYPES or glb_att:
+        if (coarse2fine and coarse2fine_type not in W.C2F_TYPES) or glb_att:
             raise NotImplementedError("coarse2fine_type in ('coarse-gated', 'coarse-fusion', 'self-agg') with glb_att=False is built: "
                                       "'coarse-gated' is every released V2 config, the other two are the C2FModule ablations "
                                       "(bi_directional_fusion_model.py:355-372); 'only-gate' (C2FNOENCModule) is not")
+        # coarse2fine=False (the "base" ablations): no c2f module -- the six refiner maps enter fusion_layers_1 as they are (:407-426)
+        self.coarse2fine = bool(coarse2fine)
+        if not self.coarse2fine:
+            coarse2fine_type = "coarse-gated"  # (unused by the reference too)
         # (fusion, gate) of every GatedConvUnit (:149-176): 'coarse-fusion' hands on the fusion_conv output itself (:79-80),
         # 'self-agg' has no fusion_conv and never looks at the coarse pyramid inside the c2f module
         self.coarse2fine_type = coarse2fine_type
@@ -320,13 +324,17 @@ class BiDirectionalFusion(_EncDec):
         self.coarse_chl, self.fine_chl = list(coarse_chl), list(fine_chl)
         self._init_encdec([c + f for c, f in zip(coarse_chl, fine_chl_after_coarse2fine)], temp_chl, dec_chl)
         self._spec = W.bidir_fusion_spec("", coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
-                                         coarse2fine_type=coarse2fine_type)
+                                         coarse2fine_type=coarse2fine_type, coarse2fine=self.coarse2fine)
         self._packed = None
 
     def _pack(self):
         if len(self._sd) < len(self._spec):
             return
         P = self._pack_encdec()
+        if not self.coarse2fine:
+            self._pack_enc1_taps(P, self.coarse_chl)
+            self._packed = P
+            return
         s = "c2f.scratch."
         P["rn"] = [self._conv(f"{s}layer{i + 1}_rn") for i in range(5)]
 
@@ -524,9 +532,18 @@ class BiDirectionalFusion(_EncDec):
         cat1 = [None if enc1_taps[l] is not None else Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l], dev) for l in range(6)]
         dests = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l] - c_feat[l].c, dev) if cat1[l] is None else
                  cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]
-        out_depth = self._c2f(P, list(f_feat[1:]), c_feat, dests)
-        if self.trace is not None:
-            self.trace["c2f_depth"], self.trace["c2f_last"] = out_depth.clone(), dests[0].to_nchw()
+        if self.coarse2fine:
+            out_depth = self._c2f(P, list(f_feat[1:]), c_feat, dests)
+            if self.trace is not None:
+                self.trace["c2f_depth"], self.trace["c2f_last"] = out_depth.clone(), dests[0].to_nchw()
+        else:
+            # the refiner's own maps; level 0 = the x2 bilinear copy of level 1 (lightweight_refiner.py:314-316) when handed over as None
+            for l, f in enumerate(f_feat):
+                if f is None:
+                    ops.upsample_bilinear(f_feat[l + 1], f_sizes[l][0], f_sizes[l][1], out=dests[l])
+                else:
+                    place(f, dests[l])
+            out_depth = pred2  # the caller's (zeros: lightweight_refiner.py:320)
 
         def fill(l):
             def fn(cat: Feat):

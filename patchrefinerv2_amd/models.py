@@ -857,10 +857,11 @@ class _PatchModel(StateDictModule):
             sd = sd[key]
         if keep is not None:
             sd = {k: v for k, v in sd.items() if keep(k)}
+        widen = getattr(getattr(module, "refiner_fine_branch", None), "coarse_condition", True)  # (:144: only with coarse_condition)
         for k in list(sd):
             # the reference loads a 3-channel timm stem first and then widens it to 4 input channels with a zero
             # plane (stem surgery, patchrefinerplus.py:144-200): same result, done on the checkpoint
-            if k.endswith(("refiner_encoder.conv_stem.weight", "refiner_encoder.stem_0.weight")) and sd[k].shape[1] == 3:
+            if widen and k.endswith(("refiner_encoder.conv_stem.weight", "refiner_encoder.stem_0.weight")) and sd[k].shape[1] == 3:
                 w = torch.zeros((sd[k].shape[0], 4) + tuple(sd[k].shape[2:]), dtype=sd[k].dtype)
                 w[:, :3] = sd[k]
                 sd[k] = w

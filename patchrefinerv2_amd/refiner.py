@@ -38,11 +38,15 @@ class LightWeightRefiner(StateDictModule):
             raise NotImplementedError(
                 f"refiner encoder '{encoder_name}': built are {sorted(SUPPORTED_ENCODERS)} (the V2 configs' three timm "
                 "encoders; SURVEY.md 8f rank 3)")
-        if with_decoder or not coarse_condition:
-            raise NotImplementedError("with_decoder=True / coarse_condition=False are not used by any V2 config")
+        if with_decoder:
+            raise NotImplementedError("with_decoder=True (SimpleDPTHead on the refiner) is not used by any V2 config")
+        if not coarse_condition and ("convnext" in encoder_name or "efficientnet" in encoder_name):
+            raise NotImplementedError("coarse_condition=False is built for the MobileNetV4 encoder only (the two configs that use it: "
+                                      "patchrefinerv2_zoedepth_ablation/plus_mobile_u4k_base{,_e2e}.py)")
         self.encoder_name = encoder_name
         self.arch = arch or SUPPORTED_ENCODERS[encoder_name]  # ``arch``: reduced dims for the parity tests
-        self.coarse_condition = True
+        # False: the encoder sees the image only (lightweight_refiner.py:298-299; a 3-channel stem, no surgery at patchrefinerplus.py:144)
+        self.coarse_condition = bool(coarse_condition)
         self.device = torch.device(device)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
         self.mean, self.std = self.arch["mean"], self.arch["std"]
@@ -58,8 +62,8 @@ class LightWeightRefiner(StateDictModule):
             self._spec["upsample_convx.0.weight"] = (d0, d0 // 2, 2, 2)
             self._spec["upsample_convx.0.bias"] = (d0 // 2,)
             return
-        self.layers, self.taps = W.mnv4_layers(self.arch, in_chans=4)
-        self._spec = W.mnv4_spec("refiner_encoder.", self.arch, in_chans=4)
+        self.layers, self.taps = W.mnv4_layers(self.arch, in_chans=4 if self.coarse_condition else 3)
+        self._spec = W.mnv4_spec("refiner_encoder.", self.arch, in_chans=4 if self.coarse_condition else 3)
 
     def _pack(self):
         if len(self._sd) < len(self._spec):
@@ -94,7 +98,7 @@ class LightWeightRefiner(StateDictModule):
             return self._forward_convnext(crop)
         if self.effnet:
             return self._forward_effnet(crop)
-        x = crop
+        x = crop if self.coarse_condition else crop.slice(0, 3)  # (the crop buffer always carries the depth ROI as channel 3)
         feats: List[Feat] = []
         skip = None
         for i, (Lr, pk) in enumerate(zip(self.layers, self._packed)):

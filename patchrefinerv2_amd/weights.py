@@ -325,7 +325,7 @@ C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self
 
 
 def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
-                      features: int = 256, coarse2fine_type: str = "coarse-gated") -> Spec:
+                      features: int = 256, coarse2fine_type: str = "coarse-gated", coarse2fine: bool = True) -> Spec:
     """BiDirectionalFusion parameter table for the C2FModule types (bi_directional_fusion_model.py:355-372): 'coarse-gated' and
     'coarse-fusion' hold the same parameters, 'self-agg' drops every fusion_conv."""
     fusion = C2F_TYPES[coarse2fine_type][0]
@@ -346,6 +346,8 @@ def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2f
         ch = dc
     last = dec_chl[-1] if len(dec_chl) else ch
     s[prefix + "final_conv.weight"] = (1, last, 3, 3)
+    if not coarse2fine:  # no c2f module (bi_directional_fusion_model.py:364): the refiner's pyramid goes straight to fusion_layers_1
+        return s
     c = prefix + "c2f.scratch."
     for i in range(5):
         s[f"{c}layer{i + 1}_rn.weight"] = (features, fine_chl[i], 3, 3)

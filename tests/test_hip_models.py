@@ -162,6 +162,28 @@ def test_bidir_fusion_c2f_ablation_types(P, golden, c2f_type, name, prec):
         close(out, g[tag], 3e-5, f"{c2f_type}/{prec}/{tag}")
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_bidir_fusion_without_c2f(P, golden, prec):
+    """BiDirectionalFusion(coarse2fine=False) (configs/patchrefinerv2_zoedepth_ablation/plus_*_u4k_base_coarse.py) against the reference's
+    outputs; level 0 of the refiner pyramid is handed over as None and built here as the x2 copy of level 1 (lightweight_refiner.py:314-316)"""
+    from oracle.cases import TINY_BIDIR_NOC2F as c
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"],
+                                                coarse2fine=False), seed=c["seed"])
+    m = BiDirectionalFusion(coarse2fine=False, coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                            fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec=prec)
+    m.load_state_dict(sd)
+    g = golden("bidir_fusion_no_c2f")
+    for tag in ("same", "resized"):
+        i = c["make_inputs"](tag)
+        f = lambda ts: [P.Feat.from_nchw(t.to(DEV)) for t in ts]  # noqa: E731
+        ff = f(i["f_feat"])
+        sizes = [(t.shape[-2], t.shape[-1]) for t in i["f_feat"]]
+        for first in (None, ff[0]):
+            out = m(f(i["c_feat"]), [first] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV), f_sizes=sizes)
+            close(out, g[tag], 3e-5, f"no c2f/{prec}/{tag}")
+
+
 def test_bidir_fusion_x2_format_is_bit_identical(P):
     """BiDirectionalFusion with the GatedConvUnits' concat buffers in the pre-split X2 operand format (default when the coarse
     pyramid arrives as ROI sources at the refiner's sizes) == the same network on fp32 buffers (PRV2_X2=0), bit for bit"""
@@ -403,6 +425,45 @@ def test_e2e_v2_other_refiner_encoders_vs_oracle(P, enc):
         depth, _ = _run(m, c, mode)
         ar, mx = absrel(depth, ref)
         assert ar < 1e-5 and mx < 1e-3, (mode, ar, mx)
+
+
+@pytest.mark.parametrize("variant", ["coarse-fusion", "self-agg", "no-c2f", "no-c2f-no-condition"])
+def test_e2e_v2_fusion_ablation_variants_vs_oracle(P, variant):
+    """PatchRefinerPlus end to end with the reference's BiDirectionalFusion ablations (configs/patchrefinerv2_zoedepth_ablation/
+    plus_mobile_c2f_wogate.py, plus_mobile_c2f_selfagg.py, plus_mobile_u4k_base_coarse.py): C2FModule without the gate, without the
+    fusion conv, and no c2f module at all (the refiner's six maps, level 0 = the x2 copy, and pred2 = zeros go straight on).  The
+    fusion module of each is pinned against the reference by test_bidir_fusion_c2f_ablation_types / test_bidir_fusion_without_c2f.
+    'no-c2f-no-condition' = plus_mobile_u4k_base.py: additionally LightWeightRefiner(coarse_condition=False), a 3-channel encoder stem."""
+    import copy
+    from collections import OrderedDict
+    c = copy.deepcopy(E2E_V2)
+    cond = variant != "no-c2f-no-condition"
+    variant = variant.replace("-no-condition", "")
+    c["ref_config"]["refiner"]["fine_branch"]["coarse_condition"] = cond
+    kw = dict(coarse2fine=False) if variant == "no-c2f" else dict(coarse2fine_type=variant)
+    f = c["fusion"]
+    if variant == "no-c2f":
+        f["fine_chl_after_coarse2fine"] = [32] + f["fine_chl"]
+    fm = c["ref_config"]["refiner"]["fusion_model"]
+    fm.update(f)
+    fm.update(coarse2fine=variant != "no-c2f", coarse2fine_type="coarse-gated" if variant == "no-c2f" else variant)
+    spec = OrderedDict()
+    spec.update(W.dav2_spec("coarse_branch.", c["da2_cfg"]))
+    spec.update(W.mnv4_spec("refiner_fine_branch.refiner_encoder.", in_chans=4 if cond else 3))
+    spec.update(W.bidir_fusion_spec("refiner_fusion_model.", f["coarse_chl"], f["fine_chl"], f["fine_chl_after_coarse2fine"], f["temp_chl"],
+                                    f["dec_chl"], **kw))
+    sd = W.synth_state_dict(spec, seed=43)
+    m = _build("PatchRefinerPlus", c, sd)
+    ora = o_tiling.OraclePatchRefinerPlus(sd, W.dav2_cfg({**c["da2_cfg"], "max_depth": c["max_depth"]}), fusion_kw=kw, coarse_condition=cond,
+                                          patch_process_shape=c["pps"], image_raw_shape=c["raw"], patch_split_num=c["split"])
+    hr = rand_image(c["seed"], 1, *c["raw"])
+    tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+    for mode in c["modes"]:
+        random.seed(621)
+        ref, _ = ora(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tc, image_lr=ora.resizer(hr), image_hr=hr)
+        depth, _ = _run(m, c, mode)
+        ar, mx = absrel(depth, ref)
+        assert ar < 1e-5 and mx < 1e-3, (variant, mode, ar, mx)
 
 
 def test_save_and_from_pretrained_roundtrip(P, tmp_path):
