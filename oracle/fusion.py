@@ -26,14 +26,23 @@ def ln_cf(x, w, b, eps=1e-6):
 
 
 def single_conv_ln(sd, p, x):
+    """SingleConvCNNLN (convs.py:67-72): conv -> LN -> GELU; with the parameters of SingleConvCNNLNHeavy (BiDirectionalFusionHeavy,
+    bi_directional_fusion_model.py:449-463): conv -> LN -> conv -> LN -> conv -> GELU (no activation behind the LayerNorms)."""
     x = F.conv2d(x, sd[p + "single_conv.0.weight"], None, padding=1)
     x = ln_cf(x, sd[p + "single_conv.1.weight"], sd[p + "single_conv.1.bias"])
+    if p + "single_conv.4.weight" in sd:
+        x = F.conv2d(x, sd[p + "single_conv.2.weight"], None, padding=1)
+        x = ln_cf(x, sd[p + "single_conv.3.weight"], sd[p + "single_conv.3.bias"])
+        x = F.conv2d(x, sd[p + "single_conv.4.weight"], None, padding=1)
     return F.gelu(x)
 
 
 def double_conv(sd, p, x):
-    x = F.gelu(F.conv2d(x, sd[p + "double_conv.0.weight"], None, padding=1))
-    return F.gelu(F.conv2d(x, sd[p + "double_conv.2.weight"], None, padding=1))
+    """DoubleConv (convs.py:31-45): two conv + GELU; DoubleConvHeavy (bi_directional_fusion_model.py:465-485): five."""
+    for i in (0, 2, 4, 6, 8):
+        if p + f"double_conv.{i}.weight" in sd:
+            x = F.gelu(F.conv2d(x, sd[p + f"double_conv.{i}.weight"], None, padding=1))
+    return x
 
 
 def upsample_hardcode(sd, p, x1, x2, pred1, pred2):

@@ -195,6 +195,31 @@ def g_bidir():
         assert maxdiff(ref, ora) < 2e-4
         res[tag] = ref
     save("bidir_fusion_no_c2f", **res)
+    # BiDirectionalFusionHeavy (:519-560), as its three configs use it: coarse2fine=False
+    spec = W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"], coarse2fine=False,
+                               heavy=True)
+    sd = W.synth_state_dict(spec, seed=c["seed"])
+    m = bm.BiDirectionalFusionHeavy(coarse2fine=False, coarse2fine_type="coarse-gated", coarse_chl=list(c["coarse_chl"]),
+                                    fine_chl=list(c["fine_chl"]), fine_chl_after_coarse2fine=list(c["fine_chl_after"]),
+                                    temp_chl=list(c["temp_chl"]), dec_chl=list(c["dec_chl"])).eval()
+    print("  heavy: strict load ok:", m.load_state_dict(sd, strict=True))
+    res = {}
+    for tag in ("same", "resized"):
+        inp = c["make_inputs"](tag)
+        ref = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]],
+                pred1=inp["pred1"], pred2=inp["pred2"], update_base=inp["pred1"])
+        ora = o_fusion.bidirectional_fusion(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"],
+                                            update_base=inp["pred1"], coarse2fine=False)
+        print(f"  heavy/{tag}: out range [{float(ref.min()):.3f},{float(ref.max()):.3f}] oracle-vs-ref max|d| {maxdiff(ref, ora):.2e}")
+        assert maxdiff(ref, ora) < 2e-4
+        res[tag] = ref
+        # the raw offset as well (update_base=None): with these synthetic weights it is ~1e-2 on a base of 0..10, so the sum hides it
+        off = m(c_feat=[t.clone() for t in inp["c_feat"]], f_feat=[t.clone() for t in inp["f_feat"]], pred1=inp["pred1"], pred2=inp["pred2"])
+        ora = o_fusion.bidirectional_fusion(sd, "", inp["c_feat"], inp["f_feat"], inp["pred1"], inp["pred2"], coarse2fine=False)
+        print(f"  heavy/{tag}: offset range [{float(off.min()):.4f},{float(off.max()):.4f}] oracle-vs-ref max|d| {maxdiff(off, ora):.2e}")
+        assert maxdiff(off, ora) < 1e-6
+        res[tag + "_offset"] = off
+    save("bidir_fusion_heavy", **res)
 
 
 def g_tiling():

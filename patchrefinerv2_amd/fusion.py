@@ -71,6 +71,7 @@ class _EncDec(StateDictModule):
     """Shared fine2coarse encoder + decoder of FusionUnet / BiDirectionalFusion."""
 
     ENC1 = ENC2 = DEC = ""
+    HEAVY = False  # BiDirectionalFusionHeavy: three convs per encoder layer, five per decoder stage
     trace = None  # tests set this to a dict: intermediate maps of the last call (c2f_depth, c2f_last, dec_last, offset)
 
     def _init_encdec(self, in_chl: Sequence[int], temp_chl: Sequence[int], dec_chl: Sequence[int]):
@@ -89,9 +90,14 @@ class _EncDec(StateDictModule):
             for e in (self.ENC1, self.ENC2):
                 P[f"{e}.{l}"] = (self._conv(f"{e}.{l}.single_conv.0"), self._dev(f"{e}.{l}.single_conv.1.weight"),
                                  self._dev(f"{e}.{l}.single_conv.1.bias"))
+                if self.HEAVY:  # SingleConvCNNLNHeavy (bi_directional_fusion_model.py:449-463): ... -> conv -> LN -> conv -> GELU
+                    P[f"{e}.{l}.heavy"] = (self._conv(f"{e}.{l}.single_conv.2"), self._dev(f"{e}.{l}.single_conv.3.weight"),
+                                           self._dev(f"{e}.{l}.single_conv.3.bias"), self._conv(f"{e}.{l}.single_conv.4"))
         for j, (c1, c2, _) in enumerate(self.dec_in):
             P[f"{self.DEC}.{j}"] = (self._conv(f"{self.DEC}.{j}.conv.double_conv.0"),
-                                    self._conv(f"{self.DEC}.{j}.conv.double_conv.2"))
+                                    self._conv(f"{self.DEC}.{j}.conv.double_conv.{8 if self.HEAVY else 2}"))
+            if self.HEAVY:  # DoubleConvHeavy (:465-485): three more n -> n convs in between
+                P[f"{self.DEC}.{j}.mid"] = [self._conv(f"{self.DEC}.{j}.conv.double_conv.{i}") for i in (2, 4, 6)]
             # UpSample.forward_hardcode (fusion_model.py:15-24): double_conv.0 over cat([interpolate(x1), x2, pred1, pred2]) is linear in
             # its input, so it splits by weight columns: the interpolated x1 part runs as tap GEMMs at x1's resolution (ops.upconv3x3),
             # the rest as an ordinary conv whose raw output is that kernel's pre-activation addend.  Worth it from 256 upsampled
@@ -109,7 +115,7 @@ class _EncDec(StateDictModule):
         ``extra[l]``: further consumers of the level's coarse map [(name, tap weights)] that share the level's GEMM.
         P["taps"][l] = (packed [sum 9 * cout, c_l] weights, [(consumer name, cout), ...]).  bf16 modes only."""
         P["taps"] = {}
-        if self.prec == ops.PREC_F32:
+        if self.prec == ops.PREC_F32 or self.HEAVY:  # (heavy: the first conv's LayerNorm has no activation behind it -- general kernels)
             return
         for l in range(len(self.temp_chl)):
             rows = list(extra[l]) if extra is not None else []
@@ -183,9 +189,15 @@ class _EncDec(StateDictModule):
         temps = [None] * L_
         dec_tail_done = [False] * nd  # decoder concat buffers whose [pred1 | pred2] tail the conv that fills x2 has written
 
-        def conv_ln_gelu(x, conv, lnw, lnb, dst, tail_c0=None, buf=None):
+        def conv_ln_gelu(x, conv, lnw, lnb, dst, tail_c0=None, buf=None, heavy=None):
             """conv -> LN -> GELU (convs.py:67-72) into ``dst``; when dst's row ends in the [pred1 | pred2] tail and the library fuses
             it, the same launch writes the tail (ops.conv2d_tail); returns whether it did"""
+            if heavy is not None:  # conv -> LN -> conv -> LN -> conv -> GELU (SingleConvCNNLNHeavy)
+                conv2, lnw2, lnb2, conv3 = heavy
+                t = ops.conv2d(x, conv, ln=(lnw, lnb))
+                t = ops.conv2d(t, conv2, ln=(lnw2, lnb2))
+                ops.conv2d(t, conv3, dst, act=ACT_GELU)
+                return False
             if tail_c0 is not None and _fused_tail(tail_c0) and ops.conv2d_tail_supported(x, conv, dst):
                 ops.conv2d_tail(x, conv, dst, pred1, pred2, act=ACT_GELU, ln=(lnw, lnb))
                 return True
@@ -208,7 +220,7 @@ class _EncDec(StateDictModule):
             else:
                 cat1 = cat1_bufs[l] if cat1_bufs is not None else Feat.alloc(B, h, w, self.in_chl[l], dev)
                 pairs[l](cat1)
-                if not conv_ln_gelu(cat1, conv, lnw, lnb, cat2.slice(0, tc), tail_c0=tc):
+                if not conv_ln_gelu(cat1, conv, lnw, lnb, cat2.slice(0, tc), tail_c0=tc, heavy=P.get(f"{self.ENC1}.{l}.heavy")):
                     place_preds(pred1, pred2, cat2, tc)
             conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
             j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
@@ -216,10 +228,10 @@ class _EncDec(StateDictModule):
                 c1, c2, _ = self.dec_in[j]
                 assert c2 == tc
                 dst = dec_bufs[j].slice(c1, c2)
-                dec_tail_done[j] = conv_ln_gelu(cat2, conv, lnw, lnb, dst, tail_c0=c1 + c2)
+                dec_tail_done[j] = conv_ln_gelu(cat2, conv, lnw, lnb, dst, tail_c0=c1 + c2, heavy=P.get(f"{self.ENC2}.{l}.heavy"))
             else:
                 dst = Feat.alloc(B, h, w, tc, dev)
-                ops.conv2d(cat2, conv, dst, act=ACT_GELU, ln=(lnw, lnb))
+                conv_ln_gelu(cat2, conv, lnw, lnb, dst, heavy=P.get(f"{self.ENC2}.{l}.heavy"))
             temps[l] = dst
         feat = temps[L_ - 1] if nd > 0 else temps[0]
         for j, (c1, c2, dc) in enumerate(self.dec_in):
@@ -239,6 +251,8 @@ class _EncDec(StateDictModule):
             else:
                 place(feat, buf.slice(0, c1))
                 t = ops.conv2d(buf, c0w, act=ACT_GELU)
+            for cm in P.get(f"{self.DEC}.{j}.mid", ()):
+                t = ops.conv2d(t, cm, act=ACT_GELU)
             feat = ops.conv2d(t, c2w, act=ACT_GELU)
         if self.trace is not None:  # tests: the last decoder stage, as the oracle sees it
             self.trace["dec_last"] = feat.to_nchw()
@@ -324,7 +338,7 @@ class BiDirectionalFusion(_EncDec):
         self.coarse_chl, self.fine_chl = list(coarse_chl), list(fine_chl)
         self._init_encdec([c + f for c, f in zip(coarse_chl, fine_chl_after_coarse2fine)], temp_chl, dec_chl)
         self._spec = W.bidir_fusion_spec("", coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
-                                         coarse2fine_type=coarse2fine_type, coarse2fine=self.coarse2fine)
+                                         coarse2fine_type=coarse2fine_type, coarse2fine=self.coarse2fine, heavy=self.HEAVY)
         self._packed = None
 
     def _pack(self):
@@ -554,3 +568,10 @@ class BiDirectionalFusion(_EncDec):
                                    update_base, out=out, cat1_bufs=cat1, enc1_taps=[None if t is None else (t[0], t[1], dests[l]) for l, t in enumerate(enc1_taps)])
 
     __call__ = forward
+
+
+class BiDirectionalFusionHeavy(BiDirectionalFusion):
+    """bi_directional_fusion_model.py:518-560: BiDirectionalFusion with SingleConvCNNLNHeavy encoder layers (conv -> LN -> conv -> LN ->
+    conv -> GELU) and DoubleConvHeavy decoder stages (five conv + GELU); the forward is the same (:598-668).  Three ablation configs
+    (patchrefinerv2_zoedepth_ablation/plus_*_u4k_base_coarse_heavy.py), all with coarse2fine=False; general conv kernels, not tuned."""
+    HEAVY = True

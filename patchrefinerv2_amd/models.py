@@ -25,13 +25,14 @@ import torch
 
 from . import ops
 from .dav2 import DepthAnythingV2, IMAGENET_MEAN, IMAGENET_STD, StateDictModule
-from .fusion import BiDirectionalFusion, FusionUnet
+from .fusion import BiDirectionalFusion, BiDirectionalFusionHeavy, FusionUnet
 from .ops import Feat
 from .refiner import LightWeightRefiner
 from .registry import MODELS, ConfigDict, build_model
 
 MODELS.register_module(module=FusionUnet)
 MODELS.register_module(module=BiDirectionalFusion)
+MODELS.register_module(module=BiDirectionalFusionHeavy)
 MODELS.register_module(module=LightWeightRefiner)
 
 

@@ -325,24 +325,35 @@ C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self
 
 
 def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
-                      features: int = 256, coarse2fine_type: str = "coarse-gated", coarse2fine: bool = True) -> Spec:
+                      features: int = 256, coarse2fine_type: str = "coarse-gated", coarse2fine: bool = True, heavy: bool = False) -> Spec:
     """BiDirectionalFusion parameter table for the C2FModule types (bi_directional_fusion_model.py:355-372): 'coarse-gated' and
-    'coarse-fusion' hold the same parameters, 'self-agg' drops every fusion_conv."""
+    'coarse-fusion' hold the same parameters, 'self-agg' drops every fusion_conv.  ``heavy``: BiDirectionalFusionHeavy (:519-560) --
+    three convs per encoder layer (SingleConvCNNLNHeavy, :449-463) and five per decoder stage (DoubleConvHeavy, :465-485)."""
     fusion = C2F_TYPES[coarse2fine_type][0]
     s: Spec = OrderedDict()
+
+    def enc(b, cin, tc):
+        s[b + "single_conv.0.weight"] = (tc, cin, 3, 3)
+        s[b + "single_conv.1.weight"] = (tc,)
+        s[b + "single_conv.1.bias"] = (tc,)
+        if heavy:
+            s[b + "single_conv.2.weight"] = (tc, tc, 3, 3)
+            s[b + "single_conv.3.weight"] = (tc,)
+            s[b + "single_conv.3.bias"] = (tc,)
+            s[b + "single_conv.4.weight"] = (tc, tc, 3, 3)
+
     for l, (cc, fc, tc) in enumerate(zip(coarse_chl, fine_chl_after_coarse2fine, temp_chl)):
-        s[f"{prefix}fusion_layers_1.{l}.single_conv.0.weight"] = (tc, cc + fc, 3, 3)
-        s[f"{prefix}fusion_layers_1.{l}.single_conv.1.weight"] = (tc,)
-        s[f"{prefix}fusion_layers_1.{l}.single_conv.1.bias"] = (tc,)
-        s[f"{prefix}fusion_layers_2.{l}.single_conv.0.weight"] = (tc, tc + 2, 3, 3)
-        s[f"{prefix}fusion_layers_2.{l}.single_conv.1.weight"] = (tc,)
-        s[f"{prefix}fusion_layers_2.{l}.single_conv.1.bias"] = (tc,)
+        enc(f"{prefix}fusion_layers_1.{l}.", cc + fc, tc)
+        enc(f"{prefix}fusion_layers_2.{l}.", tc + 2, tc)
     t = list(temp_chl)[::-1]
     ch = t[0]
     for j, (tc, dc) in enumerate(zip(t[1:], dec_chl)):
         n = tc + ch + 2
         s[f"{prefix}f2r_agg.{j}.conv.double_conv.0.weight"] = (n, n, 3, 3)
-        s[f"{prefix}f2r_agg.{j}.conv.double_conv.2.weight"] = (dc, n, 3, 3)
+        if heavy:
+            for i in (2, 4, 6):
+                s[f"{prefix}f2r_agg.{j}.conv.double_conv.{i}.weight"] = (n, n, 3, 3)
+        s[f"{prefix}f2r_agg.{j}.conv.double_conv.{8 if heavy else 2}.weight"] = (dc, n, 3, 3)
         ch = dc
     last = dec_chl[-1] if len(dec_chl) else ch
     s[prefix + "final_conv.weight"] = (1, last, 3, 3)

@@ -184,6 +184,31 @@ def test_bidir_fusion_without_c2f(P, golden, prec):
             close(out, g[tag], 3e-5, f"no c2f/{prec}/{tag}")
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_bidir_fusion_heavy(P, golden, prec):
+    """BiDirectionalFusionHeavy (three convs per encoder layer, five per decoder stage; coarse2fine=False as its configs have it) against
+    the reference's outputs: the sum with the base and the raw offset (~1e-2 with these weights: tolerance relative to ITS range)"""
+    from oracle.cases import TINY_BIDIR_NOC2F as c
+    from patchrefinerv2_amd.fusion import BiDirectionalFusionHeavy
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"],
+                                                coarse2fine=False, heavy=True), seed=c["seed"])
+    m = BiDirectionalFusionHeavy(coarse2fine=False, coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                                 fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec=prec)
+    m.load_state_dict(sd)
+    g = golden("bidir_fusion_heavy")
+    for tag in ("same", "resized"):
+        i = c["make_inputs"](tag)
+        f = lambda ts: [P.Feat.from_nchw(t.to(DEV)) for t in ts]  # noqa: E731
+        ff = f(i["f_feat"])
+        sizes = [(t.shape[-2], t.shape[-1]) for t in i["f_feat"]]
+        out = m(f(i["c_feat"]), [None] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), update_base=i["pred1"].to(DEV), f_sizes=sizes)
+        close(out, g[tag], 3e-5, f"heavy/{prec}/{tag}")
+        off = m(f(i["c_feat"]), [None] + ff[1:], i["pred1"].to(DEV), i["pred2"].to(DEV), f_sizes=sizes)
+        ref = torch.as_tensor(g[tag + "_offset"])
+        err = float((off.cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err < (2e-5 if prec == "f32" else 1e-4), (prec, tag, err)
+
+
 def test_bidir_fusion_x2_format_is_bit_identical(P):
     """BiDirectionalFusion with the GatedConvUnits' concat buffers in the pre-split X2 operand format (default when the coarse
     pyramid arrives as ROI sources at the refiner's sizes) == the same network on fp32 buffers (PRV2_X2=0), bit for bit"""
