@@ -108,6 +108,22 @@ def gated_fusion_block(sd, p, xs, coarse_feat, size=None, upscale=True, fusion=T
 C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self-agg": (False, False)}  # :355-372 -> (fusion, gate)
 
 
+def c2f_noenc_module(sd, p, fine, coarse):
+    """C2FNOENCModule.forward (bi_directional_fusion_model.py:253-286; coarse2fine_type='only-gate', built with fusion=True, gate=False):
+    per pyramid level two GatedConvUnits on the projected refiner map, no top-down path; level 0 = ConvTranspose2d(k2, s2) + ReLU +
+    conv3x3 of the highest refiner map.  fine: 5 maps, coarse: 6 maps, high -> low.  Returns ([path_5 .. path_0], depth)."""
+    s = p + "scratch."
+    rn = [F.conv2d(fine[i], sd[f"{s}layer{i + 1}_rn.weight"], None, padding=1) for i in range(5)]
+    up = F.relu(F.conv_transpose2d(fine[0], sd[s + "upsample_conv.0.weight"], sd[s + "upsample_conv.0.bias"], stride=2))
+    rn0 = F.conv2d(up, sd[s + "upsample_conv.2.weight"], None, padding=1)
+    paths = []
+    for k, (x, lvl) in enumerate(zip([rn[4], rn[3], rn[2], rn[1], rn[0], rn0], [5, 4, 3, 2, 1, 0]), start=1):  # layer1_gate* <-> level 5
+        x = gated_conv_unit(sd, f"{s}layer{k}_gate1.", x, coarse[lvl], True, False)
+        paths.append(gated_conv_unit(sd, f"{s}layer{k}_gate2.", x, coarse[lvl], True, False))
+    out = F.conv2d(paths[-1], sd[s + "output_conv.weight"], sd[s + "output_conv.bias"], padding=1)
+    return paths, out
+
+
 def c2f_module(sd, p, fine, coarse, fusion=True, gate=True):
     """C2FModule.forward (bi_directional_fusion_model.py:184-208); fine & coarse high -> low."""
     s = p + "scratch."
@@ -133,7 +149,10 @@ def bidirectional_fusion(sd, p, c_feat, f_feat, pred1, pred2, update_base=None, 
     if c_feat[-1].shape[-2:] != f_feat[-1].shape[-2:]:
         c_feat = [bilinear_ac(c, f.shape[-2:]) for c, f in zip(c_feat, f_feat)]
     if coarse2fine:  # (:407-414; without it all six refiner maps and the caller's pred2 go on)
-        f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat, *C2F_TYPES[coarse2fine_type])
+        if coarse2fine_type == "only-gate":
+            f_feat, out_depth = c2f_noenc_module(sd, p + "c2f.", list(f_feat[1:]), c_feat)
+        else:
+            f_feat, out_depth = c2f_module(sd, p + "c2f.", list(f_feat[1:]), c_feat, *C2F_TYPES[coarse2fine_type])
         f_feat, pred2 = f_feat[::-1], out_depth
         if TRACE is not None:
             TRACE["c2f_depth"], TRACE["c2f_last"] = out_depth, f_feat[0]

@@ -156,7 +156,7 @@ def g_bidir():
     c = TINY_BIDIR
     # 'coarse-gated' = every released V2 config; 'coarse-fusion' / 'self-agg' = the C2FModule ablations (:355-372)
     for c2f_type, name in (("coarse-gated", "bidir_fusion"), ("coarse-fusion", "bidir_fusion_coarse_fusion"),
-                           ("self-agg", "bidir_fusion_self_agg")):
+                           ("self-agg", "bidir_fusion_self_agg"), ("only-gate", "bidir_fusion_only_gate")):
         spec = W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"],
                                    coarse2fine_type=c2f_type)
         sd = W.synth_state_dict(spec, seed=c["seed"])

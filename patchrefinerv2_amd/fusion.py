@@ -320,9 +320,9 @@ class BiDirectionalFusion(_EncDec):
                  dec_chl=(512, 256, 128, 64, 32), glb_att=False, device="cuda", prec="f32", **_unused):
         super().__init__()
         if (coarse2fine and coarse2fine_type not in W.C2F_TYPES) or glb_att:
-            raise NotImplementedError("coarse2fine_type in ('coarse-gated', 'coarse-fusion', 'self-agg') with glb_att=False is built: "
-                                      "'coarse-gated' is every released V2 config, the other two are the C2FModule ablations "
-                                      "(bi_directional_fusion_model.py:355-372); 'only-gate' (C2FNOENCModule) is not")
+            raise NotImplementedError(f"coarse2fine_type {coarse2fine_type!r} / glb_att={glb_att}: built are {sorted(W.C2F_TYPES)} with "
+                                      "glb_att=False ('coarse-gated' is every released V2 config, the others are the ablations of "
+                                      "bi_directional_fusion_model.py:355-372); glb_att (TwoWayTransformer) is enabled by no config")
         # coarse2fine=False (the "base" ablations): no c2f module -- the six refiner maps enter fusion_layers_1 as they are (:407-426)
         self.coarse2fine = bool(coarse2fine)
         if not self.coarse2fine:
@@ -351,6 +351,17 @@ class BiDirectionalFusion(_EncDec):
             return
         s = "c2f.scratch."
         P["rn"] = [self._conv(f"{s}layer{i + 1}_rn") for i in range(5)]
+        if self.coarse2fine_type == "only-gate":  # C2FNOENCModule (:211-251)
+            fu = lambda b: dict(conv=self._conv(b + "conv"), f0=self._conv(b + "fusion_conv.0"), lnw=self._dev(b + "fusion_conv.1.weight"),  # noqa: E731
+                                lnb=self._dev(b + "fusion_conv.1.bias"), f3=self._conv(b + "fusion_conv.3"))
+            P["noenc"] = [(fu(f"{s}layer{k}_gate1."), fu(f"{s}layer{k}_gate2.")) for k in range(1, 7)]
+            P["up0"] = ops.pack_conv(self._sd[s + "upsample_conv.0.weight"], self._sd[s + "upsample_conv.0.bias"], convt_k=2,
+                                     device=self.device, prec=self.prec)
+            P["up2"] = self._conv(s + "upsample_conv.2")
+            P["outc_w"], P["outc_b"] = self._dev(s + "output_conv.weight"), self._dev(s + "output_conv.bias")
+            self._pack_enc1_taps(P, self.coarse_chl)
+            self._packed = P
+            return
 
         def unit(b):
             if not self.c2f_fusion:
@@ -422,14 +433,14 @@ class BiDirectionalFusion(_EncDec):
         return ops.conv2d(x, u["conv"], relu_in=True, res=x if res is None else ops.add(x, res))
 
     @staticmethod
-    def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None, gate: bool = True) -> Feat:
+    def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None, gate: bool = True, dst: Optional[Feat] = None) -> Feat:
         """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
         half already holds the coarse feature; the lower half receives ``out``.  ``gate=False`` ('coarse-fusion', :79-80): the
         fusion_conv output is the unit's output."""
         out = ops.conv2d(x, u["conv"], cat.slice(0, F_), relu_in=True, res=x)            # conv(relu(x)) + x
         if not gate:
             fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))   # conv -> LN -> ReLU (:47-50)
-            return ops.conv2d(fused, u["f3"], res=res)                                   # the 1x1 (:51) (+ xs[0], :127)
+            return ops.conv2d(fused, u["f3"], dst, res=res)                              # the 1x1 (:51) (+ xs[0], :127)
         if "f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]):                  # the whole fusion_conv + gate in one kernel
             return ops.conv3x3_ln_gate(cat, u["f0"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res)
         fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
@@ -492,6 +503,20 @@ class BiDirectionalFusion(_EncDec):
             return ops.upsample_bilinear(y, size[0], size[1], out=dest)
         return ops.conv2d(out, blk["out_conv"], dest)
 
+    def _c2f_noenc(self, P, fine: List[Feat], coarse: List[Feat], dests):
+        """C2FNOENCModule.forward (bi_directional_fusion_model.py:253-286; 'only-gate'): per level two fusion units on the projected refiner
+        map (no top-down path); level 0 = ConvTranspose2d(k2, s2) + ReLU + conv3x3 of the highest refiner map.  dests[l] receives path_l."""
+        rn = [ops.conv2d(fine[i], P["rn"][i]) for i in range(5)]
+        rn0 = ops.conv2d(ops.conv2d(fine[0], P["up0"], act=ACT_RELU), P["up2"])
+        for lvl, x in enumerate([rn0] + rn):               # layer{6 - lvl}_gate* works on pyramid level lvl (:265-281)
+            u1, u2 = P["noenc"][5 - lvl]
+            F_ = x.c
+            cat = Feat.alloc(x.n, x.h, x.w, 2 * F_, x.device)
+            place(coarse[lvl], cat.slice(F_, F_))
+            x = self._gated_unit(u1, x, cat, F_, gate=False)
+            self._gated_unit(u2, x, cat, F_, gate=False, dst=dests[lvl])
+        return ops.conv2d_cout1(dests[0], P["outc_w"], P["outc_b"], 3)
+
     def _c2f(self, P, fine: List[Feat], coarse: List[Feat], dests):
         """C2FModule.forward (bi_directional_fusion_model.py:184-208); fine: 5 maps, coarse: 6 maps, high -> low.
         dests[l] = where feature l of the returned list [last, path2, path3, path4, path5, rn5] is written."""
@@ -547,7 +572,7 @@ class BiDirectionalFusion(_EncDec):
         dests = [Feat.alloc(B, f_sizes[l][0], f_sizes[l][1], self.in_chl[l] - c_feat[l].c, dev) if cat1[l] is None else
                  cat1[l].slice(c_feat[l].c, self.in_chl[l] - c_feat[l].c) for l in range(6)]
         if self.coarse2fine:
-            out_depth = self._c2f(P, list(f_feat[1:]), c_feat, dests)
+            out_depth = (self._c2f_noenc if self.coarse2fine_type == "only-gate" else self._c2f)(P, list(f_feat[1:]), c_feat, dests)
             if self.trace is not None:
                 self.trace["c2f_depth"], self.trace["c2f_last"] = out_depth.clone(), dests[0].to_nchw()
         else:

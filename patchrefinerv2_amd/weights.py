@@ -321,7 +321,8 @@ def _gated_block_spec(s: Spec, b: str, F_: int, fusion: bool = True):
     _gated_unit_spec(s, b + "GateresConfUnit2.", F_, fusion)
 
 
-C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self-agg": (False, False)}  # -> (fusion, gate)
+# -> (fusion, gate) of the GatedConvUnits; 'only-gate' = C2FNOENCModule(fusion=True, gate=False) (bi_directional_fusion_model.py:355-372)
+C2F_TYPES = {"coarse-gated": (True, True), "coarse-fusion": (True, False), "self-agg": (False, False), "only-gate": (True, False)}
 
 
 def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2fine, temp_chl, dec_chl,
@@ -362,6 +363,18 @@ def bidir_fusion_spec(prefix: str, coarse_chl, fine_chl, fine_chl_after_coarse2f
     c = prefix + "c2f.scratch."
     for i in range(5):
         s[f"{c}layer{i + 1}_rn.weight"] = (features, fine_chl[i], 3, 3)
+    if coarse2fine_type == "only-gate":  # C2FNOENCModule (:211-251): two units per level, no refinenet blocks / head convs
+        for k in range(1, 6):
+            _gated_unit_spec(s, f"{c}layer{k}_gate1.", features)
+            _gated_unit_spec(s, f"{c}layer{k}_gate2.", features)
+        s[c + "upsample_conv.0.weight"] = (fine_chl[0], 32, 2, 2)  # ConvTranspose2d: [in, out, k, k]
+        s[c + "upsample_conv.0.bias"] = (32,)
+        s[c + "upsample_conv.2.weight"] = (32, 32, 3, 3)
+        _gated_unit_spec(s, c + "layer6_gate1.", 32)
+        _gated_unit_spec(s, c + "layer6_gate2.", 32)
+        s[c + "output_conv.weight"] = (1, 32, 3, 3)
+        s[c + "output_conv.bias"] = (1,)
+        return s
     for r in range(1, 6):
         _gated_block_spec(s, f"{c}refinenet{r}.", features, fusion)
     h2 = coarse_chl[0]

@@ -141,7 +141,8 @@ def test_bidir_fusion(P, golden):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-@pytest.mark.parametrize("c2f_type,name", [("coarse-fusion", "bidir_fusion_coarse_fusion"), ("self-agg", "bidir_fusion_self_agg")])
+@pytest.mark.parametrize("c2f_type,name", [("coarse-fusion", "bidir_fusion_coarse_fusion"), ("self-agg", "bidir_fusion_self_agg"),
+                                           ("only-gate", "bidir_fusion_only_gate")])
 def test_bidir_fusion_c2f_ablation_types(P, golden, c2f_type, name, prec):
     """coarse2fine_type 'coarse-fusion' (the fusion_conv output replaces the gated product) and 'self-agg' (no fusion_conv, the coarse
     pyramid only enters at fusion_layers_1) against the reference's outputs (tests/golden, oracle/make_golden.py g_bidir)"""
@@ -452,7 +453,7 @@ def test_e2e_v2_other_refiner_encoders_vs_oracle(P, enc):
         assert ar < 1e-5 and mx < 1e-3, (mode, ar, mx)
 
 
-@pytest.mark.parametrize("variant", ["coarse-fusion", "self-agg", "no-c2f", "no-c2f-no-condition"])
+@pytest.mark.parametrize("variant", ["coarse-fusion", "self-agg", "no-c2f", "no-c2f-no-condition"])  # ('only-gate' needs coarse_chl[0] = 32: module test)
 def test_e2e_v2_fusion_ablation_variants_vs_oracle(P, variant):
     """PatchRefinerPlus end to end with the reference's BiDirectionalFusion ablations (configs/patchrefinerv2_zoedepth_ablation/
     plus_mobile_c2f_wogate.py, plus_mobile_c2f_selfagg.py, plus_mobile_u4k_base_coarse.py): C2FModule without the gate, without the

@@ -364,5 +364,10 @@ def test_bidir_fusion_c2f_types_spec_and_refusal():
     assert gated == W.bidir_fusion_spec("", *a, coarse2fine_type="coarse-fusion")
     plain = W.bidir_fusion_spec("", *a, coarse2fine_type="self-agg")
     assert {k for k in gated if k not in plain} == {k for k in gated if ".fusion_conv." in k} and len(plain) == len(gated) - 12 * 5
-    with pytest.raises(NotImplementedError, match="only-gate"):
-        BiDirectionalFusion(coarse2fine_type="only-gate", device="cpu")
+    og = W.bidir_fusion_spec("", *a, coarse2fine_type="only-gate")  # C2FNOENCModule: 12 units, ConvTranspose stem, no refinenet blocks
+    assert sum(k.endswith("_gate1.conv.weight") or k.endswith("_gate2.conv.weight") for k in og) == 12 and not any("refinenet" in k for k in og)
+    assert og["c2f.scratch.upsample_conv.0.weight"] == (32, 32, 2, 2) and og["c2f.scratch.output_conv.weight"] == (1, 32, 3, 3)
+    with pytest.raises(NotImplementedError, match="coarse2fine_type"):
+        BiDirectionalFusion(coarse2fine_type="no-such-type", device="cpu")
+    with pytest.raises(NotImplementedError, match="glb_att"):
+        BiDirectionalFusion(glb_att=True, device="cpu")
