@@ -554,8 +554,8 @@ class BiDirectionalFusion(_EncDec):
         P = self._packed
         if P is None:
             raise RuntimeError("BiDirectionalFusion: weights not loaded")
-        if f_sizes is None:
-            f_sizes = [(f.h, f.w) for f in f_feat]
+        if f_sizes is None:  # (a None entry = the x2 copy of the next level: lightweight_refiner.py:314-316)
+            f_sizes = [(f.h, f.w) if f is not None else (f_feat[l + 1].h * 2, f_feat[l + 1].w * 2) for l, f in enumerate(f_feat)]
         c_feat = list(c_feat)
         # The reference resizes ALL coarse maps to the refiner's sizes iff the lowest level differs (:389-393).
         # Here the resize happens while the map is placed into its two consumers' concat buffers (no temporary).
