@@ -47,16 +47,23 @@ constexpr int LR = 11, LC = 17;              // source footprint of a tile (rows
 constexpr int RUNS = 12, MPX = RUNS * 16;    // 192 >= LR * LC = 187: three runs per wave (with 16 x 32 tiles, 224 footprint pixels and 4 / 3
                                              // runs per wave the kernel needed ~270 registers: accumulators in scratch inside the slab loop)
 constexpr int CP = 32;                       // output channels per pass: 18 column blocks of 16 (9 taps x 2)
-constexpr int AROW = 144;                    // bytes per footprint pixel in LDS: [32 bf16 hi | 32 bf16 lo | 16 B pad] (16 rows x 16 B hit 64 distinct banks)
-constexpr int A_BYTES = MPX * AROW;          // 27 648
+// bytes per footprint pixel in LDS: [32 bf16 hi | 32 bf16 lo | 32 B pad].  160, as in the conv kernels: ds_read_b128 serves the NON-contiguous
+// lane groups {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS): with 144-byte rows every fragment read was a 2-way bank conflict
+// (SQ_LDS_BANK_CONFLICT, profiles/r04_bf16x3_pmc_sq_upconv.txt), and the loader's pixel swizzle below is the one made for 160
+constexpr int AROW = 160;
+constexpr int A_BYTES = MPX * AROW;          // 30 720
 constexpr int W_BYTES = 9 * CP * 128;        // 36 864
-constexpr int STAGE = A_BYTES + W_BYTES;     // 64 512
-constexpr int CLD = 3 * CP + 4;              // G tile row pitch (floats): three taps x 32 channels + pad
+constexpr int STAGE = A_BYTES + W_BYTES;     // 67 584
+constexpr int CLD = 3 * CP + 4;              // G tile pixel pitch (floats): three taps x 32 channels + pad
+// G tile ROW pitch (floats): the last pixel's 4 pad floats are overlapped by the next row, which makes the pitch 32 banks mod 64 -- two
+// adjacent source rows x 8 channel quads then fill the 64 banks exactly (the gather's lane roles put two output rows into each lane group)
+constexpr int GRP = LC * CLD - 4;
+static_assert(GRP % 64 == 32, "G tile row pitch");
 constexpr int C_BYTES = MPX * CLD * 4;       // 76 800
 // LDS: [ G tile | stage 1 | column table ]; stage 0 aliases the G tile (main loop and gather alternate), stage 1 is never touched by the
 // gather: the NEXT pass's first slab lands there while this pass is gathered (a pass therefore starts on stage 1)
 constexpr int S1_OFF = C_BYTES;
-constexpr int TAB_OFF = S1_OFF + STAGE;      // 141 312
+constexpr int TAB_OFF = S1_OFF + STAGE;      // 144 384
 constexpr int NTAB = TW0 + 2;                // output columns x0 - 1 .. x0 + TW (the wider tile's count)
 constexpr int SMEM_BYTES = TAB_OFF + NTAB * 16;
 constexpr int NDMA = 5;                      // weight pieces per wave and slab (36 over 8 waves: 5 or 4)
@@ -299,7 +306,18 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
     //  registers -- then in scratch -- during the main loop)
     int lane_g = lane;
     asm volatile("" : "+v"(lane_g));
-    const int quad = lane_g & 7, prow_t = (lane_g >> 3) + 8 * (wave >> 2), m16g = lane_g & 15, gg = lane_g >> 4;
+    // (output row, channel quad) of a lane: every ds_read_b128 lane group -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32 -- holds
+    // TWO adjacent output rows x all 8 quads: their source rows are the same (one address per quad: broadcast) or adjacent (GRP: the other
+    // 32 banks).  With quad = lane & 7, row = lane >> 3 every read of the walk was a 2-way conflict.
+    const int seg4 = (lane_g >> 2) & 7;
+    const int quad = ((seg4 & 2) << 1) + (lane_g & 3), prow_t = ((0xD728 >> (2 * seg4)) & 3) + 4 * (lane_g >> 5) + 8 * (wave >> 2);
+    const int m16g = lane_g & 15, gg = lane_g >> 4;
+    int gpx[3];  // G tile offset (floats) of this lane's footprint pixel in each of the wave's three runs
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int px = (run0 + a) * 16 + m16g;
+      gpx[a] = px * CLD - 4 * (px / LC);
+    }
     f32x4 o[SEG];
 #pragma unroll
     for (int xi = 0; xi < SEG; ++xi) o[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -317,7 +335,7 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
         if (tp / 3 == ky) {  // wave-uniform
           const int col = (tp - 3 * ky) * CP + (b & 1) * 16 + 4 * gg;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) *reinterpret_cast<f32x4*>(&csm[((run0 + a) * 16 + m16g) * CLD + col]) = acc[a][j];
+          for (int a = 0; a < 3; ++a) *reinterpret_cast<f32x4*>(&csm[gpx[a] + col]) = acc[a][j];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -352,8 +370,8 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
       const bool vy = (unsigned)yy < (unsigned)p.H;
       const AxisTap ay = ac_tap(min(max(yy, 0), p.H - 1), p.usy, p.uH);
       const float wy0 = vy ? ay.w0 : 0.f, wy1 = vy ? ay.w1 : 0.f;
-      const unsigned g0 = (unsigned)(size_t)(csm + (ay.i0 - rbase) * LC * CLD + 4 * quad);
-      const unsigned g1 = (unsigned)(size_t)(csm + (ay.i1 - rbase) * LC * CLD + 4 * quad);
+      const unsigned g0 = (unsigned)(size_t)(csm + (ay.i0 - rbase) * GRP + 4 * quad);
+      const unsigned g1 = (unsigned)(size_t)(csm + (ay.i1 - rbase) * GRP + 4 * quad);
       // The G reads are plain LDS loads whose ADDRESS passes through an empty asm inside the branch that needs them.  As ordinary loads
       // hipcc if-converts the walk (LDS is always dereferenceable), issues every read of the unrolled walk up front and spills ~800
       // registers; the opaque address pins each read to its branch.  NOT inline-asm reads with a separate asm wait (the pattern of the
