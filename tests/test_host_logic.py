@@ -371,3 +371,23 @@ def test_bidir_fusion_c2f_types_spec_and_refusal():
         BiDirectionalFusion(coarse2fine_type="no-such-type", device="cpu")
     with pytest.raises(NotImplementedError, match="glb_att"):
         BiDirectionalFusion(glb_att=True, device="cpu")
+
+
+def test_lds_layouts_by_the_bank_model():
+    """tools/lds_bank_model.py (the per-instruction lane groups / bank moduli of MI355X_MICROARCH.md, LDS): the layouts fixed in round 4 are
+    conflict free in the model, and the model reproduces what SQ_LDS_BANK_CONFLICT showed for their predecessors (r04_experiments.txt #19-21)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(os.path.dirname(__file__), "..", "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    r = m.report()
+    assert r["a_fragment_read_arow160"] == 0 and r["a_fragment_read_arow144"] > 0
+    assert r["upconv_walk_read"] == 0 and r["upconv_walk_read_old_roles"] > 0
+    assert r["gate_gemm_read"] == 0 and r["gate_gemm_read_identity_rows"] > 0
+    assert r["halo16_epilogue_read_bn128"] == 0 and r["halo16_epilogue_read_bn32"] > 0  # (the open item)
+    assert sorted(m.upconv_gather_role(l) for l in range(64)) == [(r_, q) for r_ in range(8) for q in range(8)]
+    assert sorted(m.gate_gemm_row(i) for i in range(16)) == list(range(16))
+    # the constants of the kernels are the ones the model was run with
+    src = open(os.path.join(os.path.dirname(__file__), "..", "patchrefinerv2_amd", "csrc", "upconv.hip")).read()
+    assert "constexpr int AROW = 160;" in src and "0xD728" in src and "constexpr int GRP = LC * CLD - 4;" in src
