@@ -702,7 +702,22 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
 
     constexpr int C4 = BN / 4;
     constexpr int RPP = 512 / C4;
-    const int col4 = tid % C4;
+    // Store-loop roles: thread = (channel quad col4, rows rr0 + k RPP).  For BN = 128 a wave is two whole rows (any order is conflict free).
+    // For BN = 32 / 64 the natural tid % C4 / tid / C4 made every float4 read of the C tile 2-way: ds_read_b128 serves the lane groups
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS; tools/lds_bank_model.py) -- so each group is given whole
+    // rows: BN = 64 one row (16 quads = 64 banks), BN = 32 rows r and r + 8 (pitch 36: the other 32 banks).  SQ_LDS_BANK_CONFLICT of the
+    // narrow kernels was 10-28 % of their LDS cycles (profiles/r04_bf16x3_pmc_lds_frame.txt).
+    int col4 = tid % C4, rr0 = tid / C4;
+    if constexpr (BN == 32 || BN == 64) {
+      const int seg4 = (lane >> 2) & 7, k = (0x96 >> seg4) & 1;  // lane group of the quad-lane: [0, 1, 1, 0, 1, 0, 0, 1]
+      if constexpr (BN == 32) {
+        col4 = ((seg4 & 2) << 1) + (lane & 3);
+        rr0 = 16 * (wave >> 1) + 4 * (wave & 1) + 2 * (lane >> 5) + k + 8 * (seg4 >> 2);
+      } else {
+        col4 = 4 * (seg4 >> 1) + (lane & 3);
+        rr0 = 4 * wave + 2 * (lane >> 5) + k;
+      }
+    }
     EpiCols ec;
     if (!epi_cols(p, c.tile_n * BN + col4 * 4, ec)) return;
     const long long img_m = (long long)c.n_img * p.H * p.W, img_o = (long long)c.n_img * p.y_bstride + ec.co;
@@ -716,7 +731,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
       const float* const rbase = p.res ? p.res + img_m * p.ld_res + ec.co : nullptr;
       auto lean = [&](auto act_c, auto ln_c, auto res_c) {
         constexpr bool LN = decltype(ln_c)::value, RES = decltype(res_c)::value;
-        for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+        for (int rr = rr0; rr < TH * TW; rr += RPP) {
           const int py = rr / TW, px = rr - py * TW;
           const int oy = c.y0 + py, ox = c.x0 + px;
           if (oy >= p.H || ox >= p.W) continue;
@@ -743,7 +758,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
         float* const tbase = p.y + (long long)c.n_img * p.y_bstride + p.Cout;
         const float* const t1 = p.tail1 + (long long)c.n_img * p.tH * p.tW;
         const float* const t2 = p.tail2 + (long long)c.n_img * p.tH * p.tW;
-        for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+        for (int rr = rr0; rr < TH * TW; rr += RPP) {
           const int py = rr / TW, px = rr - py * TW;
           const int oy = c.y0 + py, ox = c.x0 + px;
           if (oy >= p.H || ox >= p.W) continue;
@@ -775,7 +790,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
       return;
     }
     dispatch_act(p.act, [&](auto act_c) {
-      for (int rr = tid / C4; rr < TH * TW; rr += RPP) {
+      for (int rr = rr0; rr < TH * TW; rr += RPP) {
         const int py = rr / TW, px = rr - py * TW;
         const int oy = c.y0 + py, ox = c.x0 + px;
         if (oy >= p.H || ox >= p.W) continue;

@@ -299,20 +299,52 @@ __device__ __forceinline__ void ln_row_stats(const IgemmParams& p, const float* 
                                              float* stats /* [2*rows] in LDS */) {
   if (tid < rows) {
     const float* r = ctile + tid * cld;
+    // Whole groups of eight channels come in as two 16-byte reads, added in the same ascending order (same bits).  One row per lane on a
+    // pitch of 4 (mod 8) floats is conflict free for ds_read_b128's lane groups, but as scalar reads every 32-lane half met on 8 banks
+    // (4-way): the LayerNorm layers of the narrow kernels spent a quarter of their LDS cycles in bank conflicts
+    // (profiles/r04_bf16x3_pmc_lds_frame.txt; tools/lds_bank_model.py).
+    const bool vec = (cld & 3) == 0 && (reinterpret_cast<size_t>(ctile) & 15) == 0;
+    auto bias_of = [&](int c) { return p.bias ? p.bias[c] : 0.f; };
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < p.Cout; c0 += 32)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        for (int c = c0 + 8 * g; c < c0 + 8 * g + 8 && c < p.Cout; ++c) s[g] += r[c] + (p.bias ? p.bias[c] : 0.f);
+      for (int g = 0; g < 4; ++g) {
+        const int b = c0 + 8 * g;
+        if (vec && b + 8 <= p.Cout) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(r + b), v1 = *reinterpret_cast<const f32x4*>(r + b + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[g] += v0[e] + bias_of(b + e);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[g] += v1[e] + bias_of(b + 4 + e);
+        } else {
+          for (int c = b; c < b + 8 && c < p.Cout; ++c) s[g] += r[c] + bias_of(c);
+        }
+      }
     const float mean = ((s[0] + s[1]) + (s[2] + s[3])) / (float)p.Cout;
     float q[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < p.Cout; c0 += 32)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        for (int c = c0 + 8 * g; c < c0 + 8 * g + 8 && c < p.Cout; ++c) {
-          const float d = r[c] + (p.bias ? p.bias[c] : 0.f) - mean;
-          q[g] += d * d;
+      for (int g = 0; g < 4; ++g) {
+        const int b = c0 + 8 * g;
+        if (vec && b + 8 <= p.Cout) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(r + b), v1 = *reinterpret_cast<const f32x4*>(r + b + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v0[e] + bias_of(b + e) - mean;
+            q[g] += d * d;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v1[e] + bias_of(b + 4 + e) - mean;
+            q[g] += d * d;
+          }
+        } else {
+          for (int c = b; c < b + 8 && c < p.Cout; ++c) {
+            const float d = r[c] + bias_of(c) - mean;
+            q[g] += d * d;
+          }
         }
+      }
     stats[tid] = mean;
     stats[rows + tid] = 1.0f / sqrtf(((q[0] + q[1]) + (q[2] + q[3])) / (float)p.Cout + p.ln_eps);
   }
