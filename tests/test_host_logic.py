@@ -385,7 +385,11 @@ def test_lds_layouts_by_the_bank_model():
     assert r["a_fragment_read_arow160"] == 0 and r["a_fragment_read_arow144"] > 0
     assert r["upconv_walk_read"] == 0 and r["upconv_walk_read_old_roles"] > 0
     assert r["gate_gemm_read"] == 0 and r["gate_gemm_read_identity_rows"] > 0
-    assert r["halo16_epilogue_read_bn128"] == 0 and r["halo16_epilogue_read_bn32"] > 0  # (the open item)
+    assert r["halo16_epilogue_read_bn128"] == 0 and r["halo16_epilogue_read_bn32"] > 0 and r["halo16_epilogue_read_bn64"] > 0  # natural roles
+    assert r["halo16_store_loop_read_bn32"] == 0 and r["halo16_store_loop_read_bn64"] == 0                                     # shipped roles
+    for bn in (32, 64, 128):
+        assert sorted(m.halo16_store_role(bn, t) for t in range(512)) == [(r_, q) for r_ in range(512 // (bn // 4)) for q in range(bn // 4)] or bn == 128
+        assert r[f"ln_stats_read_b128_bn{bn}"] == 0 and r[f"ln_stats_read_b32_bn{bn}"] >= 6  # 16-byte reads: free; scalar: 4-way per half
     assert sorted(m.upconv_gather_role(l) for l in range(64)) == [(r_, q) for r_ in range(8) for q in range(8)]
     assert sorted(m.gate_gemm_row(i) for i in range(16)) == list(range(16))
     # the constants of the kernels are the ones the model was run with

@@ -47,6 +47,16 @@ def gate_gemm_row(m16: int) -> int:
     return 2 * (m16 - 4) if 4 <= m16 < 12 else 2 * (m16 & 3) + 1 + (8 if m16 >= 12 else 0)
 
 
+def halo16_store_role(bn: int, tid: int) -> Tuple[int, int]:
+    """csrc/conv3x3_m16.hip, store loops of the BN = 32 / 64 kernels: (first row rr0, channel quad col4) of a thread"""
+    lane, wave = tid & 63, tid >> 6
+    seg4 = (lane >> 2) & 7
+    k = (0x96 >> seg4) & 1
+    if bn == 32:
+        return 16 * (wave >> 1) + 4 * (wave & 1) + 2 * (lane >> 5) + k + 8 * (seg4 >> 2), ((seg4 & 2) << 1) + (lane & 3)
+    return 4 * wave + 2 * (lane >> 5) + k, 4 * (seg4 >> 1) + (lane & 3)
+
+
 def report() -> Dict[str, int]:
     out = {}
     # MFMA A-fragment reads: row m16 of a pixel-major tile with AROW bytes per pixel, k-slice g at + 16 bytes
@@ -64,10 +74,17 @@ def report() -> Dict[str, int]:
     # gate GEMM fragment reads from the normalised C tile (row pitch 260 floats, k-slice g at + 8 floats)
     out["gate_gemm_read_identity_rows"] = extra_cycles("ds_read_b128", lambda l: ((l & 15) * 260 + 8 * (l >> 4)) * 4)
     out["gate_gemm_read"] = extra_cycles("ds_read_b128", lambda l: (gate_gemm_row(l & 15) * 260 + 8 * (l >> 4)) * 4)
-    # plain epilogue float4 reads of the halo16 kernels' C tile, pitch BN + 4 (the open item of r04_experiments.txt #21)
+    # float4 reads of the halo16 kernels' C tile, pitch BN + 4, with the natural roles tid % (BN / 4), tid / (BN / 4) (r04_experiments.txt #21)
     for bn in (32, 64, 128):
         q = bn // 4
         out[f"halo16_epilogue_read_bn{bn}"] = extra_cycles("ds_read_b128", lambda l: ((l // q) * (bn + 4) + 4 * (l % q)) * 4)
+        if bn <= 64:  # the lane roles shipped since r04_experiments.txt #21
+            out[f"halo16_store_loop_read_bn{bn}"] = max(extra_cycles("ds_read_b128", lambda l: (halo16_store_role(bn, 64 * w + l)[0] * (bn + 4) +
+                                                                                                 4 * halo16_store_role(bn, 64 * w + l)[1]) * 4) for w in range(8))
+    # LayerNorm row statistics (igemm.h ln_row_stats): one row per lane on a pitch of BN + 4 floats, scalar reads vs 16-byte reads
+    for bn in (32, 64, 128):
+        out[f"ln_stats_read_b32_bn{bn}"] = extra_cycles("ds_read_b32", lambda l: l * (bn + 4) * 4)
+        out[f"ln_stats_read_b128_bn{bn}"] = extra_cycles("ds_read_b128", lambda l: l * (bn + 4) * 4)
     return out
 
 
