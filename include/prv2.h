@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 14
+#define PRV2_ABI_VERSION 15
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -191,6 +191,50 @@ int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x, const void
 int prv2_conv2d_pre_supported(const prv2_conv_desc* d);
 int prv2_conv2d_pre(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre, int32_t ld_pre,
                     const float* ln_weight, const float* ln_bias, const float* res, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The 32-channel FULL-RESOLUTION tail of BiDirectionalFusion: two consecutive 3x3 convs with everything between and behind them in
+ * ONE kernel (csrc/chain32.hip; 8 x 16-pixel tiles, the first conv's output stays in LDS; bf16x3 arithmetic):
+ *   prv2_chain32_c2f   C2FModule ``output_conv2_fusion`` (GatedFusionBlock with one input, upscale=False) + ``output_conv3``
+ *                      bi_directional_fusion_model.py:56-82,116-146 (unit / block), :171-180 (definitions), :203-204 (use)
+ *        o     = conv3x3(relu(x); W1) + b1 + x                            GateresConfUnit2.conv + skip_add
+ *        f     = relu(LN(conv3x3(o; W2) + b2 + pre))                      fusion_conv.0-.2 over cat([o, c_feat]); pre = its coarse half
+ *        y     = Wo (o * sigmoid(Wg f + bg)) + bo                         fusion_conv.3, gate, out_conv         -> y  [n, h, w, 32]
+ *        depth = w3 . y + b3                                              output_conv3 (1x1 -> 1)              -> depth [n, h, w]
+ *   prv2_chain32_enc   ``fusion_layers_1[0]`` + ``fusion_layers_2[0]`` (SingleConvCNNLN)   bi_directional_fusion_model.py:424-431
+ *        f = gelu(LN(conv3x3(x; W1) + b1 + pre))                          over cat([c, x]); pre = the coarse half (prv2_coarse_tap_gather)
+ *        y = gelu(LN(conv3x3(cat([f, p1, p2]); W2) + b2))                 p1 / p2: dense [n, h, w] depth maps at the level's size
+ * Weight images: prv2_pack_chain32_weight(w_src [32][cin_total][taps] fp32 PyTorch layout, kind) -> prv2_chain32_weight_bytes(kind, taps)
+ *   kind 0: the FIRST conv (taps 9; input channels [0, 32) of w_src);  kind 1: the second conv (taps 9) and the 1x1 gate / out_conv
+ *   (taps 1) -- K in accumulator order;  kind 2: the [p1 | p2] tail of a 3x3 over 34 channels (channels 32, 33 of w_src).
+ *   prv2_chain32_c2f: w1 kind 0, w2 kind 1, wg / wo kind 1 (taps 1);  prv2_chain32_enc: w1 kind 0, w2 kind 1, wg = kind 2 of W2.
+ * consts: device fp32 [9][32] = b1, LN1 weight, LN1 bias, b2, bg, bo, w3, LN2 weight, LN2 bias (rows a mode does not use: zeros);
+ *   LN1 is the chain's FIRST LayerNorm (c2f: behind the second conv; enc: behind the first), LN2 enc's second.
+ * Same split products / fp32 accumulation as prv2_conv2d's bf16x3 kernels; not bit-identical to the unfused sequence (LayerNorm sums
+ * in another order; ``o`` enters the gate product as hi + lo, as ``mul`` does in prv2_conv3x3_ln_gate).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct prv2_chain32_desc {
+  const float* x;        /* NHWC input [n, h, w, ldx >= 32]                                */
+  const void* w1;
+  const void* w2;
+  const void* wg;
+  const void* wo;        /* c2f only                                                       */
+  const float* consts;
+  const float* pre;      /* [n, h, w, ld_pre >= 32] (c2f: may be NULL)                     */
+  const float* p1;       /* enc only                                                       */
+  const float* p2;
+  float* y;              /* NHWC output [n, h, w, ldy >= 32] (a channel slice is fine)     */
+  float* depth;          /* c2f only (may be NULL)                                         */
+  int64_t x_bstride;     /* image strides in floats (0 => h*w*ld)                          */
+  int64_t y_bstride;
+  int32_t n, h, w;
+  int32_t ldx, ldy, ld_pre;
+  float b3, ln_eps;
+} prv2_chain32_desc;
+int64_t prv2_chain32_weight_bytes(int32_t kind, int32_t taps);
+int prv2_pack_chain32_weight(const float* w_src, int32_t cin_total, int32_t taps, int32_t kind, void* w_packed, void* stream);
+int prv2_chain32_c2f(const prv2_chain32_desc* d, void* stream);
+int prv2_chain32_enc(const prv2_chain32_desc* d, void* stream);
 
 /* Convolution with ONE output channel (direct, HBM-bound):
  *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118

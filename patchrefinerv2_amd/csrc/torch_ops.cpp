@@ -286,6 +286,63 @@ Tensor conv3x3_pre(const Tensor& x, const Tensor& w_packed, const optional<Tenso
   return y;
 }
 
+// include/prv2.h::prv2_chain32_*: the 32-channel full-resolution tail of BiDirectionalFusion, two 3x3 convs per kernel (csrc/chain32.hip)
+Tensor pack_chain32_weight(const Tensor& w, int64_t kind) {
+  dev_f32(w, "weight");
+  TORCH_CHECK((w.dim() == 4 || w.dim() == 2) && w.size(0) == 32, "prv2::pack_chain32_weight: weight must be [32, cin, k, k] or [32, cin]");
+  const int64_t taps = w.dim() == 4 ? w.size(2) * w.size(3) : 1;
+  Tensor wc = w.contiguous();
+  Tensor packed = at::empty({prv2_chain32_weight_bytes((int)kind, (int)taps) / 4}, w.options());
+  Launch L(w);
+  ok(prv2_pack_chain32_weight(wc.data_ptr<float>(), (int)w.size(1), (int)taps, (int)kind, packed.data_ptr(), L.stream), "pack_chain32_weight");
+  return packed;
+}
+static prv2_chain32_desc chain32_desc(const Tensor& x, const Tensor& w1, const Tensor& w2, const Tensor& consts, const optional<Tensor>& pre, double ln_eps,
+                                      const Tensor& y, const char* what) {
+  prv2_chain32_desc d = {};
+  d.ldx = (int)nhwc_ld(x, "x");
+  d.ldy = (int)nhwc_ld(y, "y");
+  TORCH_CHECK(x.size(3) == 32 && y.size(3) == 32 && y.size(0) == x.size(0) && y.size(1) == x.size(1) && y.size(2) == x.size(2), "prv2::", what,
+              ": x and y are [n, h, w, 32]");
+  TORCH_CHECK(w1.numel() * 4 == prv2_chain32_weight_bytes(0, 9) && w2.numel() * 4 == prv2_chain32_weight_bytes(1, 9), "prv2::", what,
+              ": w1 / w2 are pack_chain32_weight images of 3x3 convs (kind 0 / 1)");
+  d.x = x.data_ptr<float>(); d.y = y.data_ptr<float>(); d.w1 = w1.data_ptr(); d.w2 = w2.data_ptr();
+  d.consts = opt_ptr(consts, "consts", 9 * 32);
+  d.n = (int)x.size(0); d.h = (int)x.size(1); d.w = (int)x.size(2); d.ln_eps = (float)ln_eps;
+  if (pre.has_value()) {
+    d.ld_pre = (int)nhwc_ld(*pre, "pre");
+    TORCH_CHECK(pre->size(0) == x.size(0) && pre->size(1) == x.size(1) && pre->size(2) == x.size(2) && pre->size(3) == 32, "prv2::", what, ": pre is [n, h, w, 32]");
+    d.pre = pre->data_ptr<float>();
+  }
+  return d;
+}
+void chain32_c2f(const Tensor& x, const Tensor& w1, const Tensor& w2, const Tensor& wg, const Tensor& wo, const Tensor& consts, double b3,
+                 const optional<Tensor>& pre, double ln_eps, Tensor y, optional<Tensor> depth) {
+  prv2_chain32_desc d = chain32_desc(x, w1, w2, consts, pre, ln_eps, y, "chain32_c2f");
+  TORCH_CHECK(wg.numel() * 4 == prv2_chain32_weight_bytes(1, 1) && wo.numel() * 4 == prv2_chain32_weight_bytes(1, 1),
+              "prv2::chain32_c2f: wg / wo are pack_chain32_weight images of 1x1 convs (kind 1)");
+  d.wg = wg.data_ptr(); d.wo = wo.data_ptr(); d.b3 = (float)b3;
+  if (depth.has_value()) {
+    dev_f32(*depth, "depth");
+    TORCH_CHECK(depth->is_contiguous() && depth->numel() == x.size(0) * x.size(1) * x.size(2), "prv2::chain32_c2f: depth is dense [n, (1,) h, w]");
+    d.depth = depth->data_ptr<float>();
+  }
+  Launch L(x);
+  ok(prv2_chain32_c2f(&d, L.stream), "chain32_c2f");
+}
+void chain32_enc(const Tensor& x, const Tensor& w1, const Tensor& w2, const Tensor& wt, const Tensor& consts, const Tensor& pre, const Tensor& p1,
+                 const Tensor& p2, double ln_eps, Tensor y) {
+  prv2_chain32_desc d = chain32_desc(x, w1, w2, consts, pre, ln_eps, y, "chain32_enc");
+  TORCH_CHECK(wt.numel() * 4 == prv2_chain32_weight_bytes(2, 9), "prv2::chain32_enc: wt is the kind-2 pack_chain32_weight image of the second conv");
+  dev_f32(p1, "p1");
+  dev_f32(p2, "p2");
+  const int64_t px = x.size(0) * x.size(1) * x.size(2);
+  TORCH_CHECK(p1.is_contiguous() && p2.is_contiguous() && p1.numel() == px && p2.numel() == px, "prv2::chain32_enc: p1 / p2 are dense [n, (1,) h, w] at x's size");
+  d.wg = wt.data_ptr(); d.p1 = p1.data_ptr<float>(); d.p2 = p2.data_ptr<float>();
+  Launch L(x);
+  ok(prv2_chain32_enc(&d, L.stream), "chain32_enc");
+}
+
 // the per-frame coarse half of the cat([fine, coarse_roi]) convs (include/prv2.h::prv2_coarse_tap_knots / prv2_coarse_tap_gather)
 Tensor coarse_tap_knots(const Tensor& g, int64_t cout, double knot_bh, double knot_bw) {
   const int64_t ldg = nhwc_ld(g, "g");
@@ -678,6 +735,10 @@ TORCH_LIBRARY(prv2, m) {
         "int prec, float ln_eps, Tensor(a!) out) -> ()");
   m.def("conv3x3_pre(Tensor x, Tensor w_packed, Tensor? bias, Tensor pre, int cout, int act=0, Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? res=None, "
         "int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
+  m.def("pack_chain32_weight(Tensor weight, int kind) -> Tensor");
+  m.def("chain32_c2f(Tensor x, Tensor w1, Tensor w2, Tensor wg, Tensor wo, Tensor consts, float b3, Tensor? pre, float ln_eps, Tensor(a!) y, "
+        "Tensor(b!)? depth=None) -> ()");
+  m.def("chain32_enc(Tensor x, Tensor w1, Tensor w2, Tensor wt, Tensor consts, Tensor pre, Tensor p1, Tensor p2, float ln_eps, Tensor(a!) y) -> ()");
   m.def("coarse_tap_knots(Tensor g, int cout, float knot_bh, float knot_bw) -> Tensor");
   m.def("coarse_tap_gather(Tensor v, Tensor g, float knot_bh, float knot_bw, Tensor boxes, float spatial_scale, int oh, int ow, Tensor(a!)? out=None) -> Tensor");
   m.def("conv_cout1(Tensor x, Tensor weight, Tensor? bias, int k, int act=0, float scale=1.0, Tensor? res=None, bool clamp0=False, Tensor(a!)? out=None) -> Tensor");
@@ -725,6 +786,9 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
   m.impl("conv3x3_tail", &conv3x3_tail);
   m.impl("conv3x3_pre", &conv3x3_pre);
+  m.impl("pack_chain32_weight", &pack_chain32_weight);
+  m.impl("chain32_c2f", &chain32_c2f);
+  m.impl("chain32_enc", &chain32_enc);
   m.impl("coarse_tap_knots", &coarse_tap_knots);
   m.impl("coarse_tap_gather", &coarse_tap_gather);
   m.impl("conv_cout1", &conv_cout1);

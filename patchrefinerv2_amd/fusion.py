@@ -127,6 +127,16 @@ class _EncDec(StateDictModule):
             if rows:
                 P["taps"][l] = (ops.pack_conv(torch.cat([t for _, t in rows], 0), None, device=self.device, prec=self.prec),
                                 [(n, t.shape[0] // 9) for n, t in rows])
+            # full-resolution 32-channel level: ENC1[l] (fine half) + ENC2[l] as ONE kernel (ops.chain32_enc, csrc/chain32.hip)
+            w2 = self._sd[f"{self.ENC2}.{l}.single_conv.0.weight"]
+            if (f"{self.ENC1}.{l}.fine" in P and self.prec == ops.L.PREC_BF16X3 and w1.shape[0] == 32 and w1.shape[1] - cc == 32 and tuple(w2.shape[:2]) == (32, 34)
+                    and ops.CHAIN32):
+                sd = lambda k: self._sd.get(k)  # noqa: E731
+                e1, e2 = f"{self.ENC1}.{l}.single_conv.", f"{self.ENC2}.{l}.single_conv."
+                P[f"chain_enc.{l}"] = dict(
+                    w1=ops.pack_chain32(w1[:, cc:], 0, self.device), w2=ops.pack_chain32(w2, 1, self.device), wt=ops.pack_chain32(w2, 2, self.device),
+                    consts=ops.chain32_consts(self.device, b1=sd(e1 + "0.bias"), ln1w=sd(e1 + "1.weight"), ln1b=sd(e1 + "1.bias"), b2=sd(e2 + "0.bias"),
+                                              ln2w=sd(e2 + "1.weight"), ln2b=sd(e2 + "1.bias")))
 
     def _enc1_taps_of(self, P, c_feat, f_sizes):
         """per level: (ops.CoarseTaps, the level's ops.RoiSource) when ENC1[l] takes its coarse half from the frame's tap table, else None"""
@@ -209,6 +219,15 @@ class _EncDec(StateDictModule):
             tc = self.temp_chl[l]
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
             cat2 = alloc_with_pred_tail(B, h, w, tc, dev)
+            j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
+            chain = P.get(f"chain_enc.{l}") if enc1_taps is not None and enc1_taps[l] is not None and not self.HEAVY else None
+            if chain is not None and (pred1.h, pred1.w, pred2.h, pred2.w) == (h, w, h, w) and enc1_taps[l][2].c == 32:
+                # ENC1[l] + ENC2[l] in one kernel: the level's 32-channel map never leaves the chip between the two convs
+                taps, roi, fine = enc1_taps[l]
+                pre = taps.gather(roi.boxes, roi.scale, h, w)
+                dst = dec_bufs[j].slice(self.dec_in[j][0], tc) if 0 <= j < nd else Feat.alloc(B, h, w, tc, dev)
+                temps[l] = ops.chain32_enc(fine, chain, pre, pred1.buf, pred2.buf, out=dst, pre_cin=roi.c)
+                continue
             if enc1_taps is not None and enc1_taps[l] is not None:
                 taps, roi, fine = enc1_taps[l]
                 pre = taps.gather(roi.boxes, roi.scale, h, w)  # conv3x3(c; W[:, :c_l]) of the tiles, from the frame's table
@@ -223,7 +242,6 @@ class _EncDec(StateDictModule):
                 if not conv_ln_gelu(cat1, conv, lnw, lnb, cat2.slice(0, tc), tail_c0=tc, heavy=P.get(f"{self.ENC1}.{l}.heavy")):
                     place_preds(pred1, pred2, cat2, tc)
             conv, lnw, lnb = P[f"{self.ENC2}.{l}"]
-            j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
             if 0 <= j < nd:
                 c1, c2, _ = self.dec_in[j]
                 assert c2 == tc
@@ -404,6 +422,20 @@ class BiDirectionalFusion(_EncDec):
         P["out2_fusion"] = block(s + "output_conv2_fusion.")
         P["out3_w"] = self._dev(s + "output_conv3.0.weight")
         P["out3_b"] = self._dev(s + "output_conv3.0.bias")
+        # the full-resolution tail output_conv2_fusion (one GatedConvUnit + out_conv) + output_conv3 as ONE kernel (ops.chain32_c2f)
+        b = s + "output_conv2_fusion."
+        w0 = self._sd.get(b + "GateresConfUnit2.fusion_conv.0.weight")
+        if (self.prec == ops.L.PREC_BF16X3 and ops.CHAIN32 and self.c2f_fusion and self.c2f_gate and self.coarse_chl[0] == 32 and w0 is not None and
+                tuple(w0.shape[:2]) == (32, 64)):
+            u = b + "GateresConfUnit2."
+            sd = lambda k: self._sd.get(k)  # noqa: E731
+            P["chain_c2f"] = dict(
+                w1=ops.pack_chain32(sd(u + "conv.weight"), 0, self.device), w2=ops.pack_chain32(w0[:, :32], 1, self.device),
+                wg=ops.pack_chain32(sd(u + "fusion_conv.3.weight")[:, :, 0, 0], 1, self.device), wo=ops.pack_chain32(sd(b + "out_conv.weight")[:, :, 0, 0], 1, self.device),
+                consts=ops.chain32_consts(self.device, b1=sd(u + "conv.bias"), ln1w=sd(u + "fusion_conv.1.weight"), ln1b=sd(u + "fusion_conv.1.bias"),
+                                          b2=sd(u + "fusion_conv.0.bias"), bg=sd(u + "fusion_conv.3.bias"), bo=sd(b + "out_conv.bias"),
+                                          w3=sd(s + "output_conv3.0.weight").reshape(32)),
+                b3=float(sd(s + "output_conv3.0.bias").reshape(-1)[0]))
         # Per pyramid level: every conv that reads cat([., c_feat[l]]) with no activation in front -- the level's GatedConvUnits
         # (refinenet{l}: unit 2, and unit 1 where the block has two inputs, :125-129; level 0: output_conv2_fusion's unit 2) and
         # fusion_layers_1[l] -- hands the coarse half of its weights to ONE 1x1 GEMM per level and frame (prepare_frame).
@@ -542,6 +574,13 @@ class BiDirectionalFusion(_EncDec):
         if folded:
             ops.conv_border_bias(out, P["out1_tap_bias"])
         last = ops.conv2d(out, P["out2_0"], act=ACT_RELU)
+        aux = coarse[0].feat.aux if isinstance(coarse[0], ops.RoiSource) else None
+        if ("chain_c2f" in P and aux is not None and ops.COARSE_TAPS and "u2" in aux["taps"] and (coarse[0].h, coarse[0].w) == (last.h, last.w) and
+                dests[0].c == 32 and aux["taps"]["u2"].cout == 32):
+            # GateresConfUnit2 + out_conv + output_conv3 in one kernel; the unit's coarse half from the frame's tap table as before
+            pre = aux["taps"]["u2"].gather(coarse[0].boxes, coarse[0].scale, last.h, last.w)
+            _, depth = ops.chain32_c2f(last, P["chain_c2f"], pre, out=dests[0], pre_cin=coarse[0].c)
+            return depth
         last = self._gated_block(P["out2_fusion"], [last], coarse[0], self.coarse_chl[0], upscale=False, dest=dests[0])
         depth = ops.conv2d_cout1(last, P["out3_w"], P["out3_b"], 1)
         return depth

@@ -17,7 +17,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
 FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class ConvDesc(C.Structure):
@@ -36,6 +36,13 @@ class ConvDesc(C.Structure):
 
 class UpsSrc(C.Structure):  # prv2_ups_src
     _fields_ = [("x", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("ld", C.c_int32), ("channels", C.c_int32), ("bstride", C.c_int64)]
+
+
+class Chain32Desc(C.Structure):  # prv2_chain32_desc
+    _fields_ = [("x", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p), ("wg", C.c_void_p), ("wo", C.c_void_p), ("consts", C.c_void_p),
+                ("pre", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p), ("y", C.c_void_p), ("depth", C.c_void_p),
+                ("x_bstride", C.c_int64), ("y_bstride", C.c_int64), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("ldx", C.c_int32), ("ldy", C.c_int32), ("ld_pre", C.c_int32), ("b3", C.c_float), ("ln_eps", C.c_float)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -89,6 +96,10 @@ SIGNATURES = {
     "prv2_upconv3x3": (_I, [C.POINTER(UpsSrc), _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _L, _P]),
     "prv2_conv2d_pre_supported": (_I, [C.POINTER(ConvDesc)]),
     "prv2_conv2d_pre": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "prv2_chain32_weight_bytes": (_L, [_I, _I]),
+    "prv2_pack_chain32_weight": (_I, [_P, _I, _I, _I, _P, _P]),
+    "prv2_chain32_c2f": (_I, [C.POINTER(Chain32Desc), _P]),
+    "prv2_chain32_enc": (_I, [C.POINTER(Chain32Desc), _P]),
     "prv2_coarse_tap_knots": (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
     "prv2_coarse_tap_gather": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _F, _I, _I, _P, _I, _P]),
     "prv2_conv_border_bias": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -894,6 +894,90 @@ def conv2d_pre(x: Feat, cw: ConvW, pre: Feat, out: Optional[Feat] = None, *, act
     return out
 
 
+CHAIN32 = os.environ.get("PRV2_CHAIN32", "1") != "0"  # A/B and test switch: the fused 32-channel full-resolution chains (csrc/chain32.hip)
+
+
+def pack_chain32(weight: torch.Tensor, kind: int, device=None) -> torch.Tensor:
+    """fragment image of a 32-output-channel conv for the ``chain32_*`` kernels (include/prv2.h::prv2_pack_chain32_weight): kind 0 = first
+    conv of a chain (3x3, natural K), 1 = second conv / 1x1 (K in accumulator order), 2 = the [p1 | p2] tail of a 3x3 over 34 channels"""
+    w = weight.detach().to(device=device or weight.device, dtype=torch.float32).contiguous()
+    assert w.shape[0] == 32 and w.dim() in (2, 4)
+    taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+    if DISPATCH == "torch":
+        return _tops().pack_chain32_weight(w, kind)
+    lib = L.load()
+    packed = torch.empty(lib.prv2_chain32_weight_bytes(kind, taps) // 4, device=w.device, dtype=torch.float32)
+    L.check(lib.prv2_pack_chain32_weight(w.data_ptr(), w.shape[1], taps, kind, packed.data_ptr(), _stream()), "pack_chain32_weight")
+    return packed
+
+
+def chain32_consts(device, **rows) -> torch.Tensor:
+    """the [9][32] constant table of the ``chain32_*`` kernels: b1, ln1w, ln1b, b2, bg, bo, w3, ln2w, ln2b (missing rows zero)"""
+    names = ("b1", "ln1w", "ln1b", "b2", "bg", "bo", "w3", "ln2w", "ln2b")
+    assert set(rows) <= set(names)
+    t = torch.zeros((9, 32), dtype=torch.float32, device=device)
+    for i, n in enumerate(names):
+        if rows.get(n) is not None:
+            t[i] = rows[n].detach().to(device=device, dtype=torch.float32).reshape(32)
+    return t
+
+
+def _chain32_desc(x: Feat, w1, w2, wg, wo, consts, pre, p1, p2, y: Feat, depth, b3, ln_eps):
+    assert x.c == 32 and y.c == 32 and (x.n, x.h, x.w) == (y.n, y.h, y.w) and not x.x2 and not y.x2
+    assert pre is None or ((pre.n, pre.h, pre.w, pre.c) == (x.n, x.h, x.w, 32) and not pre.x2)
+    return L.Chain32Desc(x=x.ptr, w1=w1.data_ptr(), w2=w2.data_ptr(), wg=wg.data_ptr(), wo=_ptr(wo), consts=consts.data_ptr(), pre=_ptr(pre),
+                         p1=_ptr(p1), p2=_ptr(p2), y=y.ptr, depth=_ptr(depth), x_bstride=0, y_bstride=0, n=x.n, h=x.h, w=x.w, ldx=x.ld, ldy=y.ld,
+                         ld_pre=pre.ld if pre is not None else 0, b3=b3, ln_eps=ln_eps)
+
+
+def chain32_c2f(x: Feat, cw: dict, pre: Optional[Feat], out: Optional[Feat] = None, depth: Optional[torch.Tensor] = None, ln_eps: float = 1e-6,
+                pre_cin: int = 0):
+    """C2FModule's full-resolution tail in one kernel (include/prv2.h::prv2_chain32_c2f): GateresConfUnit2 of ``output_conv2_fusion`` (conv +
+    skip, fusion_conv with the coarse half ``pre``, gate), ``out_conv`` and ``output_conv3``.  cw: dict(w1, w2, wg, wo, consts, b3) of
+    ``pack_chain32`` / ``chain32_consts`` images.  Returns (last feature [n, h, w, 32], depth [n, 1, h, w])."""
+    if out is None:
+        out = Feat(torch.empty((x.n, x.h, x.w, 32), device=x.device, dtype=torch.float32))
+    if depth is None:
+        depth = torch.empty((x.n, 1, x.h, x.w), device=x.device, dtype=torch.float32)
+    assert depth.is_contiguous() and depth.numel() == x.n * x.h * x.w
+
+    def call():
+        if DISPATCH == "torch":
+            _tops().chain32_c2f(x.view(), cw["w1"], cw["w2"], cw["wg"], cw["wo"], cw["consts"], cw["b3"], pre.view() if pre is not None else None, ln_eps,
+                                out.view(), depth)
+            return
+        d = _chain32_desc(x, cw["w1"], cw["w2"], cw["wg"], cw["wo"], cw["consts"], pre, None, None, out, depth, cw["b3"], ln_eps)
+        L.check(L.load().prv2_chain32_c2f(C.byref(d), _stream()), "chain32_c2f")
+
+    px = float(x.n * x.h * x.w)
+    flops = 2.0 * px * (2 * 9 * 32 * 32 + 2 * 32 * 32 + 32)
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops, call, shape=f"32->32->32(+{pre_cin} coarse)->gate->32->1 k3s1 {x.n}x{x.h}x{x.w}",
+                    algo=flops + 2.0 * px * 9 * 32 * pre_cin)
+    return out, depth
+
+
+def chain32_enc(x: Feat, cw: dict, pre: Feat, p1: torch.Tensor, p2: torch.Tensor, out: Optional[Feat] = None, ln_eps: float = 1e-6, pre_cin: int = 0) -> Feat:
+    """``fusion_layers_1[0]`` + ``fusion_layers_2[0]`` in one kernel (include/prv2.h::prv2_chain32_enc).  cw: dict(w1, w2, wt, consts);
+    p1 / p2: dense depth maps at x's size."""
+    if out is None:
+        out = Feat(torch.empty((x.n, x.h, x.w, 32), device=x.device, dtype=torch.float32))
+    _require_dev(p1, p2)
+    assert p1.is_contiguous() and p2.is_contiguous() and p1.numel() == p2.numel() == x.n * x.h * x.w
+
+    def call():
+        if DISPATCH == "torch":
+            _tops().chain32_enc(x.view(), cw["w1"], cw["w2"], cw["wt"], cw["consts"], pre.view(), p1, p2, ln_eps, out.view())
+            return
+        d = _chain32_desc(x, cw["w1"], cw["w2"], cw["wt"], None, cw["consts"], pre, p1, p2, out, None, 0.0, ln_eps)
+        L.check(L.load().prv2_chain32_enc(C.byref(d), _stream()), "chain32_enc")
+
+    px = float(x.n * x.h * x.w)
+    flops = 2.0 * px * (9 * 32 * 32 + 9 * 34 * 32)
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops, call, shape=f"32(+{pre_cin} coarse)->32->34->32 k3s1 {x.n}x{x.h}x{x.w}",
+                    algo=flops + 2.0 * px * 9 * 32 * pre_cin)
+    return out
+
+
 COARSE_TAPS = os.environ.get("PRV2_COARSE_TAPS", "1") != "0"  # A/B and test switch: coarse half of the cat([fine, coarse_roi]) convs once per frame
 
 
