@@ -6,6 +6,8 @@
 // of the touched pixels per call.
 #include "common.h"
 
+PRV2_NO_PACKED_FP32_BEGIN  // (common.h)
+
 namespace prv2 {
 
 template <bool PASTE>
@@ -105,3 +107,5 @@ extern "C" int prv2_blend_resize(const float* avg, const float* cnt, int32_t h, 
   PRV2_LAUNCH_CHECK("blend_resize");
   return 0;
 }
+
+PRV2_NO_PACKED_FP32_END

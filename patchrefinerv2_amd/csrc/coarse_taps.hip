@@ -16,7 +16,7 @@
 // tile's B is a 4-tap gather from V -- the cost of the roi_align it replaces -- minus, on the tile's border pixels only, the taps the
 // conv's zero padding hides (3 per edge pixel, 5 per corner, sampled from G).  Exact algebra; fp32 rounding differs (1e-7 relative).
 //
-// BUILD NOTE: this file is compiled with packed fp32 math OFF (Makefile FLAGS_coarse_taps: -target-feature -packed-fp32-ops).  With
+// BUILD NOTE: this file is compiled with packed fp32 math OFF (PRV2_NO_PACKED_FP32_BEGIN below: a function attribute, common.h).  With
 // hipcc 7.2's v_pk_fma_f32 / v_pk_add_f32 code for tap_gather_kernel the border pixels of a tile came out wrong INTERMITTENTLY --
 // always the low halves of the packed pairs (channels 4k and 4k + 2) of the last quarter-wave (lanes 48-63), values off by one tap
 // term -- but only inside a frame with two tile streams and a third stream busy; never in isolation, and independent of every
@@ -25,6 +25,8 @@
 #include <cstdlib>
 
 #include "common.h"
+
+PRV2_NO_PACKED_FP32_BEGIN  // (common.h)
 
 namespace prv2 {
 
@@ -258,3 +260,5 @@ extern "C" int prv2_coarse_tap_gather(const float* v, const float* g, int32_t h,
   PRV2_LAUNCH_CHECK("coarse_tap_gather");
   return 0;
 }
+
+PRV2_NO_PACKED_FP32_END

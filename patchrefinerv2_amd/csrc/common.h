@@ -7,6 +7,20 @@
 
 #include "../../include/prv2.h"
 
+// Packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32) OFF for every function between PRV2_NO_PACKED_FP32_BEGIN / _END, in the
+// SOURCE rather than in a build flag (so that no build route can bring the packed code back): hipcc 7.2's packed code for
+// tap_gather_kernel gave intermittently wrong border pixels inside multi-stream frames (coarse_taps.hip, BUILD NOTE); the other
+// HBM-bound gather / pointwise / blend kernels have the same code shape (float4 arithmetic under exec-masked branches) and take the
+// attribute as a precaution (v_pk_mul / v_pk_add are IEEE-identical to their scalar forms: same bits, no measurable cost).
+// Device pass only: the host pass does not know the feature.  tests/test_isa_hazards.py asserts the ISA of these files has no v_pk_*_f32.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PRV2_TAPS_PK)
+#define PRV2_NO_PACKED_FP32_BEGIN _Pragma("clang attribute push(__attribute__((target(\"no-packed-fp32-ops\"))), apply_to = function)")
+#define PRV2_NO_PACKED_FP32_END _Pragma("clang attribute pop")
+#else
+#define PRV2_NO_PACKED_FP32_BEGIN
+#define PRV2_NO_PACKED_FP32_END
+#endif
+
 namespace prv2 {
 
 void set_error(const char* fmt, ...);

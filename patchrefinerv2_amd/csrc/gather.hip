@@ -6,6 +6,8 @@
 // index decomposition these kernels started with cost more ALU time than the memory traffic.
 #include "common.h"
 
+PRV2_NO_PACKED_FP32_BEGIN  // (common.h)
+
 namespace prv2 {
 
 // ---------------------------------------------------------------------------------------------
@@ -591,3 +593,5 @@ extern "C" int prv2_nhwc_to_nchw(const float* x, int32_t n, int32_t c, int32_t h
   PRV2_LAUNCH_CHECK("nhwc_to_nchw");
   return 0;
 }
+
+PRV2_NO_PACKED_FP32_END

@@ -5,6 +5,8 @@
 
 #include "common.h"
 
+PRV2_NO_PACKED_FP32_BEGIN  // (common.h)
+
 namespace prv2 {
 
 static thread_local char g_err[512] = "";
@@ -770,3 +772,5 @@ extern "C" int prv2_zoe_logbinom_depth(const float* pt, int32_t ld_pt, const flo
   PRV2_LAUNCH_CHECK("zoe_logbinom_depth");
   return 0;
 }
+
+PRV2_NO_PACKED_FP32_END

@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprv2_hip.so")
+# (PRV2_HIP_LIB: probes / the negative-control test load a scratch build of the SAME C ABI -- e.g. coarse_taps.hip with packed fp32 math -- in a
+#  child process; the product always loads the in-tree library)
+LIB_PATH = os.environ.get("PRV2_HIP_LIB") or os.path.join(_HERE, "libprv2_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 4, 5
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2

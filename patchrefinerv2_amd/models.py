@@ -1046,6 +1046,48 @@ class PatchRefiner(_PatchModel):
 
 
 @MODELS.register_module()
+class PatchRefinerSemi(StateDictModule):
+    """estimator/models/patchrefiner_semi.py:46-210, the INFERENCE side: the configs the real-domain checkpoints ship with
+    (patchrefinerv2_dav2/semi_kitti.py, *_cs_semi_*, pr_ssi_*) name this type; at test time ``forward`` hands everything to the student
+    (:198-210).  The teacher, the pseudo-label / edge / distillation machinery and ``mode='train'`` are training and are
+    not built: only ``model_cfg_student`` is instantiated.  State-dict names carry the ``student_model.`` prefix as in the reference."""
+
+    def __init__(self, model_cfg_student, teacher_pretrain=None, model_cfg_teacher=None, **_training_only):
+        super().__init__()
+        self.student_model = build_model(model_cfg_student)
+        self._children = dict(student_model=self.student_model)
+        self.device, self.prec = self.student_model.device, self.student_model.prec
+
+    def _pack(self):
+        pass
+
+    def __getattr__(self, name):  # resizer, tile_cfg, patch_process_shape, min / max_depth, predict_tiles ... are the student's (:163)
+        if name in ("student_model", "_children", "_spec", "_sd"):
+            raise AttributeError(name)
+        return getattr(self.student_model, name)
+
+    def load_dict(self, sd):
+        """patchrefiner_semi.py:110-116: old checkpoints hold teacher + student (only the ``student_model.`` keys are loaded here: the
+        teacher is not built), new ones only the student's own names (strict=False there too)"""
+        if "student_model.coarse_branch.core.core.pretrained.model.cls_token" in sd:
+            return self.load_state_dict({k: v for k, v in sd.items() if k.startswith("student_model.")}, strict=True)
+        return self.student_model.load_state_dict(sd, strict=False)
+
+    def get_save_dict(self):
+        return self.student_model.get_save_dict()
+
+    def forward(self, mode=None, image_lr=None, image_hr=None, depth_gt=None, cai_mode="m1", **kw):
+        if mode == "train":
+            raise NotImplementedError("PatchRefinerSemi: only inference is built (training is out of scope, SURVEY.md 2 #12-14)")
+        # (:208-210 forwards cai_mode but neither tile_cfg nor process_num: the student runs with its configured tiling -- unless the
+        #  caller passes them, which the reference's wrapper would have dropped)
+        extra = {k: v for k, v in kw.items() if k in ("tile_cfg", "process_num", "next_image_lr", "return_device") and v is not None}
+        return self.student_model(mode=mode, image_lr=image_lr, image_hr=image_hr, depth_gt=depth_gt, cai_mode=cai_mode, **extra)
+
+    __call__ = forward
+
+
+@MODELS.register_module()
 class PatchRefinerPlus(_PatchModel):
     """V2 (estimator/models/patchrefinerplus.py:60)."""
 

@@ -1005,6 +1005,16 @@ class CoarseTaps:
         included (prv2_coarse_tap_gather)"""
         assert boxes.dtype == torch.float32 and boxes.is_cuda and boxes.shape[1] == 4
         k = boxes.shape[0]
+        # The knot-grid algebra holds when consecutive output pixels are exactly ``kb`` coarse pixels apart (ROI bin == knot spacing): every
+        # box must span kb * (g.h, g.w) * (oh, ow) / spatial_scale frame pixels.  The boxes live on the device (no host sync on the frame
+        # path): PRV2_CHECK_TAPS=1 verifies them here; the library checks what it can see (knot spacing in (0, 1/2]), fusion.py compares the
+        # ROI's output size with its consumer's map before taking this path.
+        if os.environ.get("PRV2_CHECK_TAPS"):
+            b = boxes.detach().cpu()
+            bin_w = (b[:, 2] - b[:, 0]) * spatial_scale / ow
+            bin_h = (b[:, 3] - b[:, 1]) * spatial_scale / oh
+            assert float((bin_h - self.kb[0]).abs().max()) < 1e-4 and float((bin_w - self.kb[1]).abs().max()) < 1e-4, \
+                ("CoarseTaps.gather: ROI bin size differs from the knot spacing the table was built for", float(bin_h[0]), float(bin_w[0]), self.kb)
         if out is None:
             out = Feat(torch.empty((k, oh, ow, self.cout), device=self.g.device, dtype=torch.float32))
         assert (out.n, out.h, out.w, out.c) == (k, oh, ow, self.cout) and not out.x2

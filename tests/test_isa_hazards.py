@@ -34,3 +34,17 @@ def test_no_inline_asm_vmem_reads_a_freshly_restored_sgpr():
     files = scan.sources_with_inline_vmem()
     assert any(f.endswith("upconv.hip") for f in files) and any(f.endswith("conv3x3_m16.hip") for f in files)
     assert scan.main(files) == 0
+
+
+def test_no_packed_fp32_math_in_the_gather_family():
+    """the only mitigation of tap_gather_kernel's intermittent border-pixel miscompute is "no v_pk_*_f32 in that code" -- it lives in
+    the SOURCES now (common.h PRV2_NO_PACKED_FP32_BEGIN, a device-pass function attribute), and this asserts the ISA: zero packed fp32
+    instructions in every kernel of coarse_taps / gather / blend / pointwise, and -- positive control -- thousands in coarse_taps.hip when the
+    attribute is disabled (-DPRV2_TAPS_PK, what ``make TAPS_PK=1`` builds for the negative-control GPU test)."""
+    for fn in scan.NO_PACKED_FP32_SOURCES:
+        counts = scan.packed_fp32_by_kernel(os.path.join(scan.CSRC, fn))
+        assert counts and all(v == 0 for v in counts.values()), (fn, {k: v for k, v in counts.items() if v})
+    taps = scan.packed_fp32_by_kernel(os.path.join(scan.CSRC, "coarse_taps.hip"))
+    assert any("tap_gather_kernel" in k for k in taps) and any("tap_knots_kernel" in k for k in taps), list(taps)
+    pk = scan.packed_fp32_by_kernel(os.path.join(scan.CSRC, "coarse_taps.hip"), defines=("-DPRV2_TAPS_PK",))
+    assert sum(v for k, v in pk.items() if "tap_gather_kernel" in k) > 100, pk

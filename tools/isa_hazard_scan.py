@@ -70,6 +70,34 @@ def compile_asm(path):
             os.unlink(tmp)
 
 
+NO_PACKED_FP32_SOURCES = ("coarse_taps.hip", "gather.hip", "blend.hip", "pointwise.hip")  # common.h PRV2_NO_PACKED_FP32_BEGIN
+
+
+def packed_fp32_by_kernel(path, defines=()):
+    """{kernel: number of v_pk_*_f32 instructions} of a source compiled as the Makefile compiles it (+ ``defines``).  The files above switch
+    packed fp32 math off in the source (hipcc 7.2's v_pk_fma_f32 code for tap_gather_kernel miscomputed under multi-stream load,
+    csrc/coarse_taps.hip BUILD NOTE): their count must stay zero whatever the build route."""
+    with tempfile.NamedTemporaryFile(suffix=".s", delete=False) as f:
+        tmp = f.name
+    try:
+        r = subprocess.run([HIPCC] + FLAGS + list(defines) + [path, "-o", tmp], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{path}: {r.stderr[-2000:]}")
+        text = open(tmp).read()
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    out, kernel = {}, None
+    for raw in text.split("\n"):
+        m = re.match(r"^(_Z\w+):", raw)
+        if m:
+            kernel = m.group(1)
+            out.setdefault(kernel, 0)
+        elif kernel and re.match(r"^\s+v_pk_[a-z0-9]+_f32\b", raw):
+            out[kernel] += 1
+    return out
+
+
 def sources_with_inline_vmem():
     """the .hip files whose inline asm issues VMEM instructions with scalar operands"""
     out = []
