@@ -1,0 +1,70 @@
+"""The REAL patch-sharded forward in two OS processes on the one GPU: ``_infer_sharded`` un-patched -- the plan tensor's
+broadcast, the asynchronous per-group exchange (``_exchange_begin``: all_gather_into_tensor / gather with async_op, every Work handle
+waited for), stream ordering and buffer lifetimes -- over the gloo backend, which carries CUDA tensors (RCCL refuses two ranks on one
+device).  Each rank is a fresh child (torch.multiprocessing spawn: no process that touched the GPU is ever re-executed); the sharded
+frame must be bit-identical to the unsharded frame computed by the same child.  Rank 1 seeds ``random`` differently: only rank 0's
+broadcast plan can make the ranks agree.  SURVEY.md 8e; reference launcher contract docs/user_infer.md:124-129."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    torch.set_grad_enabled(False)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.cases import E2E_V1, E2E_V2, e2e_v1_sd, e2e_v2_sd, rand_image
+        from test_hip_models import _build
+        ok, notes = True, []
+        for kind, c, sd, mode in (("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4"), ("PatchRefiner", E2E_V1, e2e_v1_sd(), "r8")):
+            m = _build(kind, c, sd, prec="bf16x3", n_streams=2, max_batch=3)
+            hr = rand_image(c["seed"], 1, *c["raw"]).to("cuda")
+            lr = m.resizer(hr)
+            tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+
+            def run(seed, **kw):
+                random.seed(seed)
+                return m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tc, image_lr=lr, image_hr=hr, **kw)[0]
+
+            full = run(621)                                             # the unsharded frame on rank 0's random draws
+            for dst in (None, 0):                                       # --gather all / --gather rank0
+                for rep in range(2):                                    # (twice: buffers of the previous frame's exchange are reused / freed)
+                    got = run(621 + 1000 * rank, shard=(rank, world), gather_dst=dst, next_image_lr=lr if rep == 0 else None)
+                    if dst is None or rank == dst:
+                        same = got is not None and torch.equal(got, full)
+                    else:
+                        same = got is None
+                    ok = ok and same
+                    notes.append((kind, mode, dst, rep, bool(same)))
+            assert len(m.last_shard_layout) == 2                        # [init + grids | random tiles]: two exchanges per frame
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        q.put((rank, int(flag.item()), notes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_forward_in_two_processes_on_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, "a rank failed (see its traceback above)"
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert [r[1] for r in res] == [1, 1], res
