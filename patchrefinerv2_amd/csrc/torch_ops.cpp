@@ -726,7 +726,8 @@ TORCH_LIBRARY(prv2, m) {
         "int prec=0, float ln_eps=1e-06, bool same_pad=False, Tensor(a!)? out=None, int fmt=0, bool force_generic=False, int part=0) -> Tensor");
   m.def("conv3x3_ups(Tensor? x, Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, Tensor? ln_weight=None, "
         "Tensor? ln_bias=None, Tensor? res=None, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
-  m.def("upconv3x3(Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None, Tensor? add=None) -> Tensor");
+  // (``add`` may BE ``out`` -- every output element is read by the thread that writes it --: declared as a member of the same alias set)
+  m.def("upconv3x3(Tensor u, Tensor w_packed, Tensor? bias, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None, Tensor(a)? add=None) -> Tensor");
   m.def("pack_gate_weight(Tensor weight) -> Tensor");
   m.def("conv3x3_ln_gate(Tensor x, Tensor w_packed, Tensor? bias, Tensor ln_weight, Tensor ln_bias, Tensor? gate_w_packed=None, Tensor? gate_bias=None, "
         "Tensor? mul=None, Tensor? res=None, int act=1, bool relu_in=False, int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None, Tensor? pre=None, "
