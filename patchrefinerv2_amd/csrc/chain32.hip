@@ -224,10 +224,32 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
     // (the run loop is NOT unrolled and its addresses are recomputed per run: three runs' accumulators, operands and addresses next to
     //  the 144 weight registers and the prefetched window spill)
 
+    // the epilogue's global operand of a run (MODE_C2F: the residual x, MODE_ENC: the coarse half ``pre``) is requested ONE RUN AHEAD -- the
+    // first run of a tile during the last run of the previous one: waited for at its use it is an HBM round trip per run
+    auto e_load = [&](int kk, int a, f32x4& e0, f32x4& e1) {
+      e0 = e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kk >= K) return;
+      int n, y0, x0;
+      tile_of(kk, n, y0, x0);
+      const int q = (wave * RUNS1_PER_WAVE + a) * 16 + m16, qq = min(q, MID_PX - 1);
+      const int qr = qq / MID_W, qc = qq - qr * MID_W;
+      const int gy = y0 - 1 + qr, gx = x0 - 1 + qc;
+#ifdef C32_ABL_NOE1  // (timing ablations: results wrong)
+      if (p.b3 != 12345.f) return;
+#endif
+      if (q < MID_PX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+        const float* src = MODE == 0 ? p.x + (long long)n * p.x_bstride + (gy * p.W + gx) * p.ldx
+                                     : p.pre + (long long)n * HW * p.ld_pre + (gy * p.W + gx) * p.ld_pre;
+        e0 = *reinterpret_cast<const f32x4*>(src + 4 * g);
+        e1 = *reinterpret_cast<const f32x4*>(src + 16 + 4 * g);
+      }
+    };
+    f32x4 e0, e1;
     if (K > 0) {
       load_window(0);
       store_window(0);
     }
+    e_load(0, 0, e0, e1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef C32_STAMPS
     long long st_c = 0, st_s = 0, st_b = 0;
@@ -242,6 +264,14 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
 #ifndef C32_ABL_NOWIN
       if (k + 1 < K) load_window(k + 1);  // lands while this tile is convolved
 #endif
+      float2 pv = make_float2(0.f, 0.f);  // MODE_ENC: the two depth maps on the mid window (zero outside the image), requested in front of the runs
+      if (MODE == 1 && tid < MID_PX) {
+        const int r = tid / MID_W, c = tid - r * MID_W, gy = y0 - 1 + r, gx = x0 - 1 + c;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+          const long long o = (long long)n * HW + (gy * p.W + gx);
+          pv = make_float2(p.p1[o], p.p2[o]);
+        }
+      }
 #pragma unroll 1
       for (int a = 0; a < RUNS1_PER_WAVE; ++a) {
         const int q = (wave * RUNS1_PER_WAVE + a) * 16 + m16, qq = min(q, MID_PX - 1);
@@ -250,18 +280,9 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
         const int mid_off = q < MID_PX ? OFF_MID + q * PIX + g * 16 : -1;
         const int gy = y0 - 1 + qr, gx = x0 - 1 + qc;
         const bool valid = mid_off >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        // the epilogue's global operands, requested in front of the taps: MODE_C2F the residual x, MODE_ENC the coarse half ``pre``
-        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
-#ifndef C32_ABL_NOE1  // (timing ablations: results wrong)
-        if (valid) {
-#else
-        if (valid && p.b3 == 12345.f) {
-#endif
-          const float* src = MODE == 0 ? p.x + (long long)n * p.x_bstride + (gy * p.W + gx) * p.ldx
-                                       : p.pre + (long long)n * HW * p.ld_pre + (gy * p.W + gx) * p.ld_pre;
-          e0 = *reinterpret_cast<const f32x4*>(src + 4 * g);
-          e1 = *reinterpret_cast<const f32x4*>(src + 16 + 4 * g);
-        }
+        f32x4 en0, en1;  // the next run's operand (of the next tile's first run behind this tile's last)
+        if (a + 1 < RUNS1_PER_WAVE) e_load(k, a + 1, en0, en1);
+        else e_load(k + 1, 0, en0, en1);
         f32x4 acc0 = cvec(C_B1, 0), acc1 = cvec(C_B1, 1);
         const char* const ib = smem + buf * IN_BYTES + in_off;
         // the next tap's fragments are requested in front of this tap's MFMAs (left alone hipcc reads each fragment right in front of its
@@ -287,6 +308,8 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
         }
         acc0 += e0;
         acc1 += e1;
+        e0 = en0;
+        e1 = en1;
         if (MODE == 1) {
           c32_layernorm(acc0, acc1, cvec(C_LN1W, 0), cvec(C_LN1W, 1), cvec(C_LN1B, 0), cvec(C_LN1B, 1), p.eps);
           acc0 = c32_gelu4(acc0);
@@ -302,15 +325,7 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
           *reinterpret_cast<bf16x8*>(dst + 64) = lo;
         }
       }
-      if (MODE == 1 && tid < MID_PX) {  // the two depth maps on the mid window (zero outside the image)
-        const int r = tid / MID_W, c = tid - r * MID_W, gy = y0 - 1 + r, gx = x0 - 1 + c;
-        float2 v = make_float2(0.f, 0.f);
-        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
-          const long long o = (long long)n * HW + (gy * p.W + gx);
-          v = make_float2(p.p1[o], p.p2[o]);
-        }
-        *reinterpret_cast<float2*>(smem + OFF_PRED + buf * PRED_BYTES + tid * 8) = v;
-      }
+      if (MODE == 1 && tid < MID_PX) *reinterpret_cast<float2*>(smem + OFF_PRED + buf * PRED_BYTES + tid * 8) = pv;
 #ifdef C32_STAMPS
       const long long s1 = clock64();
 #endif
@@ -361,6 +376,27 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
 #ifdef C32_STAMPS
     long long st_c = 0, st_b = 0;
 #endif
+    // the pre-LayerNorm addend of this wave's two rows (MODE_C2F), requested ONE TILE AHEAD: in the epilogue it would be a full HBM round
+    // trip in the middle of a serial chain (the rows are this wave's only outstanding loads: nothing else to wait behind)
+    f32x4 pe[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    auto load_pre = [&](int kk) {
+      if (MODE != 0 || !p.pre || kk >= K) return;
+      int n, y0, x0;
+      tile_of(kk, n, y0, x0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int gy = y0 + 2 * w2i + a, gx = x0 + m16;
+#ifdef C32_ABL_NOE2
+        if (p.b3 != 12345.f) continue;
+#endif
+        if (gy < p.H && gx < p.W) {
+          const float* src = p.pre + (long long)n * HW * p.ld_pre + (gy * p.W + gx) * p.ld_pre;
+          pe[a][0] = *reinterpret_cast<const f32x4*>(src + 4 * g);
+          pe[a][1] = *reinterpret_cast<const f32x4*>(src + 16 + 4 * g);
+        }
+      }
+    };
+    load_pre(0);
     for (int k = 0; k <= K; ++k) {
 #ifdef C32_STAMPS
       const long long s0 = clock64();
@@ -369,114 +405,124 @@ __global__ void __launch_bounds__(512) chain32_kernel(const Chain32Params p) {
         const int buf = (k - 1) & 1;
         int n, y0, x0;
         tile_of(k - 1, n, y0, x0);
-#pragma unroll 1
-        for (int a = 0; a < 2; ++a) {
-          const int row = 2 * w2i + a, gy = y0 + row, gx = x0 + m16;
-          const bool valid = gy < p.H && gx < p.W;
-          const int ipix = gy * p.W + gx;  // pixel within its image
-          f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
-          f32x4 acc0 = cvec(C_B2, 0), acc1 = cvec(C_B2, 1);
-          const char* const mb = smem + OFF_MID + buf * MID_BYTES + (row * MID_W + m16) * PIX + g * 16;
-          bf16x8 xh[2], xl[2];
-          xh[0] = *reinterpret_cast<const bf16x8*>(mb);
-          xl[0] = *reinterpret_cast<const bf16x8*>(mb + 64);
+        // the wave's two rows TOGETHER: two independent accumulator pairs through the taps (a row's next fragments are in flight under the
+        // other row's MFMAs) and two independent epilogue chains (LayerNorm reductions, gate GEMM, sigmoid, out_conv) for the scheduler
+        const int gx = x0 + m16;
+        const char* const mb0 = smem + OFF_MID + buf * MID_BYTES + ((2 * w2i) * MID_W + m16) * PIX + g * 16;
+        f32x4 acc[2][2];
+        bf16x8 xh[2], xl[2];
 #pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            if (t + 1 < 9) {
-              const int toff = (((t + 1) / 3) * MID_W + ((t + 1) % 3)) * PIX;
-              xh[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(mb + toff);
-              xl[(t + 1) & 1] = *reinterpret_cast<const bf16x8*>(mb + toff + 64);
-            }
-            if (t == 2) {  // the epilogue's addend, requested early in the taps
-              __builtin_amdgcn_sched_barrier(0);
-#ifndef C32_ABL_NOE2
-              if (MODE == 0 && valid && p.pre) {
-#else
-              if (MODE == 0 && valid && p.pre && p.b3 == 12345.f) {
-#endif
-                const float* src = p.pre + (long long)n * HW * p.ld_pre + ipix * p.ld_pre;
-                e0 = *reinterpret_cast<const f32x4*>(src + 4 * g);
-                e1 = *reinterpret_cast<const f32x4*>(src + 16 + 4 * g);
-              }
-            }
+        for (int a = 0; a < 2; ++a) {
+          acc[a][0] = cvec(C_B2, 0);
+          acc[a][1] = cvec(C_B2, 1);
+          xh[a] = *reinterpret_cast<const bf16x8*>(mb0 + a * MID_W * PIX);
+          xl[a] = *reinterpret_cast<const bf16x8*>(mb0 + a * MID_W * PIX + 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
             __builtin_amdgcn_sched_barrier(0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][0], xl[t & 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][1], xl[t & 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t][0], xh[t & 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t][1], xh[t & 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][0], xh[t & 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][1], xh[t & 1], acc1, 0, 0, 0);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][0], xl[a], acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][1], xl[a], acc[a][1], 0, 0, 0);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t][0], xh[a], acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[t][1], xh[a], acc[a][1], 0, 0, 0);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][0], xh[a], acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[t][1], xh[a], acc[a][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) {  // this row's next fragments: in flight under the other row's six MFMAs
+              const int toff = (((t + 1) / 3 + a) * MID_W + ((t + 1) % 3)) * PIX;
+              xh[a] = *reinterpret_cast<const bf16x8*>(mb0 + toff);
+              xl[a] = *reinterpret_cast<const bf16x8*>(mb0 + toff + 64);
+            }
           }
-          if (MODE == 1) {
-            // the two depth-map channels of cat([f, p1, p2]): 9 taps x 2 maps as ONE k = 32 step
-            const char* const pb = smem + OFF_PRED + buf * PRED_BYTES + (row * MID_W + m16) * 8;
-            f32x4 t0, t1;
-            {
-              const float2 v0 = pred_off[0] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[0]) : make_float2(0.f, 0.f);
-              const float2 v1 = pred_off[1] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[1]) : make_float2(0.f, 0.f);
-              const float2 v2 = pred_off[2] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[2]) : make_float2(0.f, 0.f);
-              const float2 v3 = pred_off[3] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[3]) : make_float2(0.f, 0.f);
-              t0 = f32x4{v0.x, v0.y, v1.x, v1.y};
-              t1 = f32x4{v2.x, v2.y, v3.x, v3.y};
-            }
+        }
+        if (MODE == 1) {
+          // the two depth-map channels of cat([f, p1, p2]): 9 taps x 2 maps as ONE k = 32 step
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const char* const pb = smem + OFF_PRED + buf * PRED_BYTES + ((2 * w2i + a) * MID_W + m16) * 8;
+            const float2 v0 = pred_off[0] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[0]) : make_float2(0.f, 0.f);
+            const float2 v1 = pred_off[1] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[1]) : make_float2(0.f, 0.f);
+            const float2 v2 = pred_off[2] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[2]) : make_float2(0.f, 0.f);
+            const float2 v3 = pred_off[3] >= 0 ? *reinterpret_cast<const float2*>(pb + pred_off[3]) : make_float2(0.f, 0.f);
             bf16x8 th, tl;
-            c32_split8(t0, t1, th, tl);
-            c32_mma(acc0, w1x1(0, 0, 0), w1x1(0, 0, 1), th, tl);
-            c32_mma(acc1, w1x1(0, 1, 0), w1x1(0, 1, 1), th, tl);
-            c32_layernorm(acc0, acc1, cvec(C_LN2W, 0), cvec(C_LN2W, 1), cvec(C_LN2B, 0), cvec(C_LN2B, 1), p.eps);
-            acc0 = c32_gelu4(acc0);
-            acc1 = c32_gelu4(acc1);
-          } else {
-            acc0 += e0;
-            acc1 += e1;
-            c32_layernorm(acc0, acc1, cvec(C_LN1W, 0), cvec(C_LN1W, 1), cvec(C_LN1B, 0), cvec(C_LN1B, 1), p.eps);
-            acc0 = relu4(acc0);
-            acc1 = relu4(acc1);
-            bf16x8 fh, fl;
-            c32_split8(acc0, acc1, fh, fl);
-            f32x4 g0 = cvec(C_BG, 0), g1 = cvec(C_BG, 1);
-            c32_mma(g0, w1x1(0, 0, 0), w1x1(0, 0, 1), fh, fl);
-            c32_mma(g1, w1x1(0, 1, 0), w1x1(0, 1, 1), fh, fl);
+            c32_split8(f32x4{v0.x, v0.y, v1.x, v1.y}, f32x4{v2.x, v2.y, v3.x, v3.y}, th, tl);
+            c32_mma(acc[a][0], w1x1(0, 0, 0), w1x1(0, 0, 1), th, tl);
+            c32_mma(acc[a][1], w1x1(0, 1, 0), w1x1(0, 1, 1), th, tl);
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            c32_layernorm(acc[a][0], acc[a][1], cvec(C_LN2W, 0), cvec(C_LN2W, 1), cvec(C_LN2B, 0), cvec(C_LN2B, 1), p.eps);
+            acc[a][0] = c32_gelu4(acc[a][0]);
+            acc[a][1] = c32_gelu4(acc[a][1]);
+          }
+        } else {
+          f32x4 gt[2][2];
+          bf16x8 fh[2], fl[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            acc[a][0] += pe[a][0];
+            acc[a][1] += pe[a][1];
+            c32_layernorm(acc[a][0], acc[a][1], cvec(C_LN1W, 0), cvec(C_LN1W, 1), cvec(C_LN1B, 0), cvec(C_LN1B, 1), p.eps);
+            c32_split8(relu4(acc[a][0]), relu4(acc[a][1]), fh[a], fl[a]);
+            gt[a][0] = cvec(C_BG, 0);
+            gt[a][1] = cvec(C_BG, 1);
+          }
+          load_pre(k);  // (the next tile's rows: the registers are free again)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            c32_mma(gt[a][0], w1x1(0, 0, 0), w1x1(0, 0, 1), fh[a], fl[a]);
+            c32_mma(gt[a][1], w1x1(0, 1, 0), w1x1(0, 1, 1), fh[a], fl[a]);
+          }
+          bf16x8 yh[2], yl[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
             // o = hi + lo of the centre pixel (what the matrix pipe saw of it); element j of the fragment = channel 4 g + j (j < 4), 16 + 4 g + j - 4
             // (the centre tap's fragments = this lane's own channels of ``o``; read again rather than kept across the taps)
             typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(mb + (MID_W + 1) * PIX), cl = *reinterpret_cast<const bf16x8*>(mb + (MID_W + 1) * PIX + 64);
-            const u16x8 chu = __builtin_bit_cast(u16x8, ch), clu = __builtin_bit_cast(u16x8, cl);
-            f32x4 o0, o1;
+            const char* const cb = mb0 + ((a + 1) * MID_W + 1) * PIX;
+            const u16x8 chu = __builtin_bit_cast(u16x8, *reinterpret_cast<const bf16x8*>(cb)), clu = __builtin_bit_cast(u16x8, *reinterpret_cast<const bf16x8*>(cb + 64));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              o0[e] = __builtin_bit_cast(float, (unsigned)chu[e] << 16) + __builtin_bit_cast(float, (unsigned)clu[e] << 16);
-              o1[e] = __builtin_bit_cast(float, (unsigned)chu[4 + e] << 16) + __builtin_bit_cast(float, (unsigned)clu[4 + e] << 16);
+              const float o0 = __builtin_bit_cast(float, (unsigned)chu[e] << 16) + __builtin_bit_cast(float, (unsigned)clu[e] << 16);
+              const float o1 = __builtin_bit_cast(float, (unsigned)chu[4 + e] << 16) + __builtin_bit_cast(float, (unsigned)clu[4 + e] << 16);
+              gt[a][0][e] = o0 * c32_sigmoid(gt[a][0][e]);
+              gt[a][1][e] = o1 * c32_sigmoid(gt[a][1][e]);
             }
+            c32_split8(gt[a][0], gt[a][1], yh[a], yl[a]);
+            acc[a][0] = cvec(C_BO, 0);
+            acc[a][1] = cvec(C_BO, 1);
+          }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              g0[e] = o0[e] * c32_sigmoid(g0[e]);
-              g1[e] = o1[e] * c32_sigmoid(g1[e]);
-            }
-            bf16x8 yh, yl;
-            c32_split8(g0, g1, yh, yl);
-            acc0 = cvec(C_BO, 0);
-            acc1 = cvec(C_BO, 1);
-            c32_mma(acc0, w1x1(1, 0, 0), w1x1(1, 0, 1), yh, yl);
-            c32_mma(acc1, w1x1(1, 1, 0), w1x1(1, 1, 1), yh, yl);
-            const f32x4 w30 = cvec(C_W3, 0), w31 = cvec(C_W3, 1);
-            float d = ((acc0.x * w30.x + acc0.y * w30.y) + (acc0.z * w30.z + acc0.w * w30.w)) +
-                      ((acc1.x * w31.x + acc1.y * w31.y) + (acc1.z * w31.z + acc1.w * w31.w));
+          for (int a = 0; a < 2; ++a) {
+            c32_mma(acc[a][0], w1x1(1, 0, 0), w1x1(1, 0, 1), yh[a], yl[a]);
+            c32_mma(acc[a][1], w1x1(1, 1, 0), w1x1(1, 1, 1), yh[a], yl[a]);
+          }
+          const f32x4 w30 = cvec(C_W3, 0), w31 = cvec(C_W3, 1);
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const int gy = y0 + 2 * w2i + a;
+            float d = ((acc[a][0].x * w30.x + acc[a][0].y * w30.y) + (acc[a][0].z * w30.z + acc[a][0].w * w30.w)) +
+                      ((acc[a][1].x * w31.x + acc[a][1].y * w31.y) + (acc[a][1].z * w31.z + acc[a][1].w * w31.w));
             d = c32_sum_g(d) + p.b3;
-            if (valid && g == 0 && p.depth) {
-              float* dd = p.depth + (long long)n * HW + ipix;
+            if (gy < p.H && gx < p.W && g == 0 && p.depth) {
+              float* dd = p.depth + (long long)n * HW + (gy * p.W + gx);
               asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" ::"v"(dd), "v"(d) : "memory");
             }
           }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int gy = y0 + 2 * w2i + a;
 #ifndef C32_ABL_NOSTORE
-          if (valid) {
+          if (gy < p.H && gx < p.W) {
 #else
-          if (valid && p.b3 == 12345.f) {
+          if (gy < p.H && gx < p.W && p.b3 == 12345.f) {
 #endif
-            // (inline asm: a store the compiler knows about makes its counted waits in the next row's taps wait for the store's acknowledgement)
-            float* dst = p.y + (long long)n * p.y_bstride + ipix * p.ldy + 4 * g;
-            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:64\n\ts_nop 1" ::"v"(dst), "v"(acc0), "v"(acc1) : "memory");
+            // (inline asm: a store the compiler knows about makes its counted waits in the next tile's taps wait for the store's acknowledgement)
+            float* dst = p.y + (long long)n * p.y_bstride + (gy * p.W + gx) * p.ldy + 4 * g;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:64\n\ts_nop 1" ::"v"(dst), "v"(acc[a][0]), "v"(acc[a][1]) : "memory");
           }
         }
       }
