@@ -368,6 +368,11 @@ class _PatchModel(StateDictModule):
     #                       in tile-times: tiles of the last group move from it to other ranks while that shortens the modelled
     #                       critical path max(others' tiles, its tiles + cost); config key shard_dst_cost
 
+    SHARD_MERGE_BELOW = 8   # from 8 ranks on, a first gather group with fewer than this many tiles PER RANK is merged with the random tiles:
+    #                         6 + 4 tiles per rank in two batches under-fill the chip (2.9 ms per tile against 2.2 at 41: the r04 one-GPU model lost
+    #                         36 % at 8 ranks to it); one 10-tile batch per rank and one exchange instead -- rank 0 then blends everything behind the
+    #                         last batch (order unchanged: bit-identical).  Config key shard_merge_below (0: never merge).
+
     def shard_layout(self, kinds, counts, world, dst=None):
         """Who computes which tile, and what is exchanged when (pure host arithmetic on the plan's pass structure; cached).
         Passes form GATHER GROUPS -- [init + half-offset grids] and [random tiles] -- so that the receiving rank pastes /
@@ -376,7 +381,8 @@ class _PatchModel(StateDictModule):
         that shortens max(others' tiles, its tiles + shard_dst_cost) -- its receive + blend + D2H tail.
         Returns a list of groups: dict(passes=[pass indices], base, n, per, owner=[rank per tile], mine=[[tile offsets in the
         group] per rank], perm=[position of every tile of the group in the rank-major [world * per] gathered stack])."""
-        key = (tuple(kinds), tuple(counts), int(world), dst, float(getattr(self, "shard_dst_cost", self.SHARD_DST_COST)))
+        merge_below = int(getattr(self, "shard_merge_below", self.SHARD_MERGE_BELOW))
+        key = (tuple(kinds), tuple(counts), int(world), dst, float(getattr(self, "shard_dst_cost", self.SHARD_DST_COST)), merge_below)
         cache = self.__dict__.setdefault("_shard_layouts", {})
         if key in cache:
             return cache[key]
@@ -385,6 +391,8 @@ class _PatchModel(StateDictModule):
         rnd = [i for i, k in enumerate(kinds) if k == "random" and counts[i] > 0]
         groups = []
         id_groups = [ids for ids in (fixed, rnd) if ids]
+        if len(id_groups) == 2 and world >= 8 and sum(counts[i] for i in fixed) < merge_below * world:
+            id_groups = [sorted(fixed + rnd)]      # one batch and one exchange per rank (pass order kept: the blend walks g["passes"] in order)
         for ids in id_groups:
             n = sum(counts[i] for i in ids)
             share = [n // world] * world
