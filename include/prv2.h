@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 15
+#define PRV2_ABI_VERSION 16
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -144,6 +144,33 @@ int prv2_conv2d_ups(const prv2_conv_desc* d, const float* x, const prv2_ups_src*
 int prv2_upconv3x3_supported(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec);
 int prv2_upconv3x3(const prv2_ups_src* u, const void* w_packed, const float* bias, const float* add, int32_t ld_add, int32_t n, int32_t h,
                    int32_t w, int32_t cout, int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream);
+
+/* TWO back-to-back 3x3 convs (no activation in between) of a bilinear(align_corners=True) x2 UPSAMPLE as ONE 5x5 conv computed at u's
+ * resolution (csrc/upconv5.hip) -- C2FModule's ``output_conv2[0] o output_conv1 o interpolate`` (with refinenet1.out_conv folded into
+ * output_conv1): bi_directional_fusion_model.py:139-146 (interpolate + out_conv), :169-173 (definitions), :201-203 (use):
+ *     v = act(conv3x3(conv3x3(up(u); W1) + b1(p); W2) + b2)  =  act(conv5x5(up(u); Weff) + bias_map(p) - ring_fix(p)),   Weff[d] = sum_{d1+d2=d} W2[d2] W1[d1]
+ * 205 k instead of 332 k MACs per output pixel in the reference's terms; the 128-channel full-resolution intermediate is never formed.
+ *   prv2_upconv5x5       y = act(conv5x5(interpolate(u, (h, w))) + bias_map[class(y)][class(x)]) for every pixel EXCEPT the one-pixel border
+ *                        ring, which is written WITHOUT the activation (the ring fix below finishes it).  w_packed:
+ *                        prv2_pack_conv_weight(cout, cin = u->channels, 5, 5) of Weff; bias_map: device fp32 [5][5][cout], row / column
+ *                        classes (0, 1, interior, h - 2, h - 1): the inner conv's (position dependent) bias seen through the outer conv's
+ *                        zero padding -- data independent.  cout <= 32.
+ *   prv2_upconv5x5_lines lines[n][2 uw + 2 uh][channels] = the border lines of up(u) at u's resolution: output row 0, row h - 1 (uw positions
+ *                        each), column 0, column w - 1 (uh each) -- align_corners samples of u's first / last rows and columns.
+ *   prv2_upconv5x5_ring  the 5x5 form over the zero-padded map includes inner-conv outputs one pixel OUTSIDE the image, which the outer conv's
+ *                        zero padding hides: on the ring  y = act(y - fix),  fix = per edge a 1-D five-tap conv of the border line -- as tap
+ *                        GEMMs at u's resolution: g_edges[n][2 uw + 2 uh][ldg] = prv2_conv2d (1x1) of ``lines`` with the weights
+ *                        [(edge * 7 + j) * cout + c][ci], edge = top, bottom, left, right; j < 5: sum_{k1 + k2 - 2 = j - 2} W2[edge's outer taps k2]
+ *                        W1[edge's inner taps k1]; j = 5 / 6: the corner term at the row edges' first / last pixel (the outside corner position
+ *                        is in both edges' sums).  tools/studies/composite5x5_ring.py: the float64 algebra (4e-15).
+ * Contract (prv2_upconv5x5_supported != 0): bf16 modes, u->channels % 32 == 0, cout % 4 == 0 and <= 32, source step <= 1/2 (x2 upsamples),
+ * h, w >= 5, 16-byte aligned NHWC rows.  fp32-grade, not bit-identical to the two-conv sequence. */
+int prv2_upconv5x5_supported(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, int32_t cout, int32_t prec);
+int prv2_upconv5x5(const prv2_ups_src* u, const void* w_packed, const float* bias_map, int32_t n, int32_t h, int32_t w, int32_t cout,
+                   int32_t act, int32_t prec, float* y, int32_t ldy, int64_t y_bstride, void* stream);
+int prv2_upconv5x5_lines(const prv2_ups_src* u, int32_t n, int32_t h, int32_t w, float* lines, void* stream);
+int prv2_upconv5x5_ring(float* y, int32_t ldy, int64_t y_bstride, int32_t n, int32_t h, int32_t w, int32_t cout, const float* g_edges,
+                        int32_t ldg, int32_t uh, int32_t uw, int32_t act, void* stream);
 
 /* prv2_conv2d (3x3 / stride 1 / pad 1, bias, [LayerNorm,] activation, [+ res]) that ALSO writes the two depth maps every fusion
  * level appends to its features behind its own output channels: y[pixel][cout .. cout + 3] = (p1, p2, 0, 0), p1 / p2 dense

@@ -200,7 +200,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
   };
   auto dma_b_async = [&](int s, int bbuf, int i) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dma_dst(bbuf, i));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(dma_src(s, i)) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(dma_src(s, i)) : "memory");
   };
 
   f32x4 acc[NA][NJ];

@@ -313,7 +313,7 @@ __device__ __forceinline__ void halo16_body(const IgemmParams& p, float* smem, i
   // in its model), which drains the fragment reads issued a few instructions earlier for the NEXT phase.
   auto dma_b_async = [&](int s, int bbuf, int i) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dma_dst(bbuf, i));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(dma_src(s, i)) : "memory", "m0");  // (m0 is not live anywhere else in the loop)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(dma_src(s, i)) : "memory");  // (m0 is not live anywhere else in the loop)
   };
 
   f32x4 acc[NA][NJ];

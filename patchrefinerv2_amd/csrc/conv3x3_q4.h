@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_q4_kernel(const IgemmParams p)
     const unsigned long long b = (unsigned long long)(size_t)base;
     const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sb) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sb) : "memory");
   };
   const int cslabs = p.Cin_pad / 32;            // slabs staged through the halo buffer
   const int cchunks = cslabs - (TAIL ? 1 : 0);  // slabs walked by the 9-tap loop

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_w4_gate_kernel(const GateConvP
       const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(As_b + (4 * i + wave) * 1024));
       const unsigned voff = hoff_lds[i * 256] + (unsigned)(cc * 128);  // (2^31 + cc * 128 stays out of range)
       if (i < NHD - 1 || halo_tail_ok)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc) : "memory");
     }
   };
 
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_w4_gate_kernel(const GateConvP
     const unsigned long long b = (unsigned long long)(size_t)base;
     const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sb) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sb) : "memory");
   };
   auto dma_conv_tile = [&](long long byte_off, int bbuf) {
 #pragma unroll

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
   const unsigned smem_base = (unsigned)(size_t)smem;
   auto dma = [&](const char* src, unsigned dst) {
     const unsigned d = __builtin_amdgcn_readfirstlane(dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(src) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(src) : "memory");
   };
   auto issue = [&](int stage, int k) {
     const unsigned sb = smem_base + stage * STAGE;

@@ -286,6 +286,36 @@ Tensor conv3x3_pre(const Tensor& x, const Tensor& w_packed, const optional<Tenso
   return y;
 }
 
+// include/prv2.h::prv2_upconv5x5*: output_conv2[0] o output_conv1 o interpolate as one 5x5 conv at u's resolution (csrc/upconv5.hip)
+Tensor upconv5x5(const Tensor& u, const Tensor& w_packed, const Tensor& bias_map, int64_t cout, int64_t oh, int64_t ow, int64_t act, int64_t prec,
+                 const optional<Tensor>& out) {
+  const int64_t ldu = nhwc_ld(u, "u"), n = u.size(0), cu = u.size(3);
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_packed_weight_bytes((int)cout, (int)cu, 5, 5, 0, (int)prec), "prv2::upconv5x5: w_packed does not match (cout, u channels, 5x5, prec)");
+  Tensor y = out_or_alloc(out, u, n, oh, ow, cout, "upconv5x5");
+  prv2_ups_src us = {u.data_ptr<float>(), (int)u.size(1), (int)u.size(2), (int)ldu, (int)cu, 0};
+  TORCH_CHECK(prv2_upconv5x5_supported(&us, (int)n, (int)oh, (int)ow, (int)cout, (int)prec), "prv2::upconv5x5: layer not covered (see include/prv2.h)");
+  Launch L(u);
+  ok(prv2_upconv5x5(&us, w_packed.data_ptr(), opt_ptr(bias_map, "bias_map", 25 * cout), (int)n, (int)oh, (int)ow, (int)cout, (int)act, (int)prec,
+                    y.data_ptr<float>(), (int)nhwc_ld(y, "out"), 0, L.stream), "upconv5x5");
+  return y;
+}
+Tensor upconv5x5_lines(const Tensor& u, int64_t oh, int64_t ow) {
+  const int64_t ldu = nhwc_ld(u, "u"), n = u.size(0), cu = u.size(3);
+  Tensor lines = at::empty({n, 1, 2 * u.size(2) + 2 * u.size(1), cu}, u.options());
+  prv2_ups_src us = {u.data_ptr<float>(), (int)u.size(1), (int)u.size(2), (int)ldu, (int)cu, 0};
+  Launch L(u);
+  ok(prv2_upconv5x5_lines(&us, (int)n, (int)oh, (int)ow, lines.data_ptr<float>(), L.stream), "upconv5x5_lines");
+  return lines;
+}
+void upconv5x5_ring_(Tensor y, const Tensor& g_edges, int64_t uh, int64_t uw, int64_t act) {
+  const int64_t ldy = nhwc_ld(y, "y"), ldg = nhwc_ld(g_edges, "g_edges");
+  TORCH_CHECK(g_edges.size(0) == y.size(0) && g_edges.size(1) == 1 && g_edges.size(2) == 2 * uw + 2 * uh && g_edges.size(3) == 28 * y.size(3),
+              "prv2::upconv5x5_ring_: g_edges is [n, 1, 2 uw + 2 uh, 28 * cout]");
+  Launch L(y);
+  ok(prv2_upconv5x5_ring(y.data_ptr<float>(), (int)ldy, 0, (int)y.size(0), (int)y.size(1), (int)y.size(2), (int)y.size(3), g_edges.data_ptr<float>(), (int)ldg,
+                         (int)uh, (int)uw, (int)act, L.stream), "upconv5x5_ring");
+}
+
 // include/prv2.h::prv2_chain32_*: the 32-channel full-resolution tail of BiDirectionalFusion, two 3x3 convs per kernel (csrc/chain32.hip)
 Tensor pack_chain32_weight(const Tensor& w, int64_t kind) {
   dev_f32(w, "weight");
@@ -736,6 +766,9 @@ TORCH_LIBRARY(prv2, m) {
         "int prec, float ln_eps, Tensor(a!) out) -> ()");
   m.def("conv3x3_pre(Tensor x, Tensor w_packed, Tensor? bias, Tensor pre, int cout, int act=0, Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? res=None, "
         "int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
+  m.def("upconv5x5(Tensor u, Tensor w_packed, Tensor bias_map, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None) -> Tensor");
+  m.def("upconv5x5_lines(Tensor u, int oh, int ow) -> Tensor");
+  m.def("upconv5x5_ring_(Tensor(a!) y, Tensor g_edges, int uh, int uw, int act=0) -> ()");
   m.def("pack_chain32_weight(Tensor weight, int kind) -> Tensor");
   m.def("chain32_c2f(Tensor x, Tensor w1, Tensor w2, Tensor wg, Tensor wo, Tensor consts, float b3, Tensor? pre, float ln_eps, Tensor(a!) y, "
         "Tensor(b!)? depth=None) -> ()");
@@ -787,6 +820,9 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
   m.impl("conv3x3_tail", &conv3x3_tail);
   m.impl("conv3x3_pre", &conv3x3_pre);
+  m.impl("upconv5x5", &upconv5x5);
+  m.impl("upconv5x5_lines", &upconv5x5_lines);
+  m.impl("upconv5x5_ring_", &upconv5x5_ring_);
   m.impl("pack_chain32_weight", &pack_chain32_weight);
   m.impl("chain32_c2f", &chain32_c2f);
   m.impl("chain32_enc", &chain32_enc);

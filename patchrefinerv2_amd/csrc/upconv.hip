@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
         // s_nop 4: the scalar operands may have been restored from a spill lane (v_readlane) right in front of this statement; a VMEM
         // instruction reading an SGPR that a VALU instruction wrote needs 5 wait states, and the hazard recognizer does not look into
         // inline asm (seen: the bf16 instantiation fetched some weight pieces from a stale address)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(wlane), "s"(src) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(wlane), "s"(src) : "memory");
       }
     }
   };

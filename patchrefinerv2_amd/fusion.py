@@ -414,10 +414,18 @@ class BiDirectionalFusion(_EncDec):
             # 192 x 256 (2.5 ms per frame); the f32 mode keeps the reference's layer order.
             w1, b1 = self._sd[s + "output_conv1.weight"].double(), self._sd[s + "output_conv1.bias"].double()
             woc, boc = self._sd[s + "refinenet1.out_conv.weight"].double()[:, :, 0, 0], self._sd[s + "refinenet1.out_conv.bias"].double()
-            wf = torch.einsum("omyx,mi->oiyx", w1, woc).float()
+            wf64 = torch.einsum("omyx,mi->oiyx", w1, woc)
+            wf = wf64.float()
             bt = torch.einsum("omyx,m->yxo", w1, boc)  # [3, 3, out]: what each tap contributes from the folded constant
             P["out1_folded"] = ops.pack_conv(wf, (b1 + bt.sum((0, 1))).float(), pad=1, device=self.device, prec=self.prec)
             P["out1_tap_bias"] = bt.reshape(9, -1).float().contiguous().to(self.device)
+            # output_conv2[0] follows output_conv1 with nothing non-linear in between (:201-203): the pair -- behind the bilinear x2 -- is ONE
+            # 5x5 conv 256 -> 32 evaluated at path_1's resolution (ops.upconv5x5, csrc/upconv5.hip): the 128-channel full-resolution map
+            # is never formed.  Composite weights, the 25 bias classes and the border ring's edge weights in float64 (ops.compose_upconv5x5).
+            w2 = self._sd[s + "output_conv2.0.weight"]
+            if ops.UPCONV5 and ops.UPCONV and w2.shape[0] <= 32 and w2.shape[0] % 4 == 0:
+                P["out5"] = ops.compose_upconv5x5(wf64, b1, bt.reshape(9, -1), w2, self._sd.get(s + "output_conv2.0.bias"), self.device, self.prec)
+                P["out5"]["algo_per_px"] = 2.0 * 9 * (w1.shape[1] * w1.shape[0] + w2.shape[1] * w2.shape[0])
         P["out2_0"] = self._conv(s + "output_conv2.0")
         P["out2_fusion"] = block(s + "output_conv2_fusion.")
         P["out3_w"] = self._dev(s + "output_conv3.0.weight")
@@ -563,6 +571,10 @@ class BiDirectionalFusion(_EncDec):
         w1 = P["out1_folded"] if folded else P["out1"]
         size1 = (rn[0].h * 2, rn[0].w * 2)
         path1 = self._gated_block(R[1], [path2, rn[0]], coarse[1], F_, size=size1, skip_out_conv=folded, defer_upsample=w1)
+        if (path1.h, path1.w) != size1 and folded and "out5" in P and ops.upconv5x5_supported(path1, size1[0], size1[1], P["out5"]):
+            # output_conv2[0](output_conv1(interpolate(path_1))) (:139-142, :201-203) as one 5x5 conv at path_1's resolution
+            last = ops.upconv5x5(path1, size1[0], size1[1], P["out5"], act=ACT_RELU)
+            return self._c2f_tail(P, last, coarse, dests)
         if (path1.h, path1.w) != size1 and ops.upconv3x3_supported(path1, size1[0], size1[1], w1):
             # not upsampled yet, and never: output_conv1(interpolate(path_1)) (:139-142, :201) as nine tap GEMMs at path_1's resolution
             # and a four-corner gather per tap (csrc/upconv.hip): 2.3x fewer matrix operations than the conv over the upsampled map
@@ -574,6 +586,10 @@ class BiDirectionalFusion(_EncDec):
         if folded:
             ops.conv_border_bias(out, P["out1_tap_bias"])
         last = ops.conv2d(out, P["out2_0"], act=ACT_RELU)
+        return self._c2f_tail(P, last, coarse, dests)
+
+    def _c2f_tail(self, P, last: Feat, coarse: List[Feat], dests):
+        """C2FModule.forward behind output_conv2 (:203-204): output_conv2_fusion + output_conv3; dests[0] receives the last feature"""
         aux = coarse[0].feat.aux if isinstance(coarse[0], ops.RoiSource) else None
         if ("chain_c2f" in P and aux is not None and ops.COARSE_TAPS and "u2" in aux["taps"] and (coarse[0].h, coarse[0].w) == (last.h, last.w) and
                 dests[0].c == 32 and aux["taps"]["u2"].cout == 32):

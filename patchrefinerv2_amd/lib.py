@@ -19,7 +19,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
 FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class ConvDesc(C.Structure):
@@ -96,6 +96,10 @@ SIGNATURES = {
     "prv2_conv3x3_ln_gate_pre": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "prv2_upconv3x3_supported": (_I, [C.POINTER(UpsSrc), _I, _I, _I, _I, _I]),
     "prv2_upconv3x3": (_I, [C.POINTER(UpsSrc), _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _L, _P]),
+    "prv2_upconv5x5_supported": (_I, [C.POINTER(UpsSrc), _I, _I, _I, _I, _I]),
+    "prv2_upconv5x5": (_I, [C.POINTER(UpsSrc), _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _L, _P]),
+    "prv2_upconv5x5_lines": (_I, [C.POINTER(UpsSrc), _I, _I, _I, _P, _P]),
+    "prv2_upconv5x5_ring": (_I, [_P, _I, _L, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
     "prv2_conv2d_pre_supported": (_I, [C.POINTER(ConvDesc)]),
     "prv2_conv2d_pre": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "prv2_chain32_weight_bytes": (_L, [_I, _I]),

@@ -408,6 +408,90 @@ def upconv3x3(u: Feat, h: int, w: int, cw: ConvW, out: Optional[Feat] = None, *,
     return out
 
 
+UPCONV5 = os.environ.get("PRV2_UPCONV5", "1") != "0"  # A/B and test switch: output_conv2[0] o output_conv1 o interpolate as one 5x5 conv at the source resolution
+
+
+def compose_upconv5x5(w1: torch.Tensor, b1: torch.Tensor, tap_bias: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor], device, prec) -> dict:
+    """Host side (float64) of ``upconv5x5``: two back-to-back 3x3 convs -- w1 [m, ci, 3, 3] + bias b1 [m] (+ ``tap_bias`` [9, m]: what each tap of the
+    first conv adds where it lies inside the image -- the folded bias of an upstream 1x1, fusion.py), w2 [co, m, 3, 3] + b2 -- as
+    dict(w5 = packed 5x5 composite, bias_map [5, 5, co], edge = packed 1x1 weights [28 co, ci] of the ring fix).  The algebra:
+    tools/studies/composite5x5_ring.py (include/prv2.h::prv2_upconv5x5)."""
+    import torch.nn.functional as F
+    d = lambda t: t.detach().double().cpu()  # noqa: E731
+    w1, w2 = d(w1), d(w2)
+    m, ci = w1.shape[:2]
+    co = w2.shape[0]
+    b1 = d(b1) if b1 is not None else torch.zeros(m, dtype=torch.float64)
+    b2 = d(b2) if b2 is not None else torch.zeros(co, dtype=torch.float64)
+    tap_bias = d(tap_bias) if tap_bias is not None else torch.zeros(9, m, dtype=torch.float64)
+    weff = torch.zeros(co, ci, 5, 5, dtype=torch.float64)
+    for y2 in range(3):
+        for x2 in range(3):
+            weff[:, :, y2:y2 + 3, x2:x2 + 3] += torch.einsum("om,miyx->oiyx", w2[:, :, y2, x2], w1)
+    inside = torch.ones(1, 1, 8, 8, dtype=torch.float64)
+    tb = b1.view(1, m, 1, 1) + F.conv2d(inside, tap_bias.t().reshape(m, 1, 3, 3), padding=1)
+    vb = F.conv2d(tb, w2, b2, padding=1)[0]
+    cls = [0, 1, 3, 6, 7]  # rows / columns of the 8 x 8 grid standing for the classes 0, 1, interior, h - 2, h - 1
+    bias_map = vb[:, cls][:, :, cls].permute(1, 2, 0).contiguous()
+
+    def edge(k2sel, k1sel):
+        we = torch.zeros(5, co, ci, dtype=torch.float64)
+        for k2 in range(3):
+            for k1 in range(3):
+                we[k2 + k1] += k2sel(k2) @ k1sel(k1)
+        return we
+    zero = torch.zeros(co, ci, dtype=torch.float64)
+    groups = [  # (five taps along the edge, corner term at the line's first position, at its last) per edge: top, bottom, left, right
+        (edge(lambda k: w2[:, :, 0, k], lambda k: w1[:, :, 2, k]), w2[:, :, 0, 0] @ w1[:, :, 2, 2], w2[:, :, 0, 2] @ w1[:, :, 2, 0]),
+        (edge(lambda k: w2[:, :, 2, k], lambda k: w1[:, :, 0, k]), w2[:, :, 2, 0] @ w1[:, :, 0, 2], w2[:, :, 2, 2] @ w1[:, :, 0, 0]),
+        (edge(lambda k: w2[:, :, k, 0], lambda k: w1[:, :, k, 2]), zero, zero),
+        (edge(lambda k: w2[:, :, k, 2], lambda k: w1[:, :, k, 0]), zero, zero)]
+    wedge = torch.cat([torch.cat([we.reshape(5 * co, ci), c0, c1], 0) for we, c0, c1 in groups], 0)  # [28 co, ci]
+    return dict(w5=pack_conv(weff.float(), None, pad=2, device=device, prec=prec), bias_map=bias_map.float().contiguous().to(device),
+                edge=pack_conv(wedge.float(), None, device=device, prec=prec), cout=co)
+
+
+def upconv5x5_supported(u: Feat, h: int, w: int, cw5: dict) -> bool:
+    if not UPCONV5 or type(u) is not Feat or cw5["w5"].cin != u.c:
+        return False
+    us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
+    return bool(L.load().prv2_upconv5x5_supported(C.byref(us), u.n, h, w, cw5["cout"], cw5["w5"].prec))
+
+
+def upconv5x5(u: Feat, h: int, w: int, cw5: dict, out: Optional[Feat] = None, *, act: int = ACT_NONE) -> Feat:
+    """act(conv3x3(conv3x3(bilinear_align_corners(u -> h x w); W1) + b1; W2) + b2) as ONE 5x5 conv at u's resolution + the bias classes + the
+    fix of the one-pixel border ring (include/prv2.h::prv2_upconv5x5 / _lines / _ring; ``compose_upconv5x5``): the 3x3 pair's intermediate
+    map is never formed.  fp32-grade, not bit-identical to the two-conv sequence."""
+    cw, co = cw5["w5"], cw5["cout"]
+    if out is None:
+        out = Feat.alloc(u.n, h, w, co, u.device)
+    assert (out.n, out.h, out.w, out.c) == (u.n, h, w, co) and not out.x2
+    us = L.UpsSrc(x=u.ptr, h=u.h, w=u.w, ld=u.ld, channels=u.c, bstride=0)
+
+    def main():
+        if DISPATCH == "torch":
+            _tops().upconv5x5(u.view(), cw.w, cw5["bias_map"], co, h, w, act, cw.prec, out.view())
+            return
+        L.check(L.load().prv2_upconv5x5(C.byref(us), cw.w.data_ptr(), cw5["bias_map"].data_ptr(), u.n, h, w, co, act, cw.prec, out.ptr, out.ld, 0, _stream()), "upconv5x5")
+
+    tiles = -(-h // 14) * -(-w // 24)  # (csrc/upconv5.hip: 14 x 24 output tiles, 192-pixel source footprint, five 160-column kernel-row passes)
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), 2.0 * u.n * tiles * 192 * 25 * cw.cin * 32, main,
+                    shape=f"{cw.cin}->(128)->{co} k5 {u.n}x{h}x{w} (lowres {u.c}ch {u.h}x{u.w})", algo=cw5.get("algo_per_px", 0.0) * u.n * h * w)
+    # the ring: the four border lines of up(u) at u's resolution -> tap GEMMs of the edges -> 1-D gather on the ring pixels
+    npos = 2 * u.w + 2 * u.h
+    if DISPATCH == "torch":
+        lines = Feat(_tops().upconv5x5_lines(u.view(), h, w))
+    else:
+        lines = Feat(torch.empty((u.n, 1, npos, u.c), device=u.device, dtype=torch.float32))
+        L.check(L.load().prv2_upconv5x5_lines(C.byref(us), u.n, h, w, lines.ptr, _stream()), "upconv5x5_lines")
+    ge = conv2d(lines, cw5["edge"], algo=0.0)
+    if DISPATCH == "torch":
+        _tops().upconv5x5_ring_(out.view(), ge.view(), u.h, u.w, act)
+    else:
+        L.check(L.load().prv2_upconv5x5_ring(out.ptr, out.ld, 0, u.n, h, w, co, ge.ptr, ge.ld, u.h, u.w, act, _stream()), "upconv5x5_ring")
+    return out
+
+
 def conv2d_ups(x: Feat, u: Feat, cw: ConvW, out: Optional[Feat] = None, *, act: int = ACT_NONE, res: Optional[Feat] = None, ln=None,
                ln_eps: float = 1e-6) -> Feat:
     """3x3 conv over the VIRTUAL concat [bilinear_align_corners(u -> x.h x x.w) | x[..., u.c:]]: channels [0, u.c) are interpolated
