@@ -2,7 +2,7 @@
 # Run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): regenerates the profiles/ evidence of the default
 # bench workload into gpurun_out/profiles/ (copy what should be judged into profiles/ afterwards).
 set -u
-TAG=${1:-r04}; PREC=${2:-bf16x3}
+TAG=${1:-r05}; PREC=${2:-bf16x3}
 R=$(pwd); O=$R/gpurun_out/profiles; mkdir -p $O
 WL=$(python3 -c "from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD as w; print(w)")
 export TMPDIR=/tmp
@@ -25,6 +25,12 @@ for T in 1 0 1 0; do PRV2_COARSE_TAPS=$T python3 bench.py --steps 5 --warmup 2 -
 for T in 1 0 1 0; do PRV2_UPCONV=$T python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v2_zoe_4k_r32 PRV2_UPCONV=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_upconv_ab.txt
 for T in 1 0 1 0; do PRV2_UPCONV=$T python3 bench.py --workload v1_zoe_4k_r32 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v1_zoe_4k_r32 PRV2_UPCONV=$T', round(d['ms_per_step'],2), 'ms')"; done >> $O/${TAG}_upconv_ab.txt
 python3 tools/probes/upconv_time.py 41 2>/dev/null | grep upconv >> $O/${TAG}_upconv_ab.txt
+# round 5: the fused 32-channel full-resolution chains (csrc/chain32.hip) and the 5x5 composite at the source resolution (csrc/upconv5.hip)
+for T in 1 0 1 0; do PRV2_CHAIN32=$T python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_CHAIN32=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_chain32_ab.txt
+python3 tools/bench_chain32.py 2>/dev/null | grep chain32_ >> $O/${TAG}_chain32_ab.txt
+bash tools/probes/chain32_stamps.sh 2>/dev/null | grep -E "stage|chain32_" >> $O/${TAG}_chain32_ab.txt
+for T in 1 0 1 0; do PRV2_UPCONV5=$T python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_UPCONV5=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_upconv5_ab.txt
+python3 tools/bench_upconv5.py 2>/dev/null | grep upconv5x5 >> $O/${TAG}_upconv5_ab.txt
 for D in torch ctypes torch ctypes; do PRV2_DISPATCH=$D python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_DISPATCH=$D', round(d['ms_per_step'],2), 'ms')"; done > $O/${TAG}_dispatch_ab.txt
 # kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
 cd /tmp
