@@ -160,3 +160,63 @@ def test_chain32_full_tile_size_and_determinism(P):
     ref_last, ref_depth = c2f_reference(x, pre, W)
     close(last.to_nchw(), ref_last, 3e-5, "last")
     close(depth, ref_depth, 3e-5, "depth")
+
+
+@pytest.mark.gpu
+def test_bidir_fusion_with_tap_tables_takes_the_fused_chains_and_matches_the_oracle(P):
+    """BiDirectionalFusion (bf16x3) as the frame driver runs it -- the coarse pyramid as per-frame maps + ROI boxes, the coarse half of the
+    cat([., c_feat]) convs from the per-frame tap tables (prepare_frame) -- takes ops.chain32_c2f / chain32_enc at level 0 and
+    ops.upconv5x5 behind refinenet1; against the fp32 oracle on the ROI-aligned pyramid (bi_directional_fusion_model.py:290-446) and
+    against the same network with the round-5 kernels switched off."""
+    import numpy as np
+    from oracle import fusion as o_fusion, ops as o_ops
+    from oracle.cases import TINY_BIDIR
+    from patchrefinerv2_amd import ops, weights as W
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    c = TINY_BIDIR
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"]), seed=c["seed"])
+    sizes = [(64, 96), (32, 48), (16, 24), (8, 12), (4, 6), (2, 3)]       # level sizes (tile == frame size per level: split 2 x 2 zooms x2)
+    Ph, Pw = 64, 96                                                        # patch_process_shape
+    K = 5
+    rng = np.random.default_rng(4)
+    th, tw = Ph / 2, Pw / 2
+    org = [(0.0, 0.0), (Pw - tw, Ph - th)] + [(float(rng.uniform(0, Pw - tw)), float(rng.uniform(0, Ph - th))) for _ in range(K - 2)]
+    boxes = torch.tensor([[x, y, x + tw, y + th] for x, y in org], dtype=torch.float32)
+    frame = [rnd(40 + l, 1, ch, *sizes[l]) for l, ch in enumerate(c["coarse_chl"])]
+    fine = [None] + [rnd(50 + l, K, ch, *sizes[l]) for l, ch in list(enumerate([32] + c["fine_chl"]))[1:]]
+    pred1 = torch.rand(K, 1, *sizes[0], generator=torch.Generator().manual_seed(7)) * 10
+    rois_t = [o_ops.roi_align(f, torch.cat([torch.zeros(K, 1), boxes], 1), sizes[l], sizes[l][0] / Ph) for l, f in enumerate(frame)]
+    ref = o_fusion.bidirectional_fusion(sd, "", rois_t, [torch.zeros(K, 32, *sizes[0])] + fine[1:], pred1, torch.zeros_like(pred1), update_base=pred1)
+
+    def run(chain, up5):
+        ops.CHAIN32, ops.UPCONV5 = chain, up5
+        calls = dict(c2f=0, enc=0, up5=0)
+        real = (ops.chain32_c2f, ops.chain32_enc, ops.upconv5x5)
+
+        def spy(name, fn):
+            def w(*a, **k):
+                calls[name] += 1
+                return fn(*a, **k)
+            return w
+        ops.chain32_c2f, ops.chain32_enc, ops.upconv5x5 = spy("c2f", real[0]), spy("enc", real[1]), spy("up5", real[2])
+        try:
+            m = BiDirectionalFusion(coarse2fine_type="coarse-gated", coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                                    fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec="bf16x3")
+            m.load_state_dict(sd)
+            fr = [P.Feat.from_nchw(t.to(DEV)) for t in frame]
+            m.prepare_frame(fr, (0.5, 0.5))
+            rois = [ops.RoiSource(f, boxes.to(DEV), f.h / Ph, f.h, f.w) for f in fr]
+            ff = [None] + [P.Feat.from_nchw(t.to(DEV)) for t in fine[1:]]
+            out = m(rois, ff, pred1.to(DEV), torch.zeros_like(pred1).to(DEV), update_base=pred1.to(DEV), f_sizes=sizes).clone()
+        finally:
+            ops.chain32_c2f, ops.chain32_enc, ops.upconv5x5 = real
+            ops.CHAIN32 = ops.UPCONV5 = True
+        return out, calls
+
+    new, calls = run(True, True)
+    assert calls == dict(c2f=1, enc=1, up5=1), calls
+    old, calls0 = run(False, False)
+    assert calls0 == dict(c2f=0, enc=0, up5=0), calls0
+    close(new, ref.double(), 3e-5, "fused chains + 5x5 composite vs fp32 oracle")
+    close(old, ref.double(), 3e-5, "round-4 kernels vs fp32 oracle")
+    close(new, old.cpu().double(), 3e-5, "round-5 vs round-4 kernels")
