@@ -25,7 +25,9 @@ OPS = ("abi_version", "pack_conv_weight", "conv2d", "conv3x3_ups", "pack_gate_we
        # round 4: every remaining entry point a frame uses (the host mirror's default route can be torch.ops: ops.DISPATCH)
        "conv3x3_tail", "conv3x3_pre", "coarse_tap_knots", "coarse_tap_gather", "conv_cout1", "dwconv2d", "global_avgpool", "se_gate", "channel_scale_",
        "patchify", "assemble_tokens", "split_ss", "layernorm_ss", "gemm_ss", "attention_ss", "bicubic_resize", "depth_pair_fill", "conv_border_bias_",
-       "add_nhwc", "zero_pad_channels_", "pack_attention_bias")
+       "add_nhwc", "zero_pad_channels_", "pack_attention_bias", "upconv3x3",
+       # round 5: the fused 32-channel full-resolution chains and the 5x5 composite at the source resolution
+       "pack_chain32_weight", "chain32_c2f", "chain32_enc", "upconv5x5", "upconv5x5_lines", "upconv5x5_ring_")
 _loaded = False
 
 
