@@ -320,6 +320,76 @@ __global__ void __launch_bounds__(256) conv1x1_small_kernel(const IgemmParams p,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k x k convs over <= 4 INPUT channels (the refiner encoders' stems on the 4-channel crop: 4 -> 32, 3x3 stride 2, at 41 x 384 x 512 per
+// batch): on the implicit-GEMM kernel a k-slab is 7/8 padding and the layer ran at 8 TFLOP/s = 0.7 TB/s (0.55 ms per batch against 0.1 ms
+// of HBM traffic).  Direct form on the fp32 VALU like conv1x1_small_kernel: one thread = one output pixel x 8 output channels, one 16-byte
+// load per tap, weights decoded once per block from the packed image into LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_few_in_kernel(const IgemmParams p, int prec) {
+  __shared__ __attribute__((aligned(16))) float wl[49 * 4 * 64];  // [tap][cin 4][cout_pad8]
+  const int ng = (p.Cout + 7) >> 3, ncp = ng * 8, taps = p.KH * p.KW;
+  for (int i = threadIdx.x; i < taps * 4 * ncp; i += blockDim.x) {
+    const int co = i % ncp, c = (i / ncp) & 3, tap = i / (4 * ncp);
+    float v = 0.f;
+    if (co < p.Cout && c < p.Cin) {
+      const char* row = reinterpret_cast<const char*>(p.w) + (((long long)co * taps + tap) * p.Cin_pad) * 4;
+      const int key = (co >> 1) & 7;
+      if (prec == PRV2_PREC_F32) {
+        v = reinterpret_cast<const float*>(row)[(((c >> 2) ^ key) << 2) + (c & 3)];
+      } else {
+        const __bf16* d16 = reinterpret_cast<const __bf16*>(row);
+        v = (float)d16[(((c >> 3) ^ key) << 3) + (c & 7)] + (float)d16[((((c >> 3) + 4) ^ key) << 3) + (c & 7)];
+      }
+    }
+    wl[(tap * 4 + c) * ncp + co] = v;
+  }
+  __syncthreads();
+  const int ppb = 256 / ng;
+  const int grp = threadIdx.x % ng, pl = threadIdx.x / ng;
+  if (pl >= ppb) return;
+  const float x_floor = p.relu_in ? 0.f : -INFINITY;
+  EpiCols ec0, ec1;
+  const bool v0 = epi_cols(p, grp * 8, ec0), v1 = epi_cols(p, grp * 8 + 4, ec1);
+  const long long ohw = (long long)p.OH * p.OW;
+  for (long long m = (long long)blockIdx.x * ppb + pl; m < p.M; m += (long long)gridDim.x * ppb) {
+    const int n = (int)(m / ohw), r = (int)(m - n * ohw), oy = r / p.OW, ox = r - oy * p.OW;
+    const float* img = p.x + (long long)n * p.x_bstride;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < p.KH; ++ky) {
+      const int iy = oy * p.stride - p.pad + ky;
+      if ((unsigned)iy >= (unsigned)p.H) continue;
+      for (int kx = 0; kx < p.KW; ++kx) {
+        const int ix = ox * p.stride - p.pad_x + kx;
+        if ((unsigned)ix >= (unsigned)p.W) continue;
+        const f32x4 xv = floor4(*reinterpret_cast<const f32x4*>(img + ((long long)iy * p.W + ix) * p.ldx), x_floor);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float* wt = &wl[(ky * p.KW + kx) * 4 * ncp + grp * 8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + e * ncp), w1 = *reinterpret_cast<const f32x4*>(wt + e * ncp + 4);
+          a0.x = __builtin_fmaf(xs[e], w0.x, a0.x);  // (channels >= Cin: zero weights; the pad channels of the input are finite)
+          a0.y = __builtin_fmaf(xs[e], w0.y, a0.y);
+          a0.z = __builtin_fmaf(xs[e], w0.z, a0.z);
+          a0.w = __builtin_fmaf(xs[e], w0.w, a0.w);
+          a1.x = __builtin_fmaf(xs[e], w1.x, a1.x);
+          a1.y = __builtin_fmaf(xs[e], w1.y, a1.y);
+          a1.z = __builtin_fmaf(xs[e], w1.z, a1.z);
+          a1.w = __builtin_fmaf(xs[e], w1.w, a1.w);
+        }
+      }
+    }
+    const long long o = (long long)n * p.y_bstride + (long long)r * p.ldy;
+    if (v0) epi_store(p, ec0, a0, m, o + ec0.co);
+    if (v1) epi_store(p, ec1, a1, m, o + ec1.co);
+  }
+}
+
+static bool conv_few_in_supported(const IgemmParams& p) {
+  return p.Cin <= 4 && p.ldx >= 4 && p.ldx % 4 == 0 && p.KH * p.KW <= 49 && p.KH * p.KW > 1 && p.Cout >= 8 && p.Cout <= 64 && p.convt_k == 0 && !p.ln_w &&
+         !p.w_tail && !p.rw && (long long)p.OH * p.OW >= 4096;  // per image: the choice must not depend on the batch
+}
+
 static bool conv1x1_small_supported(const IgemmParams& p) {
   // ... and the handful-of-outputs 1x1s behind a wider input (ZoeDepth's 80 -> 4 head conv on every V1 tile: 2.4 ms per 41 x 384 x 512 on
   // the generic MFMA kernel -- a 128-column tile for 4 columns -- against 0.7 ms of HBM traffic): one thread per pixel, 8 output slots
@@ -564,6 +634,13 @@ int prv2::conv2d_impl(const prv2_conv_desc* d, const float* x, const void* w_pac
   if (gate_w || ups || tail1 || pre) {
     PRV2_REQUIRE(false, "%s: layer not covered by the halo kernels (%d->%d k%d, %dx%d)", ups ? "conv2d_ups" : (tail1 ? "conv2d_tail" : (pre ? "conv2d_pre" : "conv3x3_ln_gate")), d->cin, d->cout, d->kh, d->h, d->w);
   } else
+  if (conv_few_in_supported(p) && !d->force_generic && aligned16(x)) {
+    const int ng = (p.Cout + 7) >> 3;
+    hipLaunchKernelGGL(conv_few_in_kernel, dim3(flat_grid(p.M * ng, 256)), dim3(256), 0, s, p, (int)d->prec);
+    set_kernel("conv_few_in_kernel", 64, d->prec);
+    PRV2_LAUNCH_CHECK("conv2d(few input channels)");
+    return 0;
+  }
   if (conv1x1_small_supported(p) && !d->force_generic) {
     const int ng = (p.Cout + 7) >> 3;
     hipLaunchKernelGGL(conv1x1_small_kernel, dim3(flat_grid(p.M * ng, 256)), dim3(256), 0, s, p, (int)d->prec);

@@ -50,6 +50,8 @@ CONV_CASES = [
     (2, 21, 45, 98, 32, 3, 1, dict(bias=True, act="gelu")),   # cout <= 32: 8x1 wave grid variant
     (1, 40, 64, 34, 20, 3, 1, dict(res=True)),
     (2, 64, 64, 80, 4, 1, 1, dict(bias=True)),               # ZoeDepth's 80 -> 4 head conv: the few-outputs form of conv1x1_small_kernel
+    (2, 160, 128, 4, 32, 3, 2, dict(bias=True, act="gelu")),  # the refiner stem on the 4-channel crop: conv_few_in_kernel (direct, <= 4 input channels)
+    (1, 141, 131, 3, 24, 3, 2, dict(bias=True)),             # ... 3 channels, ragged size, 24 outputs
 ]
 
 
