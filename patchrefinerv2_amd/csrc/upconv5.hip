@@ -229,7 +229,11 @@ __global__ void __launch_bounds__(512) upconv5x5_kernel(const Upconv5Params p) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef UPC5_ABL_NOMAIN  // (timing ablations: results wrong)
+    for (int cc = 0; cc < 0; ++cc) {
+#else
     for (int cc = 0; cc < cslabs; ++cc) {
+#endif
       const int st = (cc + 1) & 1;  // slab 0 of a pass sits in stage 1
       if (cc == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -316,6 +320,7 @@ __global__ void __launch_bounds__(512) upconv5x5_kernel(const Upconv5Params p) {
           v1[k] = *(lds_f32x4)(size_t)(a1 + k * CP * 4);
         }
       };
+#ifndef UPC5_ABL_NOWALK
       f32x4 lc[NT], ln[NT], q0[NT], q1[NT];
       int c = __builtin_amdgcn_readlane(vci, KX0);
       {
@@ -351,6 +356,7 @@ __global__ void __launch_bounds__(512) upconv5x5_kernel(const Upconv5Params p) {
           }
         }
       }
+#endif
       if (last && has_next) {  // the next pass's first footprint slab -> stage 1 (its weights: issued before the gather)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) store_a(1, it);
