@@ -339,11 +339,12 @@ __global__ void __launch_bounds__(512) upconv3x3_kernel(const UpconvParams p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (ky == 2) {  // (the accumulators of the first two kernel rows are dead: registers for what the next pass / the output stage need)
-        if (has_next) {
+      if (ky == 1 && has_next) {  // the next pass's first footprint slab: requested one kernel row ahead of its store (round 5: a whole walk to arrive under;
+                                  // requested in the last row its wait sat exposed in front of the output stores)
 #pragma unroll
-          for (int it = 0; it < NIT; ++it) load_a_async(0, it);
-        }
+        for (int it = 0; it < NIT; ++it) load_a_async(0, it);
+      }
+      if (ky == 2) {  // (the accumulators of the first two kernel rows are dead: registers for what the output stage needs)
         if (p.bias) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(512) upconv5x5_kernel(const Upconv5Params p) {
     const unsigned g1 = (unsigned)(size_t)(csm + (ay.i1 - rbase) * GRP + 4 * quad);
     typedef const __attribute__((address_space(3))) f32x4* lds_f32x4;
 
-    auto round = [&](auto kx0_c, auto nt_c, bool last) {
+    auto round = [&](auto kx0_c, auto nt_c, bool first, bool last) {
       constexpr int KX0 = decltype(kx0_c)::value, NT = decltype(nt_c)::value;
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(512) upconv5x5_kernel(const Upconv5Params p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (last && has_next) {
+      if (first && has_next) {  // the next pass's first footprint slab: requested in the FIRST round (both walks to arrive under), stored in the last
 #pragma unroll
         for (int it = 0; it < NIT; ++it) load_a_async(0, it);
       }
@@ -364,8 +364,8 @@ __global__ void __launch_bounds__(512) upconv5x5_kernel(const Upconv5Params p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the G tile is rewritten by the next round / the next pass's slab 1
     };
-    round(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, false);
-    round(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, true);
+    round(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, true, false);
+    round(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, false, true);
   }
 
   // ---- output: 6 pixels x 4 channels per thread; + the position's bias class; activation everywhere but on the ring ----

@@ -44,6 +44,22 @@ xc = P.Feat.alloc(20, 384, 512, 32, dev); xc.buf.normal_()
 wc1 = torch.randn(1, 32, 3, 3, device=dev)
 victims.append((lambda: P.conv2d_cout1(xc, wc1, None, 3), "conv_cout1 3x3"))
 
+# round 5: the fused 32-channel chains and the 5x5 composite (both compiled WITH packed fp32 math)
+r = lambda *sh: torch.randn(*sh)  # noqa: E731
+c_w1, c_w2, c_w34 = r(32, 32, 3, 3) / 17, r(32, 32, 3, 3) / 17, r(32, 34, 3, 3) / 17.5
+cw_c2f = dict(w1=P.pack_chain32(c_w1, 0, dev), w2=P.pack_chain32(c_w2, 1, dev), wg=P.pack_chain32(r(32, 32) / 5.6, 1, dev), wo=P.pack_chain32(r(32, 32) / 5.6, 1, dev),
+              consts=P.chain32_consts(dev, b1=r(32) * .1, ln1w=1 + .2 * r(32), ln1b=.1 * r(32), b2=r(32) * .1, bo=r(32) * .1, w3=1 + .3 * r(32)), b3=0.1)
+cw_enc = dict(w1=P.pack_chain32(c_w1, 0, dev), w2=P.pack_chain32(c_w34, 1, dev), wt=P.pack_chain32(c_w34, 2, dev),
+              consts=P.chain32_consts(dev, b1=r(32) * .1, ln1w=1 + .2 * r(32), ln1b=.1 * r(32), b2=r(32) * .1, ln2w=1 + .2 * r(32), ln2b=.1 * r(32)))
+cx = P.Feat(torch.randn(20, 384, 512, 32, device=dev).relu_())
+cpre = P.Feat(torch.randn(20, 384, 512, 32, device=dev) * 0.5)
+cp1, cp2 = torch.rand(20, 1, 384, 512, device=dev) * 10, torch.rand(20, 1, 384, 512, device=dev) * 10
+victims.append((lambda: torch.cat([t.reshape(-1) for t in (lambda o, d: (o.buf, d))(*P.chain32_c2f(cx, cw_c2f, cpre))]), "chain32_c2f 20x384x512"))
+victims.append((lambda: P.chain32_enc(cx, cw_enc, cpre, cp1, cp2).buf, "chain32_enc 20x384x512"))
+cw5 = P.compose_upconv5x5(r(128, 256, 3, 3) / 48, r(128) * .1, r(9, 128) * .1, r(32, 128, 3, 3) / 34, r(32) * .1, dev, PR)
+u5 = P.Feat(torch.randn(20, 192, 256, 256, device=dev))
+victims.append((lambda: P.upconv5x5(u5, 384, 512, cw5, act=P.ACT_RELU).buf, "upconv5x5 256->(128)->32 20x384x512"))
+
 F_ = 256
 coarse = P.Feat(torch.randn(1, 192, 256, F_, device=dev))
 cw_t = P.pack_conv(torch.randn(18 * F_, F_, device=dev) / 16, None, prec=PR)
