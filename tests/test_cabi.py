@@ -38,6 +38,38 @@ def test_conv_desc_layout_matches_header():
     assert ctypes.sizeof(L.ConvDesc) == 112
 
 
+def test_chain32_desc_layout_matches_header():
+    """prv2_chain32_desc (round 5): field order / sizes of the ctypes mirror == the header's struct"""
+    from patchrefinerv2_amd import lib as L
+    txt = open(os.path.join(ROOT, "include", "prv2.h")).read()
+    body = txt[txt.index("typedef struct prv2_chain32_desc {"):txt.index("} prv2_chain32_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in re.findall(r"(?:const\s+)?(?:float|void|int(?:32|64)_t)\s*\*?\s*([^;]+);", body):
+        fields += [f.strip().lstrip("*") for f in decl.split(",")]
+    assert fields == [f[0] for f in L.Chain32Desc._fields_], fields
+    assert ctypes.sizeof(L.Chain32Desc) == 11 * 8 + 2 * 8 + 6 * 4 + 2 * 4 == 136
+
+
+def test_round5_entry_points_reject_bad_arguments_without_gpu():
+    from patchrefinerv2_amd import lib as L
+    lib = L.load()
+    assert lib.prv2_chain32_c2f(None, None) != 0 and b"null" in lib.prv2_last_error()
+    d = L.Chain32Desc(x=16, w1=16, w2=16, wg=0, wo=0, consts=16, y=16, n=1, h=8, w=16, ldx=30, ldy=32)
+    assert lib.prv2_chain32_c2f(ctypes.byref(d), None) != 0 and b"32-channel" in lib.prv2_last_error()       # ldx < 32
+    d.ldx = 32
+    assert lib.prv2_chain32_c2f(ctypes.byref(d), None) != 0 and b"gate / out_conv" in lib.prv2_last_error()  # fragment images missing
+    assert lib.prv2_chain32_enc(ctypes.byref(d), None) != 0 and b"tail fragment" in lib.prv2_last_error()
+    assert lib.prv2_chain32_weight_bytes(0, 9) == 9 * 2 * 2 * 64 * 16 and lib.prv2_chain32_weight_bytes(2, 9) == 2 * 2 * 64 * 16
+    us = L.UpsSrc(x=16, h=12, w=16, ld=256, channels=256, bstride=0)
+    assert lib.prv2_upconv5x5_supported(ctypes.byref(us), 1, 24, 32, 32, L.PREC_BF16X3) == 1
+    assert lib.prv2_upconv5x5_supported(ctypes.byref(us), 1, 24, 32, 64, L.PREC_BF16X3) == 0      # cout > 32
+    assert lib.prv2_upconv5x5_supported(ctypes.byref(us), 1, 20, 32, 32, L.PREC_BF16X3) == 0      # source step 11 / 19 > 1/2
+    assert lib.prv2_upconv5x5_supported(ctypes.byref(us), 1, 24, 32, 32, L.PREC_F32) == 0
+    assert lib.prv2_upconv5x5(ctypes.byref(us), None, None, 1, 24, 32, 32, 0, L.PREC_BF16X3, None, 32, 0, None) != 0
+    assert lib.prv2_upconv5x5_ring(None, 32, 0, 1, 24, 32, 32, None, 896, 12, 16, 0, None) != 0
+
+
 def test_rejects_bad_arguments_without_gpu():
     from patchrefinerv2_amd import lib as L
     lib = L.load()
