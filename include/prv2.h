@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 16
+#define PRV2_ABI_VERSION 17
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -33,7 +33,9 @@ enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_AC
 enum prv2_prec {
   PRV2_PREC_F32 = 0,    /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate            */
   PRV2_PREC_BF16X3 = 1, /* operands split hi+lo bf16; hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 */
-  PRV2_PREC_BF16 = 2    /* plain bf16 operands (fast, ~1e-3 relative; not the parity path)          */
+  PRV2_PREC_BF16 = 2,   /* plain bf16 operands (fast, ~1e-3 relative; not the parity path)          */
+  PRV2_PREC_F16F6 = 3   /* fp16 product + two block-scaled fp6 (e2m3) corrections: what prv2_conv3x3_f6 computes in and reports through
+                         * prv2_last_kernel(); the other entry points do not take it                  */
 };
 
 int prv2_abi_version(void);
@@ -262,6 +264,24 @@ int64_t prv2_chain32_weight_bytes(int32_t kind, int32_t taps);
 int prv2_pack_chain32_weight(const float* w_src, int32_t cin_total, int32_t taps, int32_t kind, void* w_packed, void* stream);
 int prv2_chain32_c2f(const prv2_chain32_desc* d, void* stream);
 int prv2_chain32_enc(const prv2_chain32_desc* d, void* stream);
+
+/* The 256-channel 3x3 conv of a GatedConvUnit / ResidualConvUnit in the fp16 + block-scaled-fp6 arithmetic (csrc/conv3x3_f6.hip;
+ * PRV2_PREC_F16F6) -- estimator/models/blocks/bi_directional_fusion_model.py:40-43 (self.conv = ReLU, Conv2d 3x3), :58-64 (out =
+ * self.conv(x) + x); the same layer prv2_conv2d runs in bf16x3 on conv3x3_c256_kernel:
+ *     y[n, h, w, 0 .. 256) = out_scale * conv3x3(q(relu?(x) * x_scale); q(W * w_scale)) + bias + res        (fp32 NHWC, or X2 with d->fmt = PRV2_FMT_Y_X2)
+ * where each product x w is taken as f16(x) f16(w) + q6(x) q6(w - f16 w) + q6(x - f16 x) q6(w), q6 = fp6 e2m3 with one power-of-two
+ * scale per 32 channels, fp32 accumulation: two v_mfma_f32_16x16x32_f16 and one v_mfma_scale_f32_16x16x128_f8f6f4 per 64 channels and tap
+ * instead of six bf16 MFMAs.  rms error of a dot product against float64 1.2e-5 (bf16x3: 4.4e-6) -- fp32-grade, wider than TF32.
+ * x_scale / w_scale: powers of two chosen by the caller so that |relu(x) x_scale| and |W w_scale| stay inside fp16's range (values
+ * beyond 65504 are clamped in the fp16 part and carried by the fp6 residual: finite, imprecise); out_scale = 1 / (x_scale w_scale).
+ * range_word (device, or NULL): receives atomicMax of the float bits of max |relu(x) x_scale| the launch saw -- the caller's range monitor.
+ * Contract (prv2_conv3x3_f6_supported(d) != 0): 3x3 s1 p1, cout = 256, cin % 64 == 0, width >= 16, d->act = NONE, no LayerNorm / gate /
+ * mul; d->relu_in and d->ld_res as for prv2_conv2d.  w_packed: prv2_pack_conv3x3_f6_weight (PyTorch [256][cin][3][3] fp32). */
+int prv2_conv3x3_f6_supported(const prv2_conv_desc* d);
+int64_t prv2_conv3x3_f6_weight_bytes(int32_t cout, int32_t cin);
+int prv2_pack_conv3x3_f6_weight(const float* w_src, float w_scale, void* w_packed, int32_t cout, int32_t cin, void* stream);
+int prv2_conv3x3_f6(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* res, float x_scale,
+                    float out_scale, uint32_t* range_word, float* y, void* stream);
 
 /* Convolution with ONE output channel (direct, HBM-bound):
  *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118

@@ -1,0 +1,433 @@
+// GatedConvUnit.conv / ResidualConvUnit conv -- y = conv3x3(relu(x)) + bias + res, C -> 256 channels -- in the fp16 + block-scaled-fp6
+// arithmetic ("f16f6"; estimator/models/blocks/bi_directional_fusion_model.py:40-43, 58-64):
+//
+//   x w  ~=  f16(x) f16(w)  +  q6(x) q6(w - f16 w)  +  q6(x - f16 x) q6(w)
+//
+// q6 = fp6 e2m3 with one power-of-two (E8M0) scale per 32 channels.  Per 64 input channels and tap an accumulator takes TWO
+// v_mfma_f32_16x16x32_f16 and ONE v_mfma_scale_f32_16x16x128_f8f6f4 (its four 32-k blocks: the two corrections of the two 32-channel
+// slabs) instead of the six v_mfma_f32_16x16x32_bf16 of the bf16x3 scheme; measured rms error of a dot product against float64: 1.2e-5
+// (bf16x3: 4.4e-6, one fp16 product: 2.9e-4; profiles/r03_f16f6_study.txt).  Instruction semantics: tools/probes/f16f6_probe.hip.
+//
+// Not conv3x3_gate.hip's pipeline with other MFMAs (that mock ran 1.30x: its LDS traffic -- weights by LDS-DMA, every wave re-reading
+// them -- becomes the bound once the MFMA time halves; profiles/r05_experiments.txt #12).  Here:
+//   * wave w of 8 owns output channels 32 w .. 32 w + 31 for ALL 128 pixels of the 8 x 16 tile (8 pixel runs x 2 row blocks of 16 weights:
+//     16 accumulators).  Weights are the MFMA's A operand and come STRAIGHT from L2 into registers, fragment-major (one coalesced KB per
+//     load, every byte fetched once per workgroup), refilled part by part as the three passes of a step (f16 slab 0, f16 slab 1, fp6)
+//     finish with them -- no LDS for weights, no per-tap barrier.  An accumulator lane then holds 8 consecutive channels of one pixel:
+//     the epilogue (x out_scale, + bias, + res, fp32 or pre-split "X2" output) runs from registers with 16-byte loads / stores.
+//   * LDS holds only the activation halo: 10 x 18 pixels x one 64-channel superslab, already in operand format
+//     [32 f16 | 32 f16 | 4 x 16 B fp6 (first halves) | 4 x (8 B fp6, scale, pad)], pitch 288 B (conflict-free ds_read_b128), two buffers,
+//     ONE barrier per superslab (9 taps).  The raw fp32 halo arrives by LDS-DMA (buffer_load ... lds: zero fill outside the image) into a
+//     per-wave staging area; the wave that moved a pixel converts it (ReLU, x x_scale, fp16 + residual, block maxima, two
+//     v_cvt_scalef32_2xpk16_fp6_f32), so no cross-wave hand-off is needed for the staging.
+// Range: fp16 holds |x x_scale| <= 65504; larger values are clamped in the fp16 part and fall to the fp6 residual (finite, imprecise) --
+// the caller keeps x_scale / the weights' scale (powers of two, undone by out_scale) such that this does not happen, and reads the
+// observed maximum back through ``range_word``.
+#include <cstdlib>
+#include <type_traits>
+
+#include "igemm.h"
+
+namespace prv2 {
+
+namespace f6 {
+constexpr int TH = 8, TW = 16, HW_ = TW + 2, HALO = (TH + 2) * HW_;  // 180 halo pixels
+constexpr int PIX = 288;                                              // bytes per halo pixel and superslab in LDS
+constexpr int A_BYTES = HALO * PIX;                                   // 51,840
+constexpr int ST_CHUNK = 1040, ST_DMAS = 6, ST_WAVE = ST_DMAS * ST_CHUNK;  // staging: 6 DMAs of 4 pixels x 256 B per wave (+16 B bank shift)
+constexpr int ST_BASE = 2 * A_BYTES;
+constexpr int LDS_BYTES = ST_BASE + 8 * ST_WAVE;                      // 153,600
+constexpr int STEP_BYTES = 8 * 2 * 4 * 1024;                          // weights of one (superslab, tap): 8 waves x 2 row blocks x 4 parts x 1 KB
+constexpr int D = 4;                                                  // activation fragments in flight (ring)
+constexpr int CV_TAP = 2;                                             // tap at which the next superslab's halo is converted
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(8 * ST_DMAS * 4 >= HALO, "staging covers the halo");
+}  // namespace f6
+
+struct F6Params {
+  const float* x;
+  const char* w;      // prv2_pack_conv3x3_f6_weight
+  const float* bias;  // or null
+  const float* res;   // or null
+  float* y;
+  unsigned* range;    // or null: atomicMax of the bits of max |relu(x) x_scale| seen
+  int N, H, W, Cin, ldx, ldy, ld_res;
+  long long x_bstride, y_bstride;
+  float x_scale, out_scale;
+  int relu_in, y_x2;
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 32 floats (a: elements 0..15, b: 16..31) / scale -> 32 x e2m3, RNE; element i of a at 6-bit position 2 i, of b at 2 i + 1 (the same
+// instruction packs the weights: positions agree by construction).  Early-clobber destination: hipcc 7.2 may allocate the builtin's
+// destination over its scale operand (tools/probes/f16f6_probe.hip).
+__device__ __forceinline__ u32x6 cvt_fp6(const f32x16& a, const f32x16& b, float scale) {
+  u32x6 q;
+  asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(q) : "v"(a), "v"(b), "v"(scale));
+  return q;
+}
+// E8M0 scale of a block with maximum magnitude m (MX rule: exponent(m) - 2, e2m3's largest exponent); never 0 (an all-zero block
+// divides by 2^-126) and never 255
+__device__ __forceinline__ int e8m0_of(float m) {
+  const int eb = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  return min(max(eb - 2, 1), 254);
+}
+
+// a wave-uniform 64-bit value into an SGPR pair (readfirstlane returns int: widen its halves as UNSIGNED -- a sign-extended low half
+// whose bit 31 is set turns the address into 0xffffffff........)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+}
+
+#ifndef F6_DBG_NOW
+#define F6_LDW(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#else  // (fault bisection: the same loads from the first kilobytes of the image)
+#define F6_LDW(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(lane * 16), "s"(p.w) : "memory")
+#endif
+
+__global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params p) {
+  using namespace f6;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  // ---- XCD-aware block -> pixel tile (as conv3x3_gate.hip) ----------------------------------------------------------------
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  int t = blockIdx.x;
+  {
+    const int ntiles = gridDim.x, q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+  }
+  const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n_img = t / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, g = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  // ---- halo DMA: instruction i of this wave moves halo pixels 4 (6 wave + i) .. + 3 (lane >> 4), 16 bytes per lane ------------
+  constexpr unsigned OOB = 0x80000000u;
+  i32x4 rsrc;
+  unsigned hoff[ST_DMAS];
+  {
+    const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)n_img * p.x_bstride);
+    rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)img_base);
+    rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((img_base >> 32) & 0xffffu));
+    rsrc.z = __builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + p.Cin) * 4));
+    rsrc.w = 0x00020000;
+#pragma unroll
+    for (int i = 0; i < ST_DMAS; ++i) {
+      const int hp = (wave * ST_DMAS + i) * 4 + g;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      hoff[i] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + m16 * 4) * 4) : OOB;
+    }
+  }
+  const int nss = p.Cin >> 6, nsteps = nss * 9;
+#ifdef F6_DBG_NODMA
+  i32x4 dbg_sink;
+#endif
+  const unsigned st_wave = lds0 + ST_BASE + wave * ST_WAVE;
+  auto dma_halo = [&](int ss) {  // (behind the last superslab: clamped, data nobody converts -- the counted waits stay the same)
+    const unsigned cofs = (unsigned)(min(ss, nss - 1) * 256);
+#pragma unroll
+    for (int i = 0; i < ST_DMAS; ++i) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(st_wave + i * ST_CHUNK);
+      const unsigned voff = hoff[i] + cofs;
+#ifndef F6_DBG_NODMA
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rsrc) : "memory");
+#else
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dbg_sink) : "v"(voff), "s"(rsrc) : "memory");
+#endif
+    }
+  };
+  // ---- conversion item of a lane: staged pixel lp = lane >> 1 of this wave (halo pixel 24 wave + lp), 32-channel slab lane & 1 ---------
+  const int lp = lane >> 1, cs = lane & 1, chp = wave * 24 + lp;
+  const char* const st_rd = smem + ST_BASE + wave * ST_WAVE + (lp >> 2) * ST_CHUNK + (lp & 3) * 256 + cs * 128;
+  const float xs = p.x_scale;
+  const float relu_floor = p.relu_in ? 0.f : -__builtin_inff();
+  float seen = 0.f;
+  auto convert = [&](int wbuf) {
+    if (lane < 48) {
+      f32x16 a, b;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(st_rd + 16 * k), tb = *reinterpret_cast<const f32x4*>(st_rd + 64 + 16 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[4 * k + e] = fmaxf(ta[e], relu_floor) * xs;
+          b[4 * k + e] = fmaxf(tb[e], relu_floor) * xs;
+        }
+      }
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fmaxf(fabsf(a[i]), fabsf(b[i])));
+      seen = fmaxf(seen, mx);
+      const int ex = e8m0_of(mx);
+      const u32x6 qx = cvt_fp6(a, b, __uint_as_float((unsigned)ex << 23));
+      f16x8 h[4];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const _Float16 ha = (_Float16)__builtin_amdgcn_fmed3f(a[i], -65504.f, 65504.f), hb = (_Float16)__builtin_amdgcn_fmed3f(b[i], -65504.f, 65504.f);
+        h[i >> 3][i & 7] = ha;
+        h[2 + (i >> 3)][i & 7] = hb;
+        a[i] -= (float)ha;
+        b[i] -= (float)hb;
+      }
+      float mr = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mr = fmaxf(mr, fmaxf(fabsf(a[i]), fabsf(b[i])));
+      const int er = e8m0_of(mr);
+      const u32x6 qr = cvt_fp6(a, b, __uint_as_float((unsigned)er << 23));
+      if (chp < HALO) {
+        char* const dst = smem + wbuf * A_BYTES + chp * PIX;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f16x8*>(dst + cs * 64 + 16 * k) = h[k];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(dst + 128 + 32 * cs) = u32x4{qx[0], qx[1], qx[2], qx[3]};
+        *reinterpret_cast<u32x4*>(dst + 192 + 32 * cs) = u32x4{qx[4], qx[5], (unsigned)ex, 0u};
+        *reinterpret_cast<u32x4*>(dst + 128 + 32 * cs + 16) = u32x4{qr[0], qr[1], qr[2], qr[3]};
+        *reinterpret_cast<u32x4*>(dst + 192 + 32 * cs + 16) = u32x4{qr[4], qr[5], (unsigned)er, 0u};
+      }
+    }
+  };
+
+  // ---- weights: fragment-major [step][wave][row block j][part][lane] x 16 B; lane (row m16, k group g) -------------------------
+  const unsigned wv0 = (unsigned)(wave * 8192 + lane * 16), wv1 = wv0 + 4096;
+  i32x4 wf0[2], wf1[2], wql[2], wqh[2];
+  auto w_of = [&](int s) { return (unsigned long long)(size_t)(p.w + (long long)min(s, nsteps - 1) * STEP_BYTES); };
+#define F6_LOAD_F0(sb) do { F6_LDW(wf0[0], wv0, sb, 0); F6_LDW(wf0[1], wv1, sb, 0); } while (0)
+#define F6_LOAD_F1(sb) do { F6_LDW(wf1[0], wv0, sb, 1024); F6_LDW(wf1[1], wv1, sb, 1024); } while (0)
+#define F6_LOAD_Q(sb) do { F6_LDW(wql[0], wv0, sb, 2048); F6_LDW(wqh[0], wv0, sb, 3072); F6_LDW(wql[1], wv1, sb, 2048); F6_LDW(wqh[1], wv1, sb, 3072); } while (0)
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: halo of superslab 0 -> buffer 0; weights of step 0 ------------------------------------------------------------
+  dma_halo(0);
+  {
+    const unsigned long long sb = uniform64(w_of(0));
+    F6_LOAD_F0(sb);
+    F6_LOAD_F1(sb);
+    F6_LOAD_Q(sb);
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the six DMAs (the weights stay in flight)
+  convert(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // activation fragments: lane (pixel m16 of the run, k group g); ring of D
+  const unsigned xlane = (unsigned)(m16 * PIX + g * 16);
+  i32x4 rlo[D], rhi[D];
+
+  for (int ss = 0; ss < nss; ++ss) {
+    const char* const xb = smem + (ss & 1) * A_BYTES + xlane;
+    auto read_item = [&](int it, int tap) {  // item = (pass it >> 3, run it & 7) of tap `tap`
+      const int pp = it >> 3, a = it & 7, ky = tap / 3, kx = tap - 3 * ky;
+      const char* q = xb + ((a + ky) * HW_ + kx) * PIX + (pp == 0 ? 0 : pp == 1 ? 64 : 128);
+      rlo[it % D] = *reinterpret_cast<const i32x4*>(q);
+      if (pp == 2) rhi[it % D] = *reinterpret_cast<const i32x4*>(q + 64);
+    };
+    auto step = [&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      constexpr int DM = tap == 0 ? ST_DMAS : 0;                  // DMAs issued in this step (behind its first weight refill)
+      constexpr int DP = tap == 1 ? ST_DMAS : 0;                  // ... in the previous step
+      const int s = ss * 9 + tap;
+      const unsigned long long sb = uniform64(w_of(s + 1));
+      if constexpr (tap == 0) {
+#pragma unroll
+        for (int it = 0; it < D - 1; ++it) read_item(it, 0);
+      }
+#pragma unroll
+      for (int it = 0; it < 24; ++it) {
+        const int pp = it >> 3, a = it & 7;
+        // VMEM operations in issue order: ... f0' [DMAs] f1' q' | f0'' [DMAs] f1'' q'' ...: the counts of younger ones at each wait
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wf0[0]), "+v"(wf0[1]), "+v"(wf1[0]), "+v"(wf1[1]) : "n"(6 + DP) : "memory");
+        if (it == 8) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wf1[0]), "+v"(wf1[1]) : "n"(6 + DM) : "memory");
+        if (it == 16) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wql[0]), "+v"(wqh[0]), "+v"(wql[1]), "+v"(wqh[1]) : "n"(4 + DM) : "memory");
+        {
+          const int nt = it + D - 1;
+          if (nt < 24) read_item(nt, tap);
+          else if (tap < 8) read_item(nt - 24, tap + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pp == 0) {
+          const f16x8 xf = __builtin_bit_cast(f16x8, rlo[it % D]);
+          acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf0[0]), xf, acc[a][0], 0, 0, 0);
+          acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf0[1]), xf, acc[a][1], 0, 0, 0);
+        } else if (pp == 1) {
+          const f16x8 xf = __builtin_bit_cast(f16x8, rlo[it % D]);
+          acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf1[0]), xf, acc[a][0], 0, 0, 0);
+          acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf1[1]), xf, acc[a][1], 0, 0, 0);
+        } else {
+          const i32x4 xl = rlo[it % D], xh = rhi[it % D];
+          const i32x8 xq = {xl.x, xl.y, xl.z, xl.w, xh.x, xh.y, 0, 0};
+          const i32x8 q0 = {wql[0].x, wql[0].y, wql[0].z, wql[0].w, wqh[0].x, wqh[0].y, 0, 0};
+          const i32x8 q1 = {wql[1].x, wql[1].y, wql[1].z, wql[1].w, wqh[1].x, wqh[1].y, 0, 0};
+          acc[a][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(q0, xq, acc[a][0], 2, 2, 0, wqh[0].z, 0, xh.z);
+          acc[a][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(q1, xq, acc[a][1], 2, 2, 0, wqh[1].z, 0, xh.z);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it == 7) {
+          F6_LOAD_F0(sb);
+          if constexpr (tap == 0) dma_halo(ss + 1);
+          if constexpr (tap == CV_TAP) {
+            if (ss + 1 < nss) convert((ss + 1) & 1);
+          }
+        }
+        if (it == 15) F6_LOAD_F1(sb);
+        if (it == 23) F6_LOAD_Q(sb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // next halo converted by everyone, this one read by everyone
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf0[0]), "+v"(wf0[1]), "+v"(wf1[0]), "+v"(wf1[1]), "+v"(wql[0]), "+v"(wqh[0]), "+v"(wql[1]), "+v"(wqh[1])::"memory");
+
+  // ---- epilogue from registers: lane = pixel m16 of run a, channels 32 wave + 8 g .. + 7 (acc[a][0] the first four, acc[a][1] the rest) ------
+  if (p.range && seen > 0.f) atomicMax(p.range, __float_as_uint(seen));
+  const int c0 = wave * 32 + g * 8;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (p.bias) {
+    b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
+    b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
+  }
+  const long long img_px = (long long)n_img * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.res ? p.res + img_px * p.ld_res : p.x), 0, p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0, 0x00020000);
+  const int ix = x0 + m16;
+  f32x4 r0[8], r1[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const bool ok = y0 + a < p.H && ix < p.W;
+    const unsigned off = ok ? (unsigned)((((y0 + a) * p.W + ix) * p.ld_res + c0) * 4) : OOB;
+    r0[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
+    r1[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off + 16, 0, 0));
+  }
+#ifdef F6_DBG_NOEPI
+  if (p.N > 0) return;
+#endif
+  float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
+  const float os = p.out_scale;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    if (y0 + a < p.H && ix < p.W) {
+      const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
+      float* const dst = ybase + (long long)((y0 + a) * p.W + ix) * p.ldy;
+      if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
+        bf16x4 h0, l0, h1, l1;
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
+      } else {
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+      }
+    }
+  }
+}
+
+// PyTorch [256][cin][3][3] fp32 weights x w_scale -> the fragment-major image the kernel streams: thread = (step, wave, row block j, lane):
+// MFMA row r = lane & 15 is output channel 32 wave + 8 (r >> 2) + 4 j + (r & 3) (so that an accumulator lane holds 8 consecutive
+// channels), k group g = lane >> 4: part 0 / 1 = f16 of channels 64 ss + 32 part + 8 g .. + 7; parts 2, 3 = fp6 block g of the
+// K = 128 instruction = slab g >> 1, (g & 1) == 0: q6(w - f16 w) [meets q6(x)], == 1: q6(w) [meets q6(x - f16 x)], then its E8M0 scale
+__global__ void __launch_bounds__(256) f6_pack_weight_kernel(const float* __restrict__ w, float w_scale, char* __restrict__ dst, int cin, int nsteps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = idx & 63, j = (idx >> 6) & 1, wv = (idx >> 7) & 7, s = idx >> 10;
+  if (s >= nsteps) return;
+  const int ss = s / 9, tap = s - 9 * ss;
+  const int r = lane & 15, g = lane >> 4;
+  const int co = 32 * wv + 8 * (r >> 2) + 4 * j + (r & 3);
+  const float* wr = w + (long long)co * cin * 9 + tap;
+  char* o = dst + ((((long long)s * 8 + wv) * 2 + j) * 4) * 1024 + lane * 16;
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)(wr[(long long)(64 * ss + 32 * part + 8 * g + i) * 9] * w_scale);
+    *reinterpret_cast<f16x8*>(o + part * 1024) = h;
+  }
+  f32x16 a, b;
+  const int sl = g >> 1;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float v = wr[(long long)(64 * ss + 32 * sl + i) * 9] * w_scale;
+    const float q = (g & 1) ? v : v - (float)(_Float16)v;
+    if (i < 16) a[i] = q;
+    else b[i - 16] = q;
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = fmaxf(m, fmaxf(fabsf(a[i]), fabsf(b[i])));
+  const int e = e8m0_of(m);
+  const u32x6 q = cvt_fp6(a, b, __uint_as_float((unsigned)e << 23));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<u32x4*>(o + 2 * 1024) = u32x4{q[0], q[1], q[2], q[3]};
+  *reinterpret_cast<u32x4*>(o + 3 * 1024) = u32x4{q[4], q[5], (unsigned)e, 0u};
+}
+
+static inline bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+static bool f6_shape_ok(const prv2_conv_desc* d) {
+  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->convt_k == 0 && !d->same_pad && d->cout == 256 && d->cin >= 64 &&
+         d->cin % 64 == 0 && d->w >= f6::TW && (long long)d->h * d->w * d->ldx < (1LL << 29) && (long long)d->h * d->w * d->ldy < (1LL << 29);
+}
+
+}  // namespace prv2
+
+using namespace prv2;
+
+extern "C" int prv2_conv3x3_f6_supported(const prv2_conv_desc* d) { return d && f6_shape_ok(d) ? 1 : 0; }
+
+extern "C" int64_t prv2_conv3x3_f6_weight_bytes(int32_t cout, int32_t cin) {
+  return cout == 256 && cin >= 64 && cin % 64 == 0 ? (int64_t)(cin / 64) * 9 * f6::STEP_BYTES : 0;
+}
+
+extern "C" int prv2_pack_conv3x3_f6_weight(const float* w_src, float w_scale, void* w_packed, int32_t cout, int32_t cin, void* stream) {
+  PRV2_REQUIRE(w_src && w_packed && aligned16(w_packed), "pack_conv3x3_f6_weight: null / unaligned pointer");
+  PRV2_REQUIRE(prv2_conv3x3_f6_weight_bytes(cout, cin) > 0, "pack_conv3x3_f6_weight: 256 output channels, cin %% 64 == 0 (got %d -> %d)", cin, cout);
+  PRV2_REQUIRE(w_scale > 0.f && (__builtin_bit_cast(unsigned, w_scale) & 0x7fffffu) == 0, "pack_conv3x3_f6_weight: w_scale is a power of two");
+  const int nsteps = cin / 64 * 9;
+  hipLaunchKernelGGL(f6_pack_weight_kernel, dim3((unsigned)(nsteps * 1024 / 256)), dim3(256), 0, (hipStream_t)stream, w_src, w_scale,
+                     reinterpret_cast<char*>(w_packed), (int)cin, nsteps);
+  PRV2_LAUNCH_CHECK("pack_conv3x3_f6_weight");
+  return 0;
+}
+
+extern "C" int prv2_conv3x3_f6(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* res, float x_scale,
+                               float out_scale, uint32_t* range_word, float* y, void* stream) {
+  PRV2_REQUIRE(d && x && w_packed && y, "conv3x3_f6: null pointer");
+  PRV2_REQUIRE(f6_shape_ok(d), "conv3x3_f6: 3x3 s1 p1, cout 256, cin %% 64 == 0, width >= 16 (got %dx%d %d->%d k%d s%d)", d->h, d->w, d->cin, d->cout,
+               d->kh, d->stride);
+  PRV2_REQUIRE(d->act == PRV2_ACT_NONE && !(d->fmt & ~PRV2_FMT_Y_X2), "conv3x3_f6: no activation; the only format bit is PRV2_FMT_Y_X2");
+  PRV2_REQUIRE(x_scale > 0.f && (__builtin_bit_cast(unsigned, x_scale) & 0x7fffffu) == 0 && out_scale > 0.f, "conv3x3_f6: x_scale is a power of two");
+  F6Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = reinterpret_cast<const char*>(w_packed); p.bias = bias; p.res = res; p.y = y; p.range = range_word;
+  p.N = d->n; p.H = d->h; p.W = d->w; p.Cin = d->cin; p.ldx = d->ldx; p.ldy = d->ldy; p.ld_res = d->ld_res;
+  p.x_bstride = d->x_bstride ? d->x_bstride : (long long)d->h * d->w * d->ldx;
+  p.y_bstride = d->y_bstride ? d->y_bstride : (long long)d->h * d->w * d->ldy;
+  p.x_scale = x_scale; p.out_scale = out_scale; p.relu_in = d->relu_in; p.y_x2 = (d->fmt & PRV2_FMT_Y_X2) != 0;
+  PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->ldx >= d->cin && d->ldx % 4 == 0 && aligned16(x) && p.x_bstride % 4 == 0, "conv3x3_f6: x layout");
+  PRV2_REQUIRE(d->ldy >= d->cout && d->ldy % 4 == 0 && aligned16(y) && p.y_bstride % 4 == 0, "conv3x3_f6: y layout");
+  PRV2_REQUIRE(!bias || aligned16(bias), "conv3x3_f6: bias alignment");
+  PRV2_REQUIRE(!res || (d->ld_res >= d->cout && d->ld_res % 4 == 0 && aligned16(res) && (long long)d->h * d->w * d->ld_res < (1LL << 29)), "conv3x3_f6: res layout");
+  const int64_t blocks = (int64_t)d->n * cdiv(d->h, f6::TH) * cdiv(d->w, f6::TW);
+  PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_f6: grid too large");
+  hipLaunchKernelGGL(conv3x3_c256_f6_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, p);
+  set_kernel("conv3x3_c256_f6_kernel", 256, PRV2_PREC_F16F6);
+  PRV2_LAUNCH_CHECK("conv3x3_f6");
+  return 0;
+}

@@ -20,8 +20,8 @@ void set_error(const char* fmt, ...) {
 // the kernel the calling thread's last prv2_conv2d dispatched to (prv2_last_kernel): "name<BN,prec>"
 static thread_local char g_kernel[96] = "";
 void set_kernel(const char* name, int bn, int prec) {
-  static const char* const pn[3] = {"f32", "bf16x3", "bf16"};
-  snprintf(g_kernel, sizeof(g_kernel), "%s<%d,%s>", name, bn, prec >= 0 && prec < 3 ? pn[prec] : "?");
+  static const char* const pn[4] = {"f32", "bf16x3", "bf16", "f16f6"};
+  snprintf(g_kernel, sizeof(g_kernel), "%s<%d,%s>", name, bn, prec >= 0 && prec < 4 ? pn[prec] : "?");
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -286,6 +286,42 @@ Tensor conv3x3_pre(const Tensor& x, const Tensor& w_packed, const optional<Tenso
   return y;
 }
 
+// include/prv2.h::prv2_pack_conv3x3_f6_weight / prv2_conv3x3_f6: the 256-column 3x3 conv of a GatedConvUnit in the fp16 + fp6 arithmetic
+// (csrc/conv3x3_f6.hip; bi_directional_fusion_model.py:40-43, 58-64).  range: int32[1] (float bits of the largest |relu(x) x_scale| seen)
+void pack_conv3x3_f6_weight(const Tensor& w, double w_scale, Tensor packed) {
+  dev_f32(w, "weight"); dev_f32(packed, "packed");
+  TORCH_CHECK(w.dim() == 4 && w.size(2) == 3 && w.size(3) == 3 && w.is_contiguous(), "prv2::pack_conv3x3_f6_weight: weight must be a contiguous [256, cin, 3, 3]");
+  TORCH_CHECK(packed.numel() * 4 == prv2_conv3x3_f6_weight_bytes((int)w.size(0), (int)w.size(1)) && packed.numel() > 0, "prv2::pack_conv3x3_f6_weight: packed has the wrong size");
+  Launch L(w);
+  ok(prv2_pack_conv3x3_f6_weight(w.data_ptr<float>(), (float)w_scale, packed.data_ptr(), (int)w.size(0), (int)w.size(1), L.stream), "pack_conv3x3_f6_weight");
+}
+
+void conv3x3_f6(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, const optional<Tensor>& res, bool relu_in, double x_scale, double out_scale,
+                const optional<Tensor>& range, Tensor out, int64_t fmt) {
+  dev_f32(w_packed, "w_packed");
+  const int64_t cout = out.size(3);
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_conv3x3_f6_weight_bytes((int)cout, (int)x.size(3)), "prv2::conv3x3_f6: w_packed does not match a 3x3 ", x.size(3), " -> ", cout, " conv");
+  prv2_conv_desc d = desc3x3(x, out, cout, PRV2_ACT_NONE, PRV2_PREC_F16F6, 1e-6);
+  d.relu_in = relu_in ? 1 : 0;
+  d.fmt = (int32_t)fmt;
+  TORCH_CHECK(out.size(0) == x.size(0) && out.size(1) == x.size(1) && out.size(2) == x.size(2), "prv2::conv3x3_f6: out must have x's batch and size");
+  const float* pr = nullptr;
+  if (res.has_value()) {
+    TORCH_CHECK(res->sizes() == out.sizes(), "prv2::conv3x3_f6: res must have the output's shape");
+    d.ld_res = (int32_t)nhwc_ld(*res, "res");
+    pr = res->data_ptr<float>();
+  }
+  uint32_t* rw = nullptr;
+  if (range.has_value()) {
+    TORCH_CHECK(range->is_cuda() && range->scalar_type() == at::kInt && range->numel() == 1, "prv2::conv3x3_f6: range must be a GPU int32[1]");
+    rw = reinterpret_cast<uint32_t*>(range->data_ptr<int32_t>());
+  }
+  TORCH_CHECK(prv2_conv3x3_f6_supported(&d), "prv2::conv3x3_f6: layer not covered (3x3 s1 p1, cout 256, cin % 64 == 0, width >= 16)");
+  Launch L(x);
+  ok(prv2_conv3x3_f6(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), pr, (float)x_scale, (float)out_scale, rw, out.data_ptr<float>(), L.stream),
+     "conv3x3_f6");
+}
+
 // include/prv2.h::prv2_upconv5x5*: output_conv2[0] o output_conv1 o interpolate as one 5x5 conv at u's resolution (csrc/upconv5.hip)
 Tensor upconv5x5(const Tensor& u, const Tensor& w_packed, const Tensor& bias_map, int64_t cout, int64_t oh, int64_t ow, int64_t act, int64_t prec,
                  const optional<Tensor>& out) {
@@ -766,6 +802,9 @@ TORCH_LIBRARY(prv2, m) {
         "int prec, float ln_eps, Tensor(a!) out) -> ()");
   m.def("conv3x3_pre(Tensor x, Tensor w_packed, Tensor? bias, Tensor pre, int cout, int act=0, Tensor? ln_weight=None, Tensor? ln_bias=None, Tensor? res=None, "
         "int prec=1, float ln_eps=1e-06, Tensor(a!)? out=None) -> Tensor");
+  m.def("pack_conv3x3_f6_weight(Tensor weight, float w_scale, Tensor(a!) packed) -> ()");
+  m.def("conv3x3_f6(Tensor x, Tensor w_packed, Tensor? bias, Tensor? res, bool relu_in, float x_scale, float out_scale, Tensor(a!)? range, Tensor(b!) out, "
+        "int fmt=0) -> ()");
   m.def("upconv5x5(Tensor u, Tensor w_packed, Tensor bias_map, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None) -> Tensor");
   m.def("upconv5x5_lines(Tensor u, int oh, int ow) -> Tensor");
   m.def("upconv5x5_ring_(Tensor(a!) y, Tensor g_edges, int uh, int uw, int act=0) -> ()");
@@ -820,6 +859,8 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("conv3x3_ln_gate", &conv3x3_ln_gate);
   m.impl("conv3x3_tail", &conv3x3_tail);
   m.impl("conv3x3_pre", &conv3x3_pre);
+  m.impl("pack_conv3x3_f6_weight", &pack_conv3x3_f6_weight);
+  m.impl("conv3x3_f6", &conv3x3_f6);
   m.impl("upconv5x5", &upconv5x5);
   m.impl("upconv5x5_lines", &upconv5x5_lines);
   m.impl("upconv5x5_ring_", &upconv5x5_ring_);

@@ -381,12 +381,20 @@ class BiDirectionalFusion(_EncDec):
             self._packed = P
             return
 
+        def f6(u, b):
+            # the fp16 + fp6 arithmetic for GatedConvUnit.conv (ops.F16F6; csrc/conv3x3_f6.hip): a second packed image of the same weights
+            wc = self._sd[b + "conv.weight"]
+            if ops.F16F6 and self.prec == ops.PREC_BF16X3 and tuple(wc.shape[2:]) == (3, 3) and ops.L.load().prv2_conv3x3_f6_weight_bytes(wc.shape[0], wc.shape[1]) > 0:
+                u["conv_f6"] = ops.pack_conv3x3_f6(wc, self._sd.get(b + "conv.bias"), device=self.device)
+            return u
+
         def unit(b):
             if not self.c2f_fusion:
-                return dict(conv=self._conv(b + "conv"))
+                return f6(dict(conv=self._conv(b + "conv")), b)
             u = dict(conv=self._conv(b + "conv"), f0=self._conv(b + "fusion_conv.0"),
                      lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
                      f3=self._conv(b + "fusion_conv.3"))
+            f6(u, b)
             w3 = self._sd[b + "fusion_conv.3.weight"]
             if self.c2f_gate and self.prec != ops.PREC_F32 and w3.shape[0] == w3.shape[1] and w3.shape[0] in ops.GATE_CHANNELS:  # fused tail kernel (ops.conv3x3_ln_gate)
                 u["f3g"] = ops.pack_gate(w3.to(self.device))
@@ -458,11 +466,19 @@ class BiDirectionalFusion(_EncDec):
 
     # -- coarse2fine ---------------------------------------------------------------------------
     @staticmethod
+    def _unit_conv(u, x: Feat, out: Optional[Feat], res: Feat) -> Feat:
+        """GatedConvUnit.conv + the skip (:58-64): conv3x3(relu(x)) + res, in the fp16 + fp6 arithmetic where the unit has that image"""
+        cw6 = u.get("conv_f6")
+        if cw6 is not None and ops.conv3x3_f6_supported(x, cw6.cout, cw6.cin):
+            return ops.conv3x3_f6(x, cw6, out, relu_in=True, res=res)
+        return ops.conv2d(x, u["conv"], out, relu_in=True, res=res)
+
+    @staticmethod
     def _gated_unit_taps(u, x: Feat, taps: "ops.CoarseTaps", coarse: "ops.RoiSource", F_: int, res: Optional[Feat] = None) -> Feat:
         """GatedConvUnit.forward with the coarse half of ``fusion_conv.0`` taken from the per-frame tap table: the 3x3 conv runs over
         ``out`` only (K = F instead of 2F), ``c_feat`` is never gathered."""
         out = Feat(torch.empty((x.n, x.h, x.w, F_), device=x.device, dtype=torch.float32), x2=F_ == 256)  # (256: the gate kernel's operand format)
-        ops.conv2d(x, u["conv"], out, relu_in=True, res=x)                                          # conv(relu(x)) + x
+        BiDirectionalFusion._unit_conv(u, x, out, x)                                                # conv(relu(x)) + x
         pre = taps.gather(coarse.boxes, coarse.scale, x.h, x.w)                                      # conv3x3(c_feat; W[:, F:]) per tile
         return ops.conv3x3_ln_gate(out, u["f0a"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res, pre=pre,
                                    pre_cin=F_)
@@ -470,14 +486,14 @@ class BiDirectionalFusion(_EncDec):
     @staticmethod
     def _plain_unit(u, x: Feat, res: Optional[Feat] = None) -> Feat:
         """GatedConvUnit(fusion=False).forward ('self-agg', :65-70): conv(relu(x)) + x, plus the block's ``xs[0]`` (:127) when given."""
-        return ops.conv2d(x, u["conv"], relu_in=True, res=x if res is None else ops.add(x, res))
+        return BiDirectionalFusion._unit_conv(u, x, None, x if res is None else ops.add(x, res))
 
     @staticmethod
     def _gated_unit(u, x: Feat, cat: Feat, F_: int, res: Optional[Feat] = None, gate: bool = True, dst: Optional[Feat] = None) -> Feat:
         """GatedConvUnit.forward (bi_directional_fusion_model.py:56-82).  ``cat`` = [B,h,w,2F] whose upper
         half already holds the coarse feature; the lower half receives ``out``.  ``gate=False`` ('coarse-fusion', :79-80): the
         fusion_conv output is the unit's output."""
-        out = ops.conv2d(x, u["conv"], cat.slice(0, F_), relu_in=True, res=x)            # conv(relu(x)) + x
+        out = BiDirectionalFusion._unit_conv(u, x, cat.slice(0, F_), x)                  # conv(relu(x)) + x
         if not gate:
             fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))   # conv -> LN -> ReLU (:47-50)
             return ops.conv2d(fused, u["f3"], dst, res=res)                              # the 1x1 (:51) (+ xs[0], :127)

@@ -15,11 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRV2_HIP_LIB") or os.path.join(_HERE, "libprv2_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 4, 5
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3  # (F16F6: prv2_conv3x3_f6 only)
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
 FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class ConvDesc(C.Structure):
@@ -106,6 +106,10 @@ SIGNATURES = {
     "prv2_pack_chain32_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "prv2_chain32_c2f": (_I, [C.POINTER(Chain32Desc), _P]),
     "prv2_chain32_enc": (_I, [C.POINTER(Chain32Desc), _P]),
+    "prv2_conv3x3_f6_supported": (_I, [C.POINTER(ConvDesc)]),
+    "prv2_conv3x3_f6_weight_bytes": (_L, [_I, _I]),
+    "prv2_pack_conv3x3_f6_weight": (_I, [_P, _F, _P, _I, _I, _P]),
+    "prv2_conv3x3_f6": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _F, _F, _P, _P, _P]),
     "prv2_coarse_tap_knots": (_I, [_P, _I, _I, _I, _I, _F, _F, _P, _I, _P]),
     "prv2_coarse_tap_gather": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _F, _I, _I, _P, _I, _P]),
     "prv2_conv_border_bias": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -6,6 +6,7 @@ mechanism that makes every ``torch.cat`` of the reference free: producers write 
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -261,6 +262,73 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride:
                                           _stream()), "pack_conv_weight")
     b = bias.detach().to(device=device, dtype=torch.float32).contiguous() if bias is not None else None
     return ConvW(packed, b, cout, cin, kh, kw, convt_k if convt_k else stride, pad, convt_k, prec, same_pad)
+
+
+@dataclass
+class ConvWF6:
+    """A 256-column 3x3 conv packed for the fp16 + fp6 kernel (prv2_pack_conv3x3_f6_weight) + its bias and power-of-two scales."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cout: int
+    cin: int
+    w_scale: float          # the weights were multiplied by this before the fp16 / fp6 split (max |w w_scale| in [1, 2))
+    x_scale: float = 1.0    # what the loader multiplies the activations with (calibration: ``range``)
+    range: Optional[torch.Tensor] = None  # device uint32[1]: float bits of the largest |relu(x) x_scale| any launch saw
+
+
+F16F6 = os.environ.get("PRV2_F16F6", "0") == "1"  # the fp16 + fp6 arithmetic for the layers that have a kernel for it (default: bf16x3)
+
+
+def pack_conv3x3_f6(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device=None) -> ConvWF6:
+    """weight [256, cin, 3, 3] (cin % 64 == 0) -> the fragment-major fp16 + fp6 image of csrc/conv3x3_f6.hip."""
+    lib = L.load()
+    device = device or weight.device
+    w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+    cout, cin, kh, kw = w.shape
+    nbytes = lib.prv2_conv3x3_f6_weight_bytes(cout, cin)
+    assert (kh, kw) == (3, 3) and nbytes > 0, (cout, cin, kh, kw)
+    amax = float(w.abs().max())
+    w_scale = 2.0 ** -math.floor(math.log2(amax)) if amax > 0 else 1.0
+    packed = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+    if DISPATCH == "torch":
+        _tops().pack_conv3x3_f6_weight(w, w_scale, packed)
+    else:
+        L.check(lib.prv2_pack_conv3x3_f6_weight(w.data_ptr(), w_scale, packed.data_ptr(), cout, cin, _stream()), "pack_conv3x3_f6_weight")
+    b = bias.detach().to(device=device, dtype=torch.float32).contiguous() if bias is not None else None
+    return ConvWF6(packed, b, cout, cin, w_scale, 1.0, torch.zeros(1, device=device, dtype=torch.int32))
+
+
+def conv3x3_f6_supported(x: Feat, cout: int, cin: int) -> bool:
+    if getattr(x, "x2", False) or x.c != cin or x.ld % 4:
+        return False
+    d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cin, cout=cout, kh=3, kw=3, stride=1, pad=1, ldx=x.ld, ldy=roundup(cout, 4), x_bstride=0, y_bstride=0,
+                   relu_in=0, act=ACT_NONE, convt_k=0, ld_mul=0, ld_res=0, ld_res2=0, prec=L.PREC_F16F6, force_generic=0, ln_eps=1e-6, part=0,
+                   same_pad=0, fmt=0)
+    return bool(L.load().prv2_conv3x3_f6_supported(C.byref(d)))
+
+
+def conv3x3_f6(x: Feat, cw: ConvWF6, out: Optional[Feat] = None, *, relu_in: bool = False, res: Optional[Feat] = None) -> Feat:
+    """y = conv3x3(relu?(x)) + bias (+ res) in the fp16 + fp6 arithmetic (include/prv2.h::prv2_conv3x3_f6); ``out`` may be X2."""
+    assert x.c == cw.cin and not getattr(x, "x2", False)
+    if out is None:
+        out = Feat.alloc(x.n, x.h, x.w, cw.cout, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout)
+    assert res is None or ((res.n, res.h, res.w, res.c) == (out.n, out.h, out.w, out.c) and not res.x2)
+    d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=3, kw=3, stride=1, pad=1, ldx=x.ld, ldy=out.ld, x_bstride=0, y_bstride=0,
+                   relu_in=int(relu_in), act=ACT_NONE, convt_k=0, ld_mul=0, ld_res=res.ld if res is not None else 0, ld_res2=0, prec=L.PREC_F16F6,
+                   force_generic=0, ln_eps=1e-6, part=0, same_pad=0, fmt=L.FMT_Y_X2 if out.x2 else 0)
+    out_scale = 1.0 / (cw.x_scale * cw.w_scale)
+
+    def call():
+        if DISPATCH == "torch":
+            _tops().conv3x3_f6(x.view(), cw.w, cw.bias, res.view() if res is not None else None, relu_in, cw.x_scale, out_scale, cw.range, out.raw(), d.fmt)
+            return
+        L.check(L.load().prv2_conv3x3_f6(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(res), cw.x_scale, out_scale, _ptr(cw.range), out.ptr, _stream()),
+                "conv3x3_f6")
+
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), 2.0 * x.n * x.h * x.w * cw.cout * cw.cin * 9, call,
+                    shape=f"{cw.cin}->{cw.cout} k3s1 {x.n}x{x.h}x{x.w}")
+    return out
 
 
 def conv_out_hw(cw: ConvW, h: int, w: int):

@@ -1,0 +1,89 @@
+"""prv2_conv3x3_f6 (csrc/conv3x3_f6.hip): the 256-column 3x3 conv in the fp16 + block-scaled-fp6 arithmetic against float64 torch, beside
+the bf16x3 kernel on the same inputs.  Tolerances: the scheme's rms error per dot product is 1.2e-5 (profiles/r03_f16f6_study.txt);
+rel-L2 of a layer's output <= 4e-5 is asserted, the bf16x3 kernel's number is printed next to it."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from patchrefinerv2_amd import ops
+    return ops
+
+
+def _ref(x, w, b, res, relu_in):
+    xi = torch.relu(x.double()) if relu_in else x.double()
+    y = torch.nn.functional.conv2d(xi.permute(0, 3, 1, 2), w.double(), b.double() if b is not None else None, padding=1).permute(0, 2, 3, 1)
+    return y + (res.double() if res is not None else 0)
+
+
+def _x2_decode(buf):  # [.., C] float32 holding per 8 channels [8 bf16 hi | 8 bf16 lo] -> hi + lo as float64
+    n, h, w, c = buf.shape
+    u = buf.contiguous().view(torch.int16).view(n, h, w, c // 8, 2, 8).to(torch.int32) << 16
+    f = u.view(torch.float32).double()
+    return (f[..., 0, :] + f[..., 1, :]).reshape(n, h, w, c)
+
+
+@pytest.mark.parametrize("n,h,w,cin", [(2, 24, 32, 256), (1, 19, 37, 256), (3, 8, 16, 128), (1, 40, 48, 512), (1, 9, 16, 64)])
+@pytest.mark.parametrize("relu_in,with_res,with_bias", [(True, True, True), (False, False, False)])
+def test_conv3x3_f6_vs_fp64(n, h, w, cin, relu_in, with_res, with_bias):
+    P = _ops()
+    g = torch.Generator(device=DEV).manual_seed(n * 1000 + h * 10 + cin)
+    x = P.Feat(torch.randn(n, h, w, cin, device=DEV, generator=g))
+    wt = torch.randn(256, cin, 3, 3, device=DEV, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(256, device=DEV, generator=g) if with_bias else None
+    res = P.Feat(torch.randn(n, h, w, 256, device=DEV, generator=g)) if with_res else None
+    assert P.conv3x3_f6_supported(x, 256, cin)
+    cw = P.pack_conv3x3_f6(wt, b)
+    out = P.conv3x3_f6(x, cw, relu_in=relu_in, res=res)
+    ref = _ref(x.buf, wt, b, res.buf if res is not None else None, relu_in)
+    err = float((out.buf.double() - ref).norm() / ref.norm())
+    cwb = P.pack_conv(wt, b, pad=1, prec=P.L.PREC_NAMES["bf16x3"])
+    outb = P.conv2d(x, cwb, relu_in=relu_in, res=res)
+    errb = float((outb.buf.double() - ref).norm() / ref.norm())
+    print(f"\n{n}x{h}x{w} {cin}->256 relu_in={relu_in}: f16f6 rel-L2 {err:.2e} (bf16x3 {errb:.2e}), {P.L.load().prv2_last_kernel().decode()}")
+    assert err < 4e-5, err
+    seen = torch.tensor([int(cw.range.item())], dtype=torch.int32).view(torch.float32).item()
+    xi = torch.relu(x.buf) if relu_in else x.buf
+    assert abs(seen - float(xi.abs().max())) <= 1e-6 * seen, (seen, float(xi.abs().max()))
+
+
+def test_conv3x3_f6_x2_output():
+    P = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = P.Feat(torch.randn(2, 16, 32, 256, device=DEV, generator=g))
+    wt = torch.randn(256, 256, 3, 3, device=DEV, generator=g) / 48
+    b = torch.randn(256, device=DEV, generator=g)
+    cw = P.pack_conv3x3_f6(wt, b)
+    o32 = P.conv3x3_f6(x, cw, relu_in=True, res=x)
+    o2 = P.Feat(torch.empty(2, 16, 32, 256, device=DEV), x2=True)
+    P.conv3x3_f6(x, cw, o2, relu_in=True, res=x)
+    dec = _x2_decode(o2.buf)
+    # hi + lo of the RNE bf16 split of the fp32 result: 16 mantissa bits
+    assert float((dec - o32.buf.double()).abs().max()) <= 2.0 ** -16 * float(o32.buf.abs().max())
+
+
+def test_conv3x3_f6_range_and_scales():
+    """activations far outside fp16's range: with the caller's power-of-two x_scale the result is as accurate as at unit scale; without it
+    the fp16 part saturates (finite, never inf / nan) and the range word tells"""
+    P = _ops()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    base = torch.randn(1, 16, 32, 256, device=DEV, generator=g)
+    wt = torch.randn(256, 256, 3, 3, device=DEV, generator=g) / 48
+    for mag, x_scale in [(1e5, 2.0 ** -14), (1e-7, 2.0 ** 23), (1e5, 1.0)]:
+        x = P.Feat(base * mag)
+        cw = P.pack_conv3x3_f6(wt * 1e-3, None)  # (small weights: the weight scale is exercised too)
+        cw.x_scale = x_scale
+        out = P.conv3x3_f6(x, cw, relu_in=True)
+        ref = _ref(x.buf, wt * 1e-3, None, None, True)
+        err = float((out.buf.double() - ref).norm() / ref.norm())
+        seen = torch.tensor([int(cw.range.item())], dtype=torch.int32).view(torch.float32).item()
+        print(f"\n|x| ~ {mag:g}, x_scale 2^{torch.log2(torch.tensor(x_scale)).item():.0f}: rel-L2 {err:.2e}, max |x x_scale| seen {seen:.3g}")
+        assert torch.isfinite(out.buf).all()
+        if x_scale != 1.0:
+            assert err < 4e-5, err
+        else:
+            assert seen > 65504.0  # the monitor reports the overflow; the result is finite but only fp6-grade
