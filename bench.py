@@ -42,7 +42,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+# dense MFMA TFLOP/s (MI355X_MICROARCH.md).  f16f6: 2.5 PF x 2/3 -- per 64 channels two fp16 MFMAs and one fp6 K=128 MFMA of the same
+# 16 cycles take the place of six bf16 MFMAs; it prices the kernels tagged <.., f16f6> only, every other kernel of that mode runs bf16x3
+PEAK = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0, "f16f6": 2500.0 * 2.0 / 3.0}
+
+
+def peak_of(kernel_tag, prec):
+    """the roofline a kernel is priced against: its own arithmetic's (the tag's), else the mode's"""
+    if kernel_tag.endswith(",f16f6>"):
+        return PEAK["f16f6"]
+    return PEAK["bf16x3" if prec == "f16f6" else prec]
 
 
 def parse():
@@ -51,7 +60,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3", "bf16", "f16f6"],
                     help="matrix-kernel arithmetic (DESIGN.md 3): bf16x3 = split-bf16, AbsRel ~5e-6; f32 = exact fp32 MFMA")
     ap.add_argument("--shard", default="frames", choices=["frames", "patches"])
     ap.add_argument("--gather", default="rank0", choices=["rank0", "all"],
@@ -65,6 +74,7 @@ def parse():
                     help="do not enqueue the next frame's coarse forward beside the current frame's tile batches")
     ap.add_argument("--hip-graph", action="store_true", help="capture the device side of a frame into a hipGraph and replay it per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="--prec f16f6: skip the bf16x3 run reported beside it")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layer-report", default=None, help="write a per-layer-shape timing table (extra instrumented frame)")
     ap.add_argument("--data", default="rand", choices=["rand", "zeros"],
@@ -215,6 +225,13 @@ def pmc_traffic(kernel_tag, workload, prec):
     name, _, targs = kernel_tag.partition("<")
     bn, pr = targs.rstrip(">").split(",")
     # the tag covers every instantiation "prv2::<name><bn, prec[, ...]>" (e.g. the im2col-tail variant): launch-weighted mean
+    if pr == "f16f6":  # (a non-template kernel: its symbol carries no arguments)
+        prefix = f"prv2::{name}("
+        rows = [d for k, d in json.load(open(path)).items() if k.startswith(prefix)]
+        n = sum(d["launches"] for d in rows)
+        if not n:
+            return None, None
+        return sum((2.0 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * d["launches"] for d in rows) / n * 1024.0, os.path.relpath(path, ROOT)
     prefix = f"prv2::{name}<{bn}, {dict(f32=0, bf16x3=1, bf16=2)[pr]}"
     rows = [d for k, d in json.load(open(path)).items()
             if k.startswith(prefix + ">") or k.startswith(prefix + ",")]
@@ -336,7 +353,7 @@ def main():
         metric="4K depth maps/sec (cai-mode r32)" if w["mode"] == "r32" else f"depth maps/sec (cai-mode {w['mode']})",
         value=frames_done / elapsed, unit="depth maps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
         ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak" if shard is None else "strong",
-        vs_baseline=None, dtype=args.prec, data="synthetic" if args.data == "rand" else "synthetic (all-zero frames: upper end of the power-limited range, not a headline number)",
+        vs_baseline=None, dtype=("bf16x3+f16f6" if args.prec == "f16f6" else args.prec), data="synthetic" if args.data == "rand" else "synthetic (all-zero frames: upper end of the power-limited range, not a headline number)",
         config=dict(workload=name, model=w["kind"], image_raw_shape=w["raw"], patch_split_num=w["split"],
                     patch_process_shape=w["pps"], cai_mode=w["mode"], patches_per_frame=w["patches"],
                     coarse_branch=(w["coarse"]["encoder"] if w.get("coarse") else w.get("zoe_type", "DA-ZoeDepth") + "/" + w["zoe"]["midas_model_type"]), shard=args.shard if world > 1 else "none",
@@ -345,6 +362,30 @@ def main():
                     parity_note=("refiner encoder MobileNetV4-S: parity unpinned (timm absent; two independent transcriptions agree)"
                                  if w["kind"] == "PatchRefinerPlus" and not w.get("refiner_encoder") else None)))
     result["operating_point"] = operating_point
+    if args.prec == "f16f6":
+        result["dtype_note"] = ("bf16x3 (fp32 operands split hi + lo bf16, 3 MFMAs) everywhere except GatedConvUnit.conv (256 -> 256, 3x3), which runs "
+                                "fp16 + two block-scaled fp6 (e2m3) corrections per product (csrc/conv3x3_f6.hip): fp32-grade, rms 1.2e-5 per dot product")
+        if world == 1 and not args.no_alt:
+            # the same timed loop in the default arithmetic, beside it
+            f6_model = model
+            mc2 = model_config(name, prec="bf16x3", max_batch=args.max_batch, n_streams=args.streams)
+            mc2["config"]["device"] = str(dev)
+            mc2["config"]["hip_graph"] = bool(args.hip_graph)
+            model = build_model(mc2)
+            model.load_state_dict(sd, strict=True)
+            for i in range(args.warmup):
+                step(i, last=i == args.warmup - 1)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(args.warmup + i, timed=False, last=i == args.steps - 1)
+            barrier()
+            e2 = time.perf_counter() - t1
+            result["alt"] = dict(dtype="bf16x3", value=args.steps / e2, unit="depth maps/s", ms_per_step=1e3 * e2 / args.steps,
+                                 note="the default arithmetic, same process, same frames, measured right after the timed region")
+            del model
+            torch.cuda.empty_cache()
+            model = f6_model
 
     if world > 1:
         nt = w["patches"]
@@ -388,7 +429,8 @@ def main():
         dom = max(summ, key=lambda k: summ[k]["ms"])
         d = summ[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        peak = PEAK[args.prec]
+        peak = peak_of(dom, args.prec)
+        ideal_ms = lambda k, key: summ[k][key] / 1e12 / peak_of(k, args.prec) * 1e3  # noqa: E731  (a kernel's FLOPs at ITS roofline)
         traffic, traffic_src = pmc_traffic(dom, name, args.prec)
         result["roofline"] = dict(
             bound="mfma", kernel=dom, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
@@ -408,11 +450,11 @@ def main():
             matrix_kernel_ms_per_frame=tot_ms,
             # the whole frame against the same peak: every algorithmic FLOP of a frame / the TIMED step (all kernels, gathers,
             # blend, D2H and host gaps included) -- what the headline value is worth as a fraction of the MFMA roofline
-            whole_frame_frac=sum(x["flops"] for x in summ.values()) / 1e12 / (elapsed / args.steps) / peak,
-            whole_frame_frac_reference_flops=sum(x["algo"] for x in summ.values()) / 1e12 / (elapsed / args.steps) / peak,
+            whole_frame_frac=sum(ideal_ms(k, "flops") for k in summ) * 1e-3 / (elapsed / args.steps),
+            whole_frame_frac_reference_flops=sum(ideal_ms(k, "algo") for k in summ) * 1e-3 / (elapsed / args.steps),
             kernels={k: dict(launches=v["launches"], ms=round(v["ms"], 3),
                              tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None),
-                             frac=(round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None))
+                             frac=(round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(k, args.prec), 4) if v["ms"] > 0 else None))
                      for k, v in summ.items()})
     if rank == 0 and args.layer_report:
         model.n_streams = 1

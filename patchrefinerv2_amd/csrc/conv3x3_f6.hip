@@ -38,8 +38,19 @@ constexpr int ST_CHUNK = 1040, ST_DMAS = 6, ST_WAVE = ST_DMAS * ST_CHUNK;  // st
 constexpr int ST_BASE = 2 * A_BYTES;
 constexpr int LDS_BYTES = ST_BASE + 8 * ST_WAVE;                      // 153,600
 constexpr int STEP_BYTES = 8 * 2 * 4 * 1024;                          // weights of one (superslab, tap): 8 waves x 2 row blocks x 4 parts x 1 KB
-constexpr int D = 4;                                                  // activation fragments in flight (ring)
-constexpr int CV_TAP = 2;                                             // tap at which the next superslab's halo is converted
+#ifndef F6_D
+#define F6_D 4
+#endif
+constexpr int D = F6_D;                                               // activation fragments in flight (ring)
+// the next superslab's halo is converted by waves 0-3 at tap CV_TAP0 and by waves 4-7 (their SIMD partners) at tap CV_TAP1: while one wave
+// of a SIMD runs its ~350 conversion instructions the other keeps the matrix pipe busy (both at the same tap: the pipe idles for both)
+#ifndef F6_CV0
+#define F6_CV0 2
+#endif
+#ifndef F6_CV1
+#define F6_CV1 5
+#endif
+constexpr int CV_TAP0 = F6_CV0, CV_TAP1 = F6_CV1;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(8 * ST_DMAS * 4 >= HALO, "staging covers the halo");
 }  // namespace f6
@@ -55,6 +66,7 @@ struct F6Params {
   long long x_bstride, y_bstride;
   float x_scale, out_scale;
   int relu_in, y_x2;
+  long long* stamps;  // -DF6_STAMPS builds (tools/probes/f6_stamps.sh): per workgroup and wave [main-loop cycles, epilogue cycles, tiles, prologue cycles, total]
 };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -94,29 +106,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   using namespace f6;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
-  // ---- XCD-aware block -> pixel tile (as conv3x3_gate.hip) ----------------------------------------------------------------
-  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-  int t = blockIdx.x;
-  {
-    const int ntiles = gridDim.x, q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
-  }
-  const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n_img = t / (tiles_x * tiles_y);
-  const int y0 = ty * TH, x0 = tx * TW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)smem;
 
+  // ---- persistent: this workgroup's tile sequence.  An XCD takes a contiguous range of tiles, its workgroups walk it side by side
+  //      (neighbouring tiles share halo rows in that XCD's L2; the weights are L2-resident per XCD anyway) ------------------------------
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_xy = tiles_x * ((p.H + TH - 1) / TH), ntiles = p.N * tiles_xy;
+  const int per = max((int)gridDim.x >> 3, 1), xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3, chunk = (ntiles + 7) / 8;
+  const int t_begin = xcd * chunk + jwg, t_end = min((xcd + 1) * chunk, ntiles);
+  const int K = t_begin < t_end ? (t_end - t_begin + per - 1) / per : 0;
+  if (K == 0) return;
+  auto tile_of = [&](int k, int& n, int& y0, int& x0) {
+    const int t = t_begin + k * per;
+    n = t / tiles_xy;
+    const int r = t - n * tiles_xy, ty = r / tiles_x;
+    y0 = ty * TH;
+    x0 = (r - ty * tiles_x) * TW;
+  };
+
   // ---- halo DMA: instruction i of this wave moves halo pixels 4 (6 wave + i) .. + 3 (lane >> 4), 16 bytes per lane ------------
   constexpr unsigned OOB = 0x80000000u;
   i32x4 rsrc;
+  rsrc.z = __builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + p.Cin) * 4));
+  rsrc.w = 0x00020000;
   unsigned hoff[ST_DMAS];
-  {
-    const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)n_img * p.x_bstride);
+  auto set_loader = [&](int k) {  // image base and halo offsets of tile k
+    int n, y0, x0;
+    tile_of(k, n, y0, x0);
+    const unsigned long long img_base = (unsigned long long)(size_t)(p.x + (long long)n * p.x_bstride);
     rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)img_base);
     rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((img_base >> 32) & 0xffffu));
-    rsrc.z = __builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)p.H * p.W - 1) * p.ldx + p.Cin) * 4));
-    rsrc.w = 0x00020000;
 #pragma unroll
     for (int i = 0; i < ST_DMAS; ++i) {
       const int hp = (wave * ST_DMAS + i) * 4 + g;
@@ -125,14 +145,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
       const bool ok = hp < HALO && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       hoff[i] = ok ? (unsigned)(((iy * p.W + ix) * p.ldx + m16 * 4) * 4) : OOB;
     }
-  }
+  };
+  set_loader(0);
   const int nss = p.Cin >> 6, nsteps = nss * 9;
 #ifdef F6_DBG_NODMA
   i32x4 dbg_sink;
 #endif
   const unsigned st_wave = lds0 + ST_BASE + wave * ST_WAVE;
-  auto dma_halo = [&](int ss) {  // (behind the last superslab: clamped, data nobody converts -- the counted waits stay the same)
-    const unsigned cofs = (unsigned)(min(ss, nss - 1) * 256);
+  auto dma_halo = [&](int ss) {
+    const unsigned cofs = (unsigned)(ss * 256);
 #pragma unroll
     for (int i = 0; i < ST_DMAS; ++i) {
       const unsigned dst = __builtin_amdgcn_readfirstlane(st_wave + i * ST_CHUNK);
@@ -198,7 +219,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   // ---- weights: fragment-major [step][wave][row block j][part][lane] x 16 B; lane (row m16, k group g) -------------------------
   const unsigned wv0 = (unsigned)(wave * 8192 + lane * 16), wv1 = wv0 + 4096;
   i32x4 wf0[2], wf1[2], wql[2], wqh[2];
-  auto w_of = [&](int s) { return (unsigned long long)(size_t)(p.w + (long long)min(s, nsteps - 1) * STEP_BYTES); };
+  auto w_of = [&](int s) { return (unsigned long long)(size_t)(p.w + (long long)(s == nsteps ? 0 : s) * STEP_BYTES); };  // (behind a tile's last step: the next tile's first)
 #define F6_LOAD_F0(sb) do { F6_LDW(wf0[0], wv0, sb, 0); F6_LDW(wf0[1], wv1, sb, 0); } while (0)
 #define F6_LOAD_F1(sb) do { F6_LDW(wf1[0], wv0, sb, 1024); F6_LDW(wf1[1], wv1, sb, 1024); } while (0)
 #define F6_LOAD_Q(sb) do { F6_LDW(wql[0], wv0, sb, 2048); F6_LDW(wqh[0], wv0, sb, 3072); F6_LDW(wql[1], wv1, sb, 2048); F6_LDW(wqh[1], wv1, sb, 3072); } while (0)
@@ -208,6 +229,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   for (int a = 0; a < 8; ++a) acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: halo of superslab 0 -> buffer 0; weights of step 0 ------------------------------------------------------------
+#ifdef F6_STAMPS
+  const long long st_t0 = __builtin_readcyclecounter(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   dma_halo(0);
   {
     const unsigned long long sb = uniform64(w_of(0));
@@ -218,16 +242,74 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the six DMAs (the weights stay in flight)
   convert(0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef F6_STAMPS
+  const long long st_pro = __builtin_readcyclecounter() - st_t0;
+#endif
 
   // activation fragments: lane (pixel m16 of the run, k group g); ring of D
   const unsigned xlane = (unsigned)(m16 * PIX + g * 16);
   i32x4 rlo[D], rhi[D];
 
+  // ---- epilogue of a tile from registers: lane = pixel m16 of run a, channels 32 wave + 8 g .. + 7 (acc[a][0] the first four, acc[a][1]
+  //      the rest); the accumulators are cleared for the next tile ----------------------------------------------------------------------
+  const int c0 = wave * 32 + g * 8;
+  const float os = p.out_scale;
+  auto epilogue = [&](int n_img, int y0, int x0) {
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
+    }
+    const long long img_px = (long long)n_img * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res ? p.res + img_px * p.ld_res : p.x), 0, p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0, 0x00020000);
+    const int ix = x0 + m16;
+    f32x4 r0[8], r1[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const bool ok = y0 + a < p.H && ix < p.W;
+      const unsigned off = ok ? (unsigned)((((y0 + a) * p.W + ix) * p.ld_res + c0) * 4) : OOB;
+      r0[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
+      r1[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off + 16, 0, 0));
+    }
+    float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+#ifndef F6_DBG_NOEPI
+      if (y0 + a < p.H && ix < p.W) {
+        const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
+        float* const dst = ybase + (long long)((y0 + a) * p.W + ix) * p.ldy;
+        if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
+          bf16x4 h0, l0, h1, l1;
+          split_bf16(v0, h0, l0);
+          split_bf16(v1, h1, l1);
+          const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
+        } else {
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+        }
+      }
+#endif
+      acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+#ifdef F6_STAMPS
+  long long st_main = 0, st_epi = 0;
+#endif
+  for (int k = 0; k < K; ++k) {
+#ifdef F6_STAMPS
+  const long long st_a = __builtin_readcyclecounter();
+#endif
   for (int ss = 0; ss < nss; ++ss) {
-    const char* const xb = smem + (ss & 1) * A_BYTES + xlane;
+    const bool last_ss = ss + 1 == nss, more = !last_ss || k + 1 < K;  // (more: another superslab follows -- of this tile or of the next)
+    const char* const xb = smem + ((k * nss + ss) & 1) * A_BYTES + xlane;
     auto read_item = [&](int it, int tap) {  // item = (pass it >> 3, run it & 7) of tap `tap`
       const int pp = it >> 3, a = it & 7, ky = tap / 3, kx = tap - 3 * ky;
       const char* q = xb + ((a + ky) * HW_ + kx) * PIX + (pp == 0 ? 0 : pp == 1 ? 64 : 128);
+#ifdef F6_ABL_NOREAD  // (timing ablation: the fragment ring is filled once)
+      if (k > 0 || ss > 0 || tap > 0 || it >= D) return;
+#endif
       rlo[it % D] = *reinterpret_cast<const i32x4*>(q);
       if (pp == 2) rhi[it % D] = *reinterpret_cast<const i32x4*>(q + 64);
     };
@@ -273,10 +355,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
         __builtin_amdgcn_sched_barrier(0);
         if (it == 7) {
           F6_LOAD_F0(sb);
-          if constexpr (tap == 0) dma_halo(ss + 1);
-          if constexpr (tap == CV_TAP) {
-            if (ss + 1 < nss) convert((ss + 1) & 1);
+          if constexpr (tap == 0) {  // the next superslab's halo: of this tile, or superslab 0 of the next tile (behind the last: a repeat nobody converts)
+            if (last_ss && k + 1 < K) set_loader(k + 1);
+            dma_halo(last_ss ? (k + 1 < K ? 0 : ss) : ss + 1);
           }
+#ifndef F6_ABL_NOCV
+          if constexpr (tap == CV_TAP0) {
+            if (more && wave < 4) convert((k * nss + ss + 1) & 1);
+          }
+          if constexpr (tap == CV_TAP1) {
+            if (more && wave >= 4) convert((k * nss + ss + 1) & 1);
+          }
+#endif
         }
         if (it == 15) F6_LOAD_F1(sb);
         if (it == 23) F6_LOAD_Q(sb);
@@ -294,49 +384,32 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
     step(std::integral_constant<int, 8>{});
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // next halo converted by everyone, this one read by everyone
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf0[0]), "+v"(wf0[1]), "+v"(wf1[0]), "+v"(wf1[1]), "+v"(wql[0]), "+v"(wqh[0]), "+v"(wql[1]), "+v"(wqh[1])::"memory");
-
-  // ---- epilogue from registers: lane = pixel m16 of run a, channels 32 wave + 8 g .. + 7 (acc[a][0] the first four, acc[a][1] the rest) ------
-  if (p.range && seen > 0.f) atomicMax(p.range, __float_as_uint(seen));
-  const int c0 = wave * 32 + g * 8;
-  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-  if (p.bias) {
-    b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
-    b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
-  }
-  const long long img_px = (long long)n_img * p.H * p.W;
-  const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.res ? p.res + img_px * p.ld_res : p.x), 0, p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0, 0x00020000);
-  const int ix = x0 + m16;
-  f32x4 r0[8], r1[8];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const bool ok = y0 + a < p.H && ix < p.W;
-    const unsigned off = ok ? (unsigned)((((y0 + a) * p.W + ix) * p.ld_res + c0) * 4) : OOB;
-    r0[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
-    r1[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off + 16, 0, 0));
-  }
-#ifdef F6_DBG_NOEPI
-  if (p.N > 0) return;
+  {
+#ifdef F6_STAMPS
+    const long long st_b = __builtin_readcyclecounter();
 #endif
-  float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
-  const float os = p.out_scale;
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    if (y0 + a < p.H && ix < p.W) {
-      const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
-      float* const dst = ybase + (long long)((y0 + a) * p.W + ix) * p.ldy;
-      if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
-        bf16x4 h0, l0, h1, l1;
-        split_bf16(v0, h0, l0);
-        split_bf16(v1, h1, l1);
-        const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
-      } else {
-        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
-      }
-    }
+    int n_img, y0, x0;
+    tile_of(k, n_img, y0, x0);
+    epilogue(n_img, y0, x0);
+#ifdef F6_STAMPS
+    const long long st_c = __builtin_readcyclecounter();
+    st_main += st_b - st_a; st_epi += st_c - st_b;
+#endif
   }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf0[0]), "+v"(wf0[1]), "+v"(wf1[0]), "+v"(wf1[1]), "+v"(wql[0]), "+v"(wqh[0]), "+v"(wql[1]), "+v"(wqh[1])::"memory");
+  if (p.range) {  // one atomic per wave, and only while it would raise the word
+    float m = seen;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0 && __float_as_uint(m) > __hip_atomic_load(p.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p.range, __float_as_uint(m));
+  }
+#ifdef F6_STAMPS
+  if (p.stamps && lane == 0) {
+    long long* o = p.stamps + ((long long)blockIdx.x * 8 + wave) * 8;
+    o[0] = st_main; o[1] = st_epi; o[2] = K; o[3] = st_pro; o[4] = __builtin_readcyclecounter() - st_t0; o[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 // PyTorch [256][cin][3][3] fp32 weights x w_scale -> the fragment-major image the kernel streams: thread = (step, wave, row block j, lane):
@@ -424,8 +497,15 @@ extern "C" int prv2_conv3x3_f6(const prv2_conv_desc* d, const float* x, const vo
   PRV2_REQUIRE(d->ldy >= d->cout && d->ldy % 4 == 0 && aligned16(y) && p.y_bstride % 4 == 0, "conv3x3_f6: y layout");
   PRV2_REQUIRE(!bias || aligned16(bias), "conv3x3_f6: bias alignment");
   PRV2_REQUIRE(!res || (d->ld_res >= d->cout && d->ld_res % 4 == 0 && aligned16(res) && (long long)d->h * d->w * d->ld_res < (1LL << 29)), "conv3x3_f6: res layout");
-  const int64_t blocks = (int64_t)d->n * cdiv(d->h, f6::TH) * cdiv(d->w, f6::TW);
-  PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_f6: grid too large");
+  const int64_t ntiles = (int64_t)d->n * cdiv(d->h, f6::TH) * cdiv(d->w, f6::TW);
+  PRV2_REQUIRE(ntiles < (1LL << 31), "conv3x3_f6: too many tiles");
+  // persistent: one workgroup per CU (8 XCDs x 32), fewer when the tiles do not fill them
+  static const int wgs = getenv("PRV2_F6_WGS") ? atoi(getenv("PRV2_F6_WGS")) : 256;  // A/B switch
+  int64_t blocks = (ntiles + 7) / 8;
+  blocks = (blocks > wgs / 8 ? wgs / 8 : blocks) * 8;
+#ifdef F6_STAMPS
+  p.stamps = getenv("PRV2_F6_STAMPS") ? (long long*)strtoull(getenv("PRV2_F6_STAMPS"), nullptr, 16) : nullptr;
+#endif
   hipLaunchKernelGGL(conv3x3_c256_f6_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, p);
   set_kernel("conv3x3_c256_f6_kernel", 256, PRV2_PREC_F16F6);
   PRV2_LAUNCH_CHECK("conv3x3_f6");

@@ -351,6 +351,7 @@ class BiDirectionalFusion(_EncDec):
         self.c2f_fusion, self.c2f_gate = W.C2F_TYPES[coarse2fine_type]
         self.device = torch.device(device)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
+        self.f16f6 = prec == "f16f6" or (ops.F16F6 and self.prec == ops.PREC_BF16X3)  # GatedConvUnit.conv in the fp16 + fp6 arithmetic
         self.encoder_name = encoder_name
         self.glb_att = False
         self.coarse_chl, self.fine_chl = list(coarse_chl), list(fine_chl)
@@ -384,7 +385,7 @@ class BiDirectionalFusion(_EncDec):
         def f6(u, b):
             # the fp16 + fp6 arithmetic for GatedConvUnit.conv (ops.F16F6; csrc/conv3x3_f6.hip): a second packed image of the same weights
             wc = self._sd[b + "conv.weight"]
-            if ops.F16F6 and self.prec == ops.PREC_BF16X3 and tuple(wc.shape[2:]) == (3, 3) and ops.L.load().prv2_conv3x3_f6_weight_bytes(wc.shape[0], wc.shape[1]) > 0:
+            if self.f16f6 and tuple(wc.shape[2:]) == (3, 3) and ops.L.load().prv2_conv3x3_f6_weight_bytes(wc.shape[0], wc.shape[1]) > 0:
                 u["conv_f6"] = ops.pack_conv3x3_f6(wc, self._sd.get(b + "conv.bias"), device=self.device)
             return u
 

@@ -16,8 +16,10 @@ LIB_PATH = os.environ.get("PRV2_HIP_LIB") or os.path.join(_HERE, "libprv2_hip.so
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2, 3, 4, 5
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3  # (F16F6: prv2_conv3x3_f6 only)
-PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
-PREC_LABEL = {v: k for k, v in PREC_NAMES.items()}
+PREC_LABEL = {PREC_F32: "f32", PREC_BF16X3: "bf16x3", PREC_BF16: "bf16", PREC_F16F6: "f16f6"}
+# model-level arithmetic names.  "f16f6" = bf16x3 everywhere, with the fp16 + block-scaled-fp6 product in the layers that have a kernel for it
+# (stage 1: GatedConvUnit.conv, csrc/conv3x3_f6.hip) -- the modules map the name to PREC_BF16X3 and fusion.py looks at the name itself
+PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16f6": PREC_BF16X3}
 FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
 ABI_VERSION = 17
 

@@ -883,6 +883,7 @@ class _PatchModel(StateDictModule):
         self.patch_process_shape = tuple(config.patch_process_shape)
         self.tile_cfg = self.prepare_tile_cfg(config.image_raw_shape, config.patch_split_num)
         self.prec = ops.L.PREC_NAMES[config.get("prec", "f32")]
+        self.arith = config.get("prec", "f32")  # the model-level name ("f16f6": bf16x3 + the fp16 / fp6 layers; handed to the fusion model as is)
         self.device = torch.device(config.get("device", "cuda"))
         self.max_batch = config.get("max_batch", None)
         self.n_streams = config.get("n_streams", 1)
@@ -947,6 +948,7 @@ class BaselinePretrain(_PatchModel):
         self.patch_process_shape = tuple(patch_process_shape)
         self.tile_cfg = self.prepare_tile_cfg(image_raw_shape, patch_split_num)
         self.prec = ops.L.PREC_NAMES[prec] if isinstance(prec, str) else prec
+        self.arith = prec if isinstance(prec, str) else ops.L.PREC_LABEL[prec]
         self.device = torch.device(device)
         self.max_batch, self.n_streams = max_batch, n_streams
         self.target = target
@@ -1027,7 +1029,7 @@ class PatchRefiner(_PatchModel):
         self._load_ckpt(self.refiner_fine_branch, config.get("pretrain_fine_model", None), "model_state_dict",
                         fb["type"] == "DA2", "pretrain_fine_model")
         self.refiner_fusion_model = build_model({**config.refiner.fusion_model.to_dict(), "device": self.device,
-                                                 "prec": self.prec})
+                                                 "prec": self.arith if self.arith == "f16f6" else self.prec})
         self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
                               refiner_fusion_model=self.refiner_fusion_model)
         # config.pretrained: the refiner part only unless load_whole (patchrefiner.py:125-143)
@@ -1110,7 +1112,7 @@ class PatchRefinerPlus(_PatchModel):
         self.refiner_fine_branch = build_model({**config.refiner.fine_branch.to_dict(), "device": self.device,
                                                 "prec": self.prec})
         self.refiner_fusion_model = build_model({**config.refiner.fusion_model.to_dict(), "device": self.device,
-                                                 "prec": self.prec})
+                                                 "prec": self.arith if self.arith == "f16f6" else self.prec})
         self.crop_mean, self.crop_std = self.refiner_fine_branch.mean, self.refiner_fine_branch.std
         self._children = dict(coarse_branch=self.coarse_branch, refiner_fine_branch=self.refiner_fine_branch,
                               refiner_fusion_model=self.refiner_fusion_model)

@@ -115,16 +115,22 @@ def _report(tag, got, want, keys):
     return ar_c, ar, r
 
 
-def test_headline_v2_zoe_tile_vs_fp32_oracle():
+@pytest.mark.parametrize("arith", ["bf16x3", "f16f6"])
+def test_headline_v2_zoe_tile_vs_fp32_oracle(arith):
     """(a) ONE real tile of the benchmarked workload, bf16x3 vs the fp32 oracle: AbsRel of the coarse map and of the refined tile
     <= 1e-4; relative L2 of the refinement offset, of the coarse-to-fine module's output (depth + last 32-channel feature) and of
-    the last decoder stage <= 1e-3; the coarse depth spans more than 10x"""
+    the last decoder stage <= 1e-3; the coarse depth spans more than 10x.  ``f16f6``: the same tolerances with GatedConvUnit.conv in
+    the fp16 + block-scaled-fp6 arithmetic (csrc/conv3x3_f6.hip); the margins are printed."""
     name = "v2_zoe_4k_r32"
-    model, ora, w = _pair(name)
+    model, ora, w = _pair(name, prec=arith)
+    if arith == "f16f6":  # the mode is really on: every 256-channel unit of the c2f module carries the fp16 + fp6 image
+        R = model.refiner_fusion_model._packed["refine"]
+        assert all("conv_f6" in R[r][u] for r in range(1, 6) for u in ("u1", "u2"))
     assert model.resizer.kind == "zoe" and tuple(w["pps"]) == (384, 512)
     hr = rand_image(3, 1, *w["raw"])
     got, want = _one_tile(model, ora, hr, (270, 1440), dict(image_raw_shape=w["raw"], patch_split_num=w["split"]))
-    ar_c, ar, r = _report(f"{name} one tile bf16x3", got, want, ["c2f_depth", "c2f_last", "dec_last", "offset"])
+    ar_c, ar, r = _report(f"{name} one tile {arith}", got, want, ["c2f_depth", "c2f_last", "dec_last", "offset"])
+    print(f"{name} one tile {arith}: margins AbsRel {ABSREL_TOL / ar:.1f}x, worst relative L2 {REL_L2_TOL / max(r.values()):.1f}x")
     c = want["coarse"].flatten()
     lo, hi = float(c.kthvalue(c.numel() // 100).values), float(c.kthvalue(c.numel() - c.numel() // 100).values)
     assert hi / lo >= 8.0 and float(c.max()) / float(c.min()) >= 10.0, (lo, hi)    # the bins are exercised
@@ -198,18 +204,23 @@ def test_headline_whole_4k_r32_frame_vs_oracle():
     random.seed(621)
     ref, rlog = ora(mode="infer", cai_mode="r32", process_num=4, tile_cfg=tc, image_lr=ora.resizer(hr), image_hr=hr)
     hr_d = hr.to(DEV)
-    random.seed(621)
-    got, log = model(mode="infer", cai_mode="r32", process_num=4, tile_cfg=tc, image_lr=model.resizer(hr_d), image_hr=hr_d)
-    assert sum(len(p["raw"]) for p in model.last_plan) == 81
-    assert tuple(got.shape) == tuple(ref.shape) == (1, 1, 2160, 3840)
-    ar, mx = absrel(got, ref)
-    ar_c, _ = absrel(log["coarse_prediction"], rlog["coarse_prediction"])
     up = lambda c: torch.nn.functional.interpolate(c, (2160, 3840), mode="bilinear")  # noqa: E731
-    off = rel_l2(got - up(log["coarse_prediction"].cpu()), ref - up(rlog["coarse_prediction"]))
-    print(f"{name} whole 4K r32 frame (81 tiles) bf16x3 vs oracle: AbsRel {ar:.3e} max|d| {mx:.3e} (depth {float(ref.min()):.2f}..{float(ref.max()):.2f}); "
-          f"coarse AbsRel {ar_c:.3e}; (frame - upsampled coarse) relative L2 {off:.3e}")
-    assert ar < ABSREL_TOL and ar_c < ABSREL_TOL, (ar, mx)
-    assert off <= REL_L2_TOL, off
+    for arith in ("bf16x3", "f16f6"):  # (one oracle frame, both arithmetics of the product: the same tolerances)
+        if arith != "bf16x3":
+            del model
+            torch.cuda.empty_cache()
+            model, _, _ = _pair(name, prec=arith, max_batch=41, n_streams=3)
+        random.seed(621)
+        got, log = model(mode="infer", cai_mode="r32", process_num=4, tile_cfg=tc, image_lr=model.resizer(hr_d), image_hr=hr_d)
+        assert sum(len(p["raw"]) for p in model.last_plan) == 81
+        assert tuple(got.shape) == tuple(ref.shape) == (1, 1, 2160, 3840)
+        ar, mx = absrel(got, ref)
+        ar_c, _ = absrel(log["coarse_prediction"], rlog["coarse_prediction"])
+        off = rel_l2(got - up(log["coarse_prediction"].cpu()), ref - up(rlog["coarse_prediction"]))
+        print(f"{name} whole 4K r32 frame (81 tiles) {arith} vs oracle: AbsRel {ar:.3e} max|d| {mx:.3e} (depth {float(ref.min()):.2f}..{float(ref.max()):.2f}); "
+              f"coarse AbsRel {ar_c:.3e}; (frame - upsampled coarse) relative L2 {off:.3e}; margins {ABSREL_TOL / ar:.1f}x / {REL_L2_TOL / off:.1f}x")
+        assert ar < ABSREL_TOL and ar_c < ABSREL_TOL, (arith, ar, mx)
+        assert off <= REL_L2_TOL, (arith, off)
 
 
 def test_headline_4k_r32_bench_batching_properties_and_shards():

@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(512, 2) k(const i32x4* __restrict__ src, float
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-int main() {
-  const int blocks = 256, iters = 20000;
+int main(int argc, char** argv) {
+  const int blocks = 256, iters = argc > 1 ? atoi(argv[1]) : 20000, reps = argc > 2 ? atoi(argv[2]) : 3;  // (short kernels launched back to back: iters 1500 ~ 1.2 ms)
   const size_t nsrc = 8 * 4096 * 4;  // ints
   std::vector<int> h(nsrc);
   i32x4* src; float* out; long long* clk;
@@ -126,7 +126,7 @@ int main() {
       hipEvent_t e0, e1;
       CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       float ms = 0.f;
-      for (int rep = 0; rep < 3; ++rep) {  // the last repetition counts (the chip has settled)
+      for (int rep = 0; rep < reps; ++rep) {  // the last repetition counts (the chip has settled)
         CK(hipEventRecord(e0));
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(512), 0, 0, src, out, iters, clk);
         if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(512), 0, 0, src, out, iters, clk);
