@@ -260,8 +260,27 @@ class _PatchModel(StateDictModule):
         with torch.cuda.device(image_hr.device):
             self._next_lr = next_image_lr
             try:
-                return self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device,
-                                   gather_dst)
+                guard = getattr(self, "arith", None) == "f16f6" and ops.F6Range.active(image_hr.device)
+                rnd = random.getstate() if guard else None
+                out = self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device, gather_dst)
+                if guard:
+                    # fp16 range guard of the fp16 + fp6 layers (ops.F6Range): a frame in which a layer's input left fp16's range is
+                    # computed again with that layer's power-of-two input scale moved (the tile plan's random draws are replayed)
+                    for attempt in range(3):
+                        redo = ops.F6Range.check(image_hr.device)
+                        if not redo:
+                            break
+                        if attempt == 2:
+                            raise RuntimeError(f"f16f6: input range of {len(redo)} layer(s) not representable after two recalibrations "
+                                               f"(largest |x x_scale| seen: {[m for _, m, _ in redo]}); use prec='bf16x3'")
+                        self.f6_recalibrations = getattr(self, "f6_recalibrations", 0) + 1
+                        if shard is not None and shard[1] > 1:
+                            raise RuntimeError("f16f6: a layer's input left fp16's range inside a patch-sharded frame (a recomputation would have to be "
+                                               "agreed between the ranks): run one unsharded frame first, or use prec='bf16x3'")
+                        self.__dict__.pop("_graphs", None)  # (a captured frame carries the old scales)
+                        random.setstate(rnd)
+                        out = self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device, gather_dst)
+                return out
             finally:
                 self._next_lr = None
 

@@ -279,6 +279,59 @@ class ConvWF6:
 F16F6 = os.environ.get("PRV2_F16F6", "0") == "1"  # the fp16 + fp6 arithmetic for the layers that have a kernel for it (default: bf16x3)
 
 
+class F6Range:
+    """The fp16 range guard of the fp16 + fp6 layers.  Every packed layer owns one word of a per-device table; its kernel raises the word
+    to the float bits of the largest |relu(x) x_scale| it saw (prv2_conv3x3_f6, ``range_word``).  After a frame (one small D2H behind the
+    frame's own synchronisation) ``check`` moves each layer's power-of-two ``x_scale`` so that its largest input sits near 2^8 -- 2^8 of
+    head room below fp16's 65504, 22 binades of full-precision values below it -- and tells the caller whether the frame it just
+    computed has to be recomputed: a layer saw values beyond fp16's range (its fp16 part saturated: finite but fp6-grade) or its whole
+    input sat below 2^-10 (fp16 subnormals)."""
+    SLOTS = 256
+    TARGET_LOG2, LOW_LOG2, HIGH = 8, -10, 65504.0
+    _tables: dict = {}
+
+    @classmethod
+    def slot(cls, device, cw) -> torch.Tensor:
+        import weakref
+        device = torch.device(device)
+        ent = cls._tables.setdefault(str(device), dict(table=torch.zeros(cls.SLOTS, dtype=torch.int32, device=device), layers=[]))
+        ent["layers"] = [(i, r) for i, r in ent["layers"] if r() is not None]
+        used = {i for i, _ in ent["layers"]}
+        i = next(k for k in range(cls.SLOTS) if k not in used)
+        ent["layers"].append((i, weakref.ref(cw)))
+        ent["table"][i] = 0
+        return ent["table"][i:i + 1]
+
+    @classmethod
+    def active(cls, device) -> bool:
+        ent = cls._tables.get(str(torch.device(device)))
+        return bool(ent and any(r() is not None for _, r in ent["layers"]))
+
+    @classmethod
+    def check(cls, device) -> list:
+        """-> [(layer, seen maximum, old x_scale)] of the layers whose frame must be recomputed (their x_scale is already moved); the
+        table is cleared for the next frame"""
+        ent = cls._tables.get(str(torch.device(device)))
+        if not ent:
+            return []
+        seen = ent["table"].cpu().view(torch.float32)  # (synchronises the current stream)
+        ent["table"].zero_()
+        redo = []
+        for i, r in ent["layers"]:
+            cw = r()
+            m = float(seen[i]) if cw is not None else 0.0
+            if m <= 0.0 or not math.isfinite(m):
+                if cw is not None and not math.isfinite(m) and m != 0.0:
+                    redo.append((cw, m, cw.x_scale))  # (inf / nan inputs: nothing a scale can do -- reported)
+                continue
+            e = math.floor(math.log2(m))
+            if m > cls.HIGH or e < cls.LOW_LOG2:
+                redo.append((cw, m, cw.x_scale))
+            if m > cls.HIGH / 4 or e < cls.LOW_LOG2 + 6:  # (move early: two binades before the upper, six before the lower limit)
+                cw.x_scale = cw.x_scale * 2.0 ** (cls.TARGET_LOG2 - e)
+        return redo
+
+
 def pack_conv3x3_f6(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device=None) -> ConvWF6:
     """weight [256, cin, 3, 3] (cin % 64 == 0) -> the fragment-major fp16 + fp6 image of csrc/conv3x3_f6.hip."""
     lib = L.load()
@@ -295,7 +348,9 @@ def pack_conv3x3_f6(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, d
     else:
         L.check(lib.prv2_pack_conv3x3_f6_weight(w.data_ptr(), w_scale, packed.data_ptr(), cout, cin, _stream()), "pack_conv3x3_f6_weight")
     b = bias.detach().to(device=device, dtype=torch.float32).contiguous() if bias is not None else None
-    return ConvWF6(packed, b, cout, cin, w_scale, 1.0, torch.zeros(1, device=device, dtype=torch.int32))
+    cw = ConvWF6(packed, b, cout, cin, w_scale, 1.0, None)
+    cw.range = F6Range.slot(device, cw)
+    return cw
 
 
 def conv3x3_f6_supported(x: Feat, cout: int, cin: int) -> bool:

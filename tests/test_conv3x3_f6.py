@@ -39,12 +39,14 @@ def test_conv3x3_f6_vs_fp64(n, h, w, cin, relu_in, with_res, with_bias):
     assert P.conv3x3_f6_supported(x, 256, cin)
     cw = P.pack_conv3x3_f6(wt, b)
     out = P.conv3x3_f6(x, cw, relu_in=relu_in, res=res)
+    kernel = P.L.load().prv2_last_kernel().decode()
+    assert kernel == "conv3x3_c256_f6_kernel<256,f16f6>", kernel
     ref = _ref(x.buf, wt, b, res.buf if res is not None else None, relu_in)
     err = float((out.buf.double() - ref).norm() / ref.norm())
     cwb = P.pack_conv(wt, b, pad=1, prec=P.L.PREC_NAMES["bf16x3"])
     outb = P.conv2d(x, cwb, relu_in=relu_in, res=res)
     errb = float((outb.buf.double() - ref).norm() / ref.norm())
-    print(f"\n{n}x{h}x{w} {cin}->256 relu_in={relu_in}: f16f6 rel-L2 {err:.2e} (bf16x3 {errb:.2e}), {P.L.load().prv2_last_kernel().decode()}")
+    print(f"\n{n}x{h}x{w} {cin}->256 relu_in={relu_in}: f16f6 rel-L2 {err:.2e} (bf16x3 {errb:.2e}), {kernel}")
     assert err < 4e-5, err
     seen = torch.tensor([int(cw.range.item())], dtype=torch.int32).view(torch.float32).item()
     xi = torch.relu(x.buf) if relu_in else x.buf
@@ -87,3 +89,56 @@ def test_conv3x3_f6_range_and_scales():
             assert err < 4e-5, err
         else:
             assert seen > 65504.0  # the monitor reports the overflow; the result is finite but only fp6-grade
+
+
+@pytest.mark.parametrize("mag", [1.0, 1e5, 1e-7])
+def test_fusion_network_f16f6_range_guard(mag):
+    """BiDirectionalFusion with its 256-channel GatedConvUnit convs in the fp16 + fp6 arithmetic against the same network in bf16x3, with the
+    refiner features scaled far outside fp16's range: the guard (ops.F6Range: what models.forward runs after every frame) reports the
+    layers, moves their power-of-two input scales, and the recomputed result is as close to bf16x3 as at unit scale -- never an inf."""
+    import numpy as np
+    from oracle.cases import TINY_BIDIR
+    from patchrefinerv2_amd import ops, weights as W
+    from patchrefinerv2_amd.fusion import BiDirectionalFusion
+    c = TINY_BIDIR
+    sd = W.synth_state_dict(W.bidir_fusion_spec("", c["coarse_chl"], c["fine_chl"], c["fine_chl_after"], c["temp_chl"], c["dec_chl"]), seed=c["seed"])
+    sizes = [(64, 96), (32, 48), (16, 24), (8, 12), (4, 6), (2, 3)]
+    Ph, Pw, K = 64, 96, 3
+    rng = np.random.default_rng(4)
+    th, tw = Ph / 2, Pw / 2
+    org = [(0.0, 0.0), (Pw - tw, Ph - th)] + [(float(rng.uniform(0, Pw - tw)), float(rng.uniform(0, Ph - th))) for _ in range(K - 2)]
+    boxes = torch.tensor([[x, y, x + tw, y + th] for x, y in org], dtype=torch.float32)
+    rnd = lambda seed, *shape: torch.randn(*shape, generator=torch.Generator().manual_seed(seed))  # noqa: E731
+    frame = [rnd(40 + l, 1, ch, *sizes[l]) for l, ch in enumerate(c["coarse_chl"])]
+    fine = [None] + [rnd(50 + l, K, ch, *sizes[l]) * mag for l, ch in list(enumerate([32] + c["fine_chl"]))[1:]]
+    pred1 = torch.rand(K, 1, *sizes[0], generator=torch.Generator().manual_seed(7)) * 10
+
+    def run(prec):
+        m = BiDirectionalFusion(coarse2fine_type="coarse-gated", coarse_chl=c["coarse_chl"], fine_chl=c["fine_chl"],
+                                fine_chl_after_coarse2fine=c["fine_chl_after"], temp_chl=c["temp_chl"], dec_chl=c["dec_chl"], prec=prec)
+        m.load_state_dict(sd)
+
+        def fwd():
+            fr = [ops.Feat.from_nchw(t.to(DEV)) for t in frame]
+            m.prepare_frame(fr, (0.5, 0.5))
+            rois = [ops.RoiSource(f, boxes.to(DEV), f.h / Ph, f.h, f.w) for f in fr]
+            ff = [None] + [ops.Feat.from_nchw(t.to(DEV)) for t in fine[1:]]
+            return m(rois, ff, pred1.to(DEV), torch.zeros_like(pred1).to(DEV), update_base=pred1.to(DEV), f_sizes=sizes).clone()
+        out = fwd()
+        redo = []
+        if prec == "f16f6":
+            n6 = sum("conv_f6" in m._packed["refine"][r][u] for r in range(1, 6) for u in ("u1", "u2"))
+            assert n6 == 10, n6
+            redo = ops.F6Range.check(DEV)
+            if redo:
+                assert torch.isfinite(out).all()  # (saturated fp16 parts: finite, imprecise)
+                out = fwd()
+                assert not ops.F6Range.check(DEV)
+        return out, redo
+
+    ref, _ = run("bf16x3")
+    got, redo = run("f16f6")
+    err = float((got.double() - ref.double()).abs().max()) / max(1.0, float(ref.abs().max()))
+    print(f"\n|fine features| x {mag:g}: {len(redo)} layer(s) recomputed, max |f16f6 - bf16x3| / scale = {err:.2e}")
+    assert (len(redo) > 0) == (mag != 1.0), [(m_, s_) for _, m_, s_ in redo]
+    assert torch.isfinite(got).all() and err <= 3e-5, err
