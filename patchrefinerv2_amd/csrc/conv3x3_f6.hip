@@ -51,6 +51,10 @@ constexpr int D = F6_D;                                               // activat
 #define F6_CV1 5
 #endif
 constexpr int CV_TAP0 = F6_CV0, CV_TAP1 = F6_CV1;
+#ifndef F6_RES_EARLY
+#define F6_RES_EARLY 0   // runs whose residual rows are requested under the main loop (registers: 8 per run); the others in the epilogue
+#endif
+constexpr int RES_TAP0 = 3, RES_TAP1 = 6;                             // taps of a tile's last superslab at which its residual rows are requested
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(8 * ST_DMAS * 4 >= HALO, "staging covers the halo");
 }  // namespace f6
@@ -254,27 +258,51 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   //      the rest); the accumulators are cleared for the next tile ----------------------------------------------------------------------
   const int c0 = wave * 32 + g * 8;
   const float os = p.out_scale;
+  // residual rows of the tile, requested during its LAST superslab (waves 0-3 at tap RES_TAP0, their SIMD partners at RES_TAP1 -- behind
+  // their halo conversions, where the registers are free): the epilogue is bound by the CU's 64 B/clk of vector memory, 128 KB in and
+  // 128 KB out per tile; with the loads under the main loop it only adds and stores.  (#ifdef F6_ABL_RES_LATE: requested in the epilogue.)
+  f32x4 r0[8], r1[8];
+  auto load_res = [&](int n_img, int y0, int x0, const int A0, const int A1) {  // (run range: constants at every call site)
+    // per image resource: rows below the image lie behind num_records (zero, no fault); a column right of it reads a pixel nobody stores
+    const unsigned long long rb = (unsigned long long)(size_t)(p.res ? p.res + (long long)n_img * p.H * p.W * p.ld_res : p.x);
+    i32x4 rr;
+    rr.x = __builtin_amdgcn_readfirstlane((int)(unsigned)rb);
+    rr.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((rb >> 32) & 0xffffu));
+    rr.z = __builtin_amdgcn_readfirstlane(p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0);
+    rr.w = 0x00020000;
+    const unsigned voff = (unsigned)(((y0 * p.W + x0 + m16) * p.ld_res + c0) * 4);
+    const int row = p.W * p.ld_res * 4;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (a < A0 || a >= A1) continue;
+      const int so = __builtin_amdgcn_readfirstlane(a * row);
+      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+                   : "=&v"(r0[a]), "=&v"(r1[a]) : "v"(voff), "s"(rr), "s"(so) : "memory");
+    }
+  };
   auto epilogue = [&](int n_img, int y0, int x0) {
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (p.bias) {
       b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
       b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
     }
-    const long long img_px = (long long)n_img * p.H * p.W;
-    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.res ? p.res + img_px * p.ld_res : p.x), 0, p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0, 0x00020000);
     const int ix = x0 + m16;
-    f32x4 r0[8], r1[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const bool ok = y0 + a < p.H && ix < p.W;
-      const unsigned off = ok ? (unsigned)((((y0 + a) * p.W + ix) * p.ld_res + c0) * 4) : OOB;
-      r0[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
-      r1[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off + 16, 0, 0));
-    }
+#ifdef F6_ABL_RES_LATE
+    load_res(n_img, y0, x0, 0, F6_RES_EARLY);
+#endif
+    load_res(n_img, y0, x0, F6_RES_EARLY, 8);  // the rest: they land while the first rows are stored
+    // the youngest eight vector-memory operations are the next step's weights: everything older -- the residual rows -- has landed
+    // issue order: [early rows] ... [next step's weights: 8] [late rows: 2 per run]
     float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
+      if (a < F6_RES_EARLY) {
+        if (a == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * (8 - F6_RES_EARLY)) : "memory");  // all but the weights and the late rows
+        asm volatile("" : "+v"(r0[a]), "+v"(r1[a]));
+      } else {
+        // younger than run a's rows: the later runs' rows and the stores issued so far (2 per stored run: an upper bound keeps the wait safe)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0[a]), "+v"(r1[a]) : "n"(2 * (7 - a)) : "memory");
+      }
 #ifndef F6_DBG_NOEPI
       if (y0 + a < p.H && ix < p.W) {
         const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
@@ -368,7 +396,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
           }
 #endif
         }
-        if (it == 15) F6_LOAD_F1(sb);
+        if (it == 15) {
+          F6_LOAD_F1(sb);
+#ifndef F6_ABL_RES_LATE
+          if constexpr (tap == RES_TAP0 || tap == RES_TAP1) {
+            if (last_ss && (wave < 4) == (tap == RES_TAP0)) {
+              int n_img, y0, x0;
+              tile_of(k, n_img, y0, x0);
+              load_res(n_img, y0, x0, 0, F6_RES_EARLY);
+            }
+          }
+#endif
+        }
         if (it == 23) F6_LOAD_Q(sb);
         __builtin_amdgcn_sched_barrier(0);
       }
