@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 17
+#define PRV2_ABI_VERSION 18
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -282,6 +282,16 @@ int64_t prv2_conv3x3_f6_weight_bytes(int32_t cout, int32_t cin);
 int prv2_pack_conv3x3_f6_weight(const float* w_src, float w_scale, void* w_packed, int32_t cout, int32_t cin, void* stream);
 int prv2_conv3x3_f6(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* res, float x_scale,
                     float out_scale, uint32_t* range_word, float* y, void* stream);
+/* The GatedConvUnit tail with its 3x3 conv in the same fp16 + fp6 arithmetic (csrc/conv3x3_f6.hip: conv3x3_c256_gate_f6_kernel) -- what
+ * prv2_conv3x3_ln_gate_pre computes on conv3x3_c256_gate_x2_kernel (bi_directional_fusion_model.py:44-51, 70-80):
+ *     y = mul * sigmoid(conv1x1(act(LN(out_scale * conv3x3(q(x * x_scale); q(W * w_scale)) + bias + pre))) + gate_bias) (+ res)
+ * The LayerNorm, the 256 x 256 gate GEMM (bf16x3) and the final stage are conv3x3_gate.hip's epilogue, unchanged (csrc/conv3x3_gate_epi.h).
+ * Contract: prv2_conv3x3_f6_supported(d); x and mul pre-split (d->fmt = PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2: the unit's ``out``), no input ReLU, fp32 y;
+ * ln_weight / ln_bias / gate_w_packed (prv2_pack_gate_weight) required; pre (or NULL) as for prv2_conv3x3_ln_gate_pre; w_packed:
+ * prv2_pack_conv3x3_f6_weight of the conv's FINE half W[:, :256]. */
+int prv2_conv3x3_ln_gate_f6(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre, int32_t ld_pre,
+                            const float* ln_weight, const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul,
+                            const float* res, float x_scale, float out_scale, uint32_t* range_word, float* y, void* stream);
 
 /* Convolution with ONE output channel (direct, HBM-bound):
  *   final_conv 3x3 -> 1 + clamp(update_base + offset, 0)   bi_directional_fusion_model.py:438-442, fusion_model.py:113-118

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "igemm.h"
+#include "conv3x3_gate_epi.h"
 
 namespace prv2 {
 
@@ -51,10 +52,6 @@ constexpr int D = F6_D;                                               // activat
 #define F6_CV1 5
 #endif
 constexpr int CV_TAP0 = F6_CV0, CV_TAP1 = F6_CV1;
-#ifndef F6_RES_EARLY
-#define F6_RES_EARLY 0   // runs whose residual rows are requested under the main loop (registers: 8 per run); the others in the epilogue
-#endif
-constexpr int RES_TAP0 = 3, RES_TAP1 = 6;                             // taps of a tile's last superslab at which its residual rows are requested
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(8 * ST_DMAS * 4 >= HALO, "staging covers the halo");
 }  // namespace f6
@@ -106,21 +103,17 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 #define F6_LDW(dst, voff, sbase, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(lane * 16), "s"(p.w) : "memory")
 #endif
 
-__global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params p) {
+// The main loop over a workgroup's tile sequence t_begin, t_begin + per, ... (K tiles): ``epi(n_img, y0, x0, acc)`` takes a finished tile's
+// accumulators (lane = pixel m16 of run a, channels 32 wave + 8 (lane >> 4) .. + 7: acc[a][0] the first four, acc[a][1] the rest; UNSCALED: x
+// out_scale is the epilogue's) and leaves them cleared.  X2IN: x arrives pre-split (conv3x3_gate.hip: per 8 channels [8 bf16 hi | 8 bf16 lo], the
+// bytes of 8 floats): the staged bytes are decoded as hi + lo.
+template <bool X2IN, class Epi>
+__device__ __forceinline__ void f6_body(const F6Params& p, char* const smem, const int t_begin, const int per, const int K, Epi&& epi) {
   using namespace f6;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)smem;
-
-  // ---- persistent: this workgroup's tile sequence.  An XCD takes a contiguous range of tiles, its workgroups walk it side by side
-  //      (neighbouring tiles share halo rows in that XCD's L2; the weights are L2-resident per XCD anyway) ------------------------------
-  const int tiles_x = (p.W + TW - 1) / TW, tiles_xy = tiles_x * ((p.H + TH - 1) / TH), ntiles = p.N * tiles_xy;
-  const int per = max((int)gridDim.x >> 3, 1), xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3, chunk = (ntiles + 7) / 8;
-  const int t_begin = xcd * chunk + jwg, t_end = min((xcd + 1) * chunk, ntiles);
-  const int K = t_begin < t_end ? (t_end - t_begin + per - 1) / per : 0;
-  if (K == 0) return;
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_xy = tiles_x * ((p.H + TH - 1) / TH);
   auto tile_of = [&](int k, int& n, int& y0, int& x0) {
     const int t = t_begin + k * per;
     n = t / tiles_xy;
@@ -180,7 +173,22 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
       f32x16 a, b;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 ta = *reinterpret_cast<const f32x4*>(st_rd + 16 * k), tb = *reinterpret_cast<const f32x4*>(st_rd + 64 + 16 * k);
+        f32x4 ta, tb;
+        if constexpr (X2IN) {  // chunks 2q / 2q + 1 of the 128 bytes = bf16 hi / lo of channels 8q .. 8q + 7: k = 2q + h takes elements 4h .. 4h + 3
+          typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+          const int q = k >> 1, h = k & 1;
+          const u32x2v ah = *reinterpret_cast<const u32x2v*>(st_rd + 32 * q + 8 * h), al = *reinterpret_cast<const u32x2v*>(st_rd + 32 * q + 16 + 8 * h);
+          const u32x2v bh = *reinterpret_cast<const u32x2v*>(st_rd + 64 + 32 * q + 8 * h), bl = *reinterpret_cast<const u32x2v*>(st_rd + 64 + 32 * q + 16 + 8 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned sh = (e & 1) ? 0u : 16u;  // (element 2i in the low half of its dword)
+            ta[e] = __uint_as_float((ah[e >> 1] << sh) & 0xffff0000u) + __uint_as_float((al[e >> 1] << sh) & 0xffff0000u);
+            tb[e] = __uint_as_float((bh[e >> 1] << sh) & 0xffff0000u) + __uint_as_float((bl[e >> 1] << sh) & 0xffff0000u);
+          }
+        } else {
+          ta = *reinterpret_cast<const f32x4*>(st_rd + 16 * k);
+          tb = *reinterpret_cast<const f32x4*>(st_rd + 64 + 16 * k);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           a[4 * k + e] = fmaxf(ta[e], relu_floor) * xs;
@@ -253,74 +261,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   // activation fragments: lane (pixel m16 of the run, k group g); ring of D
   const unsigned xlane = (unsigned)(m16 * PIX + g * 16);
   i32x4 rlo[D], rhi[D];
-
-  // ---- epilogue of a tile from registers: lane = pixel m16 of run a, channels 32 wave + 8 g .. + 7 (acc[a][0] the first four, acc[a][1]
-  //      the rest); the accumulators are cleared for the next tile ----------------------------------------------------------------------
-  const int c0 = wave * 32 + g * 8;
-  const float os = p.out_scale;
-  // residual rows of the tile, requested during its LAST superslab (waves 0-3 at tap RES_TAP0, their SIMD partners at RES_TAP1 -- behind
-  // their halo conversions, where the registers are free): the epilogue is bound by the CU's 64 B/clk of vector memory, 128 KB in and
-  // 128 KB out per tile; with the loads under the main loop it only adds and stores.  (#ifdef F6_ABL_RES_LATE: requested in the epilogue.)
-  f32x4 r0[8], r1[8];
-  auto load_res = [&](int n_img, int y0, int x0, const int A0, const int A1) {  // (run range: constants at every call site)
-    // per image resource: rows below the image lie behind num_records (zero, no fault); a column right of it reads a pixel nobody stores
-    const unsigned long long rb = (unsigned long long)(size_t)(p.res ? p.res + (long long)n_img * p.H * p.W * p.ld_res : p.x);
-    i32x4 rr;
-    rr.x = __builtin_amdgcn_readfirstlane((int)(unsigned)rb);
-    rr.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((rb >> 32) & 0xffffu));
-    rr.z = __builtin_amdgcn_readfirstlane(p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0);
-    rr.w = 0x00020000;
-    const unsigned voff = (unsigned)(((y0 * p.W + x0 + m16) * p.ld_res + c0) * 4);
-    const int row = p.W * p.ld_res * 4;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      if (a < A0 || a >= A1) continue;
-      const int so = __builtin_amdgcn_readfirstlane(a * row);
-      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
-                   : "=&v"(r0[a]), "=&v"(r1[a]) : "v"(voff), "s"(rr), "s"(so) : "memory");
-    }
-  };
-  auto epilogue = [&](int n_img, int y0, int x0) {
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-    if (p.bias) {
-      b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
-      b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
-    }
-    const int ix = x0 + m16;
-#ifdef F6_ABL_RES_LATE
-    load_res(n_img, y0, x0, 0, F6_RES_EARLY);
-#endif
-    load_res(n_img, y0, x0, F6_RES_EARLY, 8);  // the rest: they land while the first rows are stored
-    // the youngest eight vector-memory operations are the next step's weights: everything older -- the residual rows -- has landed
-    // issue order: [early rows] ... [next step's weights: 8] [late rows: 2 per run]
-    float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      if (a < F6_RES_EARLY) {
-        if (a == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * (8 - F6_RES_EARLY)) : "memory");  // all but the weights and the late rows
-        asm volatile("" : "+v"(r0[a]), "+v"(r1[a]));
-      } else {
-        // younger than run a's rows: the later runs' rows and the stores issued so far (2 per stored run: an upper bound keeps the wait safe)
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0[a]), "+v"(r1[a]) : "n"(2 * (7 - a)) : "memory");
-      }
-#ifndef F6_DBG_NOEPI
-      if (y0 + a < p.H && ix < p.W) {
-        const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
-        float* const dst = ybase + (long long)((y0 + a) * p.W + ix) * p.ldy;
-        if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
-          bf16x4 h0, l0, h1, l1;
-          split_bf16(v0, h0, l0);
-          split_bf16(v1, h1, l1);
-          const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
-        } else {
-          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
-        }
-      }
-#endif
-      acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
 
 #ifdef F6_STAMPS
   long long st_main = 0, st_epi = 0;
@@ -398,15 +338,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
         }
         if (it == 15) {
           F6_LOAD_F1(sb);
-#ifndef F6_ABL_RES_LATE
-          if constexpr (tap == RES_TAP0 || tap == RES_TAP1) {
-            if (last_ss && (wave < 4) == (tap == RES_TAP0)) {
-              int n_img, y0, x0;
-              tile_of(k, n_img, y0, x0);
-              load_res(n_img, y0, x0, 0, F6_RES_EARLY);
-            }
-          }
-#endif
         }
         if (it == 23) F6_LOAD_Q(sb);
         __builtin_amdgcn_sched_barrier(0);
@@ -429,7 +360,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
 #endif
     int n_img, y0, x0;
     tile_of(k, n_img, y0, x0);
-    epilogue(n_img, y0, x0);
+    epi(n_img, y0, x0, acc);
 #ifdef F6_STAMPS
     const long long st_c = __builtin_readcyclecounter();
     st_main += st_b - st_a; st_epi += st_c - st_b;
@@ -449,6 +380,111 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
     o[0] = st_main; o[1] = st_epi; o[2] = K; o[3] = st_pro; o[4] = __builtin_readcyclecounter() - st_t0; o[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
   }
 #endif
+}
+
+// ---- GatedConvUnit.conv: persistent workgroups, epilogue from registers ------------------------------------------------------------------------------
+// An XCD takes a contiguous range of tiles, its workgroups walk it side by side (neighbouring tiles share halo rows in that XCD's L2; the weights are
+// L2-resident per XCD anyway).  Epilogue of a tile: x out_scale, + bias, + res, fp32 or X2 -- 16-byte loads / stores of the lane's 8 channels.  It is
+// bound by the CU's 64 B/clk of vector memory (128 KB in, 128 KB out per tile); requesting the residual rows under the main loop was measured: no
+// gain, 9-27 registers spilled (profiles/r05_experiments.txt #15).
+__global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params p) {
+  using namespace f6;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tiles_xy = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH), ntiles = p.N * tiles_xy;
+  const int per = max((int)gridDim.x >> 3, 1), xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3, chunk = (ntiles + 7) / 8;
+  const int t_begin = xcd * chunk + jwg, t_end = min((xcd + 1) * chunk, ntiles);
+  const int K = t_begin < t_end ? (t_end - t_begin + per - 1) / per : 0;
+  if (K == 0) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), m16 = lane & 15, g = lane >> 4;
+  const int c0 = wave * 32 + g * 8;
+  const float os = p.out_scale;
+  f6_body<false>(p, smem, t_begin, per, K, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
+    }
+    // per image resource: rows below the image lie behind num_records (zero, no fault); a column right of it reads a pixel nobody stores
+    const unsigned long long rb = (unsigned long long)(size_t)(p.res ? p.res + (long long)n_img * p.H * p.W * p.ld_res : p.x);
+    i32x4 rr;
+    rr.x = __builtin_amdgcn_readfirstlane((int)(unsigned)rb);
+    rr.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((rb >> 32) & 0xffffu));
+    rr.z = __builtin_amdgcn_readfirstlane(p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0);
+    rr.w = 0x00020000;
+    const int ix = x0 + m16;
+    const unsigned voff = (unsigned)(((y0 * p.W + ix) * p.ld_res + c0) * 4);
+    const int row = p.W * p.ld_res * 4;
+    f32x4 r0[8], r1[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int so = __builtin_amdgcn_readfirstlane(a * row);
+      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+                   : "=&v"(r0[a]), "=&v"(r1[a]) : "v"(voff), "s"(rr), "s"(so) : "memory");
+    }
+    float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      // younger than run a's rows: the later runs' rows and the stores issued so far (2 per stored run: an upper bound keeps the wait safe)
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0[a]), "+v"(r1[a]) : "n"(2 * (7 - a)) : "memory");
+#ifndef F6_DBG_NOEPI
+      if (y0 + a < p.H && ix < p.W) {
+        const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
+        float* const dst = ybase + (long long)((y0 + a) * p.W + ix) * p.ldy;
+        if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
+          bf16x4 h0, l0, h1, l1;
+          split_bf16(v0, h0, l0);
+          split_bf16(v1, h1, l1);
+          const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
+        } else {
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+        }
+      }
+#endif
+      acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  });
+}
+
+// ---- GatedConvUnit tail (round 5, stage 2): the fp16 + fp6 main loop over the unit's pre-split ``out`` in front of conv3x3_gate.hip's epilogue -- C tile
+// -> LDS, + pre (the conv's coarse half), LayerNorm, ReLU, the 256 x 256 gate GEMM (bf16x3: its A operand is formed in LDS, its weights are
+// fragment-major in L2), sigmoid, x mul, + res.  One tile per workgroup like conv3x3_c256_gate_x2_kernel: the C tile (133 KB) takes the place of the
+// halo buffers and the staging area, so nothing of a next tile can be staged under it.
+__global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_f6_kernel(const GateConvParams gp) {
+  using namespace f6;
+  static_assert(LDS_BYTES >= g256::EPI_FLOATS * 4, "the C tile fits the main loop's LDS");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const IgemmParams& c = gp.c;
+  F6Params p;
+  p.x = c.x; p.w = reinterpret_cast<const char*>(c.w); p.bias = c.bias; p.res = nullptr; p.y = nullptr; p.range = gp.f6_range;
+  p.N = c.N; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.ldx = c.ldx; p.ldy = c.ldy; p.ld_res = 0;
+  p.x_bstride = c.x_bstride; p.y_bstride = c.y_bstride; p.x_scale = gp.f6_x_scale; p.out_scale = gp.f6_out_scale; p.relu_in = c.relu_in; p.y_x2 = 0;
+  p.stamps = nullptr;
+  int t = blockIdx.x;  // XCD-aware block -> tile, as conv3x3_gate.hip
+  {
+    const int ntiles = gridDim.x, q = ntiles >> 3, r = ntiles & 7, xcd = t & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), m16 = lane & 15, g = lane >> 4;
+  const int c0 = wave * 32 + g * 8;
+  const float os = p.out_scale;
+  f6_body<true>(p, smem, t, 1, 1, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
+    // the wrapped-around weight loads and the repeated halo DMA (nobody uses either) must have landed before the C tile takes the staging area
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    c256_epilogue<PRV2_PREC_BF16X3, true, true>(gp, reinterpret_cast<float*>(smem), n_img, y0, x0, [&](float* ct) {
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (c.bias) {
+        b0 = *reinterpret_cast<const f32x4*>(c.bias + c0);
+        b1 = *reinterpret_cast<const f32x4*>(c.bias + c0 + 4);
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        float* q = ct + (a * TW + m16) * g256::CLD + c0;
+        *reinterpret_cast<f32x4*>(q) = acc[a][0] * os + b0;
+        *reinterpret_cast<f32x4*>(q + 4) = acc[a][1] * os + b1;
+      }
+    });
+  });
 }
 
 // PyTorch [256][cin][3][3] fp32 weights x w_scale -> the fragment-major image the kernel streams: thread = (step, wave, row block j, lane):
@@ -548,5 +584,45 @@ extern "C" int prv2_conv3x3_f6(const prv2_conv_desc* d, const float* x, const vo
   hipLaunchKernelGGL(conv3x3_c256_f6_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, p);
   set_kernel("conv3x3_c256_f6_kernel", 256, PRV2_PREC_F16F6);
   PRV2_LAUNCH_CHECK("conv3x3_f6");
+  return 0;
+}
+
+extern "C" int prv2_conv3x3_ln_gate_f6(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre, int32_t ld_pre,
+                                       const float* ln_weight, const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul,
+                                       const float* res, float x_scale, float out_scale, uint32_t* range_word, float* y, void* stream) {
+  PRV2_REQUIRE(d && x && w_packed && y && ln_weight && ln_bias && gate_w_packed, "conv3x3_ln_gate_f6: null pointer (the LayerNorm and the gate stage are part of the kernel)");
+  PRV2_REQUIRE(f6_shape_ok(d), "conv3x3_ln_gate_f6: 3x3 s1 p1, cout 256, cin %% 64 == 0, width >= 16 (got %dx%d %d->%d k%d s%d)", d->h, d->w, d->cin, d->cout, d->kh,
+               d->stride);
+  PRV2_REQUIRE((d->fmt & PRV2_FMT_X_X2) && !(d->fmt & PRV2_FMT_Y_X2) && (!mul || (d->fmt & PRV2_FMT_MUL_X2)) && !d->relu_in,
+               "conv3x3_ln_gate_f6: x (and mul) arrive pre-split (PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2), no input ReLU, fp32 output");
+  PRV2_REQUIRE(d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate_f6: ReLU or no activation in front of the gate (act %d)", d->act);
+  PRV2_REQUIRE(x_scale > 0.f && (__builtin_bit_cast(unsigned, x_scale) & 0x7fffffu) == 0 && out_scale > 0.f, "conv3x3_ln_gate_f6: x_scale is a power of two");
+  const long long px = (long long)d->h * d->w;
+  PRV2_REQUIRE(!pre || (ld_pre >= d->cout && ld_pre % 4 == 0 && aligned16(pre) && px * ld_pre < (1LL << 29)), "conv3x3_ln_gate_f6: pre layout");
+  GateConvParams gp;
+  memset(&gp, 0, sizeof(gp));
+  IgemmParams& p = gp.c;
+  p.x = x; p.w = w_packed; p.bias = bias; p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = d->ln_eps; p.mul = mul; p.res = res; p.y = y;
+  p.N = d->n; p.H = d->h; p.W = d->w; p.OH = d->h; p.OW = d->w;
+  p.Cin = d->cin; p.Cin_pad = d->cin; p.Cout = d->cout; p.Ncols = d->cout;
+  p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1; p.pad_x = 1;
+  p.ldx = d->ldx; p.ldy = d->ldy; p.ld_mul = d->ld_mul; p.ld_res = d->ld_res;
+  p.x_bstride = d->x_bstride ? d->x_bstride : px * d->ldx;
+  p.y_bstride = d->y_bstride ? d->y_bstride : px * d->ldy;
+  p.M = (long long)d->n * px;
+  p.relu_in = 0; p.act = d->act; p.vec_ok = 1; p.vec_epi = 1;
+  PRV2_REQUIRE(d->n > 0 && d->h > 0 && d->ldx >= d->cin && d->ldx % 4 == 0 && aligned16(x) && p.x_bstride % 4 == 0, "conv3x3_ln_gate_f6: x layout");
+  PRV2_REQUIRE(d->ldy >= d->cout && d->ldy % 4 == 0 && aligned16(y) && p.y_bstride % 4 == 0, "conv3x3_ln_gate_f6: y layout");
+  PRV2_REQUIRE(!mul || (d->ld_mul >= d->cout && d->ld_mul % 4 == 0 && aligned16(mul) && px * d->ld_mul < (1LL << 29)), "conv3x3_ln_gate_f6: mul layout");
+  PRV2_REQUIRE(!res || (d->ld_res >= d->cout && d->ld_res % 4 == 0 && aligned16(res) && px * d->ld_res < (1LL << 29)), "conv3x3_ln_gate_f6: res layout");
+  PRV2_REQUIRE(!bias || aligned16(bias), "conv3x3_ln_gate_f6: bias alignment");
+  gp.gate_w = gate_w_packed; gp.gate_bias = gate_bias; gp.pre = pre; gp.ld_pre = ld_pre;
+  gp.x_x2 = 1; gp.mul_x2 = mul ? 1 : 0; gp.y_x2 = 0;
+  gp.f6_x_scale = x_scale; gp.f6_out_scale = out_scale; gp.f6_range = range_word;
+  const int64_t blocks = (int64_t)d->n * cdiv(d->h, f6::TH) * cdiv(d->w, f6::TW);
+  PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate_f6: grid too large");
+  hipLaunchKernelGGL(conv3x3_c256_gate_f6_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, gp);
+  set_kernel("conv3x3_c256_gate_f6_kernel", 256, PRV2_PREC_F16F6);
+  PRV2_LAUNCH_CHECK("conv3x3_ln_gate_f6");
   return 0;
 }

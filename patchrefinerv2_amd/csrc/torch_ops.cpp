@@ -322,6 +322,33 @@ void conv3x3_f6(const Tensor& x, const Tensor& w_packed, const optional<Tensor>&
      "conv3x3_f6");
 }
 
+// include/prv2.h::prv2_conv3x3_ln_gate_f6: the GatedConvUnit tail with its 3x3 conv in the fp16 + fp6 arithmetic; x / mul: the unit's pre-split ``out`` (raw buffers)
+void conv3x3_ln_gate_f6(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, const optional<Tensor>& pre, const Tensor& ln_weight,
+                        const Tensor& ln_bias, const Tensor& gate_w_packed, const optional<Tensor>& gate_bias, const optional<Tensor>& mul,
+                        const optional<Tensor>& res, int64_t act, double ln_eps, double x_scale, double out_scale, const optional<Tensor>& range, Tensor out) {
+  dev_f32(w_packed, "w_packed");
+  const int64_t cout = ln_weight.numel();
+  TORCH_CHECK(w_packed.numel() * 4 == prv2_conv3x3_f6_weight_bytes((int)cout, (int)x.size(3)), "prv2::conv3x3_ln_gate_f6: w_packed does not match a 3x3 ", x.size(3), " -> ", cout, " conv");
+  TORCH_CHECK(gate_w_packed.numel() * 4 == prv2_gate_weight_bytes((int)cout), "prv2::conv3x3_ln_gate_f6: gate_w_packed is not a pack_gate_weight image");
+  prv2_conv_desc d = desc3x3(x, out, cout, act, PRV2_PREC_F16F6, ln_eps);
+  d.fmt = PRV2_FMT_X_X2 | (mul.has_value() ? PRV2_FMT_MUL_X2 : 0);
+  const float *pm = nullptr, *pr = nullptr, *pp = nullptr;
+  int32_t ld_pre = 0;
+  if (mul.has_value()) { TORCH_CHECK(mul->sizes() == out.sizes(), "prv2::conv3x3_ln_gate_f6: mul must have the output's shape"); d.ld_mul = (int32_t)nhwc_ld(*mul, "mul"); pm = mul->data_ptr<float>(); }
+  if (res.has_value()) { TORCH_CHECK(res->sizes() == out.sizes(), "prv2::conv3x3_ln_gate_f6: res must have the output's shape"); d.ld_res = (int32_t)nhwc_ld(*res, "res"); pr = res->data_ptr<float>(); }
+  if (pre.has_value()) { TORCH_CHECK(pre->sizes() == out.sizes(), "prv2::conv3x3_ln_gate_f6: pre must have the output's shape"); ld_pre = (int32_t)nhwc_ld(*pre, "pre"); pp = pre->data_ptr<float>(); }
+  uint32_t* rw = nullptr;
+  if (range.has_value()) {
+    TORCH_CHECK(range->is_cuda() && range->scalar_type() == at::kInt && range->numel() == 1, "prv2::conv3x3_ln_gate_f6: range must be a GPU int32[1]");
+    rw = reinterpret_cast<uint32_t*>(range->data_ptr<int32_t>());
+  }
+  TORCH_CHECK(prv2_conv3x3_f6_supported(&d), "prv2::conv3x3_ln_gate_f6: layer not covered (3x3 s1 p1, cout 256, cin % 64 == 0, width >= 16)");
+  Launch L(x);
+  ok(prv2_conv3x3_ln_gate_f6(&d, x.data_ptr<float>(), w_packed.data_ptr(), opt_ptr(bias, "bias", cout), pp, ld_pre, opt_ptr(ln_weight, "ln_weight", cout),
+                             opt_ptr(ln_bias, "ln_bias", cout), gate_w_packed.data_ptr(), opt_ptr(gate_bias, "gate_bias", cout), pm, pr, (float)x_scale,
+                             (float)out_scale, rw, out.data_ptr<float>(), L.stream), "conv3x3_ln_gate_f6");
+}
+
 // include/prv2.h::prv2_upconv5x5*: output_conv2[0] o output_conv1 o interpolate as one 5x5 conv at u's resolution (csrc/upconv5.hip)
 Tensor upconv5x5(const Tensor& u, const Tensor& w_packed, const Tensor& bias_map, int64_t cout, int64_t oh, int64_t ow, int64_t act, int64_t prec,
                  const optional<Tensor>& out) {
@@ -805,6 +832,8 @@ TORCH_LIBRARY(prv2, m) {
   m.def("pack_conv3x3_f6_weight(Tensor weight, float w_scale, Tensor(a!) packed) -> ()");
   m.def("conv3x3_f6(Tensor x, Tensor w_packed, Tensor? bias, Tensor? res, bool relu_in, float x_scale, float out_scale, Tensor(a!)? range, Tensor(b!) out, "
         "int fmt=0) -> ()");
+  m.def("conv3x3_ln_gate_f6(Tensor x, Tensor w_packed, Tensor? bias, Tensor? pre, Tensor ln_weight, Tensor ln_bias, Tensor gate_w_packed, Tensor? gate_bias, "
+        "Tensor? mul, Tensor? res, int act, float ln_eps, float x_scale, float out_scale, Tensor(a!)? range, Tensor(b!) out) -> ()");
   m.def("upconv5x5(Tensor u, Tensor w_packed, Tensor bias_map, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None) -> Tensor");
   m.def("upconv5x5_lines(Tensor u, int oh, int ow) -> Tensor");
   m.def("upconv5x5_ring_(Tensor(a!) y, Tensor g_edges, int uh, int uw, int act=0) -> ()");
@@ -861,6 +890,7 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("conv3x3_pre", &conv3x3_pre);
   m.impl("pack_conv3x3_f6_weight", &pack_conv3x3_f6_weight);
   m.impl("conv3x3_f6", &conv3x3_f6);
+  m.impl("conv3x3_ln_gate_f6", &conv3x3_ln_gate_f6);
   m.impl("upconv5x5", &upconv5x5);
   m.impl("upconv5x5_lines", &upconv5x5_lines);
   m.impl("upconv5x5_ring_", &upconv5x5_ring_);

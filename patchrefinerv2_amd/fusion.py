@@ -407,6 +407,8 @@ class BiDirectionalFusion(_EncDec):
                     # (prepare_frame / ops.CoarseTaps): ``f0a`` = the fine half (with the bias), ``tapw`` = the coarse half as the
                     # 1x1 GEMM weights of the nine tap maps
                     u["f0a"] = ops.pack_conv(w0[:, :F_], self._sd.get(b + "fusion_conv.0.bias"), device=self.device, prec=self.prec)
+                    if self.f16f6 and ops.F6_GATE and ops.L.load().prv2_conv3x3_f6_weight_bytes(F_, F_) > 0:  # stage 2: the unit's tail kernel too
+                        u["f0a_f6"] = ops.pack_conv3x3_f6(w0[:, :F_], self._sd.get(b + "fusion_conv.0.bias"), device=self.device)
                     u["tapw"] = ops.coarse_tap_weight(w0[:, F_:])
             return u
 
@@ -481,6 +483,9 @@ class BiDirectionalFusion(_EncDec):
         out = Feat(torch.empty((x.n, x.h, x.w, F_), device=x.device, dtype=torch.float32), x2=F_ == 256)  # (256: the gate kernel's operand format)
         BiDirectionalFusion._unit_conv(u, x, out, x)                                                # conv(relu(x)) + x
         pre = taps.gather(coarse.boxes, coarse.scale, x.h, x.w)                                      # conv3x3(c_feat; W[:, F:]) per tile
+        cw6 = u.get("f0a_f6")
+        if cw6 is not None and out.x2 and ops.conv3x3_f6_supported(x, cw6.cout, cw6.cin):
+            return ops.conv3x3_ln_gate_f6(out, cw6, (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res, pre=pre, pre_cin=F_)
         return ops.conv3x3_ln_gate(out, u["f0a"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res, pre=pre,
                                    pre_cin=F_)
 

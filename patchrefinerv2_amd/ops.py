@@ -277,6 +277,7 @@ class ConvWF6:
 
 
 F16F6 = os.environ.get("PRV2_F16F6", "0") == "1"  # the fp16 + fp6 arithmetic for the layers that have a kernel for it (default: bf16x3)
+F6_GATE = os.environ.get("PRV2_F6_GATE", "1") != "0"  # A/B switch of the mode's stage 2: the GatedConvUnit tail kernel (conv3x3_c256_gate_f6_kernel)
 
 
 class F6Range:
@@ -314,7 +315,7 @@ class F6Range:
         ent = cls._tables.get(str(torch.device(device)))
         if not ent:
             return []
-        seen = ent["table"].cpu().view(torch.float32)  # (synchronises the current stream)
+        seen = ent["table"].to("cpu", copy=True).view(torch.float32)  # (synchronises the current stream)
         ent["table"].zero_()
         redo = []
         for i, r in ent["layers"]:
@@ -742,6 +743,40 @@ def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate
     coarse = f"(+{pre_cin} coarse)" if pre is not None else ""
     PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops, call,
                     shape=f"{cw.cin}{coarse}->{cw.cout}{'->' + str(cw.cout) + ' gate' if gate_w is not None else ''} k3s1 {x.n}x{x.h}x{x.w}",
+                    algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9 if pre is not None else None)
+    return out
+
+
+def conv3x3_ln_gate_f6(x: Feat, cw: ConvWF6, ln, gate_w: torch.Tensor, gate_bias: Optional[torch.Tensor], out: Optional[Feat] = None, *,
+                       act: int = ACT_RELU, mul: Optional[Feat] = None, res: Optional[Feat] = None, ln_eps: float = 1e-6,
+                       pre: Optional[Feat] = None, pre_cin: int = 0) -> Feat:
+    """``conv3x3_ln_gate`` with the 3x3 conv in the fp16 + fp6 arithmetic (include/prv2.h::prv2_conv3x3_ln_gate_f6): x and mul are the unit's
+    pre-split (X2) ``out``; LayerNorm, gate GEMM (bf16x3) and final stage are the bf16x3 kernel's."""
+    assert getattr(x, "x2", False) and x.c == cw.cin and (mul is None or mul.x2)
+    if out is None:
+        out = Feat.alloc(x.n, x.h, x.w, cw.cout, x.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and not out.x2 and (res is None or not res.x2)
+    for aux in (mul, res, pre):
+        assert aux is None or (aux.n, aux.h, aux.w, aux.c) == (out.n, out.h, out.w, out.c)
+    d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=3, kw=3, stride=1, pad=1, ldx=x.ld, ldy=out.ld, x_bstride=0, y_bstride=0,
+                   relu_in=0, act=act, convt_k=0, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0, ld_res2=0,
+                   prec=L.PREC_F16F6, force_generic=0, ln_eps=ln_eps, part=0, same_pad=0,
+                   fmt=L.FMT_X_X2 | (L.FMT_MUL_X2 if mul is not None else 0))
+    out_scale = 1.0 / (cw.x_scale * cw.w_scale)
+    flops = 2.0 * x.n * x.h * x.w * cw.cout * (cw.cin * 9 + cw.cout)
+
+    def call():
+        if DISPATCH == "torch":
+            r = lambda f: None if f is None else f.raw()  # noqa: E731
+            _tops().conv3x3_ln_gate_f6(x.raw(), cw.w, cw.bias, r(pre), ln[0], ln[1], gate_w, gate_bias, r(mul), r(res), act, ln_eps, cw.x_scale, out_scale,
+                                       cw.range, out.view())
+            return
+        L.check(L.load().prv2_conv3x3_ln_gate_f6(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(pre), pre.ld if pre is not None else 0, _ptr(ln[0]),
+                                                 _ptr(ln[1]), _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), cw.x_scale, out_scale, _ptr(cw.range),
+                                                 out.ptr, _stream()), "conv3x3_ln_gate_f6")
+
+    coarse = f"(+{pre_cin} coarse)" if pre is not None else ""
+    PROFILER.launch(lambda: L.load().prv2_last_kernel().decode(), flops, call, shape=f"{cw.cin}{coarse}->{cw.cout}->{cw.cout} gate k3s1 {x.n}x{x.h}x{x.w}",
                     algo=flops + 2.0 * x.n * x.h * x.w * cw.cout * pre_cin * 9 if pre is not None else None)
     return out
 

@@ -27,7 +27,7 @@ OPS = ("abi_version", "pack_conv_weight", "conv2d", "conv3x3_ups", "pack_gate_we
        "patchify", "assemble_tokens", "split_ss", "layernorm_ss", "gemm_ss", "attention_ss", "bicubic_resize", "depth_pair_fill", "conv_border_bias_",
        "add_nhwc", "zero_pad_channels_", "pack_attention_bias", "upconv3x3",
        # round 5: the fused 32-channel full-resolution chains and the 5x5 composite at the source resolution
-       "pack_chain32_weight", "chain32_c2f", "chain32_enc", "upconv5x5", "upconv5x5_lines", "upconv5x5_ring_", "pack_conv3x3_f6_weight", "conv3x3_f6")
+       "pack_chain32_weight", "chain32_c2f", "chain32_enc", "upconv5x5", "upconv5x5_lines", "upconv5x5_ring_", "pack_conv3x3_f6_weight", "conv3x3_f6", "conv3x3_ln_gate_f6")
 _loaded = False
 
 

@@ -68,6 +68,18 @@ def test_round5_entry_points_reject_bad_arguments_without_gpu():
     assert lib.prv2_upconv5x5_supported(ctypes.byref(us), 1, 24, 32, 32, L.PREC_F32) == 0
     assert lib.prv2_upconv5x5(ctypes.byref(us), None, None, 1, 24, 32, 32, 0, L.PREC_BF16X3, None, 32, 0, None) != 0
     assert lib.prv2_upconv5x5_ring(None, 32, 0, 1, 24, 32, 32, None, 896, 12, 16, 0, None) != 0
+    # prv2_conv3x3_f6* (the fp16 + fp6 conv): shape contract, weight image size, scale / format validation
+    mk = lambda **k: L.ConvDesc(**{**dict(n=1, h=24, w=32, cin=256, cout=256, kh=3, kw=3, stride=1, pad=1, ldx=256, ldy=256, x_bstride=0, y_bstride=0, relu_in=1,  # noqa: E731
+                                        act=0, convt_k=0, ld_mul=0, ld_res=256, ld_res2=0, prec=L.PREC_F16F6, force_generic=0, ln_eps=1e-6, part=0, same_pad=0, fmt=0), **k})
+    assert lib.prv2_conv3x3_f6_supported(ctypes.byref(mk())) == 1
+    assert lib.prv2_conv3x3_f6_supported(ctypes.byref(mk(cin=96, ldx=96))) == 0 and lib.prv2_conv3x3_f6_supported(ctypes.byref(mk(cout=128))) == 0
+    assert lib.prv2_conv3x3_f6_supported(ctypes.byref(mk(w=12))) == 0 and lib.prv2_conv3x3_f6_supported(ctypes.byref(mk(stride=2))) == 0
+    assert lib.prv2_conv3x3_f6_weight_bytes(256, 256) == 4 * 9 * 65536 and lib.prv2_conv3x3_f6_weight_bytes(256, 96) == 0
+    assert lib.prv2_pack_conv3x3_f6_weight(16, 3.0, 16, 256, 256, None) != 0 and b"power of two" in lib.prv2_last_error()
+    assert lib.prv2_conv3x3_f6(ctypes.byref(mk()), 16, 16, None, None, 0.75, 1.0, None, 16, None) != 0 and b"power of two" in lib.prv2_last_error()
+    assert lib.prv2_conv3x3_f6(ctypes.byref(mk(act=1)), 16, 16, None, None, 1.0, 1.0, None, 16, None) != 0 and b"no activation" in lib.prv2_last_error()
+    assert lib.prv2_conv3x3_f6(ctypes.byref(mk(fmt=1)), 16, 16, None, None, 1.0, 1.0, None, 16, None) != 0   # only PRV2_FMT_Y_X2
+    assert lib.prv2_conv3x3_f6(ctypes.byref(mk()), 16, 16, None, 8, 1.0, 1.0, None, 16, None) != 0 and b"res layout" in lib.prv2_last_error()
 
 
 def test_rejects_bad_arguments_without_gpu():

@@ -142,3 +142,46 @@ def test_fusion_network_f16f6_range_guard(mag):
     print(f"\n|fine features| x {mag:g}: {len(redo)} layer(s) recomputed, max |f16f6 - bf16x3| / scale = {err:.2e}")
     assert (len(redo) > 0) == (mag != 1.0), [(m_, s_) for _, m_, s_ in redo]
     assert torch.isfinite(got).all() and err <= 3e-5, err
+
+
+@pytest.mark.parametrize("case", [(2, 24, 32), (1, 19, 37), (3, 8, 16)])
+@pytest.mark.parametrize("with_pre,with_res", [(True, True), (False, False)])
+def test_gate_unit_tail_f6_vs_fp64_and_bf16x3(case, with_pre, with_res):
+    """prv2_conv3x3_ln_gate_f6 (conv3x3_c256_gate_f6_kernel): the GatedConvUnit tail -- conv3x3 over the unit's pre-split ``out`` (+ pre), LayerNorm, ReLU,
+    256 x 256 gate, sigmoid, x out (+ res) -- with the 3x3 conv in fp16 + fp6, against float64 and against the bf16x3 kernel on the same X2 buffer"""
+    P = _ops()
+    n, h, w = case
+    F_ = 256
+    g = torch.Generator(device=DEV).manual_seed(31 + h)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    o32 = rnd(n, h, w, F_)
+    # the unit's ``out`` as its producer writes it: pre-split, i.e. exactly hi + lo of the bf16 split
+    out = P.Feat(torch.empty(n, h, w, F_, device=DEV), x2=True)
+    ident = torch.zeros(F_, F_, 3, 3, device=DEV)
+    ident[torch.arange(F_), torch.arange(F_), 1, 1] = 1.0
+    P.conv2d(P.Feat(o32), P.pack_conv(ident, None, pad=1, prec=P.L.PREC_NAMES["bf16x3"]), out)           # (identity conv: the X2 writer of the 256-column kernel)
+    ov = _x2_decode(out.buf)                                                                              # float64 view of what the kernels read
+    wt = rnd(F_, F_, 3, 3) / 48
+    b = rnd(F_) * 0.1
+    w3 = rnd(F_, F_, 1, 1) / 16
+    gw, gb = P.pack_gate(w3), rnd(F_) * 0.1
+    ln = (torch.rand(F_, device=DEV, generator=g) + 0.5, rnd(F_) * 0.1)
+    pre = P.Feat(rnd(n, h, w, F_) * 0.5) if with_pre else None
+    res = P.Feat(rnd(n, h, w, F_)) if with_res else None
+    cw6 = P.pack_conv3x3_f6(wt, b)
+    y6 = P.conv3x3_ln_gate_f6(out, cw6, ln, gw, gb, mul=out, res=res, pre=pre, pre_cin=F_)
+    assert P.L.load().prv2_last_kernel().decode() == "conv3x3_c256_gate_f6_kernel<256,f16f6>"
+    cwb = P.pack_conv(wt, b, pad=1, prec=P.L.PREC_NAMES["bf16x3"])
+    yb = P.conv3x3_ln_gate(out, cwb, ln, gw, gb, mul=out, res=res, pre=pre, pre_cin=F_)
+    t = torch.nn.functional.conv2d(ov.permute(0, 3, 1, 2), wt.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    if pre is not None:
+        t = t + pre.buf.double()
+    mu = t.mean(-1, keepdim=True)
+    t = (t - mu) / torch.sqrt(((t - mu) ** 2).mean(-1, keepdim=True) + 1e-6) * ln[0].double() + ln[1].double()
+    t = torch.relu(t)
+    gt = torch.einsum("nhwc,oc->nhwo", t, w3[:, :, 0, 0].double()) + gb.double()
+    ref = ov * torch.sigmoid(gt) + (res.buf.double() if res is not None else 0)
+    e6 = float((y6.buf.double() - ref).norm() / ref.norm())
+    eb = float((yb.buf.double() - ref).norm() / ref.norm())
+    print(f"\ngate unit tail {n}x{h}x{w} pre={with_pre} res={with_res}: f16f6 rel-L2 {e6:.2e} (bf16x3 {eb:.2e})")
+    assert torch.isfinite(y6.buf).all() and e6 < 2e-5, (e6, eb)

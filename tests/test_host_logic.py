@@ -395,3 +395,35 @@ def test_lds_layouts_by_the_bank_model():
     # the constants of the kernels are the ones the model was run with
     src = open(os.path.join(os.path.dirname(__file__), "..", "patchrefinerv2_amd", "csrc", "upconv.hip")).read()
     assert "constexpr int AROW = 160;" in src and "0xD728" in src and "constexpr int GRP = LC * CLD - 4;" in src
+
+
+def test_f6_range_guard_logic_on_cpu():
+    """ops.F6Range (the fp16 range guard of the f16f6 mode) without a GPU: the table on the CPU device, the words written by hand -- which
+    maxima trigger a recomputation, where the power-of-two scale goes, slots of dead layers are reused"""
+    import struct
+    import torch
+    from patchrefinerv2_amd import ops
+
+    class Layer:  # (stands for ops.ConvWF6: the guard only touches x_scale / range)
+        x_scale = 1.0
+        range = None
+
+    bits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]  # noqa: E731
+    a, b, c = Layer(), Layer(), Layer()
+    for l in (a, b, c):
+        l.range = ops.F6Range.slot("cpu", l)
+    assert ops.F6Range.active("cpu")
+    a.range[0], b.range[0], c.range[0] = bits(3.5), bits(4.0e5), bits(3.0e-8)
+    redo = ops.F6Range.check("cpu")
+    assert [r[0] for r in redo] == [b, c] and a.x_scale == 1.0                   # 3.5: fine; 4e5 > 65504 and 3e-8 < 2^-10: recompute
+    assert b.x_scale == 2.0 ** (8 - 18) and c.x_scale == 2.0 ** (8 + 25)        # 2^18 <= 4e5 < 2^19 -> 2^8; 2^-25 <= 3e-8 < 2^-24 -> 2^8
+    assert int(a.range[0]) == 0 and not ops.F6Range.check("cpu")                 # cleared for the next frame
+    a.range[0] = bits(20000.0)                                                  # inside fp16, but within two binades of its end: moved, not recomputed
+    assert ops.F6Range.check("cpu") == [] and a.x_scale == 2.0 ** (8 - 14)
+    slot_b = b.range.data_ptr()
+    del b, redo
+    import gc
+    gc.collect()
+    d = Layer()
+    d.range = ops.F6Range.slot("cpu", d)
+    assert d.range.data_ptr() == slot_b                                          # a dead layer's slot is handed out again

@@ -280,7 +280,7 @@ def test_every_op_test_passes_on_the_other_route():
     here = os.path.dirname(os.path.abspath(__file__))
     from patchrefinerv2_amd import ops
     env = dict(os.environ, PRV2_DISPATCH="ctypes" if ops.DISPATCH == "torch" else "torch")
-    files = [os.path.join(here, f) for f in ("test_hip_ops.py", "test_chain32.py", "test_upconv5.py")]   # (round 5: the fused chains and the 5x5 composite too)
+    files = [os.path.join(here, f) for f in ("test_hip_ops.py", "test_chain32.py", "test_upconv5.py", "test_conv3x3_f6.py")]   # (round 5: the fused chains, the 5x5 composite, the fp16 + fp6 conv)
     r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], env=env,
                        capture_output=True, text=True, timeout=1800, cwd=os.path.dirname(here))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
