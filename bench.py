@@ -365,8 +365,10 @@ def main():
                                  if w["kind"] == "PatchRefinerPlus" and not w.get("refiner_encoder") else None)))
     result["operating_point"] = operating_point
     if f6_on:
-        result["dtype_note"] = ("bf16x3 (fp32 operands split hi + lo bf16, 3 MFMAs) everywhere except GatedConvUnit.conv (256 -> 256, 3x3), which runs "
-                                "fp16 + two block-scaled fp6 (e2m3) corrections per product (csrc/conv3x3_f6.hip): fp32-grade, rms 1.2e-5 per dot product")
+        result["dtype_note"] = ("bf16x3 (fp32 operands split hi + lo bf16, 3 MFMAs) everywhere except the 3x3 convs of the 256-channel GatedConvUnits -- "
+                                "GatedConvUnit.conv and the unit's fusion_conv.0 inside the fused tail kernel (its LayerNorm, gate GEMM and final stage stay "
+                                "bf16x3 / fp32) -- which run fp16 + two block-scaled fp6 (e2m3) corrections per product (csrc/conv3x3_f6.hip): fp32-grade, rms "
+                                "1.2e-5 per dot product; kernels tagged <..,f16f6> are priced against 2.5 PF x 2/3")
         if world == 1 and not args.no_alt:
             # the same timed loop in the default arithmetic, beside it
             f6_model = model

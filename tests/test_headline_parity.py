@@ -125,7 +125,7 @@ def test_headline_v2_zoe_tile_vs_fp32_oracle(arith):
     model, ora, w = _pair(name, prec=arith)
     if arith == "f16f6":  # the mode is really on: every 256-channel unit of the c2f module carries the fp16 + fp6 image
         R = model.refiner_fusion_model._packed["refine"]
-        assert all("conv_f6" in R[r][u] for r in range(1, 6) for u in ("u1", "u2"))
+        assert all("conv_f6" in R[r][u] for r in range(1, 6) for u in ("u1", "u2")) and all("f0a_f6" in R[r]["u2"] for r in range(1, 6))
     assert model.resizer.kind == "zoe" and tuple(w["pps"]) == (384, 512)
     hr = rand_image(3, 1, *w["raw"])
     got, want = _one_tile(model, ora, hr, (270, 1440), dict(image_raw_shape=w["raw"], patch_split_num=w["split"]))

@@ -45,8 +45,15 @@ t_conv = timeit(lambda: P.conv2d(x, cw_c, out, relu_in=True, res=x))
 t_gather = timeit(lambda: taps.gather(boxes, 0.25, h, w, out=pre))
 t_gate = timeit(lambda: P.conv3x3_ln_gate(out, cw_a, ln, gw, gb, y, act=P.ACT_RELU, mul=out, res=res, pre=pre, pre_cin=F_))
 kern = P.L.load().prv2_last_kernel().decode()
+yb = y.buf.clone()
+# the same unit tail with its 3x3 conv in fp16 + fp6 (round 5, stage 2: conv3x3_c256_gate_f6_kernel)
+cw_a6 = P.pack_conv3x3_f6(wf[:, :F_].contiguous(), cw_a.bias)
+t_gate6 = timeit(lambda: P.conv3x3_ln_gate_f6(out, cw_a6, ln, gw, gb, y, act=P.ACT_RELU, mul=out, res=res, pre=pre, pre_cin=F_))
+kern6 = P.L.load().prv2_last_kernel().decode()
+d6 = float((y.buf - yb).norm() / yb.norm())
 t_prep = timeit(lambda: P.CoarseTaps(P.conv2d(coarse, cw_t), F_, (0.25, 0.25)), it=5)
 px = n * h * w
 print(f"{n}x{h}x{w}: c256 conv -> X2 {t_conv:.3f} ms ({2.0 * px * 9 * F_ * F_ / t_conv / 1e9:.0f} TF) | tap gather {t_gather:.3f} ms ({px * F_ * 4 / t_gather / 1e6:.0f} GB/s written) | "
       f"{kern} K={F_} + pre {t_gate:.3f} ms ({2.0 * px * F_ * (9 * F_ + F_) / t_gate / 1e9:.0f} TF executed; the reference's 2F -> F unit: "
-      f"{2.0 * px * F_ * (18 * F_ + F_) / t_gate / 1e9:.0f} TF algorithmic) | per-frame table (GEMM + knots, one unit) {t_prep:.3f} ms", flush=True)
+      f"{2.0 * px * F_ * (18 * F_ + F_) / t_gate / 1e9:.0f} TF algorithmic) | {kern6} {t_gate6:.3f} ms ({2.0 * px * F_ * (9 * F_ + F_) / t_gate6 / 1e9:.0f} TF executed, "
+      f"{t_gate / t_gate6:.2f}x; rel-L2 against the bf16x3 kernel {d6:.1e}) | per-frame table (GEMM + knots, one unit) {t_prep:.3f} ms", flush=True)
