@@ -34,7 +34,10 @@ python3 tools/bench_upconv5.py 2>/dev/null | grep upconv5x5 >> $O/${TAG}_upconv5
 for D in torch ctypes torch ctypes; do PRV2_DISPATCH=$D python3 bench.py --prec $PREC --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_DISPATCH=$D', round(d['ms_per_step'],2), 'ms')"; done > $O/${TAG}_dispatch_ab.txt
 # round 5, stage 1 of the fp16 + fp6 arithmetic (csrc/conv3x3_f6.hip): the kernel against conv3x3_c256_kernel<bf16x3> on the frame's shapes, the frame in
 # both arithmetics on this box (alternating), phase stamps / in-kernel clock, and the bf16x3 mode's own headline line + layer table
-python3 tools/probes/c256_bench.py --prec $PREC both 2>/dev/null | grep "256->256" > $O/${TAG}_f16f6_ab.txt
+python3 tools/probes/c256_bench.py both 2>&1 | grep "256->256" > $O/${TAG}_f16f6_ab.txt
+python3 tools/probes/gate_taps_bench.py 14 192 256 2>&1 | grep "gate" >> $O/${TAG}_f16f6_ab.txt
+python3 tools/probes/gate_taps_bench.py 14 96 128 2>&1 | grep "gate" >> $O/${TAG}_f16f6_ab.txt
+for G in 1 0 1 0; do PRV2_F6_GATE=$G python3 bench.py --prec f16f6 --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('--prec f16f6 PRV2_F6_GATE=$G (stage 2: the GatedConvUnit tail kernel)', round(d['ms_per_step'],2), 'ms')"; done >> $O/${TAG}_f16f6_ab.txt
 for T in f16f6 bf16x3 f16f6 bf16x3; do python3 bench.py --prec $T --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('--prec $T', d['dtype'], round(d['ms_per_step'],2), 'ms', round(d['value'],3), 'maps/s', d['operating_point'])"; done >> $O/${TAG}_f16f6_ab.txt
 bash tools/probes/f6_stamps.sh "" 2>/dev/null | grep -v "^$" >> $O/${TAG}_f16f6_ab.txt
 python3 bench.py --prec bf16x3 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bf16x3_bench_${WL}.json 2>> $O/bench.err
