@@ -1,5 +1,7 @@
-// GatedConvUnit.conv / ResidualConvUnit conv -- y = conv3x3(relu(x)) + bias + res, C -> 256 channels -- in the fp16 + block-scaled-fp6
-// arithmetic ("f16f6"; estimator/models/blocks/bi_directional_fusion_model.py:40-43, 58-64):
+// The 3x3 convs of the 256-channel GatedConvUnits in the fp16 + block-scaled-fp6 arithmetic ("f16f6", DESIGN.md section 9 item 0;
+// estimator/models/blocks/bi_directional_fusion_model.py:40-51, 56-82):
+//   conv3x3_c256_f6_kernel       GatedConvUnit.conv + the skip:  y = conv3x3(relu(x)) + bias + res, C -> 256              (stage 1)
+//   conv3x3_c256_gate_f6_kernel  the unit's tail: conv3x3 over its pre-split ``out`` (+ pre), LayerNorm, ReLU, gate, sigmoid x mul (+ res)  (stage 2)
 //
 //   x w  ~=  f16(x) f16(w)  +  q6(x) q6(w - f16 w)  +  q6(x - f16 x) q6(w)
 //
@@ -9,20 +11,25 @@
 // (bf16x3: 4.4e-6, one fp16 product: 2.9e-4; profiles/r03_f16f6_study.txt).  Instruction semantics: tools/probes/f16f6_probe.hip.
 //
 // Not conv3x3_gate.hip's pipeline with other MFMAs (that mock ran 1.30x: its LDS traffic -- weights by LDS-DMA, every wave re-reading
-// them -- becomes the bound once the MFMA time halves; profiles/r05_experiments.txt #12).  Here:
+// them -- becomes the bound once the MFMA time halves; profiles/r05_experiments.txt #12).  The main loop (f6_body) instead:
 //   * wave w of 8 owns output channels 32 w .. 32 w + 31 for ALL 128 pixels of the 8 x 16 tile (8 pixel runs x 2 row blocks of 16 weights:
 //     16 accumulators).  Weights are the MFMA's A operand and come STRAIGHT from L2 into registers, fragment-major (one coalesced KB per
 //     load, every byte fetched once per workgroup), refilled part by part as the three passes of a step (f16 slab 0, f16 slab 1, fp6)
-//     finish with them -- no LDS for weights, no per-tap barrier.  An accumulator lane then holds 8 consecutive channels of one pixel:
-//     the epilogue (x out_scale, + bias, + res, fp32 or pre-split "X2" output) runs from registers with 16-byte loads / stores.
+//     finish with them -- no LDS for weights, no per-tap barrier.  An accumulator lane then holds 8 consecutive channels of one pixel.
 //   * LDS holds only the activation halo: 10 x 18 pixels x one 64-channel superslab, already in operand format
 //     [32 f16 | 32 f16 | 4 x 16 B fp6 (first halves) | 4 x (8 B fp6, scale, pad)], pitch 288 B (conflict-free ds_read_b128), two buffers,
-//     ONE barrier per superslab (9 taps).  The raw fp32 halo arrives by LDS-DMA (buffer_load ... lds: zero fill outside the image) into a
-//     per-wave staging area; the wave that moved a pixel converts it (ReLU, x x_scale, fp16 + residual, block maxima, two
-//     v_cvt_scalef32_2xpk16_fp6_f32), so no cross-wave hand-off is needed for the staging.
+//     ONE barrier per superslab (9 taps).  The raw input halo (fp32, or the pre-split X2 bytes) arrives by LDS-DMA (buffer_load ... lds: zero
+//     fill outside the image) into a per-wave staging area; the wave that moved a pixel converts it (ReLU, x x_scale, fp16 + residual, block
+//     maxima, two v_cvt_scalef32_2xpk16_fp6_f32), so no cross-wave hand-off is needed for the staging.
+//   * a workgroup walks a SEQUENCE of tiles: the next tile's first superslab is staged under the current tile's last, the weight stream wraps.
+// Stage 1 is persistent (one workgroup per CU) with an epilogue from registers (x out_scale, + bias, + res, fp32 or X2 output, 16-byte loads /
+// stores); stage 2 runs one tile per workgroup and hands its accumulators to conv3x3_gate.hip's epilogue through the C tile in LDS
+// (conv3x3_gate_epi.h).
 // Range: fp16 holds |x x_scale| <= 65504; larger values are clamped in the fp16 part and fall to the fp6 residual (finite, imprecise) --
 // the caller keeps x_scale / the weights' scale (powers of two, undone by out_scale) such that this does not happen, and reads the
-// observed maximum back through ``range_word``.
+// observed maximum back through ``range_word`` (ops.F6Range).
+// Timing switches for tools/probes/f6_ablate.sh / f6_bisect.sh / f6_stamps.sh (wrong results by design): F6_ABL_*, F6_DBG_*, F6_STAMPS; F6_D,
+// F6_CV0 / F6_CV1: ring depth and conversion taps.
 #include <cstdlib>
 #include <type_traits>
 

@@ -73,7 +73,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const 
   const long long rows_here = p.M - row0 < TM ? p.M - row0 : TM;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.x + row0 * p.ldx), 0, (int)(((rows_here - 1) * p.ldx + ((p.Cin + 3) & ~3)) * 4), 0x00020000);
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr unsigned OOB = 0x80000000u;
   const int cin4 = (p.Cin + 3) & ~3;
   unsigned a_off[NA];

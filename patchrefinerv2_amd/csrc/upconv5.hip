@@ -42,7 +42,6 @@ constexpr int LR = 11, LC = 17;               // source footprint of a tile (row
 constexpr int RUNS = 12, MPX = RUNS * 16;     // 192 >= LR * LC = 187
 constexpr int CP = 32;                        // output channels (all of them: one channel group)
 constexpr int NKY = 5, NKX = 5;
-constexpr int NBLK = NKX * CP / 16;           // 10 column blocks of 16 per kernel row
 constexpr int AROW = 160;                     // bytes per footprint pixel in LDS: [32 bf16 hi | 32 bf16 lo | 32 B pad]
 constexpr int A_BYTES = MPX * AROW;           // 30 720
 constexpr int W_BYTES = NKX * CP * 128;       // 20 480
