@@ -286,9 +286,10 @@ int prv2_conv3x3_f6(const prv2_conv_desc* d, const float* x, const void* w_packe
  * prv2_conv3x3_ln_gate_pre computes on conv3x3_c256_gate_x2_kernel (bi_directional_fusion_model.py:44-51, 70-80):
  *     y = mul * sigmoid(conv1x1(act(LN(out_scale * conv3x3(q(x * x_scale); q(W * w_scale)) + bias + pre))) + gate_bias) (+ res)
  * The LayerNorm, the 256 x 256 gate GEMM (bf16x3) and the final stage are conv3x3_gate.hip's epilogue, unchanged (csrc/conv3x3_gate_epi.h).
- * Contract: prv2_conv3x3_f6_supported(d); x and mul pre-split (d->fmt = PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2: the unit's ``out``), no input ReLU, fp32 y;
+ * Contract: prv2_conv3x3_f6_supported(d); x and mul in ONE format -- pre-split (d->fmt = PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2: the unit's ``out`` / its X2 concat) or
+ * fp32 (d->fmt = 0: the [out | coarse ROI] concat of the configs whose ROI gather resizes, mul = its first half) --, no input ReLU, fp32 y;
  * ln_weight / ln_bias / gate_w_packed (prv2_pack_gate_weight) required; pre (or NULL) as for prv2_conv3x3_ln_gate_pre; w_packed:
- * prv2_pack_conv3x3_f6_weight of the conv's FINE half W[:, :256]. */
+ * prv2_pack_conv3x3_f6_weight of the conv's weights over what x holds (the fine half W[:, :256] with ``pre``, all 512 input channels of the concat form). */
 int prv2_conv3x3_ln_gate_f6(const prv2_conv_desc* d, const float* x, const void* w_packed, const float* bias, const float* pre, int32_t ld_pre,
                             const float* ln_weight, const float* ln_bias, const void* gate_w_packed, const float* gate_bias, const float* mul,
                             const float* res, float x_scale, float out_scale, uint32_t* range_word, float* y, void* stream);

@@ -457,6 +457,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
 // -> LDS, + pre (the conv's coarse half), LayerNorm, ReLU, the 256 x 256 gate GEMM (bf16x3: its A operand is formed in LDS, its weights are
 // fragment-major in L2), sigmoid, x mul, + res.  One tile per workgroup like conv3x3_c256_gate_x2_kernel: the C tile (133 KB) takes the place of the
 // halo buffers and the staging area, so nothing of a next tile can be staged under it.
+template <bool X2IN>  // x / mul pre-split (the unit's X2 ``out`` or [out | coarse ROI] concat), or fp32 (the concat as the resizing ROI gather writes it)
 __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_f6_kernel(const GateConvParams gp) {
   using namespace f6;
   static_assert(LDS_BYTES >= g256::EPI_FLOATS * 4, "the C tile fits the main loop's LDS");
@@ -475,10 +476,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_f6_kernel(const Gate
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), m16 = lane & 15, g = lane >> 4;
   const int c0 = wave * 32 + g * 8;
   const float os = p.out_scale;
-  f6_body<true>(p, smem, t, 1, 1, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
+  f6_body<X2IN>(p, smem, t, 1, 1, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
     // the wrapped-around weight loads and the repeated halo DMA (nobody uses either) must have landed before the C tile takes the staging area
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    c256_epilogue<PRV2_PREC_BF16X3, true, true>(gp, reinterpret_cast<float*>(smem), n_img, y0, x0, [&](float* ct) {
+    c256_epilogue<PRV2_PREC_BF16X3, true, X2IN>(gp, reinterpret_cast<float*>(smem), n_img, y0, x0, [&](float* ct) {
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
       if (c.bias) {
         b0 = *reinterpret_cast<const f32x4*>(c.bias + c0);
@@ -600,8 +601,9 @@ extern "C" int prv2_conv3x3_ln_gate_f6(const prv2_conv_desc* d, const float* x, 
   PRV2_REQUIRE(d && x && w_packed && y && ln_weight && ln_bias && gate_w_packed, "conv3x3_ln_gate_f6: null pointer (the LayerNorm and the gate stage are part of the kernel)");
   PRV2_REQUIRE(f6_shape_ok(d), "conv3x3_ln_gate_f6: 3x3 s1 p1, cout 256, cin %% 64 == 0, width >= 16 (got %dx%d %d->%d k%d s%d)", d->h, d->w, d->cin, d->cout, d->kh,
                d->stride);
-  PRV2_REQUIRE((d->fmt & PRV2_FMT_X_X2) && !(d->fmt & PRV2_FMT_Y_X2) && (!mul || (d->fmt & PRV2_FMT_MUL_X2)) && !d->relu_in,
-               "conv3x3_ln_gate_f6: x (and mul) arrive pre-split (PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2), no input ReLU, fp32 output");
+  const bool x2 = (d->fmt & PRV2_FMT_X_X2) != 0;
+  PRV2_REQUIRE(!(d->fmt & ~(PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2)) && (!mul || x2 == ((d->fmt & PRV2_FMT_MUL_X2) != 0)) && (mul || !(d->fmt & PRV2_FMT_MUL_X2)) && !d->relu_in,
+               "conv3x3_ln_gate_f6: x and mul in the same format (fp32, or PRV2_FMT_X_X2 | PRV2_FMT_MUL_X2), no input ReLU, fp32 output");
   PRV2_REQUIRE(d->act == PRV2_ACT_RELU || d->act == PRV2_ACT_NONE, "conv3x3_ln_gate_f6: ReLU or no activation in front of the gate (act %d)", d->act);
   PRV2_REQUIRE(x_scale > 0.f && (__builtin_bit_cast(unsigned, x_scale) & 0x7fffffu) == 0 && out_scale > 0.f, "conv3x3_ln_gate_f6: x_scale is a power of two");
   const long long px = (long long)d->h * d->w;
@@ -624,11 +626,12 @@ extern "C" int prv2_conv3x3_ln_gate_f6(const prv2_conv_desc* d, const float* x, 
   PRV2_REQUIRE(!res || (d->ld_res >= d->cout && d->ld_res % 4 == 0 && aligned16(res) && px * d->ld_res < (1LL << 29)), "conv3x3_ln_gate_f6: res layout");
   PRV2_REQUIRE(!bias || aligned16(bias), "conv3x3_ln_gate_f6: bias alignment");
   gp.gate_w = gate_w_packed; gp.gate_bias = gate_bias; gp.pre = pre; gp.ld_pre = ld_pre;
-  gp.x_x2 = 1; gp.mul_x2 = mul ? 1 : 0; gp.y_x2 = 0;
+  gp.x_x2 = x2; gp.mul_x2 = mul && x2 ? 1 : 0; gp.y_x2 = 0;
   gp.f6_x_scale = x_scale; gp.f6_out_scale = out_scale; gp.f6_range = range_word;
   const int64_t blocks = (int64_t)d->n * cdiv(d->h, f6::TH) * cdiv(d->w, f6::TW);
   PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate_f6: grid too large");
-  hipLaunchKernelGGL(conv3x3_c256_gate_f6_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, gp);
+  if (x2) hipLaunchKernelGGL(conv3x3_c256_gate_f6_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, gp);
+  else hipLaunchKernelGGL(conv3x3_c256_gate_f6_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, gp);
   set_kernel("conv3x3_c256_gate_f6_kernel", 256, PRV2_PREC_F16F6);
   PRV2_LAUNCH_CHECK("conv3x3_ln_gate_f6");
   return 0;

@@ -325,13 +325,14 @@ void conv3x3_f6(const Tensor& x, const Tensor& w_packed, const optional<Tensor>&
 // include/prv2.h::prv2_conv3x3_ln_gate_f6: the GatedConvUnit tail with its 3x3 conv in the fp16 + fp6 arithmetic; x / mul: the unit's pre-split ``out`` (raw buffers)
 void conv3x3_ln_gate_f6(const Tensor& x, const Tensor& w_packed, const optional<Tensor>& bias, const optional<Tensor>& pre, const Tensor& ln_weight,
                         const Tensor& ln_bias, const Tensor& gate_w_packed, const optional<Tensor>& gate_bias, const optional<Tensor>& mul,
-                        const optional<Tensor>& res, int64_t act, double ln_eps, double x_scale, double out_scale, const optional<Tensor>& range, Tensor out) {
+                        const optional<Tensor>& res, int64_t act, double ln_eps, double x_scale, double out_scale, const optional<Tensor>& range, Tensor out,
+                        int64_t fmt) {
   dev_f32(w_packed, "w_packed");
   const int64_t cout = ln_weight.numel();
   TORCH_CHECK(w_packed.numel() * 4 == prv2_conv3x3_f6_weight_bytes((int)cout, (int)x.size(3)), "prv2::conv3x3_ln_gate_f6: w_packed does not match a 3x3 ", x.size(3), " -> ", cout, " conv");
   TORCH_CHECK(gate_w_packed.numel() * 4 == prv2_gate_weight_bytes((int)cout), "prv2::conv3x3_ln_gate_f6: gate_w_packed is not a pack_gate_weight image");
   prv2_conv_desc d = desc3x3(x, out, cout, act, PRV2_PREC_F16F6, ln_eps);
-  d.fmt = PRV2_FMT_X_X2 | (mul.has_value() ? PRV2_FMT_MUL_X2 : 0);
+  d.fmt = (int32_t)fmt;
   const float *pm = nullptr, *pr = nullptr, *pp = nullptr;
   int32_t ld_pre = 0;
   if (mul.has_value()) { TORCH_CHECK(mul->sizes() == out.sizes(), "prv2::conv3x3_ln_gate_f6: mul must have the output's shape"); d.ld_mul = (int32_t)nhwc_ld(*mul, "mul"); pm = mul->data_ptr<float>(); }
@@ -833,7 +834,7 @@ TORCH_LIBRARY(prv2, m) {
   m.def("conv3x3_f6(Tensor x, Tensor w_packed, Tensor? bias, Tensor? res, bool relu_in, float x_scale, float out_scale, Tensor(a!)? range, Tensor(b!) out, "
         "int fmt=0) -> ()");
   m.def("conv3x3_ln_gate_f6(Tensor x, Tensor w_packed, Tensor? bias, Tensor? pre, Tensor ln_weight, Tensor ln_bias, Tensor gate_w_packed, Tensor? gate_bias, "
-        "Tensor? mul, Tensor? res, int act, float ln_eps, float x_scale, float out_scale, Tensor(a!)? range, Tensor(b!) out) -> ()");
+        "Tensor? mul, Tensor? res, int act, float ln_eps, float x_scale, float out_scale, Tensor(a!)? range, Tensor(b!) out, int fmt=3) -> ()");
   m.def("upconv5x5(Tensor u, Tensor w_packed, Tensor bias_map, int cout, int oh, int ow, int act=0, int prec=1, Tensor(a!)? out=None) -> Tensor");
   m.def("upconv5x5_lines(Tensor u, int oh, int ow) -> Tensor");
   m.def("upconv5x5_ring_(Tensor(a!) y, Tensor g_edges, int uh, int uw, int act=0) -> ()");

@@ -396,6 +396,10 @@ class BiDirectionalFusion(_EncDec):
                      lnw=self._dev(b + "fusion_conv.1.weight"), lnb=self._dev(b + "fusion_conv.1.bias"),
                      f3=self._conv(b + "fusion_conv.3"))
             f6(u, b)
+            w0f = self._sd[b + "fusion_conv.0.weight"]
+            if self.f16f6 and ops.F6_GATE and self.c2f_gate and ops.L.load().prv2_conv3x3_f6_weight_bytes(w0f.shape[0], w0f.shape[1]) > 0:
+                # the unit's tail over the whole [out | coarse ROI] concat (the configs whose ROI gather resizes: no tap tables)
+                u["f0_f6"] = ops.pack_conv3x3_f6(w0f, self._sd.get(b + "fusion_conv.0.bias"), device=self.device)
             w3 = self._sd[b + "fusion_conv.3.weight"]
             if self.c2f_gate and self.prec != ops.PREC_F32 and w3.shape[0] == w3.shape[1] and w3.shape[0] in ops.GATE_CHANNELS:  # fused tail kernel (ops.conv3x3_ln_gate)
                 u["f3g"] = ops.pack_gate(w3.to(self.device))
@@ -504,6 +508,9 @@ class BiDirectionalFusion(_EncDec):
             fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))   # conv -> LN -> ReLU (:47-50)
             return ops.conv2d(fused, u["f3"], dst, res=res)                              # the 1x1 (:51) (+ xs[0], :127)
         if "f3g" in u and ops.conv3x3_ln_gate_supported(cat, u["f0"]):                  # the whole fusion_conv + gate in one kernel
+            cw6 = u.get("f0_f6")
+            if cw6 is not None and ops.conv3x3_f6_supported(cat, cw6.cout, cw6.cin, allow_x2=True):
+                return ops.conv3x3_ln_gate_f6(cat, cw6, (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res)
             return ops.conv3x3_ln_gate(cat, u["f0"], (u["lnw"], u["lnb"]), u["f3g"], u["f3"].bias, act=ACT_RELU, mul=out, res=res)
         fused = ops.conv2d(cat, u["f0"], act=ACT_RELU, ln=(u["lnw"], u["lnb"]))       # conv -> LN -> ReLU (:47-50)
         return ops.conv2d(fused, u["f3"], act=ACT_SIGMOID, mul=out, res=res)             # out * sigmoid(.) (+ xs[0])

@@ -354,8 +354,9 @@ def pack_conv3x3_f6(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, d
     return cw
 
 
-def conv3x3_f6_supported(x: Feat, cout: int, cin: int) -> bool:
-    if getattr(x, "x2", False) or x.c != cin or x.ld % 4:
+def conv3x3_f6_supported(x: Feat, cout: int, cin: int, allow_x2: bool = False) -> bool:
+    """shape contract of the fp16 + fp6 kernels (a property of the layer, never of the batch); ``allow_x2``: the gate-tail kernel also takes pre-split input"""
+    if (getattr(x, "x2", False) and not allow_x2) or x.c != cin or x.ld % 4:
         return False
     d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cin, cout=cout, kh=3, kw=3, stride=1, pad=1, ldx=x.ld, ldy=roundup(cout, 4), x_bstride=0, y_bstride=0,
                    relu_in=0, act=ACT_NONE, convt_k=0, ld_mul=0, ld_res=0, ld_res2=0, prec=L.PREC_F16F6, force_generic=0, ln_eps=1e-6, part=0,
@@ -750,9 +751,10 @@ def conv3x3_ln_gate(x: Feat, cw: ConvW, ln, gate_w: Optional[torch.Tensor], gate
 def conv3x3_ln_gate_f6(x: Feat, cw: ConvWF6, ln, gate_w: torch.Tensor, gate_bias: Optional[torch.Tensor], out: Optional[Feat] = None, *,
                        act: int = ACT_RELU, mul: Optional[Feat] = None, res: Optional[Feat] = None, ln_eps: float = 1e-6,
                        pre: Optional[Feat] = None, pre_cin: int = 0) -> Feat:
-    """``conv3x3_ln_gate`` with the 3x3 conv in the fp16 + fp6 arithmetic (include/prv2.h::prv2_conv3x3_ln_gate_f6): x and mul are the unit's
-    pre-split (X2) ``out``; LayerNorm, gate GEMM (bf16x3) and final stage are the bf16x3 kernel's."""
-    assert getattr(x, "x2", False) and x.c == cw.cin and (mul is None or mul.x2)
+    """``conv3x3_ln_gate`` with the 3x3 conv in the fp16 + fp6 arithmetic (include/prv2.h::prv2_conv3x3_ln_gate_f6): x and mul in one format -- the unit's
+    pre-split (X2) ``out`` / concat, or the fp32 concat; LayerNorm, gate GEMM (bf16x3) and final stage are the bf16x3 kernel's."""
+    x2 = bool(getattr(x, "x2", False))
+    assert x.c == cw.cin and (mul is None or bool(mul.x2) == x2)
     if out is None:
         out = Feat.alloc(x.n, x.h, x.w, cw.cout, x.device)
     assert (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, cw.cout) and not out.x2 and (res is None or not res.x2)
@@ -761,7 +763,7 @@ def conv3x3_ln_gate_f6(x: Feat, cw: ConvWF6, ln, gate_w: torch.Tensor, gate_bias
     d = L.ConvDesc(n=x.n, h=x.h, w=x.w, cin=cw.cin, cout=cw.cout, kh=3, kw=3, stride=1, pad=1, ldx=x.ld, ldy=out.ld, x_bstride=0, y_bstride=0,
                    relu_in=0, act=act, convt_k=0, ld_mul=mul.ld if mul is not None else 0, ld_res=res.ld if res is not None else 0, ld_res2=0,
                    prec=L.PREC_F16F6, force_generic=0, ln_eps=ln_eps, part=0, same_pad=0,
-                   fmt=L.FMT_X_X2 | (L.FMT_MUL_X2 if mul is not None else 0))
+                   fmt=(L.FMT_X_X2 | (L.FMT_MUL_X2 if mul is not None else 0)) if x2 else 0)
     out_scale = 1.0 / (cw.x_scale * cw.w_scale)
     flops = 2.0 * x.n * x.h * x.w * cw.cout * (cw.cin * 9 + cw.cout)
 
@@ -769,7 +771,7 @@ def conv3x3_ln_gate_f6(x: Feat, cw: ConvWF6, ln, gate_w: torch.Tensor, gate_bias
         if DISPATCH == "torch":
             r = lambda f: None if f is None else f.raw()  # noqa: E731
             _tops().conv3x3_ln_gate_f6(x.raw(), cw.w, cw.bias, r(pre), ln[0], ln[1], gate_w, gate_bias, r(mul), r(res), act, ln_eps, cw.x_scale, out_scale,
-                                       cw.range, out.view())
+                                       cw.range, out.view(), d.fmt)
             return
         L.check(L.load().prv2_conv3x3_ln_gate_f6(C.byref(d), x.ptr, cw.w.data_ptr(), _ptr(cw.bias), _ptr(pre), pre.ld if pre is not None else 0, _ptr(ln[0]),
                                                  _ptr(ln[1]), _ptr(gate_w), _ptr(gate_bias), _ptr(mul), _ptr(res), cw.x_scale, out_scale, _ptr(cw.range),

@@ -185,3 +185,43 @@ def test_gate_unit_tail_f6_vs_fp64_and_bf16x3(case, with_pre, with_res):
     eb = float((yb.buf.double() - ref).norm() / ref.norm())
     print(f"\ngate unit tail {n}x{h}x{w} pre={with_pre} res={with_res}: f16f6 rel-L2 {e6:.2e} (bf16x3 {eb:.2e})")
     assert torch.isfinite(y6.buf).all() and e6 < 2e-5, (e6, eb)
+
+
+@pytest.mark.parametrize("x2", [False, True])
+def test_gate_unit_tail_f6_concat_form(x2):
+    """the same tail kernel over the unit's whole [out | coarse ROI] concat (K = 512: the configs whose ROI gather resizes and therefore take no tap
+    tables), fp32 or pre-split, mul = the concat's first half -- against float64 and the bf16x3 kernel"""
+    P = _ops()
+    n, h, w, F_ = 2, 24, 32, 256
+    g = torch.Generator(device=DEV).manual_seed(77)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    c32 = rnd(n, h, w, 2 * F_)
+    cat = P.Feat(c32.clone())
+    if x2:  # the concat as its producers write it in the X2 format: identity convs per half through the 256-column kernel's X2 writer
+        cat = P.Feat(torch.empty(n, h, w, 2 * F_, device=DEV), x2=True)
+        ident = torch.zeros(F_, F_, 3, 3, device=DEV)
+        ident[torch.arange(F_), torch.arange(F_), 1, 1] = 1.0
+        cwi = P.pack_conv(ident, None, pad=1, prec=P.L.PREC_NAMES["bf16x3"])
+        for half in (0, 1):
+            P.conv2d(P.Feat(c32[..., half * F_:(half + 1) * F_].contiguous()), cwi, cat.slice(half * F_, F_))
+    out = cat.slice(0, F_)
+    hi = c32.bfloat16().float()
+    cv = (hi + (c32 - hi).bfloat16().float()).double()            # what the kernels see of an X2 buffer / take of ``mul`` in either format
+    xin = cv if x2 else c32.double()
+    wt = rnd(F_, 2 * F_, 3, 3) / (3 * (2 * F_) ** 0.5)
+    b = rnd(F_) * 0.1
+    w3 = rnd(F_, F_, 1, 1) / 16
+    gw, gb = P.pack_gate(w3), rnd(F_) * 0.1
+    ln = (torch.rand(F_, device=DEV, generator=g) + 0.5, rnd(F_) * 0.1)
+    res = P.Feat(rnd(n, h, w, F_))
+    assert P.conv3x3_f6_supported(cat, F_, 2 * F_, allow_x2=True)
+    y6 = P.conv3x3_ln_gate_f6(cat, P.pack_conv3x3_f6(wt, b), ln, gw, gb, mul=out, res=res)
+    assert P.L.load().prv2_last_kernel().decode() == "conv3x3_c256_gate_f6_kernel<256,f16f6>"
+    yb = P.conv3x3_ln_gate(cat, P.pack_conv(wt, b, pad=1, prec=P.L.PREC_NAMES["bf16x3"]), ln, gw, gb, mul=out, res=res)
+    t = torch.nn.functional.conv2d(xin.permute(0, 3, 1, 2), wt.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    mu = t.mean(-1, keepdim=True)
+    t = torch.relu((t - mu) / torch.sqrt(((t - mu) ** 2).mean(-1, keepdim=True) + 1e-6) * ln[0].double() + ln[1].double())
+    ref = cv[..., :F_] * torch.sigmoid(torch.einsum("nhwc,oc->nhwo", t, w3[:, :, 0, 0].double()) + gb.double()) + res.buf.double()
+    e6, eb = float((y6.buf.double() - ref).norm() / ref.norm()), float((yb.buf.double() - ref).norm() / ref.norm())
+    print(f"\ngate unit tail, concat form K = 512, x2 = {x2}: f16f6 rel-L2 {e6:.2e} (bf16x3 {eb:.2e})")
+    assert torch.isfinite(y6.buf).all() and e6 < 2e-5, (e6, eb)
