@@ -65,6 +65,18 @@ coarse = P.Feat(torch.randn(1, 192, 256, F_, device=dev))
 cw_t = P.pack_conv(torch.randn(18 * F_, F_, device=dev) / 16, None, prec=PR)
 
 
+# round 5, second half: the fp16 + fp6 kernels (weights streamed L2 -> registers, LDS-DMA halo, counted waits)
+rd = lambda *s_: r(*s_).to(dev)  # noqa: E731
+x6 = P.Feat(rd(14, 96, 128, 256))
+cw6 = P.pack_conv3x3_f6(rd(256, 256, 3, 3) / 48, rd(256) * .1)
+victims.append((lambda: P.conv3x3_f6(x6, cw6, relu_in=True, res=x6).buf, "conv3x3_c256_f6 14x96x128"))
+o6 = P.Feat(torch.empty(14, 96, 128, 256, device=dev), x2=True)
+P.conv3x3_f6(x6, cw6, o6, relu_in=True, res=x6)
+g6w, ln6 = P.pack_gate(rd(256, 256, 1, 1) / 16), (1 + .2 * rd(256), .1 * rd(256))
+pre6 = P.Feat(rd(14, 96, 128, 256) * .5)
+gb6 = torch.full((256,), .1, device=dev)
+victims.append((lambda: P.conv3x3_ln_gate_f6(o6, cw6, ln6, g6w, gb6, mul=o6, res=x6, pre=pre6, pre_cin=256).buf, "conv3x3_c256_gate_f6 14x96x128"))
+
 def frame_prep():
     G = P.conv2d(coarse, cw_t)
     return G, [P.CoarseTaps(G.slice(i * 9 * F_, 9 * F_), F_, (0.25, 0.25)) for i in range(2)]
