@@ -298,7 +298,9 @@ class F6Range:
         ent = cls._tables.setdefault(str(device), dict(table=torch.zeros(cls.SLOTS, dtype=torch.int32, device=device), layers=[]))
         ent["layers"] = [(i, r) for i, r in ent["layers"] if r() is not None]
         used = {i for i, _ in ent["layers"]}
-        i = next(k for k in range(cls.SLOTS) if k not in used)
+        i = next((k for k in range(cls.SLOTS) if k not in used), None)
+        if i is None:
+            raise RuntimeError(f"F6Range: all {cls.SLOTS} range words of {device} are taken by live fp16 + fp6 layers")
         ent["layers"].append((i, weakref.ref(cw)))
         ent["table"][i] = 0
         return ent["table"][i:i + 1]

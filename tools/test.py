@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--image-raw-shape", nargs=2, type=int, default=[2160, 3840])
     ap.add_argument("--patch-split-num", nargs=2, type=int, default=[4, 4])
     ap.add_argument("--process-num", type=int, default=4)
-    ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--prec", default="bf16x3", choices=["f32", "bf16x3", "f16f6"], help="f16f6: bf16x3 with the 256-channel GatedConvUnit convs of the V2 fusion model in fp16 + block-scaled fp6 (what bench.py runs)")
     ap.add_argument("--max-batch", type=int, default=41, help="tiles per launch batch (the result does not depend on it; config key max_batch wins)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the tile batches are spread over (config key n_streams wins)")
     ap.add_argument("--synthetic-weights", action="store_true")
