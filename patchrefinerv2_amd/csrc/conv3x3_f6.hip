@@ -476,9 +476,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_f6_kernel(const Gate
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), m16 = lane & 15, g = lane >> 4;
   const int c0 = wave * 32 + g * 8;
   const float os = p.out_scale;
+  PRV2_STAMP(0);
+  PRV2_STAMP(1);
+  PRV2_CLK_STAMP(0);
   f6_body<X2IN>(p, smem, t, 1, 1, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
     // the wrapped-around weight loads and the repeated halo DMA (nobody uses either) must have landed before the C tile takes the staging area
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PRV2_STAMP(2);
     c256_epilogue<PRV2_PREC_BF16X3, true, X2IN>(gp, reinterpret_cast<float*>(smem), n_img, y0, x0, [&](float* ct) {
       f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
       if (c.bias) {
@@ -628,6 +632,9 @@ extern "C" int prv2_conv3x3_ln_gate_f6(const prv2_conv_desc* d, const float* x, 
   gp.gate_w = gate_w_packed; gp.gate_bias = gate_bias; gp.pre = pre; gp.ld_pre = ld_pre;
   gp.x_x2 = x2; gp.mul_x2 = mul && x2 ? 1 : 0; gp.y_x2 = 0;
   gp.f6_x_scale = x_scale; gp.f6_out_scale = out_scale; gp.f6_range = range_word;
+#ifdef PRV2_GATE_STAMPS
+  gp.stamps = getenv("PRV2_STAMP_PTR") ? (long long*)strtoull(getenv("PRV2_STAMP_PTR"), nullptr, 16) : nullptr;
+#endif
   const int64_t blocks = (int64_t)d->n * cdiv(d->h, f6::TH) * cdiv(d->w, f6::TW);
   PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate_f6: grid too large");
   if (x2) hipLaunchKernelGGL(conv3x3_c256_gate_f6_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, gp);
