@@ -427,3 +427,23 @@ def test_f6_range_guard_logic_on_cpu():
     d = Layer()
     d.range = ops.F6Range.slot("cpu", d)
     assert d.range.data_ptr() == slot_b                                          # a dead layer's slot is handed out again
+
+
+def test_winograd_f23_study_identity_and_error_growth():
+    """tools/studies/winograd_f23_study.py (the next algebraic lever): the F(2x2, 3x3) identity holds in float64 and the transforms cost the
+    split-operand arithmetics less than 2x in rms error -- bf16x3 Winograd stays below the fp16 + fp6 direct conv's error"""
+    import importlib.util
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("winograd_f23_study", os.path.join(root, "tools", "studies", "winograd_f23_study.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(1)
+    x = np.maximum(rng.standard_normal((10, 18, 64)), 0).astype(np.float32)
+    w = (rng.standard_normal((16, 64, 3, 3)) / 24).astype(np.float32)
+    ref = m.direct(x, w, "exact")
+    den = np.sqrt((ref ** 2).mean())
+    assert np.abs(m.winograd(x, w, "exact") - ref).max() < 1e-5 * den
+    err = {(k, mode): np.sqrt(((f(x, w, mode) - ref) ** 2).mean()) / den for k, f in (("direct", m.direct), ("winograd", m.winograd)) for mode in ("bf16x3", "f16f6")}
+    assert err[("winograd", "bf16x3")] < 2.0 * err[("direct", "bf16x3")] < 1.2e-5
+    assert err[("winograd", "f16f6")] < 2.0 * err[("direct", "f16f6")] and err[("winograd", "bf16x3")] < err[("direct", "f16f6")]
