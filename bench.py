@@ -226,7 +226,7 @@ def pmc_traffic(kernel_tag, workload, prec):
     bn, pr = targs.rstrip(">").split(",")
     # the tag covers every instantiation "prv2::<name><bn, prec[, ...]>" (e.g. the im2col-tail variant): launch-weighted mean
     if pr == "f16f6":  # (a non-template kernel: its symbol carries no arguments)
-        rows = [d for k, d in json.load(open(path)).items() if k == f"prv2::{name}" or k.startswith(f"prv2::{name}(")]
+        rows = [d for k, d in json.load(open(path)).items() if k == f"prv2::{name}" or k.startswith((f"prv2::{name}(", f"prv2::{name}<"))]
         n = sum(d["launches"] for d in rows)
         if not n:
             return None, None
