@@ -266,17 +266,18 @@ class _PatchModel(StateDictModule):
                 if guard:
                     # fp16 range guard of the fp16 + fp6 layers (ops.F6Range): a frame in which a layer's input left fp16's range is
                     # computed again with that layer's power-of-two input scale moved (the tile plan's random draws are replayed)
+                    reduce = None
+                    if shard is not None and shard[1] > 1:  # one decision for all ranks of a patch-sharded frame: the tables' maximum (1 KB all-reduce)
+                        import torch.distributed as dist
+                        reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)  # noqa: E731
                     for attempt in range(3):
-                        redo = ops.F6Range.check(image_hr.device)
+                        redo = ops.F6Range.check(image_hr.device, reduce)
                         if not redo:
                             break
                         if attempt == 2:
                             raise RuntimeError(f"f16f6: input range of {len(redo)} layer(s) not representable after two recalibrations "
                                                f"(largest |x x_scale| seen: {[m for _, m, _ in redo]}); use prec='bf16x3'")
                         self.f6_recalibrations = getattr(self, "f6_recalibrations", 0) + 1
-                        if shard is not None and shard[1] > 1:
-                            raise RuntimeError("f16f6: a layer's input left fp16's range inside a patch-sharded frame (a recomputation would have to be "
-                                               "agreed between the ranks): run one unsharded frame first, or use prec='bf16x3'")
                         self.__dict__.pop("_graphs", None)  # (a captured frame carries the old scales)
                         random.setstate(rnd)
                         out = self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device, gather_dst)

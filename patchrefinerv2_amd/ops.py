@@ -311,12 +311,15 @@ class F6Range:
         return bool(ent and any(r() is not None for _, r in ent["layers"]))
 
     @classmethod
-    def check(cls, device) -> list:
+    def check(cls, device, reduce=None) -> list:
         """-> [(layer, seen maximum, old x_scale)] of the layers whose frame must be recomputed (their x_scale is already moved); the
-        table is cleared for the next frame"""
+        table is cleared for the next frame.  ``reduce(table)``: an in-place MAX all-reduce over the ranks of a patch-sharded frame (the words are
+        float bits of non-negative values: integer order == float order), so that every rank takes the same decision"""
         ent = cls._tables.get(str(torch.device(device)))
         if not ent:
             return []
+        if reduce is not None:
+            reduce(ent["table"])
         seen = ent["table"].to("cpu", copy=True).view(torch.float32)  # (synchronises the current stream)
         ent["table"].zero_()
         redo = []

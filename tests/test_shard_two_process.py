@@ -27,8 +27,10 @@ def _worker(rank, world, port, q):
         from oracle.cases import E2E_V1, E2E_V2, e2e_v1_sd, e2e_v2_sd, rand_image
         from test_hip_models import _build
         ok, notes = True, []
-        for kind, c, sd, mode in (("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4"), ("PatchRefiner", E2E_V1, e2e_v1_sd(), "r8")):
-            m = _build(kind, c, sd, prec="bf16x3", n_streams=2, max_batch=3)
+        # (the third run: the f16f6 arithmetic's range guard all-reduces its table over the ranks after every sharded frame)
+        for kind, c, sd, mode, prec in (("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4", "bf16x3"), ("PatchRefiner", E2E_V1, e2e_v1_sd(), "r8", "bf16x3"),
+                                        ("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4", "f16f6")):
+            m = _build(kind, c, sd, prec=prec, n_streams=2, max_batch=3)
             hr = rand_image(c["seed"], 1, *c["raw"]).to("cuda")
             lr = m.resizer(hr)
             tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
@@ -46,7 +48,7 @@ def _worker(rank, world, port, q):
                     else:
                         same = got is None
                     ok = ok and same
-                    notes.append((kind, mode, dst, rep, bool(same)))
+                    notes.append((kind, mode, prec, dst, rep, bool(same)))
             assert len(m.last_shard_layout) == 2                        # [init + grids | random tiles]: two exchanges per frame
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
