@@ -42,6 +42,8 @@ out = P.Feat(torch.empty((n, h, w, F_), device=DEV), x2=True)
 pre = P.Feat(torch.empty((n, h, w, F_), device=DEV))
 y = P.Feat(torch.empty((n, h, w, F_), device=DEV))
 t_conv = timeit(lambda: P.conv2d(x, cw_c, out, relu_in=True, res=x))
+cw_c6 = P.pack_conv3x3_f6(rn(F_, F_, 3, 3) / (3 * F_ ** 0.5), cw_c.bias)
+t_conv6 = timeit(lambda: P.conv3x3_f6(x, cw_c6, out, relu_in=True, res=x))   # (the same layer on conv3x3_c256_f6_kernel; ``out`` keeps this one's bytes)
 t_gather = timeit(lambda: taps.gather(boxes, 0.25, h, w, out=pre))
 t_gate = timeit(lambda: P.conv3x3_ln_gate(out, cw_a, ln, gw, gb, y, act=P.ACT_RELU, mul=out, res=res, pre=pre, pre_cin=F_))
 kern = P.L.load().prv2_last_kernel().decode()
@@ -53,7 +55,7 @@ kern6 = P.L.load().prv2_last_kernel().decode()
 d6 = float((y.buf - yb).norm() / yb.norm())
 t_prep = timeit(lambda: P.CoarseTaps(P.conv2d(coarse, cw_t), F_, (0.25, 0.25)), it=5)
 px = n * h * w
-print(f"{n}x{h}x{w}: c256 conv -> X2 {t_conv:.3f} ms ({2.0 * px * 9 * F_ * F_ / t_conv / 1e9:.0f} TF) | tap gather {t_gather:.3f} ms ({px * F_ * 4 / t_gather / 1e6:.0f} GB/s written) | "
+print(f"{n}x{h}x{w}: c256 conv -> X2 {t_conv:.3f} ms ({2.0 * px * 9 * F_ * F_ / t_conv / 1e9:.0f} TF), fp16 + fp6 {t_conv6:.3f} ms ({2.0 * px * 9 * F_ * F_ / t_conv6 / 1e9:.0f} TF) | tap gather {t_gather:.3f} ms ({px * F_ * 4 / t_gather / 1e6:.0f} GB/s written) | "
       f"{kern} K={F_} + pre {t_gate:.3f} ms ({2.0 * px * F_ * (9 * F_ + F_) / t_gate / 1e9:.0f} TF executed; the reference's 2F -> F unit: "
       f"{2.0 * px * F_ * (18 * F_ + F_) / t_gate / 1e9:.0f} TF algorithmic) | {kern6} {t_gate6:.3f} ms ({2.0 * px * F_ * (9 * F_ + F_) / t_gate6 / 1e9:.0f} TF executed, "
       f"{t_gate / t_gate6:.2f}x; rel-L2 against the bf16x3 kernel {d6:.1e}) | per-frame table (GEMM + knots, one unit) {t_prep:.3f} ms", flush=True)
