@@ -22,7 +22,8 @@ for f in glob.glob('/tmp/pg_*/**/*counter_collection.csv', recursive=True):  # (
         tot[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
         dur[k].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
 print("14 x 192 x 256 pixels, bf16x3; per launch.  conv3x3_c256_gate_kernel = the 512 -> 256 concat form (3x3 + LayerNorm + ReLU + 256 -> 256 gate + sigmoid * mul + res);\n"
-      "conv3x3_c256_gate_x2_kernel = the round-4 form: K = 256 on the pre-split ``out`` + the coarse half as a pre-LayerNorm addend (tap_gather_kernel)")
+      "conv3x3_c256_gate_x2_kernel = the round-4 form: K = 256 on the pre-split ``out`` + the coarse half as a pre-LayerNorm addend (tap_gather_kernel);\n"
+      "conv3x3_c256_gate_f6_kernel / conv3x3_c256_f6_kernel = the same unit tail / GatedConvUnit.conv (K = 256) in the fp16 + fp6 arithmetic (round 5, csrc/conv3x3_f6.hip)")
 for k in sorted(tot, key=lambda k: -sum(dur[k]) / len(dur[k])):
     c={x: tot[k][x]/n[k][x] for x in tot[k]}
     d=sum(dur[k])/len(dur[k])/1e3
