@@ -429,22 +429,28 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
                    : "=&v"(r0[a]), "=&v"(r1[a]) : "v"(voff), "s"(rr), "s"(so) : "memory");
     }
     float* const ybase = p.y + (long long)n_img * p.y_bstride + c0;
+    // first every run's arithmetic (the counted waits see loads only), then every store
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      // younger than run a's rows: the later runs' rows and the stores issued so far (2 per stored run: an upper bound keeps the wait safe)
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0[a]), "+v"(r1[a]) : "n"(2 * (7 - a)) : "memory");
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0[a]), "+v"(r1[a]) : "n"(2 * (7 - a)) : "memory");  // younger: the later runs' rows
+      acc[a][0] = acc[a][0] * os + b0 + r0[a];
+      acc[a][1] = acc[a][1] * os + b1 + r1[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
 #ifndef F6_DBG_NOEPI
       if (y0 + a < p.H && ix < p.W) {
-        const f32x4 v0 = acc[a][0] * os + b0 + r0[a], v1 = acc[a][1] * os + b1 + r1[a];
+        const f32x4 v0 = acc[a][0], v1 = acc[a][1];
         float* const dst = ybase + (long long)((y0 + a) * p.W + ix) * p.ldy;
+        // (s_nop: the hazard recognizer does not look into inline asm -- a VALU write of a wide store's data registers needs wait states behind it)
         if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
           bf16x4 h0, l0, h1, l1;
           split_bf16(v0, h0, l0);
           split_bf16(v1, h1, l1);
           const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 1" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
         } else {
-          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 1" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
         }
       }
 #endif
