@@ -175,7 +175,22 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     if constexpr (PREC == PRV2_PREC_BF16X3) bl[slot] = *reinterpret_cast<const bf16x8*>(b_lane_lo + bbuf * B_BYTES + j * 16 * 128);
   };
   constexpr int NP = PREC == PRV2_PREC_BF16X3 ? 3 : 1;
-  auto mma = [&](f32x4& c, const bf16x8& xh, const bf16x8& xl, const bf16x8& wh, const bf16x8& wl, int pr) {
+  auto mma = [&](f32x4& c, const bf16x8& xh, const bf16x8& xl, const bf16x8& wh, const bf16x8& wl, int pr, [[maybe_unused]] int f6 = 1) {
+#ifdef PRV2_F6_MOCK  // TIMING ONLY, wrong results (tools/probes/f6_mock.sh; profiles/r05_experiments.txt #12): the fp16 + fp6 instruction mix -- 16 fp16 MFMAs per
+                     // tap, 16 fp6 K = 128 MFMAs every other tap -- on THIS pipeline's operand traffic: 1.30x, LDS-bound; why conv3x3_f6.hip is built differently
+    if constexpr (PREC == PRV2_PREC_BF16X3) {
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      typedef int i32x4m __attribute__((ext_vector_type(4)));
+      if (pr == 1 && f6) {
+        const i32x4m a0 = __builtin_bit_cast(i32x4m, xh), a1 = __builtin_bit_cast(i32x4m, xl), b0 = __builtin_bit_cast(i32x4m, wh), b1 = __builtin_bit_cast(i32x4m, wl);
+        const i32x8 qa = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, qb = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa, qb, c, 2, 2, 0, 127, 0, 127);
+      }
+      if (pr == 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xh), __builtin_bit_cast(f16x8, wh), c, 0, 0, 0);
+      return;
+    }
+#endif
     if constexpr (PREC == PRV2_PREC_BF16X3) {
       if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, c, 0, 0, 0);
       if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, c, 0, 0, 0);
@@ -225,8 +240,8 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
         for (int a = 0; a < NA; a += 2) {
 #pragma unroll
           for (int pr = 0; pr < NP; ++pr) {
-            mma(acc[a][j], ah[a], al[a], bh[j & 1], bl[j & 1], pr);
-            mma(acc[a + 1][j], ah[a + 1], al[a + 1], bh[j & 1], bl[j & 1], pr);
+            mma(acc[a][j], ah[a], al[a], bh[j & 1], bl[j & 1], pr, (tap & 1) | (tap == 8));
+            mma(acc[a + 1][j], ah[a + 1], al[a + 1], bh[j & 1], bl[j & 1], pr, (tap & 1) | (tap == 8));
           }
           __builtin_amdgcn_sched_barrier(0);
 #ifndef PRV2_ABL_NOA  // (timing ablations of tools/probes/gate_phase_stamps.sh: results are wrong with any of them)
@@ -258,8 +273,8 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
       for (int a = 0; a < NA; a += 2) {
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
-          mma(acc[a][NJ - 1], ah[a], al[a], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr);
-          mma(acc[a + 1][NJ - 1], ah[a + 1], al[a + 1], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr);
+          mma(acc[a][NJ - 1], ah[a], al[a], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr, (tap & 1) | (tap == 8));
+          mma(acc[a + 1][NJ - 1], ah[a + 1], al[a + 1], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr, (tap & 1) | (tap == 8));
         }
         __builtin_amdgcn_sched_barrier(0);
         read_a(a, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
