@@ -22,8 +22,8 @@
 //     fill outside the image) into a per-wave staging area; the wave that moved a pixel converts it (ReLU, x x_scale, fp16 + residual, block
 //     maxima, two v_cvt_scalef32_2xpk16_fp6_f32), so no cross-wave hand-off is needed for the staging.
 //   * a workgroup walks a SEQUENCE of tiles: the next tile's first superslab is staged under the current tile's last, the weight stream wraps.
-// Stage 1 is persistent (one workgroup per CU) with an epilogue from registers (x out_scale, + bias, + res, fp32 or X2 output, 16-byte loads /
-// stores); stage 2 runs one tile per workgroup and hands its accumulators to conv3x3_gate.hip's epilogue through the C tile in LDS
+// Stage 1 is persistent (one workgroup per CU); its epilogue (x out_scale, + bias, + res, fp32 or X2 output) stages half tiles as 1 KB pixel rows in the LDS that
+// is free at a tile's end and leaves through a row store loop; stage 2 runs one tile per workgroup and hands its accumulators to conv3x3_gate.hip's epilogue through the C tile in LDS
 // (conv3x3_gate_epi.h).
 // Range: fp16 holds |x x_scale| <= 65504; larger values are clamped in the fp16 part and fall to the fp6 residual (finite, imprecise) --
 // the caller keeps x_scale / the weights' scale (powers of two, undone by out_scale) such that this does not happen, and reads the
@@ -367,7 +367,7 @@ __device__ __forceinline__ void f6_body(const F6Params& p, char* const smem, con
 #endif
     int n_img, y0, x0;
     tile_of(k, n_img, y0, x0);
-    epi(n_img, y0, x0, acc);
+    epi(n_img, y0, x0, acc, ((k * nss + nss - 1) & 1) * A_BYTES);  // (+ the halo buffer the tile's last superslab was read from: free now)
 #ifdef F6_STAMPS
     const long long st_c = __builtin_readcyclecounter();
     st_main += st_b - st_a; st_epi += st_c - st_b;
@@ -405,7 +405,69 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), m16 = lane & 15, g = lane >> 4;
   const int c0 = wave * 32 + g * 8;
   const float os = p.out_scale;
-  f6_body<false>(p, smem, t_begin, per, K, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
+#ifndef F6_EPI_DIRECT
+  // Epilogue through LDS, two half tiles (4 runs = 64 pixel rows of 1 KB) at a time: a lane's accumulators are 32 bytes of 16 different pixels per
+  // instruction -- as direct loads / stores that is 16 half-used cache lines per wave instruction and cost 16 k cycles per tile; from a row image every
+  // instruction of the store loop takes two whole 1 KB pixel rows (thread = row tid >> 5 (+ 16 i), channels 8 (tid & 31) .. + 7).  Free LDS at this
+  // point: the staging area (48 rows of 1040 B) and the halo buffer the tile's last superslab was read from (rows 48 .. 63); the OTHER halo buffer
+  // already holds the next tile's first superslab.
+  constexpr int RP = 1040;
+  const int tid = threadIdx.x, srow = tid >> 5, c8 = (tid & 31) * 8;
+  f6_body<false>(p, smem, t_begin, per, K, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2], const int free_buf) {
+    auto row_ptr = [&](int r) { return smem + (r < 48 ? ST_BASE + r * RP : free_buf + (r - 48) * RP); };
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4);
+    }
+    const long long img_px = (long long)n_img * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res + img_px * p.ld_res : p.x), 0,
+                                                                            p.res ? (int)(((unsigned)(p.H * p.W - 1) * p.ld_res + 256) * 4u) : 0, 0x00020000);
+    float* const ybase = p.y + (long long)n_img * p.y_bstride + c8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // residual rows of this half, requested before the accumulators go to LDS: row r = srow + 16 i of the half = tile row 4 h + i, column srow
+      f32x4 r0[4], r1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = y0 + 4 * h + i, ixs = x0 + srow;
+        const unsigned off = (iy < p.H && ixs < p.W) ? (unsigned)(((iy * p.W + ixs) * p.ld_res + c8) * 4) : 0x80000000u;
+        r0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
+        r1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off + 16, 0, 0));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        char* q = row_ptr(a * TW + m16) + c0 * 4;
+        *reinterpret_cast<f32x4*>(q) = acc[4 * h + a][0] * os + b0;
+        *reinterpret_cast<f32x4*>(q + 16) = acc[4 * h + a][1] * os + b1;
+        acc[4 * h + a][0] = acc[4 * h + a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = y0 + 4 * h + i, ixs = x0 + srow;
+        const char* q = row_ptr(srow + 16 * i) + c8 * 4;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(q) + r0[i], v1 = *reinterpret_cast<const f32x4*>(q + 16) + r1[i];
+#ifndef F6_DBG_NOEPI
+        if (iy < p.H && ixs < p.W) {
+          float* const dst = ybase + (long long)(iy * p.W + ixs) * p.ldy;
+          if (p.y_x2) {  // pre-split output (conv3x3_gate.hip, head of the file): per 8 channels [8 bf16 hi | 8 bf16 lo]
+            bf16x4 h0, l0, h1, l1;
+            split_bf16(v0, h0, l0);
+            split_bf16(v1, h1, l1);
+            const bf16x8 hv = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), lv = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 1" ::"v"(dst), "v"(hv), "v"(lv) : "memory");
+          } else {
+            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 1" ::"v"(dst), "v"(v0), "v"(v1) : "memory");
+          }
+        }
+#endif
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the rows are read out: the next half / the next tile's staging and conversion may take the LDS
+    }
+  });
+#else
+  f6_body<false>(p, smem, t_begin, per, K, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2], int) {
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (p.bias) {
       b0 = *reinterpret_cast<const f32x4*>(p.bias + c0);
@@ -457,6 +519,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_f6_kernel(const F6Params 
       acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   });
+#endif
 }
 
 // ---- GatedConvUnit tail (round 5, stage 2): the fp16 + fp6 main loop over the unit's pre-split ``out`` in front of conv3x3_gate.hip's epilogue -- C tile
@@ -485,7 +548,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_f6_kernel(const Gate
   PRV2_STAMP(0);
   PRV2_STAMP(1);
   PRV2_CLK_STAMP(0);
-  f6_body<X2IN>(p, smem, t, 1, 1, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2]) {
+  f6_body<X2IN>(p, smem, t, 1, 1, [&](int n_img, int y0, int x0, f32x4 (&acc)[8][2], int) {
     // the wrapped-around weight loads and the repeated halo DMA (nobody uses either) must have landed before the C tile takes the staging area
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PRV2_STAMP(2);
