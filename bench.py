@@ -364,6 +364,9 @@ def main():
                                  if w["kind"] == "PatchRefinerPlus" and not w.get("refiner_encoder") else None)))
     result["operating_point"] = operating_point
     if f6_on:
+        # the mode's fp16 range guard (ops.F6Range, models.forward): frames recomputed in the timed region because a layer's input left fp16's range (0 on this data)
+        result["f16f6_guard"] = dict(recomputed_frames=int(getattr(model, "f6_recalibrations", 0)),
+                                     layers=sum(1 for _, r in ops.F6Range._tables[str(dev)]["layers"] if r() is not None))
         result["dtype_note"] = ("bf16x3 (fp32 operands split hi + lo bf16, 3 MFMAs) everywhere except the 3x3 convs of the 256-channel GatedConvUnits -- "
                                 "GatedConvUnit.conv and the unit's fusion_conv.0 inside the fused tail kernel (its LayerNorm, gate GEMM and final stage stay "
                                 "bf16x3 / fp32) -- which run fp16 + two block-scaled fp6 (e2m3) corrections per product (csrc/conv3x3_f6.hip): fp32-grade, rms "
