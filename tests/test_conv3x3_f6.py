@@ -226,3 +226,44 @@ def test_gate_unit_tail_f6_concat_form(x2):
     e6, eb = float((y6.buf.double() - ref).norm() / ref.norm()), float((yb.buf.double() - ref).norm() / ref.norm())
     print(f"\ngate unit tail, concat form K = 512, x2 = {x2}: f16f6 rel-L2 {e6:.2e} (bf16x3 {eb:.2e})")
     assert torch.isfinite(y6.buf).all() and e6 < 2e-5, (e6, eb)
+
+
+def test_conv3x3_f6_matches_the_documented_arithmetic():
+    """The kernel against a HOST EMULATION of exactly the arithmetic include/prv2.h documents -- x w = f16(x) f16(w) + q6(x) q6(w - f16 w) + q6(x - f16 x) q6(w), fp16 RNE,
+    e2m3 with one power-of-two scale 2^(floor(log2 max) - 2) per 32 channels (tools/studies/split_arith_study.py's quantisers, which the instruction probe
+    tools/probes/f16f6_probe.hip matched element for element), products and sums exact in float64: what remains is the kernel's fp32 accumulation order and the
+    quantiser's tie rule (the host takes the lower neighbour, the instruction the even one): below 1e-6, several times under the scheme's own error.  A wrong block pairing, a misplaced scale or a swapped correction would show here, not in the 4e-5 float64 tolerance."""
+    import importlib.util
+    import os
+    import numpy as np
+    P = _ops()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("split_arith_study", os.path.join(root, "tools", "studies", "split_arith_study.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    n, h, w, cin = 1, 9, 17, 128
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(n, h, w, cin, device=DEV, generator=g) * torch.exp(torch.randn(n, h, w, 1, device=DEV, generator=g))   # (per-pixel magnitudes over a decade)
+    wt = torch.randn(256, cin, 3, 3, device=DEV, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(256, device=DEV, generator=g)
+    res = torch.randn(n, h, w, 256, device=DEV, generator=g)
+    cw = P.pack_conv3x3_f6(wt, b)
+    out = P.conv3x3_f6(P.Feat(x), cw, relu_in=True, res=P.Feat(res)).buf.double().cpu().numpy()
+    q6 = lambda v: S.mx_quant(v, S.E2M3, 2).astype(np.float64)  # noqa: E731  (blocks of 32 along the last axis)
+    xs = np.maximum(x.cpu().numpy(), 0).astype(np.float32)                                   # relu(x) * x_scale (1.0)
+    ws = (wt.cpu().numpy() * np.float32(cw.w_scale)).transpose(0, 2, 3, 1).copy()           # [cout, ky, kx, cin]: channels last
+    xh, wh = S.f16(xs), S.f16(ws)
+    parts_x = (xh.astype(np.float64), q6(xs), q6(xs - xh))
+    parts_w = (wh.astype(np.float64), q6(ws - wh), q6(ws))
+    xp = [np.pad(p, ((0, 0), (1, 1), (1, 1), (0, 0))) for p in parts_x]
+    y = np.zeros((n, h, w, 256))
+    for ky in range(3):
+        for kx in range(3):
+            for px, pw in zip(xp, parts_w):
+                y += px[:, ky:ky + h, kx:kx + w] @ pw[:, ky, kx].T
+    y = y / cw.w_scale + b.double().cpu().numpy() + res.double().cpu().numpy()
+    err = float(np.sqrt(((out - y) ** 2).mean()) / np.sqrt((y ** 2).mean()))
+    exact = torch.nn.functional.conv2d(torch.relu(x.double()).permute(0, 3, 1, 2), wt.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    scheme = float(np.sqrt(((y - exact.cpu().numpy()) ** 2).mean()) / np.sqrt((y ** 2).mean()))
+    print(f"\nkernel vs host emulation of the documented arithmetic: rms {err:.2e}; the arithmetic itself vs float64: {scheme:.2e}")
+    assert err < 2e-6 and err * 3 < scheme, (err, scheme)
