@@ -392,6 +392,11 @@ def test_lds_layouts_by_the_bank_model():
         assert r[f"ln_stats_read_b128_bn{bn}"] == 0 and r[f"ln_stats_read_b32_bn{bn}"] >= 6  # 16-byte reads: free; scalar: 4-way per half
     assert sorted(m.upconv_gather_role(l) for l in range(64)) == [(r_, q) for r_ in range(8) for q in range(8)]
     assert sorted(m.gate_gemm_row(i) for i in range(16)) == list(range(16))
+    # round 5, csrc/conv3x3_f6.hip: the halo image's pitch and the split of an fp6 block into two 16-byte column groups
+    assert r["f6_fragment_read_pix288"] == 0 and r["f6_fragment_read_pix272"] > 0 and r["f6_fragment_read_blocks_contiguous"] > 0
+    assert r["f6_epilogue_row_write"] == 0
+    f6 = open(os.path.join(os.path.dirname(__file__), "..", "patchrefinerv2_amd", "csrc", "conv3x3_f6.hip")).read()
+    assert "constexpr int PIX = 288;" in f6 and "constexpr int RP = 1040;" in f6 and "ST_CHUNK = 1040" in f6
     # the constants of the kernels are the ones the model was run with
     src = open(os.path.join(os.path.dirname(__file__), "..", "patchrefinerv2_amd", "csrc", "upconv.hip")).read()
     assert "constexpr int AROW = 160;" in src and "0xD728" in src and "constexpr int GRP = LC * CLD - 4;" in src

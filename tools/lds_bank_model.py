@@ -85,6 +85,17 @@ def report() -> Dict[str, int]:
     for bn in (32, 64, 128):
         out[f"ln_stats_read_b32_bn{bn}"] = extra_cycles("ds_read_b32", lambda l: l * (bn + 4) * 4)
         out[f"ln_stats_read_b128_bn{bn}"] = extra_cycles("ds_read_b128", lambda l: l * (bn + 4) * 4)
+    # round 5, csrc/conv3x3_f6.hip.  Activation fragments: lane (pixel m16, k group g) of a halo row image with PIX bytes per pixel -- fp16 slab at + 16 g, the fp6
+    # block's halves at 128 + 16 g / 192 + 16 g (same offsets modulo the pitch): the pitch 288 is conflict free, 272 (256 B of data + one 16-byte pad) is not
+    for pix in (272, 288):
+        out[f"f6_fragment_read_pix{pix}"] = max(extra_cycles("ds_read_b128", lambda l: (l & 15) * pix + (l >> 4) * 16 + o) for o in (0, 64, 128, 192))
+    # the layout first drawn up -- each fp6 block's 32 bytes contiguous, lane g reading at 128 + 32 g and + 16 -- puts the k groups of a row on the same slots
+    out["f6_fragment_read_blocks_contiguous"] = extra_cycles("ds_read_b128", lambda l: (l & 15) * 288 + 128 + (l >> 4) * 32)
+    # the conversion's reads of the per-wave staging area: lane = (staged pixel lane >> 1, slab lane & 1), 4 pixels x 256 B per 1040-byte DMA chunk
+    out["f6_staging_read"] = extra_cycles("ds_read_b128", lambda l: ((l >> 1) >> 2) * 1040 + ((l >> 1) & 3) * 256 + (l & 1) * 128 if l < 48 else 100000 + 16 * l)
+    # epilogue row image (pitch 1040): accumulator writes of lane (pixel m16, k group g) at channel (32 wave + 8 g) and the row store loop's 32-byte reads
+    out["f6_epilogue_row_write"] = extra_cycles("ds_write_b128", lambda l: (l & 15) * 1040 + (l >> 4) * 32)
+    out["f6_epilogue_row_read"] = extra_cycles("ds_read_b128", lambda l: (l >> 5) * 1040 + (l & 31) * 32)
     return out
 
 
