@@ -218,7 +218,6 @@ class _EncDec(StateDictModule):
             h, w = sizes[l]
             tc = self.temp_chl[l]
             conv, lnw, lnb = P[f"{self.ENC1}.{l}"]
-            cat2 = alloc_with_pred_tail(B, h, w, tc, dev)
             j = L_ - 2 - l  # decoder stage that consumes this level as the skip x2 (fusion_model.py:104-111)
             chain = P.get(f"chain_enc.{l}") if enc1_taps is not None and enc1_taps[l] is not None and not self.HEAVY else None
             if chain is not None and (pred1.h, pred1.w, pred2.h, pred2.w) == (h, w, h, w) and enc1_taps[l][2].c == 32:
@@ -228,6 +227,7 @@ class _EncDec(StateDictModule):
                 dst = dec_bufs[j].slice(self.dec_in[j][0], tc) if 0 <= j < nd else Feat.alloc(B, h, w, tc, dev)
                 temps[l] = ops.chain32_enc(fine, chain, pre, pred1.buf, pred2.buf, out=dst, pre_cin=roi.c)
                 continue
+            cat2 = alloc_with_pred_tail(B, h, w, tc, dev)  # (behind the chain branch, which never needs it: 1.1 GB at 41 x 384 x 512 x 36)
             if enc1_taps is not None and enc1_taps[l] is not None:
                 taps, roi, fine = enc1_taps[l]
                 pre = taps.gather(roi.boxes, roi.scale, h, w)  # conv3x3(c; W[:, :c_l]) of the tiles, from the frame's table

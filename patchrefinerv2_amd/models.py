@@ -260,7 +260,9 @@ class _PatchModel(StateDictModule):
         with torch.cuda.device(image_hr.device):
             self._next_lr = next_image_lr
             try:
-                guard = getattr(self, "arith", None) == "f16f6" and ops.F6Range.active(image_hr.device)
+                # (the guard follows the fusion model's own flag: PRV2_F16F6=1 switches the layers on under arith 'bf16x3' as well)
+                f16f6 = getattr(self, "arith", None) == "f16f6" or bool(getattr(getattr(self, "refiner_fusion_model", None), "f16f6", False))
+                guard = f16f6 and ops.F6Range.active(image_hr.device)
                 rnd = random.getstate() if guard else None
                 out = self._infer(image_lr, image_hr, depth_gt, tile_cfg, cai_mode, process_num, shard, return_device, gather_dst)
                 if guard:
@@ -270,8 +272,11 @@ class _PatchModel(StateDictModule):
                     if shard is not None and shard[1] > 1:  # one decision for all ranks of a patch-sharded frame: the tables' maximum (1 KB all-reduce)
                         import torch.distributed as dist
                         reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)  # noqa: E731
+                    self.f6_guarded_frames = getattr(self, "f6_guarded_frames", 0) + 1
                     for attempt in range(3):
                         redo = ops.F6Range.check(image_hr.device, reduce)
+                        if ops.F6Range.moved:  # (also an early move without a redo: a captured frame carries the old scales as kernel arguments)
+                            self.__dict__.pop("_graphs", None)
                         if not redo:
                             break
                         if attempt == 2:
@@ -634,6 +639,7 @@ class _PatchModel(StateDictModule):
                 e = min(s0 + bs, len(tiles))
                 crops, rois, droi = self._prepare_batch(image_chw, t_dev[s0:e], boxes[s0:e] if boxes is not None else None, tile_cfg, feats, cd)
                 self.infer_forward(crops, rois, droi, out=preds[s0:e])
+            ops.F6Range.clear(dev)  # (no guarded frame here: what these launches saw must not be judged by the next frame's check)
         return preds
 
     def _device_frame(self, image_lr, image_hr, tiles_dev, boxes_dev, plan, tile_cfg, process_num, shard=None, gather_dst=None):

@@ -288,13 +288,22 @@ class F6Range:
     computed has to be recomputed: a layer saw values beyond fp16's range (its fp16 part saturated: finite but fp6-grade) or its whole
     input sat below 2^-10 (fp16 subnormals)."""
     SLOTS = 256
+    moved = False
     TARGET_LOG2, LOW_LOG2, HIGH = 8, -10, 65504.0
     _tables: dict = {}
+
+    @staticmethod
+    def _key(device) -> str:
+        """one key per physical device: 'cuda' (a config default) and 'cuda:0' (a tensor's .device) are the same table"""
+        d = torch.device(device)
+        if d.type == "cuda" and d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        return str(d)
 
     @classmethod
     def slot(cls, device, cw) -> torch.Tensor:
         import weakref
-        device = torch.device(device)
+        device = torch.device(cls._key(device))
         ent = cls._tables.setdefault(str(device), dict(table=torch.zeros(cls.SLOTS, dtype=torch.int32, device=device), layers=[]))
         ent["layers"] = [(i, r) for i, r in ent["layers"] if r() is not None]
         used = {i for i, _ in ent["layers"]}
@@ -307,15 +316,18 @@ class F6Range:
 
     @classmethod
     def active(cls, device) -> bool:
-        ent = cls._tables.get(str(torch.device(device)))
+        ent = cls._tables.get(cls._key(device))
         return bool(ent and any(r() is not None for _, r in ent["layers"]))
 
     @classmethod
     def check(cls, device, reduce=None) -> list:
         """-> [(layer, seen maximum, old x_scale)] of the layers whose frame must be recomputed (their x_scale is already moved); the
         table is cleared for the next frame.  ``reduce(table)``: an in-place MAX all-reduce over the ranks of a patch-sharded frame (the words are
-        float bits of non-negative values: integer order == float order), so that every rank takes the same decision"""
-        ent = cls._tables.get(str(torch.device(device)))
+        float bits of non-negative values: integer order == float order), so that every rank takes the same decision.
+        ``cls.moved`` tells the caller whether ANY x_scale changed (captured hipGraphs carry the old scales as kernel arguments: the
+        caller drops them, otherwise the next measurement would be taken under a scale this table no longer knows)"""
+        cls.moved = False
+        ent = cls._tables.get(cls._key(device))
         if not ent:
             return []
         if reduce is not None:
@@ -335,7 +347,15 @@ class F6Range:
                 redo.append((cw, m, cw.x_scale))
             if m > cls.HIGH / 4 or e < cls.LOW_LOG2 + 6:  # (move early: two binades before the upper, six before the lower limit)
                 cw.x_scale = cw.x_scale * 2.0 ** (cls.TARGET_LOG2 - e)
+                cls.moved = True
         return redo
+
+    @classmethod
+    def clear(cls, device) -> None:
+        """forget what the launches so far saw (callers that run the fp16 + fp6 layers outside a guarded frame)"""
+        ent = cls._tables.get(cls._key(device))
+        if ent:
+            ent["table"].zero_()
 
 
 def pack_conv3x3_f6(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device=None) -> ConvWF6:

@@ -433,6 +433,36 @@ def test_e2e_v2_vs_reference_golden(P, golden):
         assert ar < ABSREL_TOL and mx < 1e-3, (mode, ar, mx)
 
 
+def test_f16f6_range_guard_runs_for_a_model_built_on_the_default_device(P):
+    """a model built with the config default device ('cuda') registers its fp16 + fp6 layers under that name while the
+    frame asks for its input's device ('cuda:0'): the range guard must find them (ops.F6Range._key), run after every frame, and -- on an
+    image 1e5 x outside the calibrated range -- recompute the frame with moved scales instead of returning fp6-grade values."""
+    from patchrefinerv2_amd import ops
+    c = E2E_V2
+    m = _build("PatchRefinerPlus", c, e2e_v2_sd(), prec="f16f6")  # (no explicit device: torch.device('cuda'))
+    assert str(m.device) in ("cuda", "cuda:0") and m.refiner_fusion_model.f16f6
+    assert ops.F6Range.active("cuda") and ops.F6Range.active("cuda:0") and ops.F6Range.active(torch.device("cuda", 0))
+    hr = rand_image(c["seed"], 1, *c["raw"]).to(DEV)
+    tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+
+    def run(img):
+        random.seed(621)
+        return m(mode="infer", cai_mode="m1", process_num=4, tile_cfg=tc, image_lr=m.resizer(img), image_hr=img)[0]
+    d0 = run(hr)
+    assert getattr(m, "f6_guarded_frames", 0) == 1 and torch.isfinite(d0).all()
+    n0 = getattr(m, "f6_recalibrations", 0)
+    d1 = run(hr * 1e5)
+    assert m.f6_guarded_frames == 2 and getattr(m, "f6_recalibrations", 0) > n0, (m.f6_guarded_frames, getattr(m, "f6_recalibrations", 0))
+    assert torch.isfinite(d1).all()
+    # the same frame in bf16x3: the recalibrated result is as close to it as at unit scale
+    mb = _build("PatchRefinerPlus", c, e2e_v2_sd(), prec="bf16x3")
+    random.seed(621)
+    db = mb(mode="infer", cai_mode="m1", process_num=4, tile_cfg=tc, image_lr=mb.resizer(hr * 1e5), image_hr=hr * 1e5)[0]
+    ar, mx = absrel(d1, db)
+    print(f"\nx 1e5 image: recalibrations {m.f6_recalibrations - n0}, AbsRel f16f6 vs bf16x3 {ar:.2e}")
+    assert ar < ABSREL_TOL, ar
+
+
 @pytest.mark.parametrize("enc", ["convnext", "effnet"])
 def test_e2e_v2_other_refiner_encoders_vs_oracle(P, enc):
     """PatchRefinerPlus with the ConvNeXt (v2_convx_u4k.py) / EfficientNet (v2_eff_u4k.py) refiner encoder end to end; the

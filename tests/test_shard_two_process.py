@@ -50,6 +50,11 @@ def _worker(rank, world, port, q):
                     ok = ok and same
                     notes.append((kind, mode, prec, dst, rep, bool(same)))
             assert len(m.last_shard_layout) == 2                        # [init + grids | random tiles]: two exchanges per frame
+            if prec == "f16f6":  # the guard (and its all-reduce over the ranks) really ran: the model was built with device='cuda', the frames ask 'cuda:0'
+                from patchrefinerv2_amd import ops
+                has_f6 = bool(getattr(m.refiner_fusion_model, "f16f6", False)) and ops.F6Range.active("cuda")
+                assert not has_f6 or getattr(m, "f6_guarded_frames", 0) >= 5, (has_f6, getattr(m, "f6_guarded_frames", 0))
+                notes.append(("f6 guard", has_f6, getattr(m, "f6_guarded_frames", 0)))
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         q.put((rank, int(flag.item()), notes))
