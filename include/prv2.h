@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PRV2_ABI_VERSION 18
+#define PRV2_ABI_VERSION 19
 
 enum prv2_act { PRV2_ACT_NONE = 0, PRV2_ACT_RELU = 1, PRV2_ACT_GELU = 2, PRV2_ACT_SIGMOID = 3, PRV2_ACT_SOFTPLUS = 4,
                 PRV2_ACT_SILU = 5 /* x * sigmoid(x): EfficientNet refiner encoder (timm 'swish') */ };
@@ -384,6 +384,14 @@ int prv2_attention_ss(const float* qkv, int32_t b, int32_t ntok, int32_t heads, 
                       void* out_ss, void* workspace, int64_t workspace_bytes, void* stream);
 int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias, const float* gamma,
                  const float* res, int32_t ld_res, int32_t act, float* y, int32_t ldy, void* y_ss, void* stream);
+/* The attention block without a pre-pass (attention.py:49-62; MiDaS beit.py attention_forward): the qkv Linear writes its [q | k | v] rows
+ * split-swizzled with the q third (columns [0, q_cols)) multiplied by q_scale = hd^-0.5 log2 e behind the bias, and prv2_attention_qkv_ss reads
+ * those rows directly (q / k fragments are 16-byte copies; v is transposed by the LDS read).  Same values as prv2_gemm_ss (fp32 rows) ->
+ * prv2_attention_ss, bit for bit; no workspace, no fp32 qkv tensor.  Exactly one of out (fp32 rows [b * ntok, heads * hd]) / out_ss. */
+int prv2_gemm_ss_qkv(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias, int32_t q_cols, float q_scale,
+                     void* qkv_ss, void* stream);
+int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias, float* out,
+                          void* out_ss, void* stream);
 
 /* device scratch the split-bf16 attention needs (pre-split q/k rows + transposed v planes); 0 for PRV2_PREC_F32.
  * The workspace must be 256-byte aligned; its contents are dead when the call returns (stream order). */

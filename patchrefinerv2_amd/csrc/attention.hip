@@ -542,6 +542,264 @@ __global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf
 
 }  // namespace prv2
 
+// =================================================================================================
+// The same attention on the qkv Linear's SPLIT-SWIZZLED output (prv2_gemm_ss_qkv): no pre-pass.
+//
+// The qkv GEMM's epilogue already writes every channel as bf16 hi + bf16 lo (gemm_ss.hip: per 32 channels one 128-byte group
+// [4 x 16 B hi | 4 x 16 B lo], 16-byte slot c of row r stored at c ^ ((r >> 1) & 7)) and scales the q third by hd^-0.5 log2 e -- exactly the
+// values qkv_split_kernel produced, so this kernel's operands are 16-byte copies of that buffer and its results are bit-equal to
+// attention_bf16x3_kernel's.  A head's 64 channels are two such groups = 256 contiguous bytes per token.  What the pre-pass also did was
+// transpose V; here V stays [key][d] (rows like K's) in LDS and the A operand of O^T = V^T P^T comes out of ds_read_b64_tr_b16 (the hardware's
+// 4 x 16 transposing read; cdna_hip_programming.md T10): lane group G = lane >> 4 reads keys 16 s + 4 (G >> 1) + (0..3) [and + 8] of d columns
+// 32 dt + 16 (G & 1) + (0..15): the fragment's permuted k order (element j <-> key 16 s + 8 (j >> 2) + 4 half + (j & 3)) as before.
+// V row pitch 320 B: the four key rows a 32-lane half reads are 64-byte segments at 0 / 64 / 128 / 192 mod 256 -- conflict free; staging writes
+// (both tiles): 8 consecutive lanes = 128 contiguous bytes -- conflict free (the old image's ld_row / ld_q map was 2-way on every write: 21 % of
+// the kernel's LDS cycles, profiles/r05_f16f6_pmc_vit_blocks_b14.txt).
+// The pre-pass, its 341 MB per ViT-L block at 14 crops and the fp32 qkv tensor are gone.
+// =================================================================================================
+namespace prv2 {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int AQ_VP = 320;  // V tile row pitch (bytes): 128 hi + 128 lo + 64 pad
+
+template <int BIAS>
+__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qkvss_kernel(const char* __restrict__ qkv_ss, int N, int heads,
+                                                                                            const float* __restrict__ bias, int ldb,
+                                                                                            float* __restrict__ out, char* __restrict__ out_ss) {
+  __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AQ_VP];  // 37888 B; reused for the output strips (33792 B)
+  char* const Kt = smem;
+  char* const Vt = smem + 64 * AB_KP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, half = lane >> 5;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int qtiles = (N + AT_BQ - 1) / AT_BQ;
+  const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
+  const int D = heads * 64;
+  const long long ld = (long long)D * 12;                      // bytes per token row of [q | k | v]
+  const char* const qbase = qkv_ss + (long long)head * 256;    // this head's q columns; k at + D * 4, v at + D * 8
+  const long long row_b = (long long)b * N;                    // first row of this image (the swizzle key is a function of the GLOBAL row)
+
+  // Q fragments (B operand of S^T): lane (q = r32, half) holds Q[q][16 ks + 8 half + j]: 32-channel group ks >> 1, logical slot 2 (ks & 1) + half
+  const int q_row = qt * AT_BQ + wave * 32 + r32;
+  const bool wave_active = qt * AT_BQ + wave * 32 < N;  // wave-uniform
+  bf16x8 qh[4], ql[4];
+  {
+    const long long r = row_b + (q_row < N ? q_row : 0);
+    const char* qp = qbase + r * ld;
+    const int key = (int)((r >> 1) & 7);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int sl = 2 * (ks & 1) + half;
+      qh[ks] = *reinterpret_cast<const bf16x8*>(qp + (ks >> 1) * 128 + ((sl ^ key) << 4));
+      ql[ks] = *reinterpret_cast<const bf16x8*>(qp + (ks >> 1) * 128 + (((4 + sl) ^ key) << 4));
+    }
+  }
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o_acc[0][e] = 0.f; o_acc[1][e] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: a tile = 64 keys x 16 destination slots of 16 B ([8 x hi | 8 x lo] of the head's 64 channels); thread -> slots tid + 256 i:
+  // key (tid >> 4) + 16 i, slot tid & 15 -- 16 lanes read one key's 256 bytes, 8 lanes write 128 contiguous LDS bytes
+  const int st_key = tid >> 4, st_slot = tid & 15;
+  const int st_grp = (st_slot & 7) >> 2, st_log = (st_slot & 3) + 4 * (st_slot >> 3);  // source group / logical slot of destination slot
+  f32x4 kreg[4], vreg[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = k0 + st_key + 16 * i;
+      const long long r = row_b + (key < N ? key : 0);
+      const char* src = qbase + r * ld + (long long)D * 4 + st_grp * 128 + ((st_log ^ (int)((r >> 1) & 7)) << 4);
+      kreg[i] = *reinterpret_cast<const f32x4*>(src);
+      vreg[i] = *reinterpret_cast<const f32x4*>(src + (long long)D * 4);
+    }
+  };
+  fetch(0);
+  // transposing V reads: lane (G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3) addresses key row 4 (G >> 1) + q, d columns 16 (G & 1) + 4 p
+  const int tr_off = (4 * (lane >> 5) + ((lane >> 2) & 3)) * AQ_VP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  auto tile = [&](int k0, auto mask_c) {
+    constexpr bool MASK = decltype(mask_c)::value;
+    __syncthreads();
+    {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool kvalid = (k0 + st_key + 16 * i) < N;
+        *reinterpret_cast<f32x4*>(Kt + (st_key + 16 * i) * AB_KP + st_slot * 16) = kvalid ? kreg[i] : z;
+        *reinterpret_cast<f32x4*>(Vt + (st_key + 16 * i) * AQ_VP + st_slot * 16) = kvalid ? vreg[i] : z;
+      }
+    }
+    __syncthreads();
+    if (k0 + AT_BK < N) fetch(k0 + AT_BK);
+    if (!wave_active) return;
+
+    f32x4 btile[BIAS == 2 ? 8 : 1];
+    if constexpr (BIAS == 2) {
+      const int q32 = qt * (AT_BQ / 32) + wave, q32n = ((N + AT_BQ - 1) / AT_BQ) * (AT_BQ / 32);
+      const f32x4* bt = reinterpret_cast<const f32x4*>(bias) + ((((long long)head * q32n + q32) * ldb + (k0 >> 6)) * 8) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) btile[i] = bt[i * 64];
+    }
+    f32x16 st[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[0][e] = 0.f; st[1][e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const char* kr = Kt + (t * 32 + r32) * AB_KP + ks * 32 + half * 16;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kr);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kr + 128);
+        st[t] = mfma3(kh, kl, qh[ks], ql[ks], st[t]);
+      }
+    if constexpr (BIAS == 1) {
+      const float* br = bias + ((long long)head * N + (q_row < N ? q_row : 0)) * ldb + k0 + 4 * half;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(br + t * 32 + 8 * g) * 1.4426950408889634f;
+          st[t][4 * g] += bv.x; st[t][4 * g + 1] += bv.y; st[t][4 * g + 2] += bv.z; st[t][4 * g + 3] += bv.w;
+        }
+    }
+    if constexpr (BIAS == 2) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = btile[4 * t + g];
+          st[t][4 * g] += bv.x; st[t][4 * g + 1] += bv.y; st[t][4 * g + 2] += bv.z; st[t][4 * g + 3] += bv.w;
+        }
+    }
+    if constexpr (MASK) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = k0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          st[t][e] = key < N ? st[t][e] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        st[t][e] = __builtin_amdgcn_exp2f(st[t][e] - m_new);
+        rs += st[t][e];
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * corr + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o_acc[0][e] *= corr; o_acc[1][e] *= corr; }
+
+    // O^T += V^T P^T : B fragments straight from the P^T accumulators, A = V^T by transposing reads of the [key][d] image
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 p0 = {st[t][8 * s], st[t][8 * s + 1], st[t][8 * s + 2], st[t][8 * s + 3]};
+        f32x4 p1 = {st[t][8 * s + 4], st[t][8 * s + 5], st[t][8 * s + 6], st[t][8 * s + 7]};
+        bf16x4 h0, l0, h1, l1;
+        split4(p0, h0, l0);
+        split4(p1, h1, l1);
+        const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const char* vr = Vt + (t * 32 + s * 16) * AQ_VP + dt * 64 + tr_off;
+          const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr));
+          const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + 8 * AQ_VP));
+          const s16x4 wa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + 128));
+          const s16x4 wb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vr + 8 * AQ_VP + 128));
+          const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7));
+          const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(wa, wb, 0, 1, 2, 3, 4, 5, 6, 7));
+          o_acc[dt] = mfma3(vh, vl, ph, pl, o_acc[dt]);
+        }
+      }
+  };
+  int k0 = 0;
+  for (; k0 + AT_BK <= N; k0 += AT_BK) tile(k0, std::false_type{});
+  if (k0 < N) tile(k0, std::true_type{});
+
+  __syncthreads();
+  float* strip = reinterpret_cast<float*>(smem) + wave * 32 * 66;
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) strip[r32 * 66 + dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = o_acc[dt][e] * inv;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  if (out_ss) {
+    for (int i = lane; i < 32 * 8; i += 64) {
+      const int qr = i >> 3, kg = i & 7;
+      const int q = qt * AT_BQ + wave * 32 + qr;
+      if (q < N) {
+        const float* sp = strip + qr * 66 + kg * 8;
+        const f32x4 v0 = {sp[0], sp[1], sp[2], sp[3]}, v1 = {sp[4], sp[5], sp[6], sp[7]};
+        bf16x4 h0, l0, h1, l1;
+        split4(v0, h0, l0);
+        split4(v1, h1, l1);
+        const long long row = row_b + q;
+        char* const rowp = out_ss + row * ((long long)D * 4) + (head * 2 + (kg >> 2)) * 128;
+        const int chunk = kg & 3, k2 = (int)((row >> 1) & 7);
+        *reinterpret_cast<bf16x8*>(rowp + ((chunk ^ k2) << 4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8*>(rowp + (((4 + chunk) ^ k2) << 4)) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+    return;
+  }
+  for (int i = lane; i < 32 * 16; i += 64) {
+    const int qr = i >> 4, c4 = (i & 15) * 4;
+    const int q = qt * AT_BQ + wave * 32 + qr;
+    if (q < N) {
+      const float* sp = strip + qr * 66 + c4;
+      f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
+      *reinterpret_cast<f32x4*>(out + (row_b + q) * D + head * 64 + c4) = v;
+    }
+  }
+}
+
+}  // namespace prv2
+
+extern "C" int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok, int32_t heads, int32_t hd, const float* bias, int32_t ld_bias,
+                                     float* out, void* out_ss, void* stream) {
+  using namespace prv2;
+  PRV2_REQUIRE(qkv_ss && (out || out_ss) && !(out && out_ss), "attention_qkv_ss: null pointer / exactly one of out, out_ss");
+  PRV2_REQUIRE(b > 0 && ntok > 0 && heads > 0 && hd == 64, "attention: head_dim must be 64 (got %d)", hd);
+  PRV2_REQUIRE((reinterpret_cast<uintptr_t>(qkv_ss) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_ss) & 15) == 0,
+               "attention_qkv_ss: 16-byte alignment");
+  PRV2_REQUIRE(!bias || ld_bias == PRV2_ATTENTION_BIAS_IMAGE || (ld_bias >= roundup(ntok, 64) && ld_bias % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+               "attention: bias rows must be 16-byte aligned and padded to a multiple of 64 keys (ld_bias %d, ntok %d)", ld_bias, ntok);
+  const char* q = reinterpret_cast<const char*>(qkv_ss);
+  char* oss = reinterpret_cast<char*>(out_ss);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
+  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {
+    int q32n = (int)cdiv(ntok, AT_BQ) * (AT_BQ / 32), ktn = (int)cdiv(ntok, AT_BK);
+    (void)q32n;
+    hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, ntok, heads, bias, ktn, out, oss);
+  } else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
+  PRV2_LAUNCH_CHECK("attention_qkv_ss");
+  return 0;
+}
+
 namespace prv2 {
 // bias rows [heads][N][ldb] -> the image attention_bf16x3_kernel<2> reads: thread = one f32x4 of it
 __global__ void __launch_bounds__(256) pack_attention_bias_kernel(const float* __restrict__ bias, int heads, int N, int ldb, float* __restrict__ dst,

@@ -42,6 +42,9 @@ struct GemmSSParams {
   long long ldy_ss;
   int act;
   int tiles_n, tiles_m, blocked;
+  int vgrid;         // persistent form: tile ids to walk (ids behind the tiles idle, as the one-tile-per-workgroup grid's do)
+  int scale_cols;    // split output: columns [0, scale_cols) are multiplied by ``scale`` behind bias / activation (the q third of a
+  float scale;       // qkv Linear: hd^-0.5 log2 e, what qkv_split_kernel used to apply -- attention.hip reads the rows as they are)
 };
 
 // NS = LDS stages.  2: slab k + 1 in flight while slab k multiplies (what the LDS allows for 256 x 256 tiles and for two 128 x 128
@@ -308,6 +311,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
               v0[e] = act_apply(v0[e], ACT);
               v1[e] = act_apply(v1[e], ACT);
             }
+            if (gcol < p.scale_cols) {  // (scale_cols is a multiple of 8: a group is scaled whole)
+              v0 *= p.scale;
+              v1 *= p.scale;
+            }
             bf16x4 h0, l0, h1, l1;
             split_bf16(v0, h0, l0);
             split_bf16(v1, h1, l1);
@@ -322,6 +329,274 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
       }
     }
     __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next row block
+  }
+}
+
+// ---- the 256 x 256 tile as a PERSISTENT workgroup (one per CU) -------------------------------------------------------------------
+// Same tile, same slab order, same three products per slab in the same order, same epilogue arithmetic as gemm_ss_kernel<2, 4, 8, 4>: bit-equal
+// results.  What changes is what the matrix pipe waits for:
+//  * a workgroup walks its tiles v = blockIdx.x, + gridDim.x, ... of the same XCD-chunked / 4 x 8-blocked order; the LAST slab of a tile issues
+//    the DMA of the NEXT tile's first slab into the stage the epilogue does not use, so the next tile's K loop starts on landed operands (the
+//    one-tile kernel pays a cold L2 / HBM round trip per tile: nothing to overlap it with at one workgroup per CU);
+//  * the eight 1 KB LDS-DMA pieces a wave issues per slab are spread BEHIND the row blocks' MFMAs (PPB pieces after each of the first 8 / PPB
+//    row blocks) instead of all eight in front of the slab's first MFMA: issuing a piece costs a wave 60-185 cycles (MI355X_MICROARCH.md,
+//    "LDS-DMA piece issue cost"), and with all eight waves doing it right behind the barrier the pipe idled ~1 k of a slab's ~6 k cycles
+//    (profiles/r04_experiments.txt #9: "operand DMA 15 %").  The stage being filled was released by the barrier at the top of the slab, so a
+//    piece may go out at any point of it; early enough that the slab's remaining MFMA time covers its L2 round trip.
+// The epilogue strips live in the stage of the tile's last slab (free behind one barrier); the other stage is receiving the next tile.
+// The tile's store loop.  A lane's columns are the same in every row block (c4 / kg below depend on the lane only): bias and gamma are fetched
+// once per tile, the residual rows of a row block in one batch of loads AHEAD of the block's LDS round trip (the one-tile kernel's loop asks for
+// bias, gamma and residual again in each of its 32 passes and drains vmcnt(0) in each: a serial chain of L2 round trips, ~10 us per tile).
+template <int RI, int RJ, bool OUT_SS, int ACT>
+__device__ __forceinline__ void gss_store_rows(const f32x4 (&acc)[RI][RJ], const GemmSSParams& p, float* const strip, const long long wrow0, const int wcol0,
+                                               const int lane) {
+  constexpr int STRIP_LD = RJ * 16 + 4;
+  const int m16 = lane & 15, g = lane >> 4;
+  if constexpr (!OUT_SS) {
+    constexpr int LPR = RJ * 4, RPI = 64 / LPR, NQ = 16 / RPI;  // lanes per row (16 bytes each), rows per pass, passes per row block
+    const int c4 = (lane % LPR) * 4, r_in = lane / LPR;
+    const int gcol = wcol0 + c4;
+    const bool col_ok = gcol < p.N;
+    const bool has_res = p.res != nullptr, has_gamma = p.gamma != nullptr;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+    if (p.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + gcol);
+    if (has_gamma && col_ok) gv = *reinterpret_cast<const f32x4*>(p.gamma + gcol);
+    f32x4 rv[NQ];
+    auto fetch_res = [&](int i) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const long long grow = wrow0 + i * 16 + q * RPI + r_in;
+        rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (grow < p.M && col_ok) rv[q] = *reinterpret_cast<const f32x4*>(p.res + grow * p.ld_res + gcol);
+      }
+    };
+    if (has_res) fetch_res(0);
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+#pragma unroll
+      for (int j = 0; j < RJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) strip[(4 * g + e) * STRIP_LD + j * 16 + m16] = acc[i][j][e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 ov[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(&strip[(q * RPI + r_in) * STRIP_LD + c4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = act_apply(cv[e] + bv[e], ACT);
+          if (has_gamma) t *= gv[e];
+          if (has_res) t += rv[q][e];
+          ov[q][e] = t;
+        }
+      }
+      if (has_res && i + 1 < RI) fetch_res(i + 1);  // (travels under the next row block's LDS round trip)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const long long grow = wrow0 + i * 16 + q * RPI + r_in;
+        if (grow < p.M && col_ok) {
+          // (a store the compiler sees: its counted vmcnt waits for the prefetched residual rows then leave these stores in flight)
+          *reinterpret_cast<f32x4*>(p.y + grow * p.ldy + gcol) = ov[q];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next row block
+    }
+  } else {
+    constexpr int GPR = RJ * 2, RPI = 64 / GPR, NQ = 16 / RPI;  // 8-column groups per row, rows per pass
+    const int kg = lane % GPR, r_in = lane / GPR;
+    const int gcol = wcol0 + kg * 8;
+    const bool col_ok = gcol < p.N;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias && col_ok) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + gcol);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + gcol + 4);
+    }
+    const float cs = gcol < p.scale_cols ? p.scale : 1.0f;  // (scale_cols is a multiple of 8: a group is scaled whole; x 1.0f is exact)
+    const int chunk = (gcol & 31) >> 3;
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+#pragma unroll
+      for (int j = 0; j < RJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) strip[(4 * g + e) * STRIP_LD + j * 16 + m16] = acc[i][j][e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int rl = q * RPI + r_in;
+        const long long grow = wrow0 + i * 16 + rl;
+        const float* sp = &strip[rl * STRIP_LD + kg * 8];
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp) + b0, v1 = *reinterpret_cast<const f32x4*>(sp + 4) + b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = act_apply(v0[e], ACT);
+          v1[e] = act_apply(v1[e], ACT);
+        }
+        v0 *= cs;
+        v1 *= cs;
+        bf16x4 h0, l0, h1, l1;
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        if (grow < p.M && col_ok) {
+          char* const rowp = p.y_ss + grow * p.ldy_ss + (gcol >> 5) * 128;
+          const int k2 = (int)((grow >> 1) & 7);
+          *reinterpret_cast<bf16x8*>(rowp + ((chunk ^ k2) << 4)) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          *reinterpret_cast<bf16x8*>(rowp + (((4 + chunk) ^ k2) << 4)) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// PPB: DMA pieces issued behind each of the first 8 / PPB row blocks (8: all in front of the slab, the one-tile kernel's order)
+template <bool OUT_SS, int ACT, int PPB>
+__global__ void __launch_bounds__(512, 1) gemm_ss_p_kernel(const GemmSSParams p) {
+  constexpr int WN = 4, RI = 8, RJ = 4, TM = 256, TN = 256;
+  constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int STRIP_LD = RJ * 16 + 4, STRIP_BYTES = 16 * STRIP_LD * 4;
+  static_assert(8 * STRIP_BYTES <= STAGE, "the epilogue strips fit in one stage");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int G = p.vgrid, nwg = gridDim.x;
+
+  auto decode = [&](int v, int& tm, int& tn) -> bool {  // virtual id -> tile (gemm_ss_kernel's map over a grid of G workgroups)
+    const int q = G >> 3, r = G & 7, xcd = v & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    if (p.blocked) {
+      const int blk = bid >> 5, within = bid & 31, bpr = p.tiles_n >> 3;
+      tm = (blk / bpr) * 4 + (within >> 3);
+      tn = (blk % bpr) * 8 + (within & 7);
+      return tm < p.tiles_m;
+    }
+    tn = bid % p.tiles_n;
+    tm = bid / p.tiles_n;
+    return true;
+  };
+  const int dr = lane >> 3, dsl = lane & 7;
+  const char* a_src[4];
+  const char* b_src[4];
+  auto point = [&](int tm, int tn) {  // this wave's four A and four B pieces of a tile: rows (wave * 4 + i) * 8 + (lane >> 3), 16-byte slot lane & 7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long long r = (long long)tm * TM + (wave * 4 + i) * 8 + dr;
+      r = r < p.M ? r : p.M - 1;
+      a_src[i] = p.a + r * p.lda + dsl * 16;
+      int n = tn * TN + (wave * 4 + i) * 8 + dr;
+      n = n < p.w_rows ? n : p.w_rows - 1;
+      b_src[i] = p.w + (long long)n * p.ldw + dsl * 16;
+    }
+  };
+  const unsigned smem_base = (unsigned)(size_t)smem;
+  auto dma = [&](const char* src, unsigned dst) {  // (dst is wave-uniform by construction: scalar registers only)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+  };
+  auto piece = [&](int j, unsigned sb, long long koff) {
+    if (j < 4) dma(a_src[j] + koff, sb + (wave * 4 + j) * 1024);
+    else dma(b_src[j - 4] + koff, sb + A_BYTES + (wave * 4 + j - 4) * 1024);
+  };
+
+  const int key = (m16 >> 1) & 7;
+  const int a_off_hi = (wm * RI * 16 + m16) * 128 + ((g ^ key) << 4), a_off_lo = (wm * RI * 16 + m16) * 128 + (((4 + g) ^ key) << 4);
+  const int b_off_hi = A_BYTES + (wn * RJ * 16 + m16) * 128 + ((g ^ key) << 4);
+  const int b_off_lo = A_BYTES + (wn * RJ * 16 + m16) * 128 + (((4 + g) ^ key) << 4);
+
+  int v = blockIdx.x, tm = 0, tn = 0;
+  while (v < G && !decode(v, tm, tn)) v += nwg;
+  if (v >= G) return;
+  point(tm, tn);
+  int st = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) piece(j, smem_base, 0);
+
+  for (;;) {
+    const long long wrow0 = (long long)tm * TM + wm * RI * 16;
+    const int wcol0 = tn * TN + wn * RJ * 16;
+    f32x4 acc[RI][RJ];
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int vn = G, tmn = 0, tnn = 0;
+    for (int k = 0; k < p.kslabs; ++k) {
+      // my pieces of slab k have landed (and my stores of the previous tile are out); behind the barrier everyone's have, and everyone is done
+      // with the other stage (slab k - 1, or the previous tile's strips)
+#ifdef PRV2_GSS_NOBAR
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+      long long koff = (long long)(k + 1) * 128;
+      bool has_next = true;
+      if (k + 1 == p.kslabs) {  // the last slab issues the NEXT tile's first slab (this tile's sources are no longer needed)
+        vn = v + nwg;
+        while (vn < G && !decode(vn, tmn, tnn)) vn += nwg;
+        has_next = vn < G;
+        if (has_next) point(tmn, tnn);
+        koff = 0;
+      }
+#ifdef PRV2_GSS_NODMA
+      has_next = has_next && k < 1 && v == (int)blockIdx.x;
+#endif
+      const char* const sb = smem + st * STAGE;
+      const unsigned nb = smem_base + (st ^ 1) * STAGE;
+      if (PPB == 8 && has_next) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piece(j, nb, koff);
+      }
+#ifndef PRV2_GSS_NOMMA
+      bf16x8 bh[RJ], bl[RJ], ah[2], al[2];
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_off_hi + j * 2048);
+        bl[j] = *reinterpret_cast<const bf16x8*>(sb + b_off_lo + j * 2048);
+      }
+      ah[0] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi);
+      al[0] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo);
+#pragma unroll
+      for (int i = 0; i < RI; ++i) {
+        if (i + 1 < RI) {
+          ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_hi + (i + 1) * 2048);
+          al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sb + a_off_lo + (i + 1) * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PPB < 8 && i * PPB < 8 && has_next) {
+#pragma unroll
+          for (int j = 0; j < PPB; ++j) piece(i * PPB + j, nb, koff);
+        }
+      }
+#endif
+      st ^= 1;
+    }
+    // the tile's last slab sits in stage st ^ 1: once everyone has read it, it carries the epilogue strips (stage st is receiving the next tile)
+    asm volatile("s_barrier" ::: "memory");
+#ifdef PRV2_GSS_NOEPI
+    {
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < RI; ++i)
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) sum += acc[i][j];
+      if (sum[0] == 12345.678f) p.y[threadIdx.x] = sum[1] + sum[2] + sum[3];
+    }
+#else
+    gss_store_rows<RI, RJ, OUT_SS, ACT>(acc, p, reinterpret_cast<float*>(smem + (st ^ 1) * STAGE + wave * STRIP_BYTES), wrow0, wcol0, lane);
+#endif
+    if (vn >= G) break;
+    v = vn;
+    tm = tmn;
+    tn = tnn;
   }
 }
 
@@ -360,9 +635,33 @@ extern "C" int prv2_split_ss(const float* x, int64_t rows, int32_t c, int32_t ld
   return 0;
 }
 
+template <bool OUT_SS, int ACT>
+static void launch_gss_p(int ppb, dim3 grid, hipStream_t s, const GemmSSParams& p) {
+  switch (ppb) {
+    case 8: hipLaunchKernelGGL((gemm_ss_p_kernel<OUT_SS, ACT, 8>), grid, dim3(512), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((gemm_ss_p_kernel<OUT_SS, ACT, 4>), grid, dim3(512), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((gemm_ss_p_kernel<OUT_SS, ACT, 1>), grid, dim3(512), 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_ss_p_kernel<OUT_SS, ACT, 2>), grid, dim3(512), 0, s, p); break;
+  }
+}
+
+static int gemm_ss_impl(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias, const float* gamma, const float* res,
+                        int32_t ld_res, int32_t act, float* y, int32_t ldy, void* y_ss, int32_t scale_cols, float scale, void* stream);
+
 extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias,
                             const float* gamma, const float* res, int32_t ld_res, int32_t act, float* y, int32_t ldy, void* y_ss,
                             void* stream) {
+  return gemm_ss_impl(a_ss, m, k, w_packed, n, bias, gamma, res, ld_res, act, y, ldy, y_ss, 0, 1.0f, stream);
+}
+
+extern "C" int prv2_gemm_ss_qkv(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias, int32_t q_cols, float q_scale,
+                                void* qkv_ss, void* stream) {
+  PRV2_REQUIRE(q_cols >= 0 && q_cols <= n && q_cols % 32 == 0, "gemm_ss_qkv: q_cols must be a multiple of 32 within n (q_cols=%d n=%d)", q_cols, n);
+  return gemm_ss_impl(a_ss, m, k, w_packed, n, bias, nullptr, nullptr, 0, PRV2_ACT_NONE, nullptr, 0, qkv_ss, q_cols, q_scale, stream);
+}
+
+static int gemm_ss_impl(const void* a_ss, int64_t m, int32_t k, const void* w_packed, int32_t n, const float* bias, const float* gamma, const float* res,
+                        int32_t ld_res, int32_t act, float* y, int32_t ldy, void* y_ss, int32_t scale_cols, float scale, void* stream) {
   PRV2_REQUIRE(a_ss && w_packed && (y || y_ss) && !(y && y_ss), "gemm_ss: null pointer / exactly one of y, y_ss");
   PRV2_REQUIRE(m > 0 && k > 0 && k % 32 == 0 && n > 0 && n % 8 == 0, "gemm_ss: k must be a multiple of 32, n of 8 (m=%lld k=%d n=%d)",
                (long long)m, k, n);
@@ -384,6 +683,8 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
   p.y_ss = reinterpret_cast<char*>(y_ss);
   p.ldy_ss = (long long)n * 4;
   p.act = act;
+  p.scale_cols = scale_cols;
+  p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
   const char* const fe = getenv("PRV2_GEMM_SS_TILE");  // A/B switch (128 / 256), read per call so that one process can time both
   const int force = fe ? atoi(fe) : 0;
@@ -418,8 +719,21 @@ extern "C" int prv2_gemm_ss(const void* a_ss, int64_t m, int32_t k, const void* 
     p.tiles_m = (int)cdiv(m, 256);
     p.blocked = (be ? atoi(be) != 0 : true) && p.tiles_n % 8 == 0 && p.tiles_m >= 8;
     const dim3 grid((unsigned)((p.blocked ? roundup(p.tiles_m, 4) : p.tiles_m) * p.tiles_n));
+    const char* const pe = getenv("PRV2_GSS_PERSIST");  // A/B switch (0: one tile per workgroup)
     const char* const dfe = getenv("PRV2_GSS_DEFER");  // A/B switch; OFF by default: same time within noise (profiles/r04_experiments.txt)
-    if (dfe ? atoi(dfe) != 0 : false) {
+    if ((pe ? atoi(pe) != 0 : true) && (y_ss || act == PRV2_ACT_NONE)) {  // (fp32 rows + GELU: no layer has it; the one-tile kernel keeps the form)
+      // persistent workgroups, one per CU, walking the same tile order (gemm_ss_p_kernel); ids dealt to XCDs as the grid's would be
+      p.vgrid = (int)grid.x;
+      const char* const ppe = getenv("PRV2_GSS_PPB");  // A/B switch: DMA pieces behind each row block (1, 2, 4; 8 = all in front)
+      const int ppb = ppe ? atoi(ppe) : 2;
+      const dim3 pgrid((unsigned)(p.vgrid < 256 ? p.vgrid : 256));
+      if (y_ss) {
+        if (act == PRV2_ACT_GELU) launch_gss_p<true, PRV2_ACT_GELU>(ppb, pgrid, s, p);
+        else launch_gss_p<true, PRV2_ACT_NONE>(ppb, pgrid, s, p);
+      } else {
+        launch_gss_p<false, PRV2_ACT_NONE>(ppb, pgrid, s, p);
+      }
+    } else if (dfe ? atoi(dfe) != 0 : false) {
       if (y_ss) {
         if (act == PRV2_ACT_GELU) hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, true, PRV2_ACT_GELU, 2, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_ss_kernel<2, 4, 8, 4, true, PRV2_ACT_NONE, 2, true>), grid, dim3(512), 0, s, p);

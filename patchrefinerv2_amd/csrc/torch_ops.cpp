@@ -578,6 +578,31 @@ Tensor attention_ss(const Tensor& qkv, int64_t b, int64_t ntok, int64_t heads, c
   return out;
 }
 
+Tensor gemm_ss_qkv(const Tensor& a_ss, const Tensor& w_packed, int64_t cout, const optional<Tensor>& bias, int64_t q_cols, double q_scale) {
+  dev_f32(a_ss, "a_ss"); dev_f32(w_packed, "w_packed");
+  TORCH_CHECK(a_ss.dim() == 2 && a_ss.is_contiguous(), "prv2::gemm_ss_qkv: a_ss is a dense [rows, k] container");
+  Tensor y = at::empty({a_ss.size(0), cout}, a_ss.options());
+  Launch L(a_ss);
+  ok(prv2_gemm_ss_qkv(a_ss.data_ptr(), a_ss.size(0), (int)a_ss.size(1), w_packed.data_ptr(), (int)cout, opt_ptr(bias, "bias", cout), (int)q_cols, (float)q_scale, y.data_ptr(),
+                      L.stream), "gemm_ss_qkv");
+  return y;
+}
+Tensor attention_qkv_ss(const Tensor& qkv_ss, int64_t b, int64_t ntok, int64_t heads, const optional<Tensor>& bias, bool bias_image, bool out_ss) {
+  dev_f32(qkv_ss, "qkv_ss");
+  TORCH_CHECK(qkv_ss.is_contiguous() && qkv_ss.numel() == b * ntok * 3 * heads * 64, "prv2::attention_qkv_ss: qkv_ss must be a dense [b * ntok, 3 * heads * 64] container");
+  if (bias.has_value()) {
+    dev_f32(*bias, "bias");
+    TORCH_CHECK(bias->is_contiguous() && (bias_image ? bias->numel() * 4 == prv2_attention_bias_image_bytes((int)heads, (int)ntok) : bias->dim() == 3),
+                "prv2::attention_qkv_ss: bias is [heads, ntok, ld] or a pack_attention_bias image");
+  }
+  Tensor out = at::empty({b * ntok, heads * 64}, qkv_ss.options());
+  Launch L(qkv_ss);
+  ok(prv2_attention_qkv_ss(qkv_ss.data_ptr(), (int)b, (int)ntok, (int)heads, 64, bias.has_value() ? bias->data_ptr<float>() : nullptr,
+                           bias.has_value() ? (bias_image ? PRV2_ATTENTION_BIAS_IMAGE : (int)bias->size(2)) : 0, out_ss ? nullptr : out.data_ptr<float>(),
+                           out_ss ? out.data_ptr() : nullptr, L.stream), "attention_qkv_ss");
+  return out;
+}
+
 // input stage and small placement kernels
 Tensor bicubic_resize(const Tensor& img_hwc, int64_t oh, int64_t ow) {
   TORCH_CHECK(img_hwc.is_cuda() && (img_hwc.scalar_type() == at::kByte || img_hwc.scalar_type() == at::kFloat) && img_hwc.dim() == 3 && img_hwc.size(2) == 3 &&
@@ -856,6 +881,8 @@ TORCH_LIBRARY(prv2, m) {
   m.def("gemm_ss(Tensor a_ss, Tensor w_packed, int cout, Tensor? bias=None, Tensor? gamma=None, Tensor? res=None, int act=0, bool out_ss=False, "
         "Tensor(a!)? out=None) -> Tensor");
   m.def("attention_ss(Tensor qkv, int b, int ntok, int heads, Tensor? bias=None, bool bias_image=False) -> Tensor");
+  m.def("gemm_ss_qkv(Tensor a_ss, Tensor w_packed, int cout, Tensor? bias, int q_cols, float q_scale) -> Tensor");
+  m.def("attention_qkv_ss(Tensor qkv_ss, int b, int ntok, int heads, Tensor? bias=None, bool bias_image=False, bool out_ss=True) -> Tensor");
   m.def("bicubic_resize(Tensor img_hwc, int oh, int ow) -> Tensor");
   m.def("depth_pair_fill(Tensor p1, Tensor p2, Tensor(a!) tail) -> ()");
   m.def("conv_border_bias_(Tensor(a!) y, Tensor tap_bias) -> ()");
@@ -911,6 +938,8 @@ TORCH_LIBRARY_IMPL(prv2, CUDA, m) {
   m.impl("layernorm_ss", &layernorm_ss);
   m.impl("gemm_ss", &gemm_ss);
   m.impl("attention_ss", &attention_ss);
+  m.impl("gemm_ss_qkv", &gemm_ss_qkv);
+  m.impl("attention_qkv_ss", &attention_qkv_ss);
   m.impl("bicubic_resize", &bicubic_resize);
   m.impl("depth_pair_fill", &depth_pair_fill);
   m.impl("conv_border_bias_", &conv_border_bias_);

@@ -21,7 +21,7 @@ PREC_LABEL = {PREC_F32: "f32", PREC_BF16X3: "bf16x3", PREC_BF16: "bf16", PREC_F1
 # (stage 1: GatedConvUnit.conv, csrc/conv3x3_f6.hip) -- the modules map the name to PREC_BF16X3 and fusion.py looks at the name itself
 PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16f6": PREC_BF16X3}
 FMT_X_X2, FMT_MUL_X2, FMT_Y_X2 = 1, 2, 4  # prv2_conv_desc.fmt: operands in the pre-split "X2" activation format
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class ConvDesc(C.Structure):
@@ -81,6 +81,8 @@ SIGNATURES = {
     "prv2_layernorm_ss": (_I, [_P, _L, _I, _I, _P, _P, _F, _P, _P]),
     "prv2_attention_ss": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _L, _P]),
     "prv2_gemm_ss": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P]),
+    "prv2_gemm_ss_qkv": (_I, [_P, _L, _I, _P, _I, _P, _I, _F, _P, _P]),
+    "prv2_attention_qkv_ss": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "prv2_attention_workspace_bytes": (_L, [_I, _I, _I, _I]),
     "prv2_bicubic_resize": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "prv2_add": (_I, [_P, _I, _P, _I, _L, _I, _P, _I, _P]),

@@ -181,8 +181,11 @@ class MidasBeitCore(StateDictModule):
         for i, blk in enumerate(P["blocks"]):
             if use_ss:
                 ops.layernorm_ss(x, M, D, D, blk["n1w"], blk["n1b"], 1e-6, h)
-                qkv = ops.gemm_ss(h, blk["qkv"])
-                a = ops.attention(qkv, B, N, heads, self.prec, bias=biases[i], out_ss=True)
+                if ops.QKV_SS:  # (no pre-pass: the Linear writes the attention kernel's operands; same bits)
+                    a = ops.attention_qkv_ss(ops.gemm_ss_qkv(h, blk["qkv"], heads), B, N, heads, bias=biases[i])
+                else:
+                    qkv = ops.gemm_ss(h, blk["qkv"])
+                    a = ops.attention(qkv, B, N, heads, self.prec, bias=biases[i], out_ss=True)
                 ops.gemm_ss(a, blk["proj"], out=x, gamma=blk["g1"], res=x)
                 ops.layernorm_ss(x, M, D, D, blk["n2w"], blk["n2b"], 1e-6, h)
                 f = ops.gemm_ss(h, blk["fc1"], act=ACT_GELU, out_ss=True)

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import numpy as np
 import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -980,6 +981,57 @@ def gemm_ss(a_ss: torch.Tensor, cw: ConvW, out: Optional[torch.Tensor] = None, *
                                  out.data_ptr() if out_ss else None, _stream()), "gemm_ss")
     PROFILER.launch(lambda: lib.prv2_last_kernel().decode(), 2.0 * M * K * cw.cout, call, shape=f"{K}->{cw.cout} k1s1 1x{M}x1")
     return out
+
+
+QKV_SS = os.environ.get("PRV2_QKV_SS", "1") != "0"  # A/B and test switch: the attention block without the qkv_split pre-pass
+Q_SCALE = float(np.float32(0.125) * np.float32(1.4426950408889634))  # hd^-0.5 log2 e at head_dim 64: the float32 product qkv_split_kernel multiplies with
+
+
+def gemm_ss_qkv(a_ss: torch.Tensor, cw: ConvW, heads: int) -> torch.Tensor:
+    """the qkv Linear of an attention block on split-swizzled rows -> split-swizzled [q * hd^-0.5 log2 e | k | v] rows, the operand of
+    ``attention_qkv_ss`` (include/prv2.h::prv2_gemm_ss_qkv)"""
+    M, K = a_ss.shape
+    assert cw.prec == L.PREC_BF16X3 and cw.kh == 1 and cw.kw == 1 and cw.cin == K and K % 32 == 0 and cw.cout == 3 * heads * 64, (cw.prec, cw.cin, K, cw.cout)
+    lib = L.load()
+    q_scale = Q_SCALE
+    res = []
+
+    def call():
+        if DISPATCH == "torch":
+            res.append(_tops().gemm_ss_qkv(a_ss, cw.w, cw.cout, cw.bias, heads * 64, q_scale))
+            return
+        out = torch.empty((M, cw.cout), device=a_ss.device, dtype=torch.float32)
+        L.check(lib.prv2_gemm_ss_qkv(a_ss.data_ptr(), M, K, cw.w.data_ptr(), cw.cout, _ptr(cw.bias), heads * 64, q_scale, out.data_ptr(), _stream()), "gemm_ss_qkv")
+        res.append(out)
+    PROFILER.launch(lambda: lib.prv2_last_kernel().decode(), 2.0 * M * K * cw.cout, call, shape=f"{K}->{cw.cout} k1s1 1x{M}x1")
+    return res[0]
+
+
+def attention_qkv_ss(qkv_ss: torch.Tensor, b: int, ntok: int, heads: int, bias=None, out_ss: bool = True) -> torch.Tensor:
+    """softmax(q k^T + bias) v on ``gemm_ss_qkv``'s rows (bf16x3); bit-equal to ``attention`` on the fp32 rows of the same Linear"""
+    lib = L.load()
+    image = isinstance(bias, AttnBiasImage)
+    if image:
+        assert (bias.heads, bias.ntok) == (heads, ntok)
+        bias_t, ld_bias = bias.image, -1
+    elif bias is not None:
+        _require_dev(bias)
+        assert bias.is_contiguous() and bias.shape[0] == heads and bias.shape[1] == ntok
+        bias_t, ld_bias = bias, bias.shape[2]
+    else:
+        bias_t, ld_bias = None, 0
+    res = []
+
+    def call():
+        if DISPATCH == "torch":
+            res.append(_tops().attention_qkv_ss(qkv_ss, b, ntok, heads, bias_t, image, out_ss))
+            return
+        out = torch.empty((b * ntok, heads * 64), device=qkv_ss.device, dtype=torch.float32)
+        L.check(lib.prv2_attention_qkv_ss(qkv_ss.data_ptr(), b, ntok, heads, 64, _ptr(bias_t), ld_bias, None if out_ss else out.data_ptr(),
+                                          out.data_ptr() if out_ss else None, _stream()), "attention_qkv_ss")
+        res.append(out)
+    PROFILER.launch("attention_qkvss_kernel", 4.0 * b * heads * ntok * ntok * 64, call)
+    return res[0]
 
 
 def patchify(img: Feat, p: int, ldo: int) -> torch.Tensor:

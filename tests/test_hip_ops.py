@@ -742,6 +742,63 @@ def test_gemm_ss_bit_equal_to_gemm16(P, M, K, N, tile, monkeypatch):
     assert torch.equal(a, bq)
 
 
+@pytest.mark.parametrize("M,K,N", [(9000, 96, 2048), (23000, 160, 768), (16500, 128, 1024)])  # 288 (4 x 8-blocked) / 270 / 260 tiles of 256 x 256: > 256 workgroups
+@pytest.mark.parametrize("ppb", ["1", "2", "4", "8"])
+def test_gemm_ss_persistent_workgroups_walk_several_tiles_bit_equal(P, M, K, N, ppb, monkeypatch):
+    """gemm_ss_p_kernel (one persistent workgroup per CU: the next tile's first slab is DMA'd under the current tile's last slab and
+    epilogue, the LDS stage parity carries over from tile to tile -- odd and even slab counts) == the one-tile-per-workgroup kernel
+    == gemm16_kernel, bit for bit, for every DMA spread PPB; fp32 rows with gamma + residual (in place, as the ViT blocks call it) and
+    split-swizzled rows with GELU / the qkv column scale."""
+    monkeypatch.setenv("PRV2_GEMM_SS_TILE", "256")
+    monkeypatch.setenv("PRV2_GSS_PPB", ppb)
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    cw = P.pack_conv((torch.randn(N, K, generator=g) / K ** 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV), prec=P.L.PREC_BF16X3)
+    gam, res = (1 + 0.1 * torch.randn(N, generator=g)).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    xs = P.split_ss(x)
+    got = {}
+    for persist in ("1", "0"):
+        monkeypatch.setenv("PRV2_GSS_PERSIST", persist)
+        r_in = res.clone()
+        got[persist] = (P.gemm_ss(xs, cw), P.gemm_ss(xs, cw, gamma=gam, res=r_in, out=r_in), P.gemm_ss(xs, cw, act=P.ACT_GELU, out_ss=True))
+        assert P.L.load().prv2_last_kernel().decode().startswith("gemm_ss")
+    for a, b in zip(got["1"], got["0"]):
+        assert torch.equal(a, b)
+    assert torch.equal(got["1"][0], P.linear(x, cw)) and torch.equal(got["1"][1], P.linear(x, cw, gamma=gam, res=res))
+
+
+@pytest.mark.parametrize("B,N,H,bias", [(3, 259, 6, None), (2, 1025, 16, None), (2, 769, 16, "image"), (1, 130, 2, "rows"), (5, 37, 3, None)])
+def test_attention_on_split_swizzled_qkv_is_bit_equal_to_the_pre_pass_path(P, B, N, H, bias):
+    """prv2_gemm_ss_qkv -> prv2_attention_qkv_ss (the Linear writes bf16 hi / lo with q pre-scaled, the attention kernel reads those rows and
+    transposes V with ds_read_b64_tr_b16) == prv2_gemm_ss (fp32 rows) -> qkv_split_kernel -> attention_bf16x3_kernel, bit for bit: split-swizzled
+    and fp32 output rows, no bias / bias rows / the packed bias image; 1025 and 769 tokens are the DINOv2 / BEiT sequence lengths (one query in the
+    last query tile, keys masked in the last key tile); rows of a batch > 1 start at odd global rows (the swizzle key is a function of the global row)."""
+    g = torch.Generator().manual_seed(B * N + H)
+    D, M = H * 64, B * N
+    x = torch.randn(M, D, generator=g).to(DEV)
+    cw = P.pack_conv((torch.randn(3 * D, D, generator=g) / D ** 0.5).to(DEV), (torch.randn(3 * D, generator=g) * 0.1).to(DEV), prec=P.L.PREC_BF16X3)
+    xs = P.split_ss(x)
+    bt = None
+    if bias is not None:
+        ld = -(-N // 64) * 64
+        rows = torch.zeros(H, N, ld)
+        rows[:, :, :N] = torch.randn(H, N, N, generator=g)
+        bt = P.pack_attention_bias(rows.to(DEV), N) if bias == "image" else rows.to(DEV)
+    qkv = P.gemm_ss(xs, cw)
+    qkv_ss = P.gemm_ss_qkv(xs, cw, H)
+    for out_ss in (True, False):
+        ref = P.attention(qkv, B, N, H, P.L.PREC_BF16X3, bias=bt, out_ss=out_ss)
+        got = P.attention_qkv_ss(qkv_ss, B, N, H, bias=bt, out_ss=out_ss)
+        assert torch.equal(ref, got), (out_ss, float((ref - got).abs().max()))
+    # and against float64 softmax attention (the tolerance of test_attention's bf16x3 case)
+    q, k, v = (t.reshape(B, N, H, 64).permute(0, 2, 1, 3).double().cpu() for t in qkv.reshape(B, N, 3, H, 64).unbind(2))
+    sc = q @ k.transpose(-1, -2) * 0.125
+    if bias is not None:
+        sc = sc + rows[None, :, :, :N].double()
+    want = (sc.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(M, D)
+    assert float((got.double().cpu() - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_layernorm_ss_and_attention_ss_feed_gemm_ss_bit_equal(P):
     g = torch.Generator().manual_seed(5)
     M, D = 777, 384
