@@ -430,8 +430,13 @@ __device__ __forceinline__ void gss_store_rows(const f32x4 (&acc)[RI][RJ], const
         f32x4 v0 = *reinterpret_cast<const f32x4*>(sp) + b0, v1 = *reinterpret_cast<const f32x4*>(sp + 4) + b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+#ifdef PRV2_GSS_FAST_GELU  // measurement variant (changes bits against gemm16_kernel: not shipped unless both kernels switch)
+          v0[e] = act_apply_bf(v0[e], ACT);
+          v1[e] = act_apply_bf(v1[e], ACT);
+#else
           v0[e] = act_apply(v0[e], ACT);
           v1[e] = act_apply(v1[e], ACT);
+#endif
         }
         v0 *= cs;
         v1 *= cs;
@@ -528,6 +533,9 @@ __global__ void __launch_bounds__(512, 1) gemm_ss_p_kernel(const GemmSSParams p)
 #ifdef PRV2_GSS_NOBAR
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
+      // (a counted wait that leaves a full tile's 32 store instructions in flight at k == 0 -- vmcnt(32): the counter retires in issue order --
+      //  measured nothing: 238.6 / 239.6 vs 238.8 / 240.3 us on the qkv shape, profiles/r06_experiments.txt #2: the store burst of all CUs'
+      //  epilogues together is bound by the memory side, 64 MB per round at ~6 TB/s, not by this wave's wait)
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
       long long koff = (long long)(k + 1) * 128;

@@ -36,6 +36,8 @@ for name, K, N, kw in shapes:
     cw = P.pack_conv(torch.randn(N, K, device="cuda") / K ** 0.5, torch.randn(N, device="cuda") * 0.1, prec=pr)
     data[name] = (P.split_ss(x), cw, 1 + 0.1 * torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda"))
 variants = [("one-tile", dict(PRV2_GSS_PERSIST="0"))] + [(f"persist ppb{p}", dict(PRV2_GSS_PERSIST="1", PRV2_GSS_PPB=str(p))) for p in (8, 4, 2, 1)]
+if os.environ.get("GSS_ONLY"):  # (tools/probes/gss_ab2.sh: one variant, GEMMs only)
+    variants = [v for v in variants if v[0].endswith(os.environ["GSS_ONLY"])]
 res = {}
 for rnd in range(ROUNDS):
     for vname, env in variants:
@@ -55,6 +57,8 @@ for vname, _ in variants:
         line += f"  {name} {t[0]:7.1f} / {t[len(t) // 2]:7.1f} ({2.0 * M * K * N / t[0] / 1e6:5.0f} TF)"
     print(line, flush=True)
 
+if os.environ.get("GSS_ONLY"):
+    sys.exit(0)
 # attention block: qkv Linear + attention
 os.environ.pop("PRV2_GSS_PPB", None)
 os.environ["PRV2_GSS_PERSIST"] = "1"
