@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict_
   }
 }
 
+__host__ __device__ inline int attention_tail_queries(int N);
 constexpr int AB_KP = 272;  // K tile row pitch (bytes): 128 hi + 128 lo + 16 pad -> conflict-free ds_read_b128
 constexpr int AB_VP = 264;  // V^T tile row pitch (bytes): conflict-free ds_read_b64 (66 dwords: 2r mod 64)
 
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qtiles = (N + AT_BQ - 1) / AT_BQ;
+  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (attention_tail_queries(N) ? 1 : 0);  // (the tail queries: attention_tail_kernel)
   const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const long long bh = (long long)b * heads + head;
 
@@ -542,6 +543,153 @@ __global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf
 
 }  // namespace prv2
 
+namespace prv2 {
+// =================================================================================================
+// The last few queries of 128 q + r token sequences (r <= AT_TAIL_MAX): DINOv2's 1025 and BEiT's 769 tokens are 8 resp. 6 full query tiles plus
+// ONE query.  As a ninth / seventh workgroup that query cost a full workgroup's residency -- one wave running all key tiles, the other three only
+// staging: a ninth of the launch's workgroup slots for 1 / 1025 of its work.  These queries go to attention_tail_kernel instead: one wave per
+// (batch, head, query), plain fp32 FMAs on the values the matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v), lanes over keys.  It runs
+// as a second small launch on the same stream (a few us, overlapping the main kernel's tail).  Both attention kernels (pre-pass operands and
+// split-swizzled qkv) hand their tail queries to the SAME routine on the same values in the same order: the two paths stay bit-equal to each other,
+// and a token's result does not depend on the batch it is computed in.  (Against the MFMA path a tail query differs in summation order only, and
+// keeps the lo x lo term the three-product scheme drops: closer to float64, not bit-equal.)
+// =================================================================================================
+constexpr int AT_TAIL_MAX = 4;
+__host__ __device__ inline int attention_tail_queries(int N) { const int r = N % AT_BQ; return (r >= 1 && r <= AT_TAIL_MAX && N > AT_BQ) ? r : 0; }
+
+__device__ __forceinline__ float bf16_bits_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// SRC 0: pre-pass operands (Qs / Ks rows [hi 64 | lo 64], V^T planes [d][Npad]); SRC 1: split-swizzled [q | k | v] rows
+template <int SRC, int BIAS>
+__global__ void __launch_bounds__(64) attention_tail_kernel(const __bf16* __restrict__ Qs, const __bf16* __restrict__ Ks, const __bf16* __restrict__ VtH,
+                                                            const __bf16* __restrict__ VtL, const char* __restrict__ qkv_ss, int N, int Npad, int heads,
+                                                            int ntail, const float* __restrict__ bias, int ldb, float* __restrict__ out,
+                                                            char* __restrict__ out_ss) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];  // [N scores | 64 x 65 partial outputs]
+  float* const sc = tsm;
+  float* const part = tsm + ((N + 3) & ~3);
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x % ntail, head = (blockIdx.x / ntail) % heads, b = blockIdx.x / (ntail * heads);
+  const int q = N - ntail + qi;
+  const long long bh = (long long)b * heads + head;
+  const int D = heads * 64;
+  const long long ld = (long long)D * 12, row_b = (long long)b * N;
+  // a token's 64-channel head slice as fp32 (hi + lo, exact), 8 channels per 16-byte slot.  Split-swizzled row r: channel block cb = 0..7 is logical
+  // slot cb & 3 (+ 4: lo) of group cb >> 2, stored at slot ^ ((r >> 1) & 7); pre-pass rows: [hi 64 | lo 64]
+  auto slice8 = [&](const char* rowp, long long r, int cb, float (&v)[8]) {
+    uint4 h, l;
+    if constexpr (SRC == 0) {
+      h = *reinterpret_cast<const uint4*>(rowp + cb * 16);
+      l = *reinterpret_cast<const uint4*>(rowp + 128 + cb * 16);
+    } else {
+      const int key = (int)((r >> 1) & 7), sl = cb & 3;
+      h = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + ((sl ^ key) << 4));
+      l = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + (((4 + sl) ^ key) << 4));
+    }
+    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+      v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
+    }
+  };
+  float qv[64];
+  {
+    const long long r = row_b + q;
+    const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Qs + (bh * N + q) * 128) : qkv_ss + r * ld + (long long)head * 256;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      float v[8];
+      slice8(rowp, r, cb, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[cb * 8 + e] = v[e];
+    }
+  }
+  // pass 1: this lane's keys lane, lane + 64, ...: base-2 logits into LDS, running maximum
+  float mx = -INFINITY;
+  for (int key = lane; key < N; key += 64) {
+    float s = 0.f;
+    {
+      const long long r = row_b + key;
+      const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Ks + (bh * N + key) * 128) : qkv_ss + r * ld + (long long)D * 4 + (long long)head * 256;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        float v[8];
+        slice8(rowp, r, cb, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(qv[cb * 8 + e], v[e], s);  // (channels 0..63 in order, both sources)
+      }
+    }
+    if constexpr (BIAS == 1) s += bias[((long long)head * N + q) * ldb + key] * 1.4426950408889634f;
+    if constexpr (BIAS == 2) {  // the prv2_pack_attention_bias image: [head][query block of 32][key tile of 64][i = 4 t + g][lane][4]
+      const int q32n = ((N + AT_BQ - 1) / AT_BQ) * (AT_BQ / 32), kk = key & 31, e = (kk & 3) + 4 * (kk >> 3);
+      const long long idx = (((((long long)head * q32n + (q >> 5)) * ldb + (key >> 6)) * 8 + 4 * ((key & 63) >> 5) + (e >> 2)) * 64 + ((kk >> 2) & 1) * 32 + (q & 31)) * 4 + (e & 3);
+      s += bias[idx];
+    }
+    sc[key] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  // pass 2: p = exp2(s - max); this lane's partial sum of p and of p v over its keys
+  float l = 0.f, ov[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) ov[d] = 0.f;
+  for (int key = lane; key < N; key += 64) {
+    const float pj = __builtin_amdgcn_exp2f(sc[key] - mx);
+    l += pj;
+    if constexpr (SRC == 0) {
+      const unsigned short* vh = reinterpret_cast<const unsigned short*>(VtH + bh * 64 * Npad + key);
+      const unsigned short* vl = reinterpret_cast<const unsigned short*>(VtL + bh * 64 * Npad + key);
+#pragma unroll
+      for (int d = 0; d < 64; ++d) ov[d] = fmaf(pj, bf16_bits_f32(vh[(long long)d * Npad]) + bf16_bits_f32(vl[(long long)d * Npad]), ov[d]);
+    } else {
+      const long long r = row_b + key;
+      const char* rowp = qkv_ss + r * ld + (long long)D * 8 + (long long)head * 256;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        float v[8];
+        slice8(rowp, r, cb, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[cb * 8 + e] = fmaf(pj, v[e], ov[cb * 8 + e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+#pragma unroll
+  for (int d = 0; d < 64; ++d) part[lane * 65 + d] = ov[d];
+  __syncthreads();
+  float o = 0.f;  // lane = channel d: the 64 lanes' partial sums in lane order
+  for (int j = 0; j < 64; ++j) o += part[j * 65 + lane];
+  o *= 1.0f / l;
+  const long long row = row_b + q;
+  if (out_ss) {
+    const __bf16 hi = (__bf16)o, lo = (__bf16)(o - (float)hi);
+    char* const rowp = out_ss + row * ((long long)D * 4) + (head * 2 + (lane >> 5)) * 128;
+    const int sl = (lane & 31) >> 3, k2 = (int)((row >> 1) & 7);
+    reinterpret_cast<__bf16*>(rowp + ((sl ^ k2) << 4))[lane & 7] = hi;
+    reinterpret_cast<__bf16*>(rowp + (((4 + sl) ^ k2) << 4))[lane & 7] = lo;
+  } else {
+    out[row * D + head * 64 + lane] = o;
+  }
+}
+
+template <int SRC>
+static void launch_attention_tail(const __bf16* Qs, const __bf16* Ks, const __bf16* VtH, const __bf16* VtL, const char* qkv_ss, int b, int N, int Npad, int heads,
+                                  const float* bias, int ld_bias, float* out, char* out_ss, hipStream_t s) {
+  const int ntail = attention_tail_queries(N);
+  if (!ntail) return;
+  const dim3 grid((unsigned)(b * heads * ntail));
+  const size_t lds = (size_t)(((N + 3) & ~3) + 64 * 65) * 4;
+  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE)
+    hipLaunchKernelGGL((attention_tail_kernel<SRC, 2>), grid, dim3(64), lds, s, Qs, Ks, VtH, VtL, qkv_ss, N, Npad, heads, ntail, bias, (int)cdiv(N, AT_BK), out, out_ss);
+  else if (bias) hipLaunchKernelGGL((attention_tail_kernel<SRC, 1>), grid, dim3(64), lds, s, Qs, Ks, VtH, VtL, qkv_ss, N, Npad, heads, ntail, bias, ld_bias, out, out_ss);
+  else hipLaunchKernelGGL((attention_tail_kernel<SRC, 0>), grid, dim3(64), lds, s, Qs, Ks, VtH, VtL, qkv_ss, N, Npad, heads, ntail, bias, ld_bias, out, out_ss);
+}
+
+}  // namespace prv2
+
 // =================================================================================================
 // The same attention on the qkv Linear's SPLIT-SWIZZLED output (prv2_gemm_ss_qkv): no pre-pass.
 //
@@ -576,7 +724,7 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qk
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qtiles = (N + AT_BQ - 1) / AT_BQ;
+  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (attention_tail_queries(N) ? 1 : 0);  // (the tail queries: attention_tail_kernel)
   const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const int D = heads * 64;
   const long long ld = (long long)D * 12;                      // bytes per token row of [q | k | v]
@@ -789,13 +937,12 @@ extern "C" int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok
   const char* q = reinterpret_cast<const char*>(qkv_ss);
   char* oss = reinterpret_cast<char*>(out_ss);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
+  const dim3 grid((unsigned)((cdiv(ntok, AT_BQ) - (attention_tail_queries(ntok) ? 1 : 0)) * heads * b));
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {
-    int q32n = (int)cdiv(ntok, AT_BQ) * (AT_BQ / 32), ktn = (int)cdiv(ntok, AT_BK);
-    (void)q32n;
-    hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, ntok, heads, bias, ktn, out, oss);
+    hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, ntok, heads, bias, (int)cdiv(ntok, AT_BK), out, oss);
   } else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
   else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
+  launch_attention_tail<1>(nullptr, nullptr, nullptr, nullptr, q, b, ntok, 0, heads, bias, ld_bias, out, oss, s);
   PRV2_LAUNCH_CHECK("attention_qkv_ss");
   return 0;
 }
@@ -867,7 +1014,7 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   __bf16* VtL = VtH + (int64_t)b * heads * 64 * npad;
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
-  dim3 g2((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
+  dim3 g2((unsigned)((cdiv(ntok, AT_BQ) - (attention_tail_queries(ntok) ? 1 : 0)) * heads * b));
   char* oss = reinterpret_cast<char*>(out_ss);
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {  // the prv2_pack_attention_bias image: ldb carries the key tiles per block row
     int q32n, ktn;
@@ -875,5 +1022,6 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
     hipLaunchKernelGGL(attention_bf16x3_kernel<2>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ktn, out, oss);
   } else if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<1>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
   else hipLaunchKernelGGL(attention_bf16x3_kernel<0>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
+  launch_attention_tail<0>(Qs, Ks, VtH, VtL, nullptr, b, ntok, npad, heads, bias, ld_bias, out, oss, s);
   return 0;
 }

@@ -68,7 +68,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // GELU for the store loops of the bf16-mode conv kernels (16 rows x 4 channels per thread: VALU-bound; the exact-erf GELU above
 // is ocml's two-branch erff, ~45 instructions under divergence -- +4..9 % on the short-K decoder layers): Abramowitz-Stegun 7.1.26
 // on v_rcp_f32 / v_exp_f32, ~14 instructions.  Max |error| against float64 GELU over [-8, 8]: 4.7e-7 -- the same as the exact
-// formula evaluated in fp32 (4.5e-7).  The f32 mode, the ViT linears and the generic kernels keep act_apply.
+// formula evaluated in fp32 (4.5e-7).  The f32 mode and the generic kernels keep act_apply (the ViT linears -- gemm16_kernel's lean store loop and
+// gemm_ss.hip -- moved to gelu_fast in round 6, together, so that they stay bit-equal to each other).
 __device__ __forceinline__ float gelu_fast(float v) {
   const float x = v * 0.70710678118654752440f, ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) gemm16_kernel(const 
         f32x4 ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = act_apply(cv[e] + ec.bias[e], decltype(act_c)::value);
+          float t = PREC == PRV2_PREC_F32 ? act_apply(cv[e] + ec.bias[e], decltype(act_c)::value) : act_apply_bf(cv[e] + ec.bias[e], decltype(act_c)::value);  // (bf16 modes: gelu_fast, as gemm_ss.hip)
           if constexpr (MUL) t = mv[e] * t;
           if constexpr (RES) t += rv[e];
           ov[e] = e < ec.nvalid ? t : 0.f;  // pad channels behind cout stay zero

@@ -16,6 +16,8 @@
 // Arithmetic is IDENTICAL to gemm16_kernel (same split, same three products in the same order, same MFMA, same epilogue
 // formula): the two kernels give bit-equal results (tests/test_hip_ops.py::test_gemm_ss_bit_equal_to_gemm16), so the host may
 // choose between them by problem size without making results depend on the batch.
+// GELU (fc1) is gelu_fast (common.h: |error| 4.7e-7 against float64, the exact-erf formula's own fp32 error; ~14 instead of ~45 instructions) in both
+// kernels since round 6: the fc1 store loop was VALU-bound (381 -> 362 us at 14 350 x 4096, profiles/r06_experiments.txt #3).
 // TM x TN = 256 x 256 (rows >= 4096), 128 x 128 (4 waves as 2 x 2, wave = 64 x 64; two workgroups per CU) or 64 x 64 (grids of one image).
 #include <cstdlib>
 
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
             f32x4 ov;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float t = act_apply(cv[e] + bv[e], ACT);
+              float t = act_apply_bf(cv[e] + bv[e], ACT);
               if (p.gamma) t *= gv[e];
               if (p.res) t += rv[e];
               ov[e] = t;
@@ -308,8 +310,8 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 8 || NS > 2) ? 1 : 2
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v0[e] = act_apply(v0[e], ACT);
-              v1[e] = act_apply(v1[e], ACT);
+              v0[e] = act_apply_bf(v0[e], ACT);
+              v1[e] = act_apply_bf(v1[e], ACT);
             }
             if (gcol < p.scale_cols) {  // (scale_cols is a multiple of 8: a group is scaled whole)
               v0 *= p.scale;
@@ -385,7 +387,7 @@ __device__ __forceinline__ void gss_store_rows(const f32x4 (&acc)[RI][RJ], const
         const f32x4 cv = *reinterpret_cast<const f32x4*>(&strip[(q * RPI + r_in) * STRIP_LD + c4]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = act_apply(cv[e] + bv[e], ACT);
+          float t = act_apply_bf(cv[e] + bv[e], ACT);
           if (has_gamma) t *= gv[e];
           if (has_res) t += rv[q][e];
           ov[q][e] = t;
@@ -430,13 +432,8 @@ __device__ __forceinline__ void gss_store_rows(const f32x4 (&acc)[RI][RJ], const
         f32x4 v0 = *reinterpret_cast<const f32x4*>(sp) + b0, v1 = *reinterpret_cast<const f32x4*>(sp + 4) + b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-#ifdef PRV2_GSS_FAST_GELU  // measurement variant (changes bits against gemm16_kernel: not shipped unless both kernels switch)
           v0[e] = act_apply_bf(v0[e], ACT);
           v1[e] = act_apply_bf(v1[e], ACT);
-#else
-          v0[e] = act_apply(v0[e], ACT);
-          v1[e] = act_apply(v1[e], ACT);
-#endif
         }
         v0 *= cs;
         v1 *= cs;

@@ -16,7 +16,7 @@ tot=collections.defaultdict(lambda: collections.defaultdict(float)); n=collectio
 for f in glob.glob('/tmp/pv_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0].replace('void ','').replace('prv2::','')
-        if not any(t in k for t in ('gemm16','gemm_ss','attention_bf16x3','qkv_split','layernorm')): continue
+        if not any(t in k for t in ('gemm16','gemm_ss','attention_','qkv_split','layernorm')): continue
         tot[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
         dur[k].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
 for k in sorted(tot, key=lambda k: -sum(dur[k])):

@@ -17,5 +17,4 @@ wait
 build bare -DPRV2_GSS_NOEPI -DPRV2_GSS_NODMA -DPRV2_GSS_NOBAR &
 build nomma -DPRV2_GSS_NOEPI -DPRV2_GSS_NOMMA &
 wait
-build fastgelu -DPRV2_GSS_FAST_GELU &
 wait
