@@ -289,7 +289,149 @@ __global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict_
   }
 }
 
-__host__ __device__ inline int attention_tail_queries(int N);
+// =================================================================================================
+// The last few queries of 128 q + r token sequences (r <= AT_TAIL_MAX): DINOv2's 1025 and BEiT's 769 tokens are 8 resp. 6 full query tiles plus
+// ONE query.  As a ninth / seventh workgroup that query cost a full workgroup's residency -- one wave running all key tiles on the matrix pipe, the
+// other three only staging: a ninth of the launch's workgroup slots for 1 / 1025 of its work.  Such queries are computed by plain fp32 FMAs
+// instead, one WAVE per (batch, head, query), lanes over keys with an online softmax per lane and one merge across the lanes, on the values the
+// matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v).  The waves are the FIRST workgroups of the launch (four queries each): they wait on
+// memory (a query still reads its head's whole K and V), occupy one wave slot each and finish under the matrix workgroups.
+// Both attention kernels (pre-pass operands and split-swizzled qkv) run the same routine on the same values in the same order: the two operand
+// paths stay bit-equal to each other and a token's result does not depend on the batch.  (Against the MFMA path a tail query differs in summation
+// order and keeps the lo x lo term the three-product scheme drops: closer to float64, not bit-equal.)
+// =================================================================================================
+constexpr int AT_TAIL_MAX = 4;
+__host__ __device__ inline int attention_tail_queries(int N) { const int r = N % AT_BQ; return (r >= 1 && r <= AT_TAIL_MAX && N > AT_BQ) ? r : 0; }
+constexpr int AT_TAIL_LDS = (64 * 17 + 64) * 4;  // bytes of LDS per wave (the merge, 16 channels at a time; the query vector)
+
+// SRC 0: pre-pass operands (Qs / Ks rows [hi 64 | lo 64], V^T planes [d][Npad]); SRC 1: split-swizzled [q | k | v] rows.  item = (b, head, tail query).
+template <int SRC, int BIAS>
+__device__ __forceinline__ void attention_tail_wave(const __bf16* __restrict__ Qs, const __bf16* __restrict__ Ks, const __bf16* __restrict__ VtH,
+                                                    const __bf16* __restrict__ VtL, const char* __restrict__ qkv_ss, int N, int Npad, int heads, int ntail,
+                                                    int item, const float* __restrict__ bias, int ldb, float* __restrict__ out, char* __restrict__ out_ss,
+                                                    float* const part, const int lane) {
+  const int qi = item % ntail, head = (item / ntail) % heads, b = item / (ntail * heads);
+  const int q = N - ntail + qi;
+  const long long bh = (long long)b * heads + head;
+  const int D = heads * 64;
+  const long long ld = (long long)D * 12, row_b = (long long)b * N;
+  // a token's 64-channel head slice as fp32 (hi + lo, exact), 8 channels per 16-byte slot.  Split-swizzled row r: channel block cb = 0..7 is logical
+  // slot cb & 3 (+ 4: lo) of group cb >> 2, stored at slot ^ ((r >> 1) & 7); pre-pass rows: [hi 64 | lo 64]
+  auto slice8 = [&](const char* rowp, long long r, int cb, float (&v)[8]) {
+    uint4 h, l;
+    if constexpr (SRC == 0) {
+      h = *reinterpret_cast<const uint4*>(rowp + cb * 16);
+      l = *reinterpret_cast<const uint4*>(rowp + 128 + cb * 16);
+    } else {
+      const int key = (int)((r >> 1) & 7), sl = cb & 3;
+      h = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + ((sl ^ key) << 4));
+      l = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + (((4 + sl) ^ key) << 4));
+    }
+    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+      v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
+    }
+  };
+  // the query vector (the same for every lane) lives in LDS behind the merge buffer: 64 registers less -- the routine stays inside the 168 the
+  // matrix path of its kernel is capped at (no scratch)
+  float* const qv = part + 64 * 17;
+  {
+    const long long r = row_b + q;
+    const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Qs + (bh * N + q) * 128) : qkv_ss + r * ld + (long long)head * 256;
+    float v[8];
+    slice8(rowp, r, lane & 7, v);
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[lane * 8 + e] = v[e];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // this lane's keys lane, lane + 64, ...: online softmax in the base-2 domain
+  float m = -INFINITY, l = 0.f, ov[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) ov[d] = 0.f;
+  for (int key = lane; key < N; key += 64) {
+    const long long r = row_b + key;
+    float sj = 0.f;
+    {
+      const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Ks + (bh * N + key) * 128) : qkv_ss + r * ld + (long long)D * 4 + (long long)head * 256;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        float v[8];
+        slice8(rowp, r, cb, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sj = fmaf(qv[cb * 8 + e], v[e], sj);  // (channels 0..63 in order, both sources)
+        if (cb == 3) asm volatile("" ::: "memory");  // (at most 8 slots = 32 registers of loads in flight: the routine stays within 168, no scratch)
+      }
+    }
+    if constexpr (BIAS == 1) sj += bias[((long long)head * N + q) * ldb + key] * 1.4426950408889634f;
+    if constexpr (BIAS == 2) {  // the prv2_pack_attention_bias image: [head][query block of 32][key tile of 64][i = 4 t + g][lane][4]
+      const int q32n = ((N + AT_BQ - 1) / AT_BQ) * (AT_BQ / 32), kk = key & 31, e = (kk & 3) + 4 * (kk >> 3);
+      const long long idx = (((((long long)head * q32n + (q >> 5)) * ldb + (key >> 6)) * 8 + 4 * ((key & 63) >> 5) + (e >> 2)) * 64 + ((kk >> 2) & 1) * 32 + (q & 31)) * 4 + (e & 3);
+      sj += bias[idx];
+    }
+    const float m_new = fmaxf(m, sj), corr = __builtin_amdgcn_exp2f(m - m_new), pj = __builtin_amdgcn_exp2f(sj - m_new);
+    l = l * corr + pj;
+    m = m_new;
+    if constexpr (SRC == 0) {
+      const unsigned short* vh = reinterpret_cast<const unsigned short*>(VtH + bh * 64 * Npad + key);
+      const unsigned short* vl = reinterpret_cast<const unsigned short*>(VtL + bh * 64 * Npad + key);
+#pragma unroll
+      for (int d = 0; d < 64; ++d) {
+        ov[d] = fmaf(pj, __uint_as_float((unsigned)vh[(long long)d * Npad] << 16) + __uint_as_float((unsigned)vl[(long long)d * Npad] << 16), ov[d] * corr);
+        if ((d & 15) == 15) asm volatile("" ::: "memory");
+      }
+    } else {
+      const char* rowp = qkv_ss + r * ld + (long long)D * 8 + (long long)head * 256;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        float v[8];
+        slice8(rowp, r, cb, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[cb * 8 + e] = fmaf(pj, v[e], ov[cb * 8 + e] * corr);
+        if (cb == 3) asm volatile("" ::: "memory");
+      }
+    }
+  }
+  // merge the 64 lanes: common maximum, lane weights 2^(m_lane - max) (a lane without keys: m = -inf -> weight 0)
+  float mx = m;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float wgt = __builtin_amdgcn_exp2f(m - mx);
+  float lt = l * wgt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lt += __shfl_xor(lt, o, 64);
+  float o = 0.f;  // lane = channel d after the merge: the 64 lanes' weighted partial sums added in lane order, 16 channels per round
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[lane * 17 + e] = ov[c * 16 + e] * wgt;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if ((lane >> 4) == c) {
+      float acc = 0.f;
+      for (int j = 0; j < 64; ++j) acc += part[j * 17 + (lane & 15)];
+      o = acc;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  o *= 1.0f / lt;
+  const long long row = row_b + q;
+  if (out_ss) {
+    const __bf16 hi = (__bf16)o, lo = (__bf16)(o - (float)hi);
+    char* const rowp = out_ss + row * ((long long)D * 4) + (head * 2 + (lane >> 5)) * 128;
+    const int sl = (lane & 31) >> 3, k2 = (int)((row >> 1) & 7);
+    reinterpret_cast<__bf16*>(rowp + ((sl ^ k2) << 4))[lane & 7] = hi;
+    reinterpret_cast<__bf16*>(rowp + (((4 + sl) ^ k2) << 4))[lane & 7] = lo;
+  } else {
+    out[row * D + head * 64 + lane] = o;
+  }
+}
+
 constexpr int AB_KP = 272;  // K tile row pitch (bytes): 128 hi + 128 lo + 16 pad -> conflict-free ds_read_b128
 constexpr int AB_VP = 264;  // V^T tile row pitch (bytes): conflict-free ds_read_b64 (66 dwords: 2r mod 64)
 
@@ -310,10 +452,10 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const 
 #define ATT_WG_BIAS 2
 #endif
 template <int BIAS>
-__global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
+__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
                                                                   const __bf16* __restrict__ Ks,
                                                                   const __bf16* __restrict__ VtH,
-                                                                  const __bf16* __restrict__ VtL, int N, int Npad,
+                                                                  const __bf16* __restrict__ VtL, int B, int N, int Npad,
                                                                   int heads, const float* __restrict__ bias, int ldb,
                                                                   float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AB_VP];  // 34304 B; reused for the output strips
@@ -324,12 +466,20 @@ __global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf
   // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (ids b, b + 8, ... share one), so consecutive ids
   // are remapped to one XCD -- the query tiles of a (batch, head) then read its K / V through ONE L2 instead of eight
   // (PMC before: L2 hit rate 26 %, 5.5x the unique bytes fetched)
-  int bid = blockIdx.x;
+  const int ntail = attention_tail_queries(N);
+  const int tail_wgs = (B * heads * ntail + 3) >> 2;  // the first workgroups of the launch: four tail queries each (attention_tail_wave)
+  if ((int)blockIdx.x < tail_wgs) {
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: the query vector stays in scalar registers)
+    if (item < B * heads * ntail)
+      attention_tail_wave<0, BIAS>(Qs, Ks, VtH, VtL, nullptr, N, Npad, heads, ntail, item, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem + wave * AT_TAIL_LDS), lane);
+    return;
+  }
+  int bid = blockIdx.x - tail_wgs;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = gridDim.x - tail_wgs, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (attention_tail_queries(N) ? 1 : 0);  // (the tail queries: attention_tail_kernel)
+  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (ntail ? 1 : 0);
   const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const long long bh = (long long)b * heads + head;
 
@@ -543,153 +693,6 @@ __global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf
 
 }  // namespace prv2
 
-namespace prv2 {
-// =================================================================================================
-// The last few queries of 128 q + r token sequences (r <= AT_TAIL_MAX): DINOv2's 1025 and BEiT's 769 tokens are 8 resp. 6 full query tiles plus
-// ONE query.  As a ninth / seventh workgroup that query cost a full workgroup's residency -- one wave running all key tiles, the other three only
-// staging: a ninth of the launch's workgroup slots for 1 / 1025 of its work.  These queries go to attention_tail_kernel instead: one wave per
-// (batch, head, query), plain fp32 FMAs on the values the matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v), lanes over keys.  It runs
-// as a second small launch on the same stream (a few us, overlapping the main kernel's tail).  Both attention kernels (pre-pass operands and
-// split-swizzled qkv) hand their tail queries to the SAME routine on the same values in the same order: the two paths stay bit-equal to each other,
-// and a token's result does not depend on the batch it is computed in.  (Against the MFMA path a tail query differs in summation order only, and
-// keeps the lo x lo term the three-product scheme drops: closer to float64, not bit-equal.)
-// =================================================================================================
-constexpr int AT_TAIL_MAX = 4;
-__host__ __device__ inline int attention_tail_queries(int N) { const int r = N % AT_BQ; return (r >= 1 && r <= AT_TAIL_MAX && N > AT_BQ) ? r : 0; }
-
-__device__ __forceinline__ float bf16_bits_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-
-// SRC 0: pre-pass operands (Qs / Ks rows [hi 64 | lo 64], V^T planes [d][Npad]); SRC 1: split-swizzled [q | k | v] rows
-template <int SRC, int BIAS>
-__global__ void __launch_bounds__(64) attention_tail_kernel(const __bf16* __restrict__ Qs, const __bf16* __restrict__ Ks, const __bf16* __restrict__ VtH,
-                                                            const __bf16* __restrict__ VtL, const char* __restrict__ qkv_ss, int N, int Npad, int heads,
-                                                            int ntail, const float* __restrict__ bias, int ldb, float* __restrict__ out,
-                                                            char* __restrict__ out_ss) {
-  extern __shared__ __attribute__((aligned(16))) float tsm[];  // [N scores | 64 x 65 partial outputs]
-  float* const sc = tsm;
-  float* const part = tsm + ((N + 3) & ~3);
-  const int lane = threadIdx.x;
-  const int qi = blockIdx.x % ntail, head = (blockIdx.x / ntail) % heads, b = blockIdx.x / (ntail * heads);
-  const int q = N - ntail + qi;
-  const long long bh = (long long)b * heads + head;
-  const int D = heads * 64;
-  const long long ld = (long long)D * 12, row_b = (long long)b * N;
-  // a token's 64-channel head slice as fp32 (hi + lo, exact), 8 channels per 16-byte slot.  Split-swizzled row r: channel block cb = 0..7 is logical
-  // slot cb & 3 (+ 4: lo) of group cb >> 2, stored at slot ^ ((r >> 1) & 7); pre-pass rows: [hi 64 | lo 64]
-  auto slice8 = [&](const char* rowp, long long r, int cb, float (&v)[8]) {
-    uint4 h, l;
-    if constexpr (SRC == 0) {
-      h = *reinterpret_cast<const uint4*>(rowp + cb * 16);
-      l = *reinterpret_cast<const uint4*>(rowp + 128 + cb * 16);
-    } else {
-      const int key = (int)((r >> 1) & 7), sl = cb & 3;
-      h = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + ((sl ^ key) << 4));
-      l = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + (((4 + sl) ^ key) << 4));
-    }
-    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[2 * e] = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
-      v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
-    }
-  };
-  float qv[64];
-  {
-    const long long r = row_b + q;
-    const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Qs + (bh * N + q) * 128) : qkv_ss + r * ld + (long long)head * 256;
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      float v[8];
-      slice8(rowp, r, cb, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qv[cb * 8 + e] = v[e];
-    }
-  }
-  // pass 1: this lane's keys lane, lane + 64, ...: base-2 logits into LDS, running maximum
-  float mx = -INFINITY;
-  for (int key = lane; key < N; key += 64) {
-    float s = 0.f;
-    {
-      const long long r = row_b + key;
-      const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Ks + (bh * N + key) * 128) : qkv_ss + r * ld + (long long)D * 4 + (long long)head * 256;
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb) {
-        float v[8];
-        slice8(rowp, r, cb, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(qv[cb * 8 + e], v[e], s);  // (channels 0..63 in order, both sources)
-      }
-    }
-    if constexpr (BIAS == 1) s += bias[((long long)head * N + q) * ldb + key] * 1.4426950408889634f;
-    if constexpr (BIAS == 2) {  // the prv2_pack_attention_bias image: [head][query block of 32][key tile of 64][i = 4 t + g][lane][4]
-      const int q32n = ((N + AT_BQ - 1) / AT_BQ) * (AT_BQ / 32), kk = key & 31, e = (kk & 3) + 4 * (kk >> 3);
-      const long long idx = (((((long long)head * q32n + (q >> 5)) * ldb + (key >> 6)) * 8 + 4 * ((key & 63) >> 5) + (e >> 2)) * 64 + ((kk >> 2) & 1) * 32 + (q & 31)) * 4 + (e & 3);
-      s += bias[idx];
-    }
-    sc[key] = s;
-    mx = fmaxf(mx, s);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  // pass 2: p = exp2(s - max); this lane's partial sum of p and of p v over its keys
-  float l = 0.f, ov[64];
-#pragma unroll
-  for (int d = 0; d < 64; ++d) ov[d] = 0.f;
-  for (int key = lane; key < N; key += 64) {
-    const float pj = __builtin_amdgcn_exp2f(sc[key] - mx);
-    l += pj;
-    if constexpr (SRC == 0) {
-      const unsigned short* vh = reinterpret_cast<const unsigned short*>(VtH + bh * 64 * Npad + key);
-      const unsigned short* vl = reinterpret_cast<const unsigned short*>(VtL + bh * 64 * Npad + key);
-#pragma unroll
-      for (int d = 0; d < 64; ++d) ov[d] = fmaf(pj, bf16_bits_f32(vh[(long long)d * Npad]) + bf16_bits_f32(vl[(long long)d * Npad]), ov[d]);
-    } else {
-      const long long r = row_b + key;
-      const char* rowp = qkv_ss + r * ld + (long long)D * 8 + (long long)head * 256;
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb) {
-        float v[8];
-        slice8(rowp, r, cb, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[cb * 8 + e] = fmaf(pj, v[e], ov[cb * 8 + e]);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
-#pragma unroll
-  for (int d = 0; d < 64; ++d) part[lane * 65 + d] = ov[d];
-  __syncthreads();
-  float o = 0.f;  // lane = channel d: the 64 lanes' partial sums in lane order
-  for (int j = 0; j < 64; ++j) o += part[j * 65 + lane];
-  o *= 1.0f / l;
-  const long long row = row_b + q;
-  if (out_ss) {
-    const __bf16 hi = (__bf16)o, lo = (__bf16)(o - (float)hi);
-    char* const rowp = out_ss + row * ((long long)D * 4) + (head * 2 + (lane >> 5)) * 128;
-    const int sl = (lane & 31) >> 3, k2 = (int)((row >> 1) & 7);
-    reinterpret_cast<__bf16*>(rowp + ((sl ^ k2) << 4))[lane & 7] = hi;
-    reinterpret_cast<__bf16*>(rowp + (((4 + sl) ^ k2) << 4))[lane & 7] = lo;
-  } else {
-    out[row * D + head * 64 + lane] = o;
-  }
-}
-
-template <int SRC>
-static void launch_attention_tail(const __bf16* Qs, const __bf16* Ks, const __bf16* VtH, const __bf16* VtL, const char* qkv_ss, int b, int N, int Npad, int heads,
-                                  const float* bias, int ld_bias, float* out, char* out_ss, hipStream_t s) {
-  const int ntail = attention_tail_queries(N);
-  if (!ntail) return;
-  const dim3 grid((unsigned)(b * heads * ntail));
-  const size_t lds = (size_t)(((N + 3) & ~3) + 64 * 65) * 4;
-  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE)
-    hipLaunchKernelGGL((attention_tail_kernel<SRC, 2>), grid, dim3(64), lds, s, Qs, Ks, VtH, VtL, qkv_ss, N, Npad, heads, ntail, bias, (int)cdiv(N, AT_BK), out, out_ss);
-  else if (bias) hipLaunchKernelGGL((attention_tail_kernel<SRC, 1>), grid, dim3(64), lds, s, Qs, Ks, VtH, VtL, qkv_ss, N, Npad, heads, ntail, bias, ld_bias, out, out_ss);
-  else hipLaunchKernelGGL((attention_tail_kernel<SRC, 0>), grid, dim3(64), lds, s, Qs, Ks, VtH, VtL, qkv_ss, N, Npad, heads, ntail, bias, ld_bias, out, out_ss);
-}
-
-}  // namespace prv2
-
 // =================================================================================================
 // The same attention on the qkv Linear's SPLIT-SWIZZLED output (prv2_gemm_ss_qkv): no pre-pass.
 //
@@ -711,7 +714,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int AQ_VP = 320;  // V tile row pitch (bytes): 128 hi + 128 lo + 64 pad
 
 template <int BIAS>
-__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qkvss_kernel(const char* __restrict__ qkv_ss, int N, int heads,
+__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qkvss_kernel(const char* __restrict__ qkv_ss, int B, int N, int heads,
                                                                                             const float* __restrict__ bias, int ldb,
                                                                                             float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AQ_VP];  // 37888 B; reused for the output strips (33792 B)
@@ -719,12 +722,20 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qk
   char* const Vt = smem + 64 * AB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  const int ntail = attention_tail_queries(N);
+  const int tail_wgs = (B * heads * ntail + 3) >> 2;  // the first workgroups of the launch: four tail queries each (attention_tail_wave)
+  if ((int)blockIdx.x < tail_wgs) {
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: the query vector stays in scalar registers)
+    if (item < B * heads * ntail)
+      attention_tail_wave<1, BIAS>(nullptr, nullptr, nullptr, nullptr, qkv_ss, N, 0, heads, ntail, item, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem + wave * AT_TAIL_LDS), lane);
+    return;
+  }
+  int bid = blockIdx.x - tail_wgs;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = gridDim.x - tail_wgs, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (attention_tail_queries(N) ? 1 : 0);  // (the tail queries: attention_tail_kernel)
+  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (ntail ? 1 : 0);
   const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const int D = heads * 64;
   const long long ld = (long long)D * 12;                      // bytes per token row of [q | k | v]
@@ -937,12 +948,11 @@ extern "C" int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok
   const char* q = reinterpret_cast<const char*>(qkv_ss);
   char* oss = reinterpret_cast<char*>(out_ss);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)((cdiv(ntok, AT_BQ) - (attention_tail_queries(ntok) ? 1 : 0)) * heads * b));
-  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {
-    hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, ntok, heads, bias, (int)cdiv(ntok, AT_BK), out, oss);
-  } else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
-  else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
-  launch_attention_tail<1>(nullptr, nullptr, nullptr, nullptr, q, b, ntok, 0, heads, bias, ld_bias, out, oss, s);
+  const int ntail = attention_tail_queries(ntok);
+  const dim3 grid((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + (b * heads * ntail + 3) / 4));  // [tail workgroups | query tiles]
+  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, (int)cdiv(ntok, AT_BK), out, oss);
+  else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
   PRV2_LAUNCH_CHECK("attention_qkv_ss");
   return 0;
 }
@@ -1014,14 +1024,14 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   __bf16* VtL = VtH + (int64_t)b * heads * 64 * npad;
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
-  dim3 g2((unsigned)((cdiv(ntok, AT_BQ) - (attention_tail_queries(ntok) ? 1 : 0)) * heads * b));
+  const int ntail = attention_tail_queries(ntok);
+  dim3 g2((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + (b * heads * ntail + 3) / 4));  // [tail workgroups | query tiles]
   char* oss = reinterpret_cast<char*>(out_ss);
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {  // the prv2_pack_attention_bias image: ldb carries the key tiles per block row
     int q32n, ktn;
     bias_image_dims(ntok, q32n, ktn);
-    hipLaunchKernelGGL(attention_bf16x3_kernel<2>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ktn, out, oss);
-  } else if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<1>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
-  else hipLaunchKernelGGL(attention_bf16x3_kernel<0>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
-  launch_attention_tail<0>(Qs, Ks, VtH, VtL, nullptr, b, ntok, npad, heads, bias, ld_bias, out, oss, s);
+    hipLaunchKernelGGL(attention_bf16x3_kernel<2>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, b, ntok, npad, heads, bias, ktn, out, oss);
+  } else if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<1>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, b, ntok, npad, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_bf16x3_kernel<0>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, b, ntok, npad, heads, bias, ld_bias, out, oss);
   return 0;
 }
