@@ -293,23 +293,25 @@ __global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict_
 // The last few queries of 128 q + r token sequences (r <= AT_TAIL_MAX): DINOv2's 1025 and BEiT's 769 tokens are 8 resp. 6 full query tiles plus
 // ONE query.  As a ninth / seventh workgroup that query cost a full workgroup's residency -- one wave running all key tiles on the matrix pipe, the
 // other three only staging: a ninth of the launch's workgroup slots for 1 / 1025 of its work.  Such queries are computed by plain fp32 FMAs
-// instead, one WAVE per (batch, head, query), lanes over keys with an online softmax per lane and one merge across the lanes, on the values the
-// matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v).  The waves are the FIRST workgroups of the launch (four queries each): they wait on
-// memory (a query still reads its head's whole K and V), occupy one wave slot each and finish under the matrix workgroups.
+// instead, one workgroup per (batch, head, query), its 256 threads over the keys with an online softmax per thread and one merge across them, on the
+// values the matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v).  These are the FIRST workgroups of the launch: they wait on memory (a
+// query still reads its head's whole K and V: 4-5 keys per thread), hold four wave slots for ~30 us and finish under the matrix workgroups.
+// (One WAVE per query -- 17 dependent rounds of gathers -- was the launch's long pole: 212 us against 184 for 1024 tokens, profiles/r06_experiments.txt #5.)
 // Both attention kernels (pre-pass operands and split-swizzled qkv) run the same routine on the same values in the same order: the two operand
 // paths stay bit-equal to each other and a token's result does not depend on the batch.  (Against the MFMA path a tail query differs in summation
 // order and keeps the lo x lo term the three-product scheme drops: closer to float64, not bit-equal.)
 // =================================================================================================
 constexpr int AT_TAIL_MAX = 4;
 __host__ __device__ inline int attention_tail_queries(int N) { const int r = N % AT_BQ; return (r >= 1 && r <= AT_TAIL_MAX && N > AT_BQ) ? r : 0; }
-constexpr int AT_TAIL_LDS = (64 * 17 + 64) * 4;  // bytes of LDS per wave (the merge, 16 channels at a time; the query vector)
+constexpr int AT_TAIL_LDS = (256 * 17 + 64 + 8) * 4;  // bytes of LDS per workgroup (the merge, 16 channels at a time; the query vector; 4 + 4 wave partials)
 
 // SRC 0: pre-pass operands (Qs / Ks rows [hi 64 | lo 64], V^T planes [d][Npad]); SRC 1: split-swizzled [q | k | v] rows.  item = (b, head, tail query).
 template <int SRC, int BIAS>
 __device__ __forceinline__ void attention_tail_wave(const __bf16* __restrict__ Qs, const __bf16* __restrict__ Ks, const __bf16* __restrict__ VtH,
                                                     const __bf16* __restrict__ VtL, const char* __restrict__ qkv_ss, int N, int Npad, int heads, int ntail,
                                                     int item, const float* __restrict__ bias, int ldb, float* __restrict__ out, char* __restrict__ out_ss,
-                                                    float* const part, const int lane) {
+                                                    float* const part, const int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
   const int qi = item % ntail, head = (item / ntail) % heads, b = item / (ntail * heads);
   const int q = N - ntail + qi;
   const long long bh = (long long)b * heads + head;
@@ -336,24 +338,24 @@ __device__ __forceinline__ void attention_tail_wave(const __bf16* __restrict__ Q
   };
   // the query vector (the same for every lane) lives in LDS behind the merge buffer: 64 registers less -- the routine stays inside the 168 the
   // matrix path of its kernel is capped at (no scratch)
-  float* const qv = part + 64 * 17;
+  float* const qv = part + 256 * 17;
+  float* const wred = qv + 64;  // [4 wave maxima | 4 wave sums]
   {
     const long long r = row_b + q;
     const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Qs + (bh * N + q) * 128) : qkv_ss + r * ld + (long long)head * 256;
     float v[8];
-    slice8(rowp, r, lane & 7, v);
-    if (lane < 8) {
+    slice8(rowp, r, tid & 7, v);
+    if (tid < 8) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qv[lane * 8 + e] = v[e];
+      for (int e = 0; e < 8; ++e) qv[tid * 8 + e] = v[e];
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
-  // this lane's keys lane, lane + 64, ...: online softmax in the base-2 domain
+  // this thread's keys tid, tid + 256, ...: online softmax in the base-2 domain
   float m = -INFINITY, l = 0.f, ov[64];
 #pragma unroll
   for (int d = 0; d < 64; ++d) ov[d] = 0.f;
-  for (int key = lane; key < N; key += 64) {
+  for (int key = tid; key < N; key += 256) {
     const long long r = row_b + key;
     float sj = 0.f;
     {
@@ -396,29 +398,35 @@ __device__ __forceinline__ void attention_tail_wave(const __bf16* __restrict__ Q
       }
     }
   }
-  // merge the 64 lanes: common maximum, lane weights 2^(m_lane - max) (a lane without keys: m = -inf -> weight 0)
+  // merge the 256 threads: common maximum, thread weights 2^(m_thread - max) (a thread without keys: m = -inf -> weight 0)
   float mx = m;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) wred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
   const float wgt = __builtin_amdgcn_exp2f(m - mx);
   float lt = l * wgt;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) lt += __shfl_xor(lt, o, 64);
-  float o = 0.f;  // lane = channel d after the merge: the 64 lanes' weighted partial sums added in lane order, 16 channels per round
+  if (lane == 0) wred[4 + wave] = lt;
+  float o = 0.f;  // wave 0, lane = channel d after the merge: 16 channels per round, each summed over the 256 threads in a fixed order
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) part[lane * 17 + e] = ov[c * 16 + e] * wgt;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if ((lane >> 4) == c) {
+    for (int e = 0; e < 16; ++e) part[tid * 17 + e] = ov[c * 16 + e] * wgt;
+    __syncthreads();
+    if (wave == 0) {  // lane (segment sg = lane >> 4 of 64 threads, channel lane & 15); the four segments combined by two butterflies
       float acc = 0.f;
-      for (int j = 0; j < 64; ++j) acc += part[j * 17 + (lane & 15)];
-      o = acc;
+      for (int j = 0; j < 64; ++j) acc += part[((lane >> 4) * 64 + j) * 17 + (lane & 15)];
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      if ((lane >> 4) == c) o = acc;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
+  if (wave != 0) return;
+  lt = (wred[4] + wred[5]) + (wred[6] + wred[7]);
   o *= 1.0f / lt;
   const long long row = row_b + q;
   if (out_ss) {
@@ -459,6 +467,7 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_bf
                                                                   int heads, const float* __restrict__ bias, int ldb,
                                                                   float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AB_VP];  // 34304 B; reused for the output strips
+  static_assert(AT_TAIL_LDS <= 64 * AB_KP + 64 * AB_VP, "the tail routine's merge buffer fits in the tile memory");
   char* const Kt = smem;
   char* const Vt = smem + 64 * AB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -467,11 +476,9 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_bf
   // are remapped to one XCD -- the query tiles of a (batch, head) then read its K / V through ONE L2 instead of eight
   // (PMC before: L2 hit rate 26 %, 5.5x the unique bytes fetched)
   const int ntail = attention_tail_queries(N);
-  const int tail_wgs = (B * heads * ntail + 3) >> 2;  // the first workgroups of the launch: four tail queries each (attention_tail_wave)
+  const int tail_wgs = B * heads * ntail;  // the first workgroups of the launch: one tail query each (attention_tail_wave)
   if ((int)blockIdx.x < tail_wgs) {
-    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: the query vector stays in scalar registers)
-    if (item < B * heads * ntail)
-      attention_tail_wave<0, BIAS>(Qs, Ks, VtH, VtL, nullptr, N, Npad, heads, ntail, item, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem + wave * AT_TAIL_LDS), lane);
+    attention_tail_wave<0, BIAS>(Qs, Ks, VtH, VtL, nullptr, N, Npad, heads, ntail, (int)blockIdx.x, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
     return;
   }
   int bid = blockIdx.x - tail_wgs;
@@ -718,16 +725,15 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qk
                                                                                             const float* __restrict__ bias, int ldb,
                                                                                             float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AQ_VP];  // 37888 B; reused for the output strips (33792 B)
+  static_assert(AT_TAIL_LDS <= 64 * AB_KP + 64 * AQ_VP, "the tail routine's merge buffer fits in the tile memory");
   char* const Kt = smem;
   char* const Vt = smem + 64 * AB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
   const int ntail = attention_tail_queries(N);
-  const int tail_wgs = (B * heads * ntail + 3) >> 2;  // the first workgroups of the launch: four tail queries each (attention_tail_wave)
+  const int tail_wgs = B * heads * ntail;  // the first workgroups of the launch: one tail query each (attention_tail_wave)
   if ((int)blockIdx.x < tail_wgs) {
-    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: the query vector stays in scalar registers)
-    if (item < B * heads * ntail)
-      attention_tail_wave<1, BIAS>(nullptr, nullptr, nullptr, nullptr, qkv_ss, N, 0, heads, ntail, item, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem + wave * AT_TAIL_LDS), lane);
+    attention_tail_wave<1, BIAS>(nullptr, nullptr, nullptr, nullptr, qkv_ss, N, 0, heads, ntail, (int)blockIdx.x, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
     return;
   }
   int bid = blockIdx.x - tail_wgs;
@@ -949,7 +955,7 @@ extern "C" int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok
   char* oss = reinterpret_cast<char*>(out_ss);
   hipStream_t s = (hipStream_t)stream;
   const int ntail = attention_tail_queries(ntok);
-  const dim3 grid((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + (b * heads * ntail + 3) / 4));  // [tail workgroups | query tiles]
+  const dim3 grid((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + b * heads * ntail));  // [tail workgroups | query tiles]
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, (int)cdiv(ntok, AT_BK), out, oss);
   else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
   else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
@@ -1025,7 +1031,7 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
   const int ntail = attention_tail_queries(ntok);
-  dim3 g2((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + (b * heads * ntail + 3) / 4));  // [tail workgroups | query tiles]
+  dim3 g2((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + b * heads * ntail));  // [tail workgroups | query tiles]
   char* oss = reinterpret_cast<char*>(out_ss);
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {  // the prv2_pack_attention_bias image: ldb carries the key tiles per block row
     int q32n, ktn;
