@@ -294,8 +294,8 @@ __global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict_
 // ONE query.  As a ninth / seventh workgroup that query cost a full workgroup's residency -- one wave running all key tiles on the matrix pipe, the
 // other three only staging: a ninth of the launch's workgroup slots for 1 / 1025 of its work.  Such queries are computed by plain fp32 FMAs
 // instead, one workgroup per (batch, head, query), its 256 threads over the keys with an online softmax per thread and one merge across them, on the
-// values the matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v).  These are the FIRST workgroups of the launch: they wait on memory (a
-// query still reads its head's whole K and V: 4-5 keys per thread), hold four wave slots for ~30 us and finish under the matrix workgroups.
+// values the matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v).  It is the first of its (batch, head)'s workgroups: it waits on memory (a
+// query still reads its head's whole K and V: 4-5 keys per thread), holds four wave slots for a fraction of a matrix workgroup's time.
 // (One WAVE per query -- 17 dependent rounds of gathers -- was the launch's long pole: 212 us against 184 for 1024 tokens, profiles/r06_experiments.txt #5.)
 // Both attention kernels (pre-pass operands and split-swizzled qkv) run the same routine on the same values in the same order: the two operand
 // paths stay bit-equal to each other and a token's result does not depend on the batch.  (Against the MFMA path a tail query differs in summation
@@ -425,7 +425,7 @@ __device__ __forceinline__ void attention_tail_wave(const __bf16* __restrict__ Q
     }
     __syncthreads();
   }
-  if (wave != 0) return;
+  if (wave != 0) return;  // (back to the caller's barrier; only wave 0 stores)
   lt = (wred[4] + wred[5]) + (wred[6] + wred[7]);
   o *= 1.0f / lt;
   const long long row = row_b + q;
@@ -476,18 +476,24 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_bf
   // are remapped to one XCD -- the query tiles of a (batch, head) then read its K / V through ONE L2 instead of eight
   // (PMC before: L2 hit rate 26 %, 5.5x the unique bytes fetched)
   const int ntail = attention_tail_queries(N);
-  const int tail_wgs = B * heads * ntail;  // the first workgroups of the launch: one tail query each (attention_tail_wave)
-  if ((int)blockIdx.x < tail_wgs) {
-    attention_tail_wave<0, BIAS>(Qs, Ks, VtH, VtL, nullptr, N, Npad, heads, ntail, (int)blockIdx.x, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
-    return;
-  }
-  int bid = blockIdx.x - tail_wgs;
+  int bid = blockIdx.x;
   {
-    const int nwg = gridDim.x - tail_wgs, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (ntail ? 1 : 0);
-  const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
+  // a (batch, head)'s workgroups are consecutive ids on one XCD: [the tail queries' workgroup (if any) | the full query tiles] -- the tail reads the
+  // same K / V as its siblings, at the same time, through the same L2 (as the launch's first workgroups it fetched them a second time from HBM:
+  // +17 us on 178, profiles/r06_experiments.txt #5)
+  const int slots = ((N + AT_BQ - 1) / AT_BQ);  // workgroups per (batch, head)
+  const int head = (bid / slots) % heads, b = bid / (slots * heads);
+  if (ntail && bid % slots == 0) {
+    for (int qi = 0; qi < ntail; ++qi) {
+      attention_tail_wave<0, BIAS>(Qs, Ks, VtH, VtL, nullptr, N, Npad, heads, ntail, ((b * heads) + head) * ntail + qi, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
+      __syncthreads();
+    }
+    return;
+  }
+  const int qt = bid % slots - (ntail ? 1 : 0);
   const long long bh = (long long)b * heads + head;
 
   // Q fragments (B operand of S^T): lane (q = r32, half) holds Q[q][16ks + 8half + j]
@@ -731,18 +737,24 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
   const int ntail = attention_tail_queries(N);
-  const int tail_wgs = B * heads * ntail;  // the first workgroups of the launch: one tail query each (attention_tail_wave)
-  if ((int)blockIdx.x < tail_wgs) {
-    attention_tail_wave<1, BIAS>(nullptr, nullptr, nullptr, nullptr, qkv_ss, N, 0, heads, ntail, (int)blockIdx.x, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
-    return;
-  }
-  int bid = blockIdx.x - tail_wgs;
+  int bid = blockIdx.x;
   {
-    const int nwg = gridDim.x - tail_wgs, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int qtiles = ((N + AT_BQ - 1) / AT_BQ) - (ntail ? 1 : 0);
-  const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
+  // a (batch, head)'s workgroups are consecutive ids on one XCD: [the tail queries' workgroup (if any) | the full query tiles] -- the tail reads the
+  // same K / V as its siblings, at the same time, through the same L2 (as the launch's first workgroups it fetched them a second time from HBM:
+  // +17 us on 178, profiles/r06_experiments.txt #5)
+  const int slots = ((N + AT_BQ - 1) / AT_BQ);  // workgroups per (batch, head)
+  const int head = (bid / slots) % heads, b = bid / (slots * heads);
+  if (ntail && bid % slots == 0) {
+    for (int qi = 0; qi < ntail; ++qi) {
+      attention_tail_wave<1, BIAS>(nullptr, nullptr, nullptr, nullptr, qkv_ss, N, 0, heads, ntail, ((b * heads) + head) * ntail + qi, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
+      __syncthreads();
+    }
+    return;
+  }
+  const int qt = bid % slots - (ntail ? 1 : 0);
   const int D = heads * 64;
   const long long ld = (long long)D * 12;                      // bytes per token row of [q | k | v]
   const char* const qbase = qkv_ss + (long long)head * 256;    // this head's q columns; k at + D * 4, v at + D * 8
@@ -954,8 +966,7 @@ extern "C" int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok
   const char* q = reinterpret_cast<const char*>(qkv_ss);
   char* oss = reinterpret_cast<char*>(out_ss);
   hipStream_t s = (hipStream_t)stream;
-  const int ntail = attention_tail_queries(ntok);
-  const dim3 grid((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + b * heads * ntail));  // [tail workgroups | query tiles]
+  const dim3 grid((unsigned)(cdiv(ntok, AT_BQ) * heads * b));  // per (batch, head): [tail queries' workgroup, if any | full query tiles]
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, (int)cdiv(ntok, AT_BK), out, oss);
   else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
   else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
@@ -1030,8 +1041,7 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   __bf16* VtL = VtH + (int64_t)b * heads * 64 * npad;
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
-  const int ntail = attention_tail_queries(ntok);
-  dim3 g2((unsigned)((cdiv(ntok, AT_BQ) - (ntail ? 1 : 0)) * heads * b + b * heads * ntail));  // [tail workgroups | query tiles]
+  dim3 g2((unsigned)(cdiv(ntok, AT_BQ) * heads * b));  // per (batch, head): [tail queries' workgroup, if any | full query tiles]
   char* oss = reinterpret_cast<char*>(out_ss);
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {  // the prv2_pack_attention_bias image: ldb carries the key tiles per block row
     int q32n, ktn;
