@@ -289,157 +289,6 @@ __global__ void __launch_bounds__(256) qkv_split_kernel(const float* __restrict_
   }
 }
 
-// =================================================================================================
-// The last few queries of 128 q + r token sequences (r <= AT_TAIL_MAX): DINOv2's 1025 and BEiT's 769 tokens are 8 resp. 6 full query tiles plus
-// ONE query.  As a ninth / seventh workgroup that query cost a full workgroup's residency -- one wave running all key tiles on the matrix pipe, the
-// other three only staging: a ninth of the launch's workgroup slots for 1 / 1025 of its work.  Such queries are computed by plain fp32 FMAs
-// instead, one workgroup per (batch, head, query), its 256 threads over the keys with an online softmax per thread and one merge across them, on the
-// values the matrix kernels see (bf16 hi + bf16 lo of q hd^-0.5 log2 e, k, v).  It is the first of its (batch, head)'s workgroups: it waits on memory (a
-// query still reads its head's whole K and V: 4-5 keys per thread), holds four wave slots for a fraction of a matrix workgroup's time.
-// (One WAVE per query -- 17 dependent rounds of gathers -- was the launch's long pole: 212 us against 184 for 1024 tokens, profiles/r06_experiments.txt #5.)
-// Both attention kernels (pre-pass operands and split-swizzled qkv) run the same routine on the same values in the same order: the two operand
-// paths stay bit-equal to each other and a token's result does not depend on the batch.  (Against the MFMA path a tail query differs in summation
-// order and keeps the lo x lo term the three-product scheme drops: closer to float64, not bit-equal.)
-// =================================================================================================
-constexpr int AT_TAIL_MAX = 4;
-__host__ __device__ inline int attention_tail_queries(int N) { const int r = N % AT_BQ; return (r >= 1 && r <= AT_TAIL_MAX && N > AT_BQ) ? r : 0; }
-constexpr int AT_TAIL_LDS = (256 * 17 + 64 + 8) * 4;  // bytes of LDS per workgroup (the merge, 16 channels at a time; the query vector; 4 + 4 wave partials)
-
-// SRC 0: pre-pass operands (Qs / Ks rows [hi 64 | lo 64], V^T planes [d][Npad]); SRC 1: split-swizzled [q | k | v] rows.  item = (b, head, tail query).
-template <int SRC, int BIAS>
-__device__ __forceinline__ void attention_tail_wave(const __bf16* __restrict__ Qs, const __bf16* __restrict__ Ks, const __bf16* __restrict__ VtH,
-                                                    const __bf16* __restrict__ VtL, const char* __restrict__ qkv_ss, int N, int Npad, int heads, int ntail,
-                                                    int item, const float* __restrict__ bias, int ldb, float* __restrict__ out, char* __restrict__ out_ss,
-                                                    float* const part, const int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const int qi = item % ntail, head = (item / ntail) % heads, b = item / (ntail * heads);
-  const int q = N - ntail + qi;
-  const long long bh = (long long)b * heads + head;
-  const int D = heads * 64;
-  const long long ld = (long long)D * 12, row_b = (long long)b * N;
-  // a token's 64-channel head slice as fp32 (hi + lo, exact), 8 channels per 16-byte slot.  Split-swizzled row r: channel block cb = 0..7 is logical
-  // slot cb & 3 (+ 4: lo) of group cb >> 2, stored at slot ^ ((r >> 1) & 7); pre-pass rows: [hi 64 | lo 64]
-  auto slice8 = [&](const char* rowp, long long r, int cb, float (&v)[8]) {
-    uint4 h, l;
-    if constexpr (SRC == 0) {
-      h = *reinterpret_cast<const uint4*>(rowp + cb * 16);
-      l = *reinterpret_cast<const uint4*>(rowp + 128 + cb * 16);
-    } else {
-      const int key = (int)((r >> 1) & 7), sl = cb & 3;
-      h = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + ((sl ^ key) << 4));
-      l = *reinterpret_cast<const uint4*>(rowp + (cb >> 2) * 128 + (((4 + sl) ^ key) << 4));
-    }
-    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[2 * e] = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
-      v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
-    }
-  };
-  // the query vector (the same for every lane) lives in LDS behind the merge buffer: 64 registers less -- the routine stays inside the 168 the
-  // matrix path of its kernel is capped at (no scratch)
-  float* const qv = part + 256 * 17;
-  float* const wred = qv + 64;  // [4 wave maxima | 4 wave sums]
-  {
-    const long long r = row_b + q;
-    const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Qs + (bh * N + q) * 128) : qkv_ss + r * ld + (long long)head * 256;
-    float v[8];
-    slice8(rowp, r, tid & 7, v);
-    if (tid < 8) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qv[tid * 8 + e] = v[e];
-    }
-    __syncthreads();
-  }
-  // this thread's keys tid, tid + 256, ...: online softmax in the base-2 domain
-  float m = -INFINITY, l = 0.f, ov[64];
-#pragma unroll
-  for (int d = 0; d < 64; ++d) ov[d] = 0.f;
-  for (int key = tid; key < N; key += 256) {
-    const long long r = row_b + key;
-    float sj = 0.f;
-    {
-      const char* rowp = SRC == 0 ? reinterpret_cast<const char*>(Ks + (bh * N + key) * 128) : qkv_ss + r * ld + (long long)D * 4 + (long long)head * 256;
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb) {
-        float v[8];
-        slice8(rowp, r, cb, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sj = fmaf(qv[cb * 8 + e], v[e], sj);  // (channels 0..63 in order, both sources)
-        if (cb == 3) asm volatile("" ::: "memory");  // (at most 8 slots = 32 registers of loads in flight: the routine stays within 168, no scratch)
-      }
-    }
-    if constexpr (BIAS == 1) sj += bias[((long long)head * N + q) * ldb + key] * 1.4426950408889634f;
-    if constexpr (BIAS == 2) {  // the prv2_pack_attention_bias image: [head][query block of 32][key tile of 64][i = 4 t + g][lane][4]
-      const int q32n = ((N + AT_BQ - 1) / AT_BQ) * (AT_BQ / 32), kk = key & 31, e = (kk & 3) + 4 * (kk >> 3);
-      const long long idx = (((((long long)head * q32n + (q >> 5)) * ldb + (key >> 6)) * 8 + 4 * ((key & 63) >> 5) + (e >> 2)) * 64 + ((kk >> 2) & 1) * 32 + (q & 31)) * 4 + (e & 3);
-      sj += bias[idx];
-    }
-    const float m_new = fmaxf(m, sj), corr = __builtin_amdgcn_exp2f(m - m_new), pj = __builtin_amdgcn_exp2f(sj - m_new);
-    l = l * corr + pj;
-    m = m_new;
-    if constexpr (SRC == 0) {
-      const unsigned short* vh = reinterpret_cast<const unsigned short*>(VtH + bh * 64 * Npad + key);
-      const unsigned short* vl = reinterpret_cast<const unsigned short*>(VtL + bh * 64 * Npad + key);
-#pragma unroll
-      for (int d = 0; d < 64; ++d) {
-        ov[d] = fmaf(pj, __uint_as_float((unsigned)vh[(long long)d * Npad] << 16) + __uint_as_float((unsigned)vl[(long long)d * Npad] << 16), ov[d] * corr);
-        if ((d & 15) == 15) asm volatile("" ::: "memory");
-      }
-    } else {
-      const char* rowp = qkv_ss + r * ld + (long long)D * 8 + (long long)head * 256;
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb) {
-        float v[8];
-        slice8(rowp, r, cb, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[cb * 8 + e] = fmaf(pj, v[e], ov[cb * 8 + e] * corr);
-        if (cb == 3) asm volatile("" ::: "memory");
-      }
-    }
-  }
-  // merge the 256 threads: common maximum, thread weights 2^(m_thread - max) (a thread without keys: m = -inf -> weight 0)
-  float mx = m;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (lane == 0) wred[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-  const float wgt = __builtin_amdgcn_exp2f(m - mx);
-  float lt = l * wgt;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lt += __shfl_xor(lt, o, 64);
-  if (lane == 0) wred[4 + wave] = lt;
-  float o = 0.f;  // wave 0, lane = channel d after the merge: 16 channels per round, each summed over the 256 threads in a fixed order
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) part[tid * 17 + e] = ov[c * 16 + e] * wgt;
-    __syncthreads();
-    if (wave == 0) {  // lane (segment sg = lane >> 4 of 64 threads, channel lane & 15); the four segments combined by two butterflies
-      float acc = 0.f;
-      for (int j = 0; j < 64; ++j) acc += part[((lane >> 4) * 64 + j) * 17 + (lane & 15)];
-      acc += __shfl_xor(acc, 16, 64);
-      acc += __shfl_xor(acc, 32, 64);
-      if ((lane >> 4) == c) o = acc;
-    }
-    __syncthreads();
-  }
-  if (wave != 0) return;  // (back to the caller's barrier; only wave 0 stores)
-  lt = (wred[4] + wred[5]) + (wred[6] + wred[7]);
-  o *= 1.0f / lt;
-  const long long row = row_b + q;
-  if (out_ss) {
-    const __bf16 hi = (__bf16)o, lo = (__bf16)(o - (float)hi);
-    char* const rowp = out_ss + row * ((long long)D * 4) + (head * 2 + (lane >> 5)) * 128;
-    const int sl = (lane & 31) >> 3, k2 = (int)((row >> 1) & 7);
-    reinterpret_cast<__bf16*>(rowp + ((sl ^ k2) << 4))[lane & 7] = hi;
-    reinterpret_cast<__bf16*>(rowp + (((4 + sl) ^ k2) << 4))[lane & 7] = lo;
-  } else {
-    out[row * D + head * 64 + lane] = o;
-  }
-}
-
 constexpr int AB_KP = 272;  // K tile row pitch (bytes): 128 hi + 128 lo + 16 pad -> conflict-free ds_read_b128
 constexpr int AB_VP = 264;  // V^T tile row pitch (bytes): conflict-free ds_read_b64 (66 dwords: 2r mod 64)
 
@@ -460,14 +309,13 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const 
 #define ATT_WG_BIAS 2
 #endif
 template <int BIAS>
-__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
+__global__ void __launch_bounds__(256, BIAS == 2 ? ATT_WG_BIAS : 3) attention_bf16x3_kernel(const __bf16* __restrict__ Qs,
                                                                   const __bf16* __restrict__ Ks,
                                                                   const __bf16* __restrict__ VtH,
-                                                                  const __bf16* __restrict__ VtL, int B, int N, int Npad,
+                                                                  const __bf16* __restrict__ VtL, int N, int Npad,
                                                                   int heads, const float* __restrict__ bias, int ldb,
                                                                   float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AB_VP];  // 34304 B; reused for the output strips
-  static_assert(AT_TAIL_LDS <= 64 * AB_KP + 64 * AB_VP, "the tail routine's merge buffer fits in the tile memory");
   char* const Kt = smem;
   char* const Vt = smem + 64 * AB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -475,25 +323,13 @@ __global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_bf
   // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (ids b, b + 8, ... share one), so consecutive ids
   // are remapped to one XCD -- the query tiles of a (batch, head) then read its K / V through ONE L2 instead of eight
   // (PMC before: L2 hit rate 26 %, 5.5x the unique bytes fetched)
-  const int ntail = attention_tail_queries(N);
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // a (batch, head)'s workgroups are consecutive ids on one XCD: [the tail queries' workgroup (if any) | the full query tiles] -- the tail reads the
-  // same K / V as its siblings, at the same time, through the same L2 (as the launch's first workgroups it fetched them a second time from HBM:
-  // +17 us on 178, profiles/r06_experiments.txt #5)
-  const int slots = ((N + AT_BQ - 1) / AT_BQ);  // workgroups per (batch, head)
-  const int head = (bid / slots) % heads, b = bid / (slots * heads);
-  if (ntail && bid % slots == 0) {
-    for (int qi = 0; qi < ntail; ++qi) {
-      attention_tail_wave<0, BIAS>(Qs, Ks, VtH, VtL, nullptr, N, Npad, heads, ntail, ((b * heads) + head) * ntail + qi, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
-      __syncthreads();
-    }
-    return;
-  }
-  const int qt = bid % slots - (ntail ? 1 : 0);
+  const int qtiles = (N + AT_BQ - 1) / AT_BQ;
+  const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const long long bh = (long long)b * heads + head;
 
   // Q fragments (B operand of S^T): lane (q = r32, half) holds Q[q][16ks + 8half + j]
@@ -727,34 +563,21 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int AQ_VP = 320;  // V tile row pitch (bytes): 128 hi + 128 lo + 64 pad
 
 template <int BIAS>
-__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qkvss_kernel(const char* __restrict__ qkv_ss, int B, int N, int heads,
+__global__ void __launch_bounds__(256, BIAS == 0 ? 3 : ATT_WG_BIAS) attention_qkvss_kernel(const char* __restrict__ qkv_ss, int N, int heads,
                                                                                             const float* __restrict__ bias, int ldb,
                                                                                             float* __restrict__ out, char* __restrict__ out_ss) {
   __shared__ __attribute__((aligned(16))) char smem[64 * AB_KP + 64 * AQ_VP];  // 37888 B; reused for the output strips (33792 B)
-  static_assert(AT_TAIL_LDS <= 64 * AB_KP + 64 * AQ_VP, "the tail routine's merge buffer fits in the tile memory");
   char* const Kt = smem;
   char* const Vt = smem + 64 * AB_KP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
-  const int ntail = attention_tail_queries(N);
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // a (batch, head)'s workgroups are consecutive ids on one XCD: [the tail queries' workgroup (if any) | the full query tiles] -- the tail reads the
-  // same K / V as its siblings, at the same time, through the same L2 (as the launch's first workgroups it fetched them a second time from HBM:
-  // +17 us on 178, profiles/r06_experiments.txt #5)
-  const int slots = ((N + AT_BQ - 1) / AT_BQ);  // workgroups per (batch, head)
-  const int head = (bid / slots) % heads, b = bid / (slots * heads);
-  if (ntail && bid % slots == 0) {
-    for (int qi = 0; qi < ntail; ++qi) {
-      attention_tail_wave<1, BIAS>(nullptr, nullptr, nullptr, nullptr, qkv_ss, N, 0, heads, ntail, ((b * heads) + head) * ntail + qi, bias, ldb, out, out_ss, reinterpret_cast<float*>(smem), tid);
-      __syncthreads();
-    }
-    return;
-  }
-  const int qt = bid % slots - (ntail ? 1 : 0);
+  const int qtiles = (N + AT_BQ - 1) / AT_BQ;
+  const int qt = bid % qtiles, head = (bid / qtiles) % heads, b = bid / (qtiles * heads);
   const int D = heads * 64;
   const long long ld = (long long)D * 12;                      // bytes per token row of [q | k | v]
   const char* const qbase = qkv_ss + (long long)head * 256;    // this head's q columns; k at + D * 4, v at + D * 8
@@ -966,10 +789,13 @@ extern "C" int prv2_attention_qkv_ss(const void* qkv_ss, int32_t b, int32_t ntok
   const char* q = reinterpret_cast<const char*>(qkv_ss);
   char* oss = reinterpret_cast<char*>(out_ss);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)(cdiv(ntok, AT_BQ) * heads * b));  // per (batch, head): [tail queries' workgroup, if any | full query tiles]
-  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, (int)cdiv(ntok, AT_BK), out, oss);
-  else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
-  else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, b, ntok, heads, bias, ld_bias, out, oss);
+  const dim3 grid((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
+  if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {
+    int q32n = (int)cdiv(ntok, AT_BQ) * (AT_BQ / 32), ktn = (int)cdiv(ntok, AT_BK);
+    (void)q32n;
+    hipLaunchKernelGGL(attention_qkvss_kernel<2>, grid, dim3(256), 0, s, q, ntok, heads, bias, ktn, out, oss);
+  } else if (bias) hipLaunchKernelGGL(attention_qkvss_kernel<1>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_qkvss_kernel<0>, grid, dim3(256), 0, s, q, ntok, heads, bias, ld_bias, out, oss);
   PRV2_LAUNCH_CHECK("attention_qkv_ss");
   return 0;
 }
@@ -1041,13 +867,13 @@ int launch_attention_bf16x3(const float* qkv, int b, int ntok, int heads, const 
   __bf16* VtL = VtH + (int64_t)b * heads * 64 * npad;
   dim3 g1((unsigned)(npad / 64), (unsigned)heads, (unsigned)b);
   hipLaunchKernelGGL(qkv_split_kernel, g1, dim3(256), 0, s, qkv, ntok, heads, npad, Qs, Ks, VtH, VtL);
-  dim3 g2((unsigned)(cdiv(ntok, AT_BQ) * heads * b));  // per (batch, head): [tail queries' workgroup, if any | full query tiles]
+  dim3 g2((unsigned)(cdiv(ntok, AT_BQ) * heads * b));
   char* oss = reinterpret_cast<char*>(out_ss);
   if (bias && ld_bias == PRV2_ATTENTION_BIAS_IMAGE) {  // the prv2_pack_attention_bias image: ldb carries the key tiles per block row
     int q32n, ktn;
     bias_image_dims(ntok, q32n, ktn);
-    hipLaunchKernelGGL(attention_bf16x3_kernel<2>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, b, ntok, npad, heads, bias, ktn, out, oss);
-  } else if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<1>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, b, ntok, npad, heads, bias, ld_bias, out, oss);
-  else hipLaunchKernelGGL(attention_bf16x3_kernel<0>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, b, ntok, npad, heads, bias, ld_bias, out, oss);
+    hipLaunchKernelGGL(attention_bf16x3_kernel<2>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ktn, out, oss);
+  } else if (bias) hipLaunchKernelGGL(attention_bf16x3_kernel<1>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
+  else hipLaunchKernelGGL(attention_bf16x3_kernel<0>, g2, dim3(256), 0, s, Qs, Ks, VtH, VtL, ntok, npad, heads, bias, ld_bias, out, oss);
   return 0;
 }

@@ -39,6 +39,8 @@ variants = [("one-tile", dict(PRV2_GSS_PERSIST="0"))] + [(f"persist ppb{p}", dic
 if os.environ.get("GSS_ONLY"):  # (tools/probes/gss_ab2.sh: one variant, GEMMs only)
     variants = [v for v in variants if v[0].endswith(os.environ["GSS_ONLY"])]
 res = {}
+if os.environ.get("ATT_ONLY"):  # (the attention block alone)
+    variants = []
 for rnd in range(ROUNDS):
     for vname, env in variants:
         os.environ.update(env)
@@ -49,7 +51,8 @@ for rnd in range(ROUNDS):
             else:
                 fn = lambda: P.gemm_ss(xs, cw, **kw)  # noqa: E731
             res.setdefault((vname, name), []).append(timed(fn))
-print(f"gemm_ss at {M} rows (us per launch, {ROUNDS} interleaved rounds: min / median)")
+if variants:
+    print(f"gemm_ss at {M} rows (us per launch, {ROUNDS} interleaved rounds: min / median)")
 for vname, _ in variants:
     line = f"  {vname:14s}"
     for name, K, N, kw in shapes:
