@@ -274,7 +274,8 @@ class _PatchModel(StateDictModule):
                     reduce = None
                     if shard is not None and shard[1] > 1:  # one decision for all ranks of a patch-sharded frame: the tables' maximum (1 KB all-reduce)
                         import torch.distributed as dist
-                        reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)  # noqa: E731
+                        if dist.is_available() and dist.is_initialized():  # (not in the one-process emulations of the ranks: tests' ShardEmulation, tools/shard_model.py)
+                            reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX)  # noqa: E731
                     self.f6_guarded_frames = getattr(self, "f6_guarded_frames", 0) + 1
                     for attempt in range(3):
                         redo = ops.F6Range.check(image_hr.device, reduce)
