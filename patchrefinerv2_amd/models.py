@@ -403,8 +403,9 @@ class _PatchModel(StateDictModule):
     #                         36 % at 8 ranks to it); one 10-tile batch per rank and one exchange instead -- rank 0 then blends everything behind the
     #                         last batch (order unchanged: bit-identical).  Config key shard_merge_below (0: never merge).
 
-    SHARD_OWNER_COST = 5.0  # what the rank that computes the NEXT frame's coarse pyramid does beside its tiles (coarse forward + per-level G GEMMs +
-    #                         knot tables: ~11 ms on the headline = ~5 tile-times), in tile-times; config key shard_owner_cost
+    SHARD_OWNER_COST = 3.5  # what the rank that computes the NEXT frame's coarse pyramid does beside its tiles (the coarse forward: ~8 of the ~11 ms
+    #                         every rank used to spend per frame on the headline; the ~2-3 ms of tap tables stay with every rank), in tile-times;
+    #                         config key shard_owner_cost
 
     def shard_layout(self, kinds, counts, world, dst=None, owner=None):
         """Who computes which tile, and what is exchanged when (pure host arithmetic on the plan's pass structure; cached).
@@ -482,9 +483,9 @@ class _PatchModel(StateDictModule):
         rh, rw = tile_cfg["patch_raw_shape"]
         RH, RW = tile_cfg["patch_reensemble_shape"]
         n_all = plan["n_all"]
-        # The NEXT frame's coarse pyramid (+ its per-level tap tables) is computed by ONE rank beside this frame's tiles and broadcast: the owner
-        # rotates with the frame index, every other rank spends that time on tiles (shard_layout hands the owner's tiles over).  Every rank
-        # replicating the coarse forward was the cap of the patch-sharded mode: ~11 ms beside ~18 ms of tiles at 8 ranks.
+        # The NEXT frame's coarse pyramid is computed by ONE rank beside this frame's tiles and broadcast (~100 MB): the owner rotates with the
+        # frame index, every other rank spends that time on tiles (shard_layout hands the owner's tiles over).  Every rank replicating the coarse
+        # forward was the cap of the patch-sharded mode: ~11 ms beside ~18 ms of tiles at 8 ranks.
         fi = self.__dict__.get("_frame_index")
         if fi is None:
             fi = self._shard_frames = getattr(self, "_shard_frames", -1) + 1  # (every rank calls the frames in the same order)
@@ -823,19 +824,16 @@ class _PatchModel(StateDictModule):
         return self.__dict__.get("_coarse_recipes", {}).get(self._coarse_recipe_key(lr, tile_cfg))
 
     def _record_coarse_recipe(self, lr, tile_cfg, feats, pred):
-        """what a rank has to allocate to RECEIVE a coarse pyramid of this image size instead of computing it: the pyramid's buffers, the
-        prediction, and per level the tap tables ``prepare_frame`` attached (fusion._EncDec.prepare_frame: g + one knot table per consumer)"""
+        """what a rank has to allocate to RECEIVE a coarse pyramid of this image size instead of computing it: the pyramid's buffers and the
+        prediction.  (NOT the per-level tap tables ``prepare_frame`` derives from them: 3.8 GB per frame on the headline -- 9 x cout columns at coarse
+        resolution + the 3H x 3W knot grids -- against ~100 MB of pyramid; every rank derives its own, ~2 ms.)"""
         bufs, index, fl = [], {}, []
         for f in feats:
             k = f.buf.data_ptr()
             if k not in index:
                 index[k] = len(bufs)
                 bufs.append(tuple(f.buf.shape))
-            aux = None
-            if f.aux is not None:
-                aux = dict(kb=f.aux["kb"], g=(tuple(f.aux["g"].buf.shape), f.aux["g"].c),
-                           taps=[(n, t.cout, t.g.c0 - f.aux["g"].c0, tuple(t.v.buf.shape)) for n, t in f.aux["taps"].items()])
-            fl.append(dict(buf=index[k], c=f.c, c0=f.c0, x2=f.x2, aux=aux))
+            fl.append(dict(buf=index[k], c=f.c, c0=f.c0, x2=f.x2))
         self.__dict__.setdefault("_coarse_recipes", {})[self._coarse_recipe_key(lr, tile_cfg)] = dict(bufs=bufs, feats=fl, pred=tuple(pred.shape))
 
     def _bcast(self, tensors, src):
@@ -851,8 +849,9 @@ class _PatchModel(StateDictModule):
             dist.broadcast(t, src=src, group=grp)
 
     def _prefetch_coarse_sharded(self, next_lr, main, tile_cfg, rank, world, owner):
-        """``_prefetch_coarse`` where only ``owner`` computes: the others allocate the recipe's tensors and receive them.  Results are the owner's
-        bits on every rank: identical to what each rank would have computed itself (same kernels, same inputs, one device type)."""
+        """``_prefetch_coarse`` where only ``owner`` runs the coarse forward: the others allocate the recipe's tensors and receive the pyramid; the
+        per-level tap tables are derived from it on every rank.  The pyramid is the owner's bits on every rank: identical to what each rank would
+        have computed itself (same kernels, same inputs, one device type)."""
         if torch.cuda.is_current_stream_capturing():
             return
         dev = next_lr.device
@@ -864,29 +863,20 @@ class _PatchModel(StateDictModule):
         with torch.cuda.stream(st):
             if rank == owner:
                 feats, pred = self.coarse_forward(next_lr)
-                self._prepare_frame(feats, tile_cfg)
             else:
                 bufs = [torch.empty(shape, device=dev, dtype=torch.float32) for shape in rec["bufs"]]
-                feats = []
-                for fr in rec["feats"]:
-                    f = Feat(bufs[fr["buf"]], fr["c"], fr["c0"], fr["x2"])
-                    if fr["aux"] is not None:
-                        a = fr["aux"]
-                        g = Feat(torch.empty(a["g"][0], device=dev, dtype=torch.float32), a["g"][1])
-                        f.aux = dict(kb=a["kb"], g=g, taps={n: ops.CoarseTaps.from_tables(g.slice(o, 9 * co), co, a["kb"],
-                                                                                              Feat(torch.empty(vs, device=dev, dtype=torch.float32)))
-                                                               for n, co, o, vs in a["taps"]})
-                    feats.append(f)
+                feats = [Feat(bufs[fr["buf"]], fr["c"], fr["c0"], fr["x2"]) for fr in rec["feats"]]
                 pred = torch.empty(rec["pred"], device=dev, dtype=torch.float32)
             uniq, seen = [], set()
             for f in feats:
-                for t in [f.buf] + ([f.aux["g"].buf] + [c.v.buf for c in f.aux["taps"].values()] if f.aux is not None else []):
-                    if t.data_ptr() not in seen:
-                        seen.add(t.data_ptr())
-                        uniq.append(t)
+                if f.buf.data_ptr() not in seen:
+                    seen.add(f.buf.data_ptr())
+                    uniq.append(f.buf)
             uniq.append(pred)
             self.last_coarse_bcast_bytes = sum(t.numel() * 4 for t in uniq)
             self._bcast(uniq, owner)
+            extra = self._prepare_frame(feats, tile_cfg)  # (every rank: the tap tables of the pyramid it now holds)
+            uniq = uniq + list(extra)
             done = torch.cuda.Event()
             done.record(st)
         self._coarse_prefetched = dict(lr=next_lr, version=next_lr._version, feats=feats, pred=pred, done=done, tensors=uniq)

@@ -1321,14 +1321,6 @@ class CoarseTaps:
                             lambda: L.check(L.load().prv2_coarse_tap_knots(g.ptr, g.h, g.w, cout, g.ld, self.kb[0], self.kb[1], self.v.ptr, self.v.ld,
                                                                            _stream()), "coarse_tap_knots"), f"{cout}ch {g.h}x{g.w}")
 
-    @classmethod
-    def from_tables(cls, g: Feat, cout: int, kb, v: Feat) -> "CoarseTaps":
-        """the same object around tables that already exist (a rank that RECEIVES the frame's tables in the patch-sharded mode: models._prefetch_coarse_sharded)"""
-        assert g.n == 1 and g.c == 9 * cout and (v.n, v.h, v.w, v.c) == (1, 3 * g.h, 3 * g.w, cout)
-        self = cls.__new__(cls)
-        self.g, self.cout, self.kb, self.v = g, cout, (float(kb[0]), float(kb[1])), v
-        return self
-
     def gather(self, boxes: torch.Tensor, spatial_scale: float, oh: int, ow: int, out: Optional[Feat] = None) -> Feat:
         """the conv's coarse half for the tiles ``boxes`` (as roi_align takes them): [k, oh, ow, cout], zero padding at the tile border
         included (prv2_coarse_tap_gather)"""
