@@ -175,22 +175,7 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
     if constexpr (PREC == PRV2_PREC_BF16X3) bl[slot] = *reinterpret_cast<const bf16x8*>(b_lane_lo + bbuf * B_BYTES + j * 16 * 128);
   };
   constexpr int NP = PREC == PRV2_PREC_BF16X3 ? 3 : 1;
-  auto mma = [&](f32x4& c, const bf16x8& xh, const bf16x8& xl, const bf16x8& wh, const bf16x8& wl, int pr, [[maybe_unused]] int f6 = 1) {
-#ifdef PRV2_F6_MOCK  // TIMING ONLY, wrong results (tools/probes/f6_mock.sh; profiles/r05_experiments.txt #12): the fp16 + fp6 instruction mix -- 16 fp16 MFMAs per
-                     // tap, 16 fp6 K = 128 MFMAs every other tap -- on THIS pipeline's operand traffic: 1.30x, LDS-bound; why conv3x3_f6.hip is built differently
-    if constexpr (PREC == PRV2_PREC_BF16X3) {
-      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-      typedef int i32x8 __attribute__((ext_vector_type(8)));
-      typedef int i32x4m __attribute__((ext_vector_type(4)));
-      if (pr == 1 && f6) {
-        const i32x4m a0 = __builtin_bit_cast(i32x4m, xh), a1 = __builtin_bit_cast(i32x4m, xl), b0 = __builtin_bit_cast(i32x4m, wh), b1 = __builtin_bit_cast(i32x4m, wl);
-        const i32x8 qa = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, qb = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa, qb, c, 2, 2, 0, 127, 0, 127);
-      }
-      if (pr == 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xh), __builtin_bit_cast(f16x8, wh), c, 0, 0, 0);
-      return;
-    }
-#endif
+  auto mma = [&](f32x4& c, const bf16x8& xh, const bf16x8& xl, const bf16x8& wh, const bf16x8& wl, int pr) {
     if constexpr (PREC == PRV2_PREC_BF16X3) {
       if (pr == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, c, 0, 0, 0);
       if (pr == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, c, 0, 0, 0);
@@ -240,8 +225,8 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
         for (int a = 0; a < NA; a += 2) {
 #pragma unroll
           for (int pr = 0; pr < NP; ++pr) {
-            mma(acc[a][j], ah[a], al[a], bh[j & 1], bl[j & 1], pr, (tap & 1) | (tap == 8));
-            mma(acc[a + 1][j], ah[a + 1], al[a + 1], bh[j & 1], bl[j & 1], pr, (tap & 1) | (tap == 8));
+            mma(acc[a][j], ah[a], al[a], bh[j & 1], bl[j & 1], pr);
+            mma(acc[a + 1][j], ah[a + 1], al[a + 1], bh[j & 1], bl[j & 1], pr);
           }
           __builtin_amdgcn_sched_barrier(0);
 #ifndef PRV2_ABL_NOA  // (timing ablations of tools/probes/gate_phase_stamps.sh: results are wrong with any of them)
@@ -273,8 +258,8 @@ __device__ __forceinline__ void c256_body(const GateConvParams& gp, float* smem)
       for (int a = 0; a < NA; a += 2) {
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
-          mma(acc[a][NJ - 1], ah[a], al[a], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr, (tap & 1) | (tap == 8));
-          mma(acc[a + 1][NJ - 1], ah[a + 1], al[a + 1], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr, (tap & 1) | (tap == 8));
+          mma(acc[a][NJ - 1], ah[a], al[a], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr);
+          mma(acc[a + 1][NJ - 1], ah[a + 1], al[a + 1], bh[(NJ - 1) & 1], bl[(NJ - 1) & 1], pr);
         }
         __builtin_amdgcn_sched_barrier(0);
         read_a(a, tap == 8 ? ab ^ 1 : ab, (tap + 1) % 9);
@@ -334,11 +319,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_c256_gate_x2_kernel(const Gate
   c256_body<PREC, true, true>(gp, smem);
 }
 
-}  // namespace prv2
-#ifdef PRV2_EXPERIMENTS  // (make EXPERIMENTS=1: the round-3 power-wall experiment; not part of the default build)
-#include "conv3x3_w4.h"
-#endif
-namespace prv2 {
 
 // C x C gate weights (PyTorch [cout][cin][1][1]; C = 32, 128, 256) -> the fragment-major image of igemm.h::gate_frag_index
 __global__ void __launch_bounds__(256) pack_gate_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int c) {
@@ -464,19 +444,6 @@ extern "C" int prv2_conv3x3_ln_gate_pre(const prv2_conv_desc* d, const float* x,
   PRV2_REQUIRE(blocks < (1LL << 31), "conv3x3_ln_gate: grid too large");
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = d->prec == PRV2_PREC_BF16X3;
-  // PRV2_W4=1: the four-wave kernel of conv3x3_w4.h (two workgroups per CU).  NOT the default: it needs 7 % fewer shader cycles per tile
-  // (all-zero operands, where the chip holds 2.39 GHz: 646 vs 607 TF), but on real operands the chip is at its power limit -- the clock
-  // falls from 1.94 to 1.81 GHz and the launch takes the same 3.48 ms; inside a frame (two streams) it is 1 % slower
-  // (tools/probes/gate_clock.sh, profiles/r03_power_wall.txt)
-#ifdef PRV2_EXPERIMENTS
-  static const int use_w4 = getenv("PRV2_W4") ? atoi(getenv("PRV2_W4")) : 0;
-  if (gate_w_packed && gp.x_x2 && x3 && use_w4 && (!mul || gp.mul_x2)) {
-    hipLaunchKernelGGL((conv3x3_w4_gate_kernel<PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(256), 0, s, gp);
-    set_kernel("conv3x3_w4_gate_kernel", 256, d->prec);
-    PRV2_LAUNCH_CHECK("conv3x3_ln_gate");
-    return 0;
-  }
-#endif
   if (gate_w_packed && gp.x_x2) {
     if (x3) hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16X3>), dim3((unsigned)blocks), dim3(512), 0, s, gp);
     else hipLaunchKernelGGL((conv3x3_c256_gate_x2_kernel<256, PRV2_PREC_BF16>), dim3((unsigned)blocks), dim3(512), 0, s, gp);

@@ -905,55 +905,9 @@ static int persist_workgroups() {  // one persistent workgroup per CU of the CUR
   return n[dev];
 }
 
-}  // namespace prv2
-#ifdef PRV2_EXPERIMENTS  // (make EXPERIMENTS=1: round-3 experiment, slower inside the frame; not part of the default build)
-#include "conv3x3_q4.h"
-namespace prv2 {
-
-// conv3x3_q4.h: the 128-column layers on four-wave workgroups, two per CU.  OPT-IN (PRV2_Q4=1: the single-column-tile layers at large
-// images, PRV2_Q4=2: every layer it covers): on dense random operands, where the 8-wave kernels are held down by the chip's clock, it is
-// 8-15 % faster on those layers (256 -> 128 behind a x2 upsample at 41 x 384 x 512: 13.2 -> 12.1 ms, 98 -> 98: 6.7 -> 5.7 ms); on the
-// frame's real activations (sparser: the 8-wave kernel runs the same layers at 451 instead of 360 TFLOP/s) its lower cycle efficiency
-// (376 vs 444 TFLOP/s on all-zero operands: six half items of loader VALU per thread and slab) makes it 9 % slower:
-// 186.1 / 185.7 -> 189.6 / 191.1 ms per frame (profiles/r03_experiments.txt)
-static bool force_q4() {
-  static const int v = getenv("PRV2_Q4") ? atoi(getenv("PRV2_Q4")) : 0;
-  return v == 2;
-}
-static bool conv3x3_q4_usable(const IgemmParams& p, int prec) {
-  static const int on = getenv("PRV2_Q4") ? atoi(getenv("PRV2_Q4")) : 0;
-  // one column tile, large images: where the 8-wave kernels lose most to their exposed prologue / epilogue (same-box A/B, 41-tile
-  // batches: 256 -> 128 behind a x2 upsample at 384 x 512 13.2 -> 12.1 ms, 98 -> 98 6.7 -> 5.7 ms).  With several column tiles every
-  // one of them re-stages the halo for 128 pixels only: 194 -> 194 at 192 x 256 4.1 -> 4.6 ms, deeper levels -10 ... -20 %.
-  const bool pays = force_q4() || (p.Ncols <= 128 && (long long)p.H * p.W >= 128 * 1024);
-  return on && pays && prec == PRV2_PREC_BF16X3 && p.Ncols > 64 && p.vec_epi && !p.gamma && !p.mul && !p.res2 && !p.gate_w && !p.tail1 && p.convt_k == 0 &&
-         (!p.ln_w || p.Ncols <= 128) && (!p.xu || p.ups_c % 32 == 0) && (p.w_tail != nullptr) == (p.Cin % 32 == 2) && (p.Cin % 32 == 0 || p.Cin % 32 == 2) &&
-         (long long)p.H * p.W * p.ldx < (1LL << 29) && (long long)p.H * p.W * p.ldy < (1LL << 29);
-}
-static void launch_conv3x3_q4(IgemmParams& p, int prec, hipStream_t s) {
-  p.tiles_n = (int)cdiv(p.Ncols, 128);
-  const int blocks = p.N * (int)cdiv(p.H, 8) * (int)cdiv(p.W, 16) * p.tiles_n;
-  set_kernel(p.xu ? "conv3x3_q4_ups_kernel" : "conv3x3_q4_kernel", 128, prec);
-  if (p.xu) {
-    if (p.w_tail) hipLaunchKernelGGL((conv3x3_q4_kernel<true, true>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_q4_kernel<true, false>), dim3(blocks), dim3(256), 0, s, p);
-  } else {
-    if (p.w_tail) hipLaunchKernelGGL((conv3x3_q4_kernel<false, true>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_q4_kernel<false, false>), dim3(blocks), dim3(256), 0, s, p);
-  }
-}
-}  // namespace prv2
-#endif
-namespace prv2 {
 
 void launch_conv3x3_halo16(IgemmParams& p, int prec, hipStream_t s) {
   using namespace m16;
-#ifdef PRV2_EXPERIMENTS
-  if (conv3x3_q4_usable(p, prec)) {
-    launch_conv3x3_q4(p, prec, s);
-    return;
-  }
-#endif
   static const int wave_map = getenv("PRV2_HALO_WAVE_MAP") ? atoi(getenv("PRV2_HALO_WAVE_MAP")) : 1;  // A/B switch
   p.wave_map = wave_map;
   p.tiles_n = p.Ncols > 64 ? (int)cdiv(p.Ncols, 128) : 1;

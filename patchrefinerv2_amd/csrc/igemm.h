@@ -293,7 +293,7 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const EpiCols& c
 // Row statistics for the fused LayerNorm: the C tile sits in LDS as [rows][cld]; thread t (< rows) owns row t.
 // Two passes (mean, then biased variance of the centred values) exactly like convs.py:25-27.  Summation order: four partial sums --
 // partial g over the channels 32 s + 8 g + i (i < 8, ascending) -- combined as (p0 + p1) + (p2 + p3): the order in which the four
-// lanes of a pixel hold and reduce the channels in conv3x3_q4.h's wave-local epilogue, so that a layer's result does not depend on
+// lanes of a pixel hold and reduce the channels in a wave-local epilogue (the round-3 four-wave experiment kernels, since removed), so that a layer's result does not depend on
 // which of the kernels took it.
 __device__ __forceinline__ void ln_row_stats(const IgemmParams& p, const float* ctile, int cld, int rows, int tid,
                                              float* stats /* [2*rows] in LDS */) {

@@ -1049,61 +1049,6 @@ def test_x2_presplit_format_gate_unit(P, case, prec):
         P.conv2d(x, narrow, dst)
 
 
-def _built_with_experiments():
-    """the opt-in round-3 kernels (csrc/conv3x3_w4.h, conv3x3_q4.h) are only in builds made with ``make EXPERIMENTS=1``"""
-    import os
-    from patchrefinerv2_amd import lib
-    if not os.path.exists(lib.LIB_PATH):  # (unbuilt tree: skip at run time, never a collection error of ``-m "not gpu"``)
-        return False
-    with open(lib.LIB_PATH, "rb") as f:
-        return b"conv3x3_w4_gate_kernel" in f.read()
-
-
-needs_experiments = pytest.mark.skipif(not _built_with_experiments(), reason="library built without EXPERIMENTS=1 (conv3x3_w4.h / conv3x3_q4.h)")
-
-
-@needs_experiments
-@pytest.mark.parametrize("shape", [(2, 24, 32), (1, 17, 29)])
-def test_w4_gate_kernel_matches_the_eight_wave_kernel(shape):
-    """csrc/conv3x3_w4.h (opt-in, PRV2_W4=1: four waves, two workgroups per CU, halo by buffer_load ... lds, wave-local LayerNorm and
-    gate GEMM) against the 8-wave kernel on the same GatedConvUnit tail (bi_directional_fusion_model.py:44-51,70-80), ragged tiles
-    included: the same products in the same order, LayerNorm partial sums in another order -- ~1e-6 relative.  (The switch is read
-    once per process: the comparison runs in a child.)"""
-    import os
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PRV2_W4="1", PRV2_X2="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "w4_check.py"), *map(str, shape)], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "conv3x3_w4_gate_kernel<256,bf16x3>" in r.stdout and "conv3x3_c256_gate_kernel<256,bf16x3>" in r.stdout, r.stdout
-    m = re.search(r"max\|d\| (\S+) scale (\S+) .* finite (\S+)", r.stdout)
-    assert m and m.group(3) == "True", r.stdout
-    assert float(m.group(1)) <= 3e-6 * float(m.group(2)), r.stdout
-
-
-@needs_experiments
-def test_q4_kernels_pass_the_conv_tests():
-    """csrc/conv3x3_q4.h (opt-in, PRV2_Q4=2: four-wave workgroups, two per CU, for every 3x3 layer with 65 .. 128-column tiles it covers):
-    the fused-upsample, tail-tile and plain conv tests of this file pass bit for bit with it switched on (the switch is read once per
-    process: a child runs them)"""
-    import os
-    import subprocess
-    import sys
-    here = os.path.abspath(__file__)
-    env = dict(os.environ, PRV2_Q4="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-k", "conv2d_ups_equals or conv2d_tail_equals or fused_tail or halo16", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    chk = subprocess.run([sys.executable, "-c", "import torch, numpy as np\nfrom patchrefinerv2_amd import ops as P\n"
-                          "x = P.Feat(torch.randn(1, 24, 32, 64, device='cuda'))\n"
-                          "cw = P.pack_conv(torch.randn(128, 64, 3, 3, device='cuda') / 24, None, pad=1, prec=P.L.PREC_NAMES['bf16x3'])\n"
-                          "P.conv2d(x, cw)\nprint(P.L.load().prv2_last_kernel().decode())"],
-                         env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(here)))
-    assert "conv3x3_q4_kernel" in chk.stdout, chk.stdout + chk.stderr[-2000:]
-
-
 def _frame_boxes(split, P_hw, k_random, seed):
     """lr-frame ROI boxes [k, 4] (x1, y1, x2, y2) of tiles 1/split of the frame: the four frame corners, then random positions"""
     ph, pw = P_hw
