@@ -2,7 +2,7 @@
 # Run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01'): regenerates the profiles/ evidence of the default
 # bench workload into gpurun_out/profiles/ (copy what should be judged into profiles/ afterwards).
 set -u
-TAG=${1:-r05}; PREC=${2:-f16f6}   # PREC: the bench's arithmetic (its default: bf16x3 + the fp16 / fp6 layers)
+TAG=${1:-r06}; PREC=${2:-f16f6}   # PREC: the bench's arithmetic (its default: bf16x3 + the fp16 / fp6 layers)
 R=$(pwd); O=$R/gpurun_out/profiles; mkdir -p $O
 WL=$(python3 -c "from patchrefinerv2_amd.workloads import DEFAULT_WORKLOAD as w; print(w)")
 export TMPDIR=/tmp
@@ -20,26 +20,14 @@ python3 tools/cpu_baseline_validate.py > $O/${TAG}_cpu_baseline_validation.json 
 python3 tools/shard_model.py > $O/${TAG}_shard_model.json 2>> $O/bench.err
 # the power-limited frame's operating range: all-zero frames (upper end) beside the default random frames
 python3 bench.py --prec $PREC --no-alt --data zeros --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/${TAG}_${PREC}_bench_${WL}_zeros.json 2>> $O/bench.err
-# same-box A/B of the round's frame-level changes
-for T in 1 0 1 0; do PRV2_COARSE_TAPS=$T python3 bench.py --prec $PREC --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_COARSE_TAPS=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_coarse_taps_ab.txt
-for T in 1 0 1 0; do PRV2_UPCONV=$T python3 bench.py --prec $PREC --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v2_zoe_4k_r32 PRV2_UPCONV=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_upconv_ab.txt
-for T in 1 0 1 0; do PRV2_UPCONV=$T python3 bench.py --prec $PREC --no-alt --workload v1_zoe_4k_r32 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v1_zoe_4k_r32 PRV2_UPCONV=$T', round(d['ms_per_step'],2), 'ms')"; done >> $O/${TAG}_upconv_ab.txt
-python3 tools/probes/upconv_time.py 41 2>/dev/null | grep upconv >> $O/${TAG}_upconv_ab.txt
-# round 5: the fused 32-channel full-resolution chains (csrc/chain32.hip) and the 5x5 composite at the source resolution (csrc/upconv5.hip)
-for T in 1 0 1 0; do PRV2_CHAIN32=$T python3 bench.py --prec $PREC --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_CHAIN32=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_chain32_ab.txt
-python3 tools/bench_chain32.py 2>/dev/null | grep chain32_ >> $O/${TAG}_chain32_ab.txt
-bash tools/probes/chain32_stamps.sh 2>/dev/null | grep -E "stage|chain32_" >> $O/${TAG}_chain32_ab.txt
-for T in 1 0 1 0; do PRV2_UPCONV5=$T python3 bench.py --prec $PREC --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_UPCONV5=$T', round(d['ms_per_step'],2), 'ms', d['operating_point'])"; done > $O/${TAG}_upconv5_ab.txt
-python3 tools/bench_upconv5.py 2>/dev/null | grep upconv5x5 >> $O/${TAG}_upconv5_ab.txt
-for D in torch ctypes torch ctypes; do PRV2_DISPATCH=$D python3 bench.py --prec $PREC --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('PRV2_DISPATCH=$D', round(d['ms_per_step'],2), 'ms')"; done > $O/${TAG}_dispatch_ab.txt
-# round 5, stage 1 of the fp16 + fp6 arithmetic (csrc/conv3x3_f6.hip): the kernel against conv3x3_c256_kernel<bf16x3> on the frame's shapes, the frame in
-# both arithmetics on this box (alternating), phase stamps / in-kernel clock, and the bf16x3 mode's own headline line + layer table
-python3 tools/probes/c256_bench.py both 2>&1 | grep "256->256" > $O/${TAG}_f16f6_ab.txt
-python3 tools/probes/gate_taps_bench.py 14 192 256 2>&1 | grep "gate" >> $O/${TAG}_f16f6_ab.txt
-python3 tools/probes/gate_taps_bench.py 14 96 128 2>&1 | grep "gate" >> $O/${TAG}_f16f6_ab.txt
-for G in 1 0 1 0; do PRV2_F6_GATE=$G python3 bench.py --prec f16f6 --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('--prec f16f6 PRV2_F6_GATE=$G (stage 2: the GatedConvUnit tail kernel)', round(d['ms_per_step'],2), 'ms')"; done >> $O/${TAG}_f16f6_ab.txt
+# (the per-feature A/Bs of rounds 4-5 -- coarse taps, upconv, chain32, upconv5, dispatch route, PRV2_F6_GATE -- are in profiles/r04_*, r05_*: git history of this script)
+# round 6: the ViT blocks -- persistent gemm_ss workgroups and the attention block without the qkv_split pre-pass -- on the ViT-heavy V1 workload, alternating
+for T in 1 0 1 0; do PRV2_GSS_PERSIST=$T PRV2_QKV_SS=$T python3 bench.py --prec $PREC --no-alt --workload v1_zoe_4k_r32 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('v1_zoe_4k_r32 PRV2_GSS_PERSIST = PRV2_QKV_SS = $T', round(d['ms_per_step'],1), 'ms', round(d['value'],3), 'maps/s')" >> $O/${TAG}_vit_ab.txt; done
+python3 tools/probes/vit_ab.py 14 3 2>/dev/null | grep -v amdgpu.ids >> $O/${TAG}_vit_ab.txt
+NTOK=769 python3 tools/probes/vit_ab.py 41 2 2>/dev/null | grep -v amdgpu.ids >> $O/${TAG}_vit_ab.txt
+bash tools/probes/gss_ablate_run.sh > $O/${TAG}_gemm_ss_ablations.txt 2>&1
+# the frame in both arithmetics on this box (alternating), and the bf16x3 mode's own headline line + layer table
 for T in f16f6 bf16x3 f16f6 bf16x3; do python3 bench.py --prec $T --no-alt --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>> $O/bench.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('--prec $T', d['dtype'], round(d['ms_per_step'],2), 'ms', round(d['value'],3), 'maps/s', d['operating_point'])"; done >> $O/${TAG}_f16f6_ab.txt
-bash tools/probes/f6_stamps.sh "" 2>/dev/null | grep -v "^$" >> $O/${TAG}_f16f6_ab.txt
 python3 bench.py --prec bf16x3 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bf16x3_bench_${WL}.json 2>> $O/bench.err
 python3 bench.py --prec bf16x3 --layer-report $O/${TAG}_bf16x3_layers_${WL}.csv --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>> $O/bench.err
 # kernel durations only mean something un-overlapped: the traced runs use one stream, like the roofline pass inside bench.py
