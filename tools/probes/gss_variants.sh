@@ -18,3 +18,4 @@ build bare -DPRV2_GSS_NOEPI -DPRV2_GSS_NODMA -DPRV2_GSS_NOBAR &
 build nomma -DPRV2_GSS_NOEPI -DPRV2_GSS_NOMMA &
 wait
 wait
+wait
