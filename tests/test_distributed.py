@@ -122,6 +122,34 @@ def test_shard_layout_covers_every_tile_once(mode, n):
             assert sorted(seen) == list(range(n))
 
 
+@pytest.mark.parametrize("mode,n", [("r32", 81), ("r64", 113), ("m1", 16)])
+def test_shard_layout_with_a_rotating_coarse_owner(mode, n):
+    """round 6: the rank that computes the NEXT frame's coarse pyramid beside this frame's tiles (models._prefetch_coarse_sharded) hands tiles of the last
+    gather group to the others (shard_owner_cost tile-times); every tile is still computed exactly once, whoever the owner is, also when the owner is
+    the blending rank; without an owner the layout is the round-5 one"""
+    h = _Host()
+    h.patch_process_shape = (448, 448)
+    random.seed(621)
+    kinds, counts, _ = _plan(h, mode)
+    for world in (2, 4, 8):
+        base = h.shard_layout(kinds, counts, world, 0)
+        assert h.shard_layout(kinds, counts, world, 0, None) is base                  # (cached; owner None == the old call)
+        for owner in range(world):
+            groups = h.shard_layout(kinds, counts, world, 0, owner)
+            seen = []
+            for g in groups:
+                assert sorted(i for m in g["mine"] for i in m) == list(range(g["n"]))
+                assert all(len(g["mine"][q]) == g["share"][q] <= g["per"] for q in range(world))
+                seen += [g["base"] + i for m in g["mine"] for i in m]
+            assert sorted(seen) == list(range(n))
+            tiles = [sum(g["share"][q] for g in groups) for q in range(world)]
+            others = [tiles[q] for q in range(world) if q not in (0, owner)]
+            if n >= 4 * world and others:
+                assert tiles[owner] <= min(others), (mode, world, owner, tiles)       # the owner never computes more tiles than a rank without side work
+                if owner != 0:
+                    assert tiles[owner] < max(others) or groups[-1]["share"][owner] == 0, (mode, world, owner, tiles)
+
+
 def test_boxes_on_device_equal_host_boxes():
     """_boxes_dev (patch-sharded mode: boxes from the broadcast plan tensor) == _boxes (host numpy) bit for bit"""
     h = _Host()
