@@ -742,7 +742,7 @@ def test_gemm_ss_bit_equal_to_gemm16(P, M, K, N, tile, monkeypatch):
     assert torch.equal(a, bq)
 
 
-@pytest.mark.parametrize("M,K,N", [(9000, 96, 2048), (23000, 160, 768), (16500, 128, 1024)])  # 288 (4 x 8-blocked) / 270 / 260 tiles of 256 x 256: > 256 workgroups
+@pytest.mark.parametrize("M,K,N", [(9000, 96, 2048), (23000, 160, 768), (16500, 128, 1024), (9300, 32, 2048)])  # 288 (4 x 8-blocked) / 270 / 260 tiles of 256 x 256: > 256 workgroups; 37 row tiles blocked: 24 idle ids, one slab
 @pytest.mark.parametrize("ppb", ["1", "2", "4", "8"])
 def test_gemm_ss_persistent_workgroups_walk_several_tiles_bit_equal(P, M, K, N, ppb, monkeypatch):
     """gemm_ss_p_kernel (one persistent workgroup per CU: the next tile's first slab is DMA'd under the current tile's last slab and
